@@ -1,0 +1,161 @@
+/*
+ * mlmap_hip.h — C ABI of the MI355X-native MLMapping map-update path (libmlmap_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of the reference: mlmap::update_map()
+ * (src/mlmap.cpp:382-386 = awareness_map_cylindrical::input_pc_pose, src/map_awareness.cpp:173-282,
+ *  + local_map_cartesian::input_pc_pose_direct, src/map_local.cpp:143-237) and the query inlines
+ * planners call on the result (include/mlmap.h:142-295, src/mlmap.cpp:388-407).
+ *
+ * The reference has no FFI: it is one C++ process.  Each entry point below names the C++ member it
+ * replaces; INTEGRATION.md shows the mlmap-side stubs a maintainer would add, and
+ * include/mlmap_facade.hpp is a header-only class with the reference's public names on top of this ABI.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative mlm_status otherwise; no exceptions cross the ABI
+ *    (the reference has no error channel at all: yaml-cpp / vector::at exceptions kill the nodelet);
+ *  - plain pointers and sizes only; host buffers are borrowed for the duration of the call;
+ *  - one handle = one device + one HIP stream.  integrate_* calls on a handle are serialised by the
+ *    caller; query_* calls observe the map as of the last integrate call issued before them;
+ *  - poses are q_wb = (w,x,y,z) and t_wb of T_wb (body in world), exactly what mlmap.cpp:494 builds;
+ *  - positions are world-frame doubles (Vec3 of include/common.h:22), n x 3 row-major.
+ */
+#ifndef MLMAP_HIP_H
+#define MLMAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLM_ABI_VERSION 1
+
+typedef enum mlm_status {
+    MLM_OK = 0,
+    MLM_ERR_INVALID = -1,     /* bad argument */
+    MLM_ERR_HIP = -2,         /* HIP runtime error, see mlm_last_error */
+    MLM_ERR_CAPACITY = -3,    /* block pool / point capacity exceeded (map unchanged by the failing frame's tail) */
+    MLM_ERR_UNSUPPORTED = -4, /* configuration outside the supported envelope */
+} mlm_status;
+
+/* mlmap::getOccupancy return values, include/mlmap.h:109-114 */
+enum { MLM_FREE = 1, MLM_OCCUPIED = 0, MLM_UNKNOWN = -1 };
+
+/* The YAML keys mlmap::init_map reads (src/mlmap.cpp:10-33,75-85); same meaning, same units.
+ * Doubles that the reference casts to float (mlmap.cpp:77-81, mlmap.h:92) are cast the same way inside. */
+typedef struct mlm_config {
+    double am_d_rho;       /* mlmapping_am_d_Rho */
+    double am_d_phi_deg;   /* mlmapping_am_d_Phi_deg */
+    double am_d_z;         /* mlmapping_am_d_Z */
+    int32_t am_n_rho;      /* mlmapping_am_n_Rho */
+    int32_t am_n_z_below;  /* mlmapping_am_n_Z_below */
+    int32_t am_n_z_over;   /* mlmapping_am_n_Z_over */
+    int32_t use_raycasting;/* mlmapping_use_raycasting */
+    double depth_noise_coe;/* mlmapping_depth_noise_coe */
+    double subbox_d_xyz;   /* mlmapping_subbox_d_xyz */
+    int32_t subbox_n;      /* mlmapping_subbox_n */
+    int32_t use_exploration_frontiers; /* use_exploration_frontiers */
+    double log_odds_min;   /* mlmapping_lm_log_odds_min */
+    double log_odds_max;   /* mlmapping_lm_log_odds_max */
+    double measurement_hit;/* mlmapping_lm_measurement_hit (stored, never used: map_local.cpp:128,159) */
+    double measurement_miss;/* mlmapping_lm_measurement_miss */
+    double occupied_sh;    /* mlmapping_lm_occupied_sh */
+    int32_t inflate_n;     /* mlmapping_inflate_n */
+    int32_t inflate_global_n; /* mlmapping_inflate_global_n */
+    int32_t apply_inflate; /* mlmapping_apply_inflate */
+    int32_t sample_cnt;    /* mlmapping_sample_cnt */
+    double cam_cx, cam_cy, cam_fx, cam_fy; /* mlmapping_cam_* */
+    double T_bs[16];       /* T_B_S, 4x4 row major (include/yamlRead.h:16-24) */
+} mlm_config;
+
+/* Sizing of the device-resident state (no reference counterpart: the reference grows std containers). */
+typedef struct mlm_limits {
+    int32_t max_blocks;      /* capacity of the hashed block pool (n^3 cells each); 0 = default 65536 */
+    int32_t max_points;      /* largest point count of one frame; 0 = 1280*720 */
+    int32_t max_batch;       /* frames per mlm_integrate_depth_batch call; 0 = 32 */
+    int32_t record_awareness;/* keep per-frame hit/miss lists readable via mlm_get_awareness_* (tests) */
+} mlm_limits;
+
+typedef struct mlm_handle mlm_handle;
+
+/* Counters of the last integrated frame (the reference exposes the same facts as container sizes:
+ * hit_idx_odds_hashmap.size(), miss_idx_set.size(), observed_group_map.size()). */
+typedef struct mlm_frame_stats {
+    int64_t n_points;      /* points fed (raw != 0) */
+    int64_t n_hit_cells;   /* unique awareness hit cells  == hit_idx_odds_hashmap.size() */
+    int64_t n_miss_cells;  /* unique awareness miss cells == miss_idx_set.size() */
+    int64_t n_out_of_range;/* "point out range" branch, map_awareness.cpp:277 */
+    int64_t n_blocks;      /* observed_group_map.size() */
+    int64_t n_rehash_epochs; /* libstdc++ rehash epochs replayed for the hit container this frame (1 = none) */
+    int64_t hit_bucket_count;/* emulated hit_idx_odds_hashmap.bucket_count() after this frame */
+} mlm_frame_stats;
+
+/* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */
+int mlm_create(const mlm_config *cfg, const mlm_limits *limits_or_null, int device, mlm_handle **out);
+int mlm_destroy(mlm_handle *h);
+const char *mlm_last_error(mlm_handle *h);
+int mlm_abi_version(void);
+
+/* Use an externally owned HIP stream (e.g. the framework's current stream) instead of the handle's own. */
+int mlm_set_stream(mlm_handle *h, void *hip_stream);
+
+/* replaces mlmap::project_depth + update_map (src/mlmap.cpp:311-349,382-386).
+ * img: uint16 millimetres (the 16UC1 image of mlmap.cpp:477-484), row_stride in pixels.
+ * pixel_idx == NULL: dense — every pixel with raw != 0 in row-major order (v outer).
+ * pixel_idx != NULL: exactly those pixels (v*width+u) in list order, raw == 0 skipped — lets a host reproduce
+ * the reference's rand() sampler (mlmap.cpp:322-327) outside and keep parity. */
+int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img_host, int width, int height, int row_stride,
+                            const int32_t *pixel_idx, int n_idx, const double q_wb[4], const double t_wb[3]);
+/* same with the image already resident in device memory (HBM) */
+int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int width, int height, int row_stride,
+                                const int32_t *pixel_idx_dev, int n_idx, const double q_wb[4],
+                                const double t_wb[3]);
+/* K frames of one stream, device resident, frame k at img_dev + k*frame_stride (in pixels); poses 4K / 3K doubles.
+ * Frames are integrated in order (the update is order dependent). */
+int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_frames, size_t frame_stride,
+                                  int width, int height, int row_stride, const double *q_wb, const double *t_wb);
+/* replaces awareness_map_cylindrical::input_pc_pose(PC_s, T_wb) + input_pc_pose_direct on an explicit
+ * sensor-frame point list (include/map_awareness.h:74) */
+int mlm_integrate_points(mlm_handle *h, const double *xyz_s_host, int n, const double q_wb[4],
+                         const double t_wb[3]);
+
+/* queries: include/mlmap.h:170-193 / :142-169 / :195-211 / :213-225 / :237-295 */
+int mlm_query_occupancy(mlm_handle *h, const double *pos, int n, int8_t *out);
+int mlm_query_occupancy_inflate(mlm_handle *h, const double *pos, int n, float inflate, int8_t *out);
+int mlm_query_inflate_occupancy(mlm_handle *h, const double *pos, int n, int8_t *out);
+int mlm_query_odds(mlm_handle *h, const double *pos, int n, float *out);
+int mlm_query_odd_grad(mlm_handle *h, const double *pos, int n, int max_iter, double *out3);
+/* src/mlmap.cpp:388-407 */
+int mlm_set_free_in_bound(mlm_handle *h, const double box_min[3], const double box_max[3]);
+/* mlmap::inflate_map (src/mlmap.cpp:286-309) around vehicle position ct_pos */
+int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]);
+
+/* map read-out: what visualisers get by iterating local_map->observed_group_map (rviz_vis.cpp:280-321) */
+int mlm_block_count(mlm_handle *h, int *n_out);
+/* keys [cap*3], log_odds [cap*cells], occ / infl [cap*cells] ('u','f','o'); any pointer may be NULL */
+int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, uint8_t *occ, uint8_t *infl,
+                      int *n_out);
+/* float xyz of inflated-'o' cell centres = PointCloud2 payload of /global_map (rviz_vis.cpp:296-327) */
+int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out);
+
+int mlm_sync(mlm_handle *h);
+int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out);
+
+/* test hooks (need limits.record_awareness): unique hit cells (linear cell idx, odd, first-touch time) and
+ * unique miss cells of the LAST frame, unordered */
+int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *odds, uint32_t *t_first, int *n_out);
+int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_out);
+/* derived constants, for cross-checking against the oracle: T_ls of the last frame, odds table [21*n_rho] */
+int mlm_get_T_ls(mlm_handle *h, double q[4], double t[3]);
+int mlm_get_odds_table(mlm_handle *h, float *out);
+
+/* device-time of the kernels launched by the last integrate call, measured with HIP events on the handle's
+ * stream (milliseconds); names are static strings.  Used by bench.py's roofline leg. */
+int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out);
+int mlm_enable_kernel_timing(mlm_handle *h, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

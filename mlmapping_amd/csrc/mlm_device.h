@@ -1,0 +1,190 @@
+// mlm_device.h — device helpers shared by the map-update kernels.
+//
+// Index arithmetic is FP64 in the reference's operation order; the TU is built with -ffp-contract=off so
+// no mul+add is fused (the reference is an SSE2 build: CMakeLists.txt:4, SURVEY.md §7 hard part 2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mlm_types.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+// x86-64 static_cast<int>(double) == cvttsd2si: NaN / out-of-range -> INT_MIN.  gfx950 v_cvt_i32_f64 saturates
+// and maps NaN to 0, so the x86 behaviour the reference silently relies on is spelled out.
+__device__ __forceinline__ int mlm_cvt_int(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
+    return (int)v;
+}
+
+// QuaternionBase::_transformVector (Eigen generic path): v + w*(2 q x v) + q x (2 q x v); so3.cpp:80-84
+__device__ __forceinline__ void mlm_quat_rot(const double q[4], double vx, double vy, double vz, double &ox,
+                                             double &oy, double &oz) {
+    const double qx = q[1], qy = q[2], qz = q[3], qw = q[0];
+    double ux = qy * vz - qz * vy;
+    double uy = qz * vx - qx * vz;
+    double uz = qx * vy - qy * vx;
+    ux = ux + ux;
+    uy = uy + uy;
+    uz = uz + uz;
+    const double cx = qy * uz - qz * uy;
+    const double cy = qz * ux - qx * uz;
+    const double cz = qx * uy - qy * ux;
+    ox = (vx + qw * ux) + cx;
+    oy = (vy + qw * uy) + cy;
+    oz = (vz + qw * uz) + cz;
+}
+
+// map_awareness.h:115-118
+__device__ __forceinline__ double mlm_fast_atan(double x) { return x * (45 - (x - 1) * (14 + 3.83 * x)); }
+// map_awareness.h:86-113 (deg2rad is the unparenthesised macro M_PI / 180, map_awareness.h:7)
+__device__ __forceinline__ double mlm_fast_atan2(double y, double x) {
+    const double input = y / x;
+    const double a_input = fabs(input);
+    double res;
+    if (a_input > 1)
+        res = copysign(M_PI / 180 * (90 - mlm_fast_atan(1 / a_input)), input);
+    else
+        res = copysign(M_PI / 180 * mlm_fast_atan(a_input), input);
+    if (x > 0) return res;
+    if (y >= 0) return res + M_PI;
+    return res - M_PI;
+}
+
+// xyz2RhoPhiZwithBoderCheck, map_awareness.cpp:84-107
+__device__ __forceinline__ bool mlm_bin_point(const MlmDev &P, double x, double y, double z, int &rho_idx,
+                                              int &phi_idx, int &z_idx, bool &can_do_cast) {
+    const double rho = sqrt(x * x + y * y);
+    rho_idx = mlm_cvt_int(rho / P.dRho);
+    double phi = mlm_fast_atan2(y, x);
+    if (phi < 0) phi += 2 * M_PI;
+    phi_idx = mlm_cvt_int(phi / P.dPhi);
+    const double zz = z - P.z_border_min;
+    z_idx = mlm_cvt_int(floor(zz / P.dZ));
+    can_do_cast = (rho_idx >= 0 && phi_idx >= 0 && phi_idx < P.nPhi);
+    return can_do_cast && z_idx >= 0 && rho_idx < P.nRho && z_idx < P.nZ;
+}
+
+// VectorHasher (map_awareness.h:31-41): 32-bit wrap-around int arithmetic, arithmetic >>, result sign-extended
+// to size_t by libstdc++; bucket = code % bucket_count (std::__detail::_Mod_range_hashing).
+__device__ __forceinline__ uint32_t mlm_hash_step(uint32_t h, int v) {
+    return h ^ ((uint32_t)v + 0x9e3779b9u + (h << 6) + (uint32_t)((int32_t)h >> 2));
+}
+__device__ __forceinline__ unsigned long long mlm_hash_rpz(int rho, int phi, int z) {
+    uint32_t h = 3u;
+    h = mlm_hash_step(h, rho);
+    h = mlm_hash_step(h, phi);
+    h = mlm_hash_step(h, z);
+    return (unsigned long long)(long long)(int32_t)h;
+}
+
+// cell-centre of an awareness cell (fill loop map_awareness.cpp:57-62) moved to world by T_wa (pure translation:
+// map_awareness.cpp:184, map_local.cpp:151,180)
+__device__ __forceinline__ void mlm_cell_center_w(const MlmDev &P, const double t_wa[3], int rho, int phi, int z,
+                                                  double &wx, double &wy, double &wz) {
+    const double center_z = P.z_border_min + (P.dZ / 2) + (z * P.dZ);
+    const double center_rho = P.dRho / 2 + (rho * P.dRho);
+    wx = center_rho * P.cos_phi[phi] + t_wa[0];
+    wy = center_rho * P.sin_phi[phi] + t_wa[1];
+    wz = center_z + t_wa[2];
+}
+
+// get_global_idx / get_subbox_id, map_local.h:148-152,167-173: two independent divisions per axis; a cell
+// coordinate outside [0,n) maps to id 0 (operator[] default-inserts in the reference).
+__device__ __forceinline__ void mlm_voxel_of(const MlmDev &P, double x, double y, double z, int &gx, int &gy,
+                                             int &gz, int &cid) {
+    gx = mlm_cvt_int(floor(x / P.d_glb));
+    gy = mlm_cvt_int(floor(y / P.d_glb));
+    gz = mlm_cvt_int(floor(z / P.d_glb));
+    const int cx = mlm_cvt_int(floor(x / P.d_sub) - gx * P.n);
+    const int cy = mlm_cvt_int(floor(y / P.d_sub) - gy * P.n);
+    const int cz = mlm_cvt_int(floor(z / P.d_sub) - gz * P.n);
+    if (cx < 0 || cy < 0 || cz < 0 || cx >= P.n || cy >= P.n || cz >= P.n)
+        cid = 0;
+    else
+        cid = cz * P.n * P.n + cy * P.n + cx;
+}
+
+// ---- hashed block table -------------------------------------------------------------------------------------
+// key: three 21-bit biased block indices.  Blocks are never freed (the reference only ever "collapses" them).
+__device__ __forceinline__ unsigned long long mlm_pack_key(int gx, int gy, int gz) {
+    return ((unsigned long long)((uint32_t)(gx + (1 << 20)) & 0x1FFFFFu) << 42) |
+           ((unsigned long long)((uint32_t)(gy + (1 << 20)) & 0x1FFFFFu) << 21) |
+           (unsigned long long)((uint32_t)(gz + (1 << 20)) & 0x1FFFFFu);
+}
+__device__ __forceinline__ uint32_t mlm_mix(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+// lookup only; -1 if absent
+__device__ __forceinline__ int mlm_block_find(const MlmDev &P, int gx, int gy, int gz) {
+    const unsigned long long key = mlm_pack_key(gx, gy, gz);
+    uint32_t h = mlm_mix(key) & P.ht_mask;
+    for (uint32_t probe = 0; probe <= P.ht_mask; ++probe) {
+        const unsigned long long k = P.ht_keys[h];
+        if (k == key) return P.ht_slot[h];
+        if (k == MLM_HT_EMPTY) return -1;
+        h = (h + 1) & P.ht_mask;
+    }
+    return -1;
+}
+// allocate_ram (map_local.h:215-231): find or create.  One loop whose divergent arms reconverge every
+// iteration, so a lane waiting for another lane's slot publication can never starve it.
+__device__ __forceinline__ int mlm_block_find_or_insert(const MlmDev &P, int gx, int gy, int gz) {
+    const unsigned long long key = mlm_pack_key(gx, gy, gz);
+    uint32_t h = mlm_mix(key) & P.ht_mask;
+    int slot = -1;
+    bool done = false;
+    uint32_t probes = 0;
+    while (!done) {
+        const unsigned long long k = __hip_atomic_load(&P.ht_keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == key) {
+            const int s = __hip_atomic_load(&P.ht_slot[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s != -1) {
+                slot = s;
+                done = true;
+            }
+        } else if (k == MLM_HT_EMPTY) {
+            const unsigned long long prev = atomicCAS(&P.ht_keys[h], MLM_HT_EMPTY, key);
+            if (prev == MLM_HT_EMPTY) {
+                int s = (int)atomicAdd(&P.ctr->n_blocks, 1u);
+                if (s >= P.max_blocks) {
+                    atomicOr(&P.ctr->err, 1u);
+                    s = -2; // published as "pool full"
+                } else {
+                    P.block_keys[3 * s + 0] = gx;
+                    P.block_keys[3 * s + 1] = gy;
+                    P.block_keys[3 * s + 2] = gz;
+                }
+                __hip_atomic_store(&P.ht_slot[h], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                slot = s;
+                done = true;
+            }
+            // else: someone else claimed this entry — re-examine it next iteration
+        } else {
+            h = (h + 1) & P.ht_mask;
+            if (++probes > P.ht_mask) {
+                atomicOr(&P.ctr->err, 1u);
+                slot = -2;
+                done = true;
+            }
+        }
+    }
+    return slot;
+}
+
+// wave64-aggregated append: returns this lane's position (only meaningful where `has`)
+__device__ __forceinline__ unsigned int mlm_wave_append(unsigned int *counter, bool has) {
+    const unsigned long long mask = __ballot(has);
+    if (mask == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+}

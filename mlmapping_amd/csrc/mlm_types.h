@@ -1,0 +1,88 @@
+// mlm_types.h — device-visible parameter blocks of the map-update path (gfx950).
+#pragma once
+#include <stdint.h>
+
+#define MLM_EMPTY_T 0xFFFFFFFFu      // hit_t: cell not hit this frame
+#define MLM_HT_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define MLM_TIME_SLOTS 21            // insertion slots per point: centre + (+d,-d) for d = 1..10
+#define MLM_DIFF_RANGE 10            // get_odds_table rows = 2*10+1 (map_awareness.cpp:36)
+#define MLM_LNQ_SCALE 274877906944.0 // 2^38: fixed-point scale of ln(1-odd) accumulators
+
+struct MlmCounters {
+    // per-frame (zeroed at the start of every frame)
+    unsigned int n_points;    // points with raw != 0
+    unsigned int u_hit;       // unique hit cells
+    unsigned int u_miss;      // unique miss cells
+    unsigned int n_oor;       // "point out range"
+    unsigned int n_miss_vox;  // voxels touched by misses this frame
+    unsigned int n_miss_list; // entries of ml_cell (record_awareness only)
+    // persistent
+    unsigned int n_blocks;    // allocated blocks
+    unsigned int err;         // sticky error bits (1 = block pool / hash table full)
+};
+#define MLM_CTR_FRAME_BYTES 24
+
+struct MlmDev {
+    // ---- awareness map constants (map_awareness.cpp:19-82)
+    double dRho, dPhi, dZ, z_border_min;
+    int nRho, nPhi, nZ, zc;    // zc = map_center_z_idx
+    int nRhoPhi, nCells;
+    int RW;                    // 32-bit words per (phi,z) row of the miss bit mask = ceil(nRho/32)
+    int nMissWords;
+    int visibility;
+    // ---- local map constants (map_local.cpp:46-139)
+    double d_sub, d_glb, d_sub_half;
+    int n, cells;
+    float lo_min, lo_max, lo_miss, lo_sh;
+    // ---- camera (mlmap.h:85-92)
+    float cx, cy, fx, fy;
+    double inv_factor;
+    // ---- tables
+    const int64_t *lnq_table;  // [21*nRho] round(ln(1-odds_table)*2^38)
+    const float *sigma3;       // [nRho] 3*sigma_in_dr(rho)  (float, map_awareness.cpp:149)
+    const double *cos_phi;     // [nPhi] cos/sin of the cell-centre azimuth (map_awareness.cpp:59-61)
+    const double *sin_phi;
+    // ---- per-frame awareness scratch
+    uint32_t *hit_t;           // [nCells] first-touch time of a hit cell (min over contributions)
+    int64_t *hit_lnq;          // [nCells] sum of fixed-point ln(1-odd) over contributions
+    uint32_t *start_bits;      // [ceil(nCells/32)] hit-centre cells whose ray has been walked
+    uint32_t *miss_bits;       // [nMissWords] free cells, row-major (z,phi) rows of RW words, bit = rho
+    // ---- unique-hit list (capacity nCells)
+    uint32_t *hl_cell;         // linear awareness cell idx
+    uint32_t *hl_t;            // first-touch time
+    float *hl_odd;             // noisy-OR odd
+    float *hl_inc;             // logit(odd), the log-odds increment
+    uint32_t *hl_vt;           // virtual insertion time (== hl_t when no rehash happened this frame)
+    uint32_t *hl_arr;          // arrival index (rank of hl_t), only valid on rehash frames
+    uint64_t *hl_key;          // iteration-order key: (bucket_first << 32) | vt ; larger = earlier in iteration
+    int *hl_next;              // per-voxel pending list link
+    int *hl_vox;               // voxel address (slot*cells + cell id)
+    uint32_t *bkt_first;       // [max buckets] min vt per hash bucket
+    uint32_t *ml_cell;         // unique-miss list (only with record_awareness)
+    int record_awareness;
+    // ---- hashed block table + pool
+    unsigned long long *ht_keys; // [ht_mask+1] packed block key or MLM_HT_EMPTY
+    int *ht_slot;              // [ht_mask+1] pool slot, -1 until published
+    uint32_t ht_mask;
+    int max_blocks;
+    int *block_keys;           // [max_blocks*3]
+    float *log_odds;           // [max_blocks*cells]
+    uint8_t *occ;              // [max_blocks*cells] 'u','f','o'
+    uint8_t *infl;             // [max_blocks*cells]
+    int *vox_head;             // [max_blocks*cells] head of this frame's pending hit list, -1 = none
+    uint32_t *vox_miss;        // [max_blocks*cells] miss count of this frame
+    int *miss_vox;             // [max_blocks*cells] list of voxels touched by misses
+    MlmCounters *ctr;
+};
+
+struct MlmFrame {
+    // T_ls = T_wa^-1 * T_wb * T_bs (map_awareness.cpp:184-186), t_wa = t_wb
+    double q_ls[4]; // w,x,y,z
+    double t_ls[3];
+    double t_wa[3];
+    const uint16_t *img;   // device
+    const int32_t *pix;    // device or null
+    const double *pts;     // device or null
+    int width, height, row_stride;
+    int n;                 // work items: pixels (dense), list length (indexed) or points
+};

@@ -1,0 +1,840 @@
+// mlmap_hip.hip — host side of libmlmap_hip.so: the C ABI of include/mlmap_hip.h.
+//
+// Host work per frame is O(1): the pose composition T_ls (map_awareness.cpp:184-186), the bookkeeping of the
+// emulated libstdc++ rehash policy of hit_idx_odds_hashmap, and kernel launches.  All per-point / per-cell /
+// per-voxel work runs in the kernels of mlm_kernels.h.  There is no CPU fallback: every entry point fails with
+// MLM_ERR_HIP when the device is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mlmap_hip.h"
+#include "mlm_kernels.h"
+
+extern "C" size_t mlm_sort_temp_bytes(size_t n);
+extern "C" int mlm_sort_pairs_u64_u32(void *temp, size_t temp_bytes, const unsigned long long *kin,
+                                      unsigned long long *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                                      hipStream_t stream);
+
+namespace {
+
+// ---- Eigen::Quaterniond / Sophus::SE3 pieces of the frame setup (so3.cpp:36-96, se3.cpp:29-95) -----------------
+struct Q4 {
+    double w, x, y, z;
+};
+struct D3 {
+    double x, y, z;
+};
+inline Q4 q_mul(const Q4 &a, const Q4 &b) { // Eigen generic quat_product
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+inline Q4 q_norm(const Q4 &q) { // normalize(): coeffs / sqrt(x²+y²+z²+w²)
+    const double n = std::sqrt(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    return {q.w / n, q.x / n, q.y / n, q.z / n};
+}
+inline D3 q_rot(const Q4 &q, const D3 &v) { // _transformVector
+    D3 uv{q.y * v.z - q.z * v.y, q.z * v.x - q.x * v.z, q.x * v.y - q.y * v.x};
+    uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+    const D3 c{q.y * uv.z - q.z * uv.y, q.z * uv.x - q.x * uv.z, q.x * uv.y - q.y * uv.x};
+    return {(v.x + q.w * uv.x) + c.x, (v.y + q.w * uv.y) + c.y, (v.z + q.w * uv.z) + c.z};
+}
+Q4 q_from_R(const double m[9]) { // Eigen Quaternion(Matrix3): Shepperd, no normalisation (so3.cpp:39-40)
+    auto M = [&](int r, int c) { return m[r * 3 + c]; };
+    Q4 q;
+    double t = M(0, 0) + M(1, 1) + M(2, 2);
+    if (t > 0.0) {
+        t = std::sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (M(2, 1) - M(1, 2)) * t;
+        q.y = (M(0, 2) - M(2, 0)) * t;
+        q.z = (M(1, 0) - M(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (M(1, 1) > M(0, 0)) i = 1;
+        if (M(2, 2) > M(i, i)) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+        double v[3];
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (M(k, j) - M(j, k)) * t;
+        v[j] = (M(j, i) + M(i, j)) * t;
+        v[k] = (M(k, i) + M(i, k)) * t;
+        q.x = v[0];
+        q.y = v[1];
+        q.z = v[2];
+    }
+    return q;
+}
+
+// ---- odds table (map_awareness.cpp:36-46,119-132; map_awareness.h:120-146) -------------------------------------
+struct OddsModel {
+    double dRho, noise;
+    float sigma_in_dr(size_t x) const {
+        float dis = (x * dRho);
+        return noise * dis * dis / dRho;
+    }
+    static float standard_ND(float x) { // A&S 7.1.26; fabs/exp resolve to the float overloads
+        const double a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
+        const double p = 0.3275911;
+        int sign = 1;
+        if (x < 0) sign = -1;
+        x = std::fabs(x) / std::sqrt(2.0);
+        const double t = 1.0 / (1.0 + p * x);
+        const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+        return 0.5 * (1.0 + sign * y);
+    }
+    float get_odds(int diff, size_t r) const {
+        if (r == 0) r = 1;
+        const float up = standard_ND(static_cast<float>(diff + 0.5) / sigma_in_dr(r));
+        const float down = standard_ND(static_cast<float>(diff - 0.5) / sigma_in_dr(r));
+        float res = up - down < 0.001 ? 0.001 : up - down;
+        res = res >= 0.999 ? 0.999 : res;
+        return res;
+    }
+};
+
+struct KernelTime {
+    const char *name;
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct mlm_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    mlm_config cfg{};
+    mlm_limits lim{};
+    MlmDev P{};
+    Q4 q_bs{};
+    D3 t_bs{};
+    std::vector<float> odds_table;
+    std::vector<void *> allocs;
+    // staging for host inputs
+    uint16_t *d_img = nullptr;
+    size_t img_cap = 0;
+    int32_t *d_pix = nullptr;
+    double *d_pts = nullptr;
+    double *d_qpos = nullptr; // query positions
+    void *d_qout = nullptr;
+    size_t q_cap = 0;
+    // sort buffers (rehash frames only)
+    unsigned long long *sk_in = nullptr, *sk_out = nullptr;
+    uint32_t *sv_in = nullptr, *sv_out = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    MlmCounters *h_ctr = nullptr; // pinned
+    // emulated libstdc++ state of awareness_map->hit_idx_odds_hashmap: bucket count + rehash policy.
+    // clear() (map_awareness.cpp:178) keeps both, so they persist across frames.
+    size_t hit_n_bkt = 1;
+    std::__detail::_Prime_rehash_policy hit_pol;
+    size_t max_buckets = 0;
+    mlm_frame_stats stats{};
+    MlmFrame last{};
+    std::string err;
+    bool timing = false;
+    std::vector<KernelTime> ktimes;
+    std::vector<KernelTime> kpool;
+    size_t kpool_used = 0;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                                               \
+    do {                                                                                                              \
+        hipError_t e__ = (expr);                                                                                      \
+        if (e__ != hipSuccess) {                                                                                      \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                            \
+            return MLM_ERR_HIP;                                                                                       \
+        }                                                                                                             \
+    } while (0)
+
+template <class T> int dev_alloc(mlm_handle *h, T **p, size_t n) {
+    void *v = nullptr;
+    HIPCHK(h, hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(T)));
+    h->allocs.push_back(v);
+    *p = (T *)v;
+    return MLM_OK;
+}
+inline unsigned int grid_for(size_t n) { return (unsigned int)((n + MLM_BLOCK - 1) / MLM_BLOCK); }
+
+struct Timed {
+    mlm_handle *h;
+    KernelTime *kt = nullptr;
+    Timed(mlm_handle *hh, const char *name) : h(hh) {
+        if (!h->timing) return;
+        if (h->kpool_used == h->kpool.size()) {
+            KernelTime k{name, nullptr, nullptr};
+            hipEventCreate(&k.a);
+            hipEventCreate(&k.b);
+            h->kpool.push_back(k);
+        }
+        kt = &h->kpool[h->kpool_used++];
+        kt->name = name;
+        hipEventRecord(kt->a, h->stream);
+    }
+    ~Timed() {
+        if (kt) {
+            hipEventRecord(kt->b, h->stream);
+            h->ktimes.push_back(*kt);
+        }
+    }
+};
+
+// T_ls and t_wa of one frame (map_awareness.cpp:184-186) — SURVEY.md App. C1, evaluated in that order
+void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb_in[3], MlmFrame &F) {
+    const Q4 q_wb = q_norm(Q4{q_wb_in[0], q_wb_in[1], q_wb_in[2], q_wb_in[3]}); // SO3(Quaterniond), so3.cpp:43-47
+    const D3 t_wb{t_wb_in[0], t_wb_in[1], t_wb_in[2]};
+    // T_wa = (I, t_wb)
+    const Q4 q_wa = q_norm(Q4{1, 0, 0, 0});
+    // T_ws = T_wb * T_bs
+    const D3 r1 = q_rot(q_wb, h->t_bs);
+    const D3 t_ws{t_wb.x + r1.x, t_wb.y + r1.y, t_wb.z + r1.z};
+    const Q4 q_ws = q_norm(q_mul(q_wb, h->q_bs));
+    // T_wa^-1
+    const Q4 q_ai = q_norm(Q4{q_wa.w, -q_wa.x, -q_wa.y, -q_wa.z});
+    const D3 t_ai = q_rot(q_ai, D3{t_wb.x * -1., t_wb.y * -1., t_wb.z * -1.});
+    // T_ls = T_wa^-1 * T_ws
+    const D3 r2 = q_rot(q_ai, t_ws);
+    const Q4 q_ls = q_norm(q_mul(q_ai, q_ws));
+    F.q_ls[0] = q_ls.w;
+    F.q_ls[1] = q_ls.x;
+    F.q_ls[2] = q_ls.y;
+    F.q_ls[3] = q_ls.z;
+    F.t_ls[0] = t_ai.x + r2.x;
+    F.t_ls[1] = t_ai.y + r2.y;
+    F.t_ls[2] = t_ai.z + r2.z;
+    F.t_wa[0] = t_wb.x;
+    F.t_wa[1] = t_wb.y;
+    F.t_wa[2] = t_wb.z;
+}
+
+// Replay the rehash policy of libstdc++'s _Hashtable for `U` unique insertions into a cleared container.
+// Returns the epochs: (number of elements present when the epoch ends, bucket count during the epoch).
+// Uses the very policy object std::unordered_map uses, so it follows whatever libstdc++ this library is linked to.
+std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
+    std::vector<std::pair<size_t, size_t>> ep;
+    size_t n = h->hit_n_bkt;
+    size_t i = 0;
+    while (i < U) {
+        // _M_insert_unique_node: _M_need_rehash(bucket_count, element_count, 1) before linking the node
+        const auto r = h->hit_pol._M_need_rehash(n, i, 1);
+        if (r.first) {
+            if (i > 0) ep.emplace_back(i, n);
+            n = r.second;
+        }
+        // the policy is inert while element_count + 1 <= _M_next_resize
+        const size_t next = std::max<size_t>(i + 1, h->hit_pol._M_next_resize);
+        i = std::min(U, next);
+    }
+    ep.emplace_back(U, n);
+    h->hit_n_bkt = n;
+    return ep;
+}
+
+int order_hits(mlm_handle *h, unsigned int U) {
+    const MlmDev &P = h->P;
+    const auto ep = plan_epochs(h, U);
+    h->stats.n_rehash_epochs = (int64_t)ep.size();
+    h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
+    if (h->hit_n_bkt > h->max_buckets) {
+        h->err = "emulated bucket count exceeds capacity";
+        return MLM_ERR_CAPACITY;
+    }
+    if (U == 0) return MLM_OK;
+    const unsigned int g = grid_for(U);
+    const bool multi = ep.size() > 1;
+    if (multi) {
+        // arrival index = rank of the first-touch time
+        {
+            Timed t(h, "k_time_keys");
+            hipLaunchKernelGGL(k_time_keys, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
+        }
+        if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U,
+                                   h->stream) != 0) {
+            h->err = "radix sort failed";
+            return MLM_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_assign_rank, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
+    }
+    for (size_t e = 0; e < ep.size(); ++e) {
+        const unsigned int m = (unsigned int)ep[e].first;
+        const unsigned long long nb = ep[e].second;
+        const bool final_pass = (e + 1 == ep.size());
+        HIPCHK(h, hipMemsetAsync(P.bkt_first, 0xFF, nb * sizeof(uint32_t), h->stream));
+        {
+            Timed t(h, "k_bucket_min");
+            hipLaunchKernelGGL(k_bucket_min, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0);
+        }
+        {
+            Timed t(h, "k_make_keys");
+            hipLaunchKernelGGL(k_make_keys, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0,
+                               final_pass ? 1 : 0, h->sk_in, h->sv_in);
+        }
+        if (!final_pass) {
+            // list order of the epoch = descending key; the rehash re-inserts the nodes in that order
+            if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U,
+                                       h->stream) != 0) {
+                h->err = "radix sort failed";
+                return MLM_ERR_HIP;
+            }
+            hipLaunchKernelGGL(k_assign_rank, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
+        }
+    }
+    return MLM_OK;
+}
+
+int read_counters(mlm_handle *h) {
+    HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+// One frame: stage A -> (host: rehash plan) -> stage B -> stage C
+int integrate_frame(mlm_handle *h, const MlmFrame &F, int mode) {
+    const MlmDev &P = h->P;
+    h->ktimes.clear();
+    h->kpool_used = 0;
+    h->last = F;
+    HIPCHK(h, hipMemsetAsync(P.ctr, 0, MLM_CTR_FRAME_BYTES, h->stream));
+    HIPCHK(h, hipMemsetAsync(P.start_bits, 0, ((size_t)P.nCells + 31) / 32 * sizeof(uint32_t), h->stream));
+    if (F.n > 0) {
+        Timed t(h, "k_bin_points");
+        const unsigned int g = grid_for((size_t)F.n);
+        if (mode == 0)
+            hipLaunchKernelGGL(k_bin_points<0>, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, F);
+        else if (mode == 1)
+            hipLaunchKernelGGL(k_bin_points<1>, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, F);
+        else
+            hipLaunchKernelGGL(k_bin_points<2>, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, F);
+    }
+    {
+        Timed t(h, "k_collect_hits");
+        hipLaunchKernelGGL(k_collect_hits, dim3(grid_for((size_t)P.nCells)), dim3(MLM_BLOCK), 0, h->stream, P);
+    }
+    int rc = read_counters(h);
+    if (rc) return rc;
+    const unsigned int U = h->h_ctr->u_hit;
+    rc = order_hits(h, U);
+    if (rc) return rc;
+    if (U > 0) {
+        {
+            Timed t(h, "k_hits_to_voxels");
+            hipLaunchKernelGGL(k_hits_to_voxels, dim3(grid_for(U)), dim3(MLM_BLOCK), 0, h->stream, P, F, U);
+        }
+        {
+            Timed t(h, "k_apply_hits");
+            hipLaunchKernelGGL(k_apply_hits, dim3(grid_for(U)), dim3(MLM_BLOCK), 0, h->stream, P, U);
+        }
+    }
+    {
+        Timed t(h, "k_misses_to_voxels");
+        hipLaunchKernelGGL(k_misses_to_voxels, dim3(grid_for((size_t)P.nMissWords)), dim3(MLM_BLOCK), 0, h->stream, P,
+                           F);
+    }
+    {
+        Timed t(h, "k_apply_misses");
+        hipLaunchKernelGGL(k_apply_misses, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, P);
+    }
+    HIPCHK(h, hipGetLastError());
+    rc = read_counters(h);
+    if (rc) return rc;
+    h->stats.n_points = h->h_ctr->n_points;
+    h->stats.n_hit_cells = h->h_ctr->u_hit;
+    h->stats.n_miss_cells = h->h_ctr->u_miss;
+    h->stats.n_out_of_range = h->h_ctr->n_oor;
+    h->stats.n_blocks = std::min<unsigned int>(h->h_ctr->n_blocks, (unsigned int)P.max_blocks);
+    if (h->h_ctr->err) {
+        h->err = "block pool or block hash table full (raise mlm_limits.max_blocks)";
+        return MLM_ERR_CAPACITY;
+    }
+    return MLM_OK;
+}
+
+int ensure_img(mlm_handle *h, size_t n_px) {
+    if (n_px <= h->img_cap) return MLM_OK;
+    if (h->d_img) hipFree(h->d_img);
+    h->d_img = nullptr;
+    HIPCHK(h, hipMalloc((void **)&h->d_img, n_px * sizeof(uint16_t)));
+    h->img_cap = n_px;
+    return MLM_OK;
+}
+
+int ensure_query(mlm_handle *h, size_t n) {
+    if (n <= h->q_cap) return MLM_OK;
+    if (h->d_qpos) hipFree(h->d_qpos);
+    if (h->d_qout) hipFree(h->d_qout);
+    h->d_qpos = nullptr;
+    h->d_qout = nullptr;
+    const size_t cap = std::max<size_t>(n, 4096);
+    HIPCHK(h, hipMalloc((void **)&h->d_qpos, cap * 3 * sizeof(double)));
+    HIPCHK(h, hipMalloc(&h->d_qout, cap * 3 * sizeof(double)));
+    h->q_cap = cap;
+    return MLM_OK;
+}
+
+int run_query(mlm_handle *h, int mode, const double *pos, int n, float inflate, int max_iter, void *out,
+              size_t out_elem) {
+    if (!h || !pos || !out || n < 0) return MLM_ERR_INVALID;
+    if (n == 0) return MLM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ensure_query(h, (size_t)n);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_qpos, pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_query, dim3(grid_for((size_t)n)), dim3(MLM_BLOCK), 0, h->stream, h->P, mode, h->d_qpos, n,
+                       inflate, max_iter, (int8_t *)h->d_qout, (float *)h->d_qout, (double *)h->d_qout);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->d_qout, (size_t)n * out_elem, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mlm_abi_version(void) { return MLM_ABI_VERSION; }
+
+const char *mlm_last_error(mlm_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_handle **out) {
+    if (!cfg || !out) return MLM_ERR_INVALID;
+    *out = nullptr;
+    if (cfg->am_n_rho <= 1 || cfg->am_d_rho <= 0 || cfg->am_d_phi_deg <= 0 || cfg->am_d_z <= 0 || cfg->subbox_n <= 0 ||
+        cfg->subbox_d_xyz <= 0 || cfg->am_n_z_below < 0 || cfg->am_n_z_over < 0)
+        return MLM_ERR_INVALID;
+    if (cfg->use_exploration_frontiers) return MLM_ERR_UNSUPPORTED; // frontier bookkeeping: SURVEY §8f rank 1
+    mlm_handle *h = new mlm_handle();
+    *out = h; // returned even on failure so that mlm_last_error can be read; caller must mlm_destroy it
+    h->device = device;
+    h->cfg = *cfg;
+    if (lim_in) h->lim = *lim_in;
+    if (h->lim.max_blocks <= 0) h->lim.max_blocks = 65536;
+    if (h->lim.max_points <= 0) h->lim.max_points = 1280 * 720;
+    if (h->lim.max_batch <= 0) h->lim.max_batch = 32;
+    int ndev = 0;
+    HIPCHK(h, hipGetDeviceCount(&ndev));
+    if (ndev <= 0 || device < 0 || device >= ndev) {
+        h->err = "no such HIP device";
+        return MLM_ERR_HIP;
+    }
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+
+    MlmDev &P = h->P;
+    // awareness constants, map_awareness.cpp:21-32
+    P.dRho = cfg->am_d_rho;
+    P.dPhi = cfg->am_d_phi_deg * M_PI / 180;
+    P.dZ = cfg->am_d_z;
+    P.nRho = cfg->am_n_rho;
+    P.nPhi = static_cast<int>(360 / cfg->am_d_phi_deg);
+    P.nZ = cfg->am_n_z_below + cfg->am_n_z_over + 1;
+    P.zc = cfg->am_n_z_below;
+    P.z_border_min = -(cfg->am_n_z_below * cfg->am_d_z) - 0.5 * cfg->am_d_z;
+    P.nRhoPhi = P.nRho * P.nPhi;
+    const long long ncells = (long long)P.nRhoPhi * P.nZ;
+    if (ncells <= 0 || ncells > (1ll << 31) - 64) {
+        h->err = "awareness map too large";
+        return MLM_ERR_UNSUPPORTED;
+    }
+    if ((long long)h->lim.max_points * MLM_TIME_SLOTS > 0xFFFFFFF0ll) {
+        h->err = "max_points too large for 32-bit insertion times";
+        return MLM_ERR_UNSUPPORTED;
+    }
+    P.nCells = (int)ncells;
+    P.RW = (P.nRho + 31) / 32;
+    P.nMissWords = P.nZ * P.nPhi * P.RW;
+    P.visibility = cfg->use_raycasting != 0;
+    // local constants, map_local.cpp:56-62,126-130 (float casts as mlmap.cpp:77-81)
+    P.d_sub = cfg->subbox_d_xyz;
+    P.d_sub_half = P.d_sub * 0.5;
+    P.n = cfg->subbox_n;
+    P.d_glb = P.d_sub * P.n;
+    P.cells = P.n * P.n * P.n;
+    P.lo_min = static_cast<float>(cfg->log_odds_min);
+    P.lo_max = static_cast<float>(cfg->log_odds_max);
+    P.lo_miss = static_cast<float>(cfg->measurement_miss);
+    P.lo_sh = static_cast<float>(cfg->occupied_sh);
+    // camera, mlmap.cpp:15-18 (float members) and mlmap.h:85-86
+    P.cx = (float)cfg->cam_cx;
+    P.cy = (float)cfg->cam_cy;
+    P.fx = (float)cfg->cam_fx;
+    P.fy = (float)cfg->cam_fy;
+    P.inv_factor = 1.0 / 1000.0;
+    P.record_awareness = h->lim.record_awareness;
+    P.max_blocks = h->lim.max_blocks;
+
+    // T_bs, mlmap.cpp:22-25
+    const double R[9] = {cfg->T_bs[0], cfg->T_bs[1], cfg->T_bs[2], cfg->T_bs[4], cfg->T_bs[5],
+                         cfg->T_bs[6], cfg->T_bs[8], cfg->T_bs[9], cfg->T_bs[10]};
+    h->q_bs = q_from_R(R);
+    h->t_bs = D3{cfg->T_bs[3], cfg->T_bs[7], cfg->T_bs[11]};
+
+    // tables (host libm, uploaded once)
+    OddsModel om{cfg->am_d_rho, cfg->depth_noise_coe};
+    h->odds_table.resize((size_t)21 * P.nRho);
+    std::vector<int64_t> lnq((size_t)21 * P.nRho);
+    for (int d = -MLM_DIFF_RANGE; d <= MLM_DIFF_RANGE; ++d)
+        for (int r = 0; r < P.nRho; ++r) {
+            const float a = om.get_odds(d, (size_t)r);
+            h->odds_table[(size_t)(d + MLM_DIFF_RANGE) * P.nRho + r] = a;
+            lnq[(size_t)(d + MLM_DIFF_RANGE) * P.nRho + r] = std::llround(std::log(1.0 - (double)a) * MLM_LNQ_SCALE);
+        }
+    std::vector<float> sigma3(P.nRho);
+    for (int r = 0; r < P.nRho; ++r) sigma3[r] = 3 * om.sigma_in_dr((size_t)r); // map_awareness.cpp:149
+    std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
+    for (int p = 0; p < P.nPhi; ++p) {
+        const double center_phi = P.dPhi / 2 + (p * P.dPhi); // map_awareness.cpp:59
+        cphi[p] = std::cos(center_phi);
+        sphi[p] = std::sin(center_phi);
+    }
+    int64_t *d_lnq;
+    float *d_s3;
+    double *d_c, *d_s;
+    int rc;
+    if ((rc = dev_alloc(h, &d_lnq, lnq.size()))) return rc;
+    if ((rc = dev_alloc(h, &d_s3, sigma3.size()))) return rc;
+    if ((rc = dev_alloc(h, &d_c, cphi.size()))) return rc;
+    if ((rc = dev_alloc(h, &d_s, sphi.size()))) return rc;
+    HIPCHK(h, hipMemcpy(d_lnq, lnq.data(), lnq.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_s3, sigma3.data(), sigma3.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_c, cphi.data(), cphi.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_s, sphi.data(), sphi.size() * sizeof(double), hipMemcpyHostToDevice));
+    P.lnq_table = d_lnq;
+    P.sigma3 = d_s3;
+    P.cos_phi = d_c;
+    P.sin_phi = d_s;
+
+    // awareness scratch + unique-hit list
+    const size_t NC = (size_t)P.nCells;
+    if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hit_lnq, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
+    if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_t, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_odd, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_inc, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_vt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_arr, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_key, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_next, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_vox, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
+    // the emulated container can never hold more than nCells keys: bucket counts stay below the first
+    // libstdc++ prime >= 2*nCells
+    {
+        std::__detail::_Prime_rehash_policy pol;
+        h->max_buckets = pol._M_next_bkt(2 * NC + 2);
+    }
+    if ((rc = dev_alloc(h, &P.bkt_first, h->max_buckets))) return rc;
+    HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.hit_lnq, 0, NC * sizeof(int64_t)));
+    HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
+
+    // block table + pool
+    size_t ht = 1;
+    while (ht < (size_t)P.max_blocks * 4) ht <<= 1;
+    P.ht_mask = (uint32_t)(ht - 1);
+    const size_t NV = (size_t)P.max_blocks * P.cells;
+    if ((rc = dev_alloc(h, &P.ht_keys, ht))) return rc;
+    if ((rc = dev_alloc(h, &P.ht_slot, ht))) return rc;
+    if ((rc = dev_alloc(h, &P.block_keys, (size_t)P.max_blocks * 3))) return rc;
+    if ((rc = dev_alloc(h, &P.log_odds, NV))) return rc;
+    if ((rc = dev_alloc(h, &P.occ, NV))) return rc;
+    if ((rc = dev_alloc(h, &P.infl, NV))) return rc;
+    if ((rc = dev_alloc(h, &P.vox_head, NV))) return rc;
+    if ((rc = dev_alloc(h, &P.vox_miss, NV))) return rc;
+    if ((rc = dev_alloc(h, &P.miss_vox, std::min(NV, NC)))) return rc;
+    if ((rc = dev_alloc(h, &P.ctr, 1))) return rc;
+    HIPCHK(h, hipMemset(P.ht_keys, 0xFF, ht * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(P.ht_slot, 0xFF, ht * sizeof(int)));
+    HIPCHK(h, hipMemset(P.log_odds, 0, NV * sizeof(float)));            // allocate_ram: log_odds 0
+    HIPCHK(h, hipMemset(P.occ, 'u', NV));                               //               occupancy 'u'
+    HIPCHK(h, hipMemset(P.infl, 'u', NV));                              //               inflate_occupancy 'u'
+    HIPCHK(h, hipMemset(P.vox_head, 0xFF, NV * sizeof(int)));
+    HIPCHK(h, hipMemset(P.vox_miss, 0, NV * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.ctr, 0, sizeof(MlmCounters)));
+
+    // inputs
+    if ((rc = ensure_img(h, (size_t)h->lim.max_points))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pix, (size_t)h->lim.max_points))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pts, (size_t)h->lim.max_points * 3))) return rc;
+    // sort buffers
+    h->sort_tmp_bytes = mlm_sort_temp_bytes(NC);
+    if ((rc = dev_alloc(h, &h->sk_in, NC))) return rc;
+    if ((rc = dev_alloc(h, &h->sk_out, NC))) return rc;
+    if ((rc = dev_alloc(h, &h->sv_in, NC))) return rc;
+    if ((rc = dev_alloc(h, &h->sv_out, NC))) return rc;
+    if ((rc = dev_alloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes))) return rc;
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ctr, sizeof(MlmCounters), hipHostMallocDefault));
+    HIPCHK(h, hipDeviceSynchronize());
+    return MLM_OK;
+}
+
+int mlm_destroy(mlm_handle *h) {
+    if (!h) return MLM_ERR_INVALID;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->d_img) hipFree(h->d_img);
+    if (h->d_qpos) hipFree(h->d_qpos);
+    if (h->d_qout) hipFree(h->d_qout);
+    if (h->h_ctr) hipHostFree(h->h_ctr);
+    for (auto &k : h->kpool) {
+        hipEventDestroy(k.a);
+        hipEventDestroy(k.b);
+    }
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return MLM_OK;
+}
+
+int mlm_set_stream(mlm_handle *h, void *s) {
+    if (!h) return MLM_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)s;
+    h->own_stream = false;
+    return MLM_OK;
+}
+
+int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int width, int height, int row_stride,
+                                const int32_t *pixel_idx_dev, int n_idx, const double q_wb[4], const double t_wb[3]) {
+    if (!h || !img_dev || width <= 0 || height <= 0 || row_stride < width || !q_wb || !t_wb) return MLM_ERR_INVALID;
+    if (pixel_idx_dev && n_idx < 0) return MLM_ERR_INVALID;
+    const long long n = pixel_idx_dev ? n_idx : (long long)width * height;
+    if (n > h->lim.max_points) {
+        h->err = "frame has more points than mlm_limits.max_points";
+        return MLM_ERR_CAPACITY;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    MlmFrame F{};
+    frame_setup(h, q_wb, t_wb, F);
+    F.img = img_dev;
+    F.pix = pixel_idx_dev;
+    F.width = width;
+    F.height = height;
+    F.row_stride = row_stride;
+    F.n = (int)n;
+    return integrate_frame(h, F, pixel_idx_dev ? 1 : 0);
+}
+
+int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int height, int row_stride,
+                            const int32_t *pixel_idx, int n_idx, const double q_wb[4], const double t_wb[3]) {
+    if (!h || !img || width <= 0 || height <= 0 || row_stride < width) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n_px = (size_t)row_stride * height;
+    int rc = ensure_img(h, n_px);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    if (pixel_idx) {
+        if (n_idx < 0 || n_idx > h->lim.max_points) return MLM_ERR_CAPACITY;
+        HIPCHK(h, hipMemcpyAsync(h->d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice,
+                                 h->stream));
+    }
+    return mlm_integrate_depth_u16_dev(h, h->d_img, width, height, row_stride, pixel_idx ? h->d_pix : nullptr, n_idx,
+                                       q_wb, t_wb);
+}
+
+int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_frames, size_t frame_stride, int width,
+                                  int height, int row_stride, const double *q_wb, const double *t_wb) {
+    if (!h || !img_dev || n_frames < 0 || !q_wb || !t_wb) return MLM_ERR_INVALID;
+    for (int k = 0; k < n_frames; ++k) {
+        const int rc = mlm_integrate_depth_u16_dev(h, img_dev + (size_t)k * frame_stride, width, height, row_stride,
+                                                   nullptr, 0, q_wb + 4 * k, t_wb + 3 * k);
+        if (rc) return rc;
+    }
+    return MLM_OK;
+}
+
+int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q_wb[4], const double t_wb[3]) {
+    if (!h || (!xyz && n > 0) || n < 0 || !q_wb || !t_wb) return MLM_ERR_INVALID;
+    if (n > h->lim.max_points) {
+        h->err = "frame has more points than mlm_limits.max_points";
+        return MLM_ERR_CAPACITY;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n > 0)
+        HIPCHK(h, hipMemcpyAsync(h->d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    MlmFrame F{};
+    frame_setup(h, q_wb, t_wb, F);
+    F.pts = h->d_pts;
+    F.n = n;
+    F.width = 1;
+    return integrate_frame(h, F, 2);
+}
+
+int mlm_query_occupancy(mlm_handle *h, const double *pos, int n, int8_t *out) {
+    return run_query(h, 0, pos, n, 0.f, 0, out, 1);
+}
+int mlm_query_occupancy_inflate(mlm_handle *h, const double *pos, int n, float inflate, int8_t *out) {
+    return run_query(h, 1, pos, n, inflate, 0, out, 1);
+}
+int mlm_query_inflate_occupancy(mlm_handle *h, const double *pos, int n, int8_t *out) {
+    return run_query(h, 2, pos, n, 0.f, 0, out, 1);
+}
+int mlm_query_odds(mlm_handle *h, const double *pos, int n, float *out) {
+    return run_query(h, 3, pos, n, 0.f, 0, out, sizeof(float));
+}
+int mlm_query_odd_grad(mlm_handle *h, const double *pos, int n, int max_iter, double *out3) {
+    if (max_iter < 0) return MLM_ERR_INVALID;
+    return run_query(h, 4, pos, n, 0.f, max_iter, out3, 3 * sizeof(double));
+}
+
+int mlm_set_free_in_bound(mlm_handle *h, const double bmin[3], const double bmax[3]) {
+    if (!h || !bmin || !bmax) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    // mlmap.cpp:392-396: `for (double x = min; x <= max; x += d)` — the accumulated coordinates, not i*d
+    std::vector<double> ax[3];
+    for (int a = 0; a < 3; ++a) {
+        for (double v = bmin[a]; v <= bmax[a]; v += h->P.d_sub) {
+            ax[a].push_back(v);
+            if (ax[a].size() > (1u << 22)) return MLM_ERR_INVALID;
+        }
+        if (ax[a].empty()) return MLM_OK;
+    }
+    const size_t total = ax[0].size() * ax[1].size() * ax[2].size();
+    const size_t na = ax[0].size() + ax[1].size() + ax[2].size();
+    int rc = ensure_query(h, (na + 2) / 3 + 1);
+    if (rc) return rc;
+    double *d = h->d_qpos;
+    HIPCHK(h, hipMemcpyAsync(d, ax[0].data(), ax[0].size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d + ax[0].size(), ax[1].data(), ax[1].size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d + ax[0].size() + ax[1].size(), ax[2].data(), ax[2].size() * 8, hipMemcpyHostToDevice,
+                             h->stream));
+    hipLaunchKernelGGL(k_set_free, dim3(grid_for(total)), dim3(MLM_BLOCK), 0, h->stream, h->P, d, (int)ax[0].size(),
+                       d + ax[0].size(), (int)ax[1].size(), d + ax[0].size() + ax[1].size(), (int)ax[2].size());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
+    (void)ct_pos;
+    if (!h) return MLM_ERR_INVALID;
+    h->err = "inflate_map not implemented yet (SURVEY §8f rank 2)";
+    return MLM_ERR_UNSUPPORTED;
+}
+
+int mlm_block_count(mlm_handle *h, int *n_out) {
+    if (!h || !n_out) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = read_counters(h);
+    if (rc) return rc;
+    *n_out = (int)std::min<unsigned int>(h->h_ctr->n_blocks, (unsigned int)h->P.max_blocks);
+    return MLM_OK;
+}
+
+int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, uint8_t *occ, uint8_t *infl, int *n_out) {
+    if (!h || cap < 0) return MLM_ERR_INVALID;
+    int n = 0;
+    int rc = mlm_block_count(h, &n);
+    if (rc) return rc;
+    if (n_out) *n_out = n;
+    const size_t m = (size_t)std::min(n, cap);
+    const size_t C = (size_t)h->P.cells;
+    if (m == 0) return MLM_OK;
+    if (keys) HIPCHK(h, hipMemcpyAsync(keys, h->P.block_keys, m * 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (log_odds) HIPCHK(h, hipMemcpyAsync(log_odds, h->P.log_odds, m * C * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (occ) HIPCHK(h, hipMemcpyAsync(occ, h->P.occ, m * C, hipMemcpyDeviceToHost, h->stream));
+    if (infl) HIPCHK(h, hipMemcpyAsync(infl, h->P.infl, m * C, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out) {
+    (void)cap_points;
+    (void)xyz;
+    if (!h) return MLM_ERR_INVALID;
+    if (n_out) *n_out = 0;
+    h->err = "global map export not implemented yet (SURVEY §8f rank 4)";
+    return MLM_ERR_UNSUPPORTED;
+}
+
+int mlm_sync(mlm_handle *h) {
+    if (!h) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {
+    if (!h || !out) return MLM_ERR_INVALID;
+    *out = h->stats;
+    return MLM_OK;
+}
+
+int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *odds, uint32_t *t_first, int *n_out) {
+    if (!h || cap < 0) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->stats.n_hit_cells;
+    if (n_out) *n_out = (int)n;
+    const size_t m = std::min<size_t>(n, (size_t)cap);
+    if (m == 0) return MLM_OK;
+    if (cell_idx) HIPCHK(h, hipMemcpy(cell_idx, h->P.hl_cell, m * 4, hipMemcpyDeviceToHost));
+    if (odds) HIPCHK(h, hipMemcpy(odds, h->P.hl_odd, m * 4, hipMemcpyDeviceToHost));
+    if (t_first) HIPCHK(h, hipMemcpy(t_first, h->P.hl_t, m * 4, hipMemcpyDeviceToHost));
+    return MLM_OK;
+}
+
+int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_out) {
+    if (!h || cap < 0) return MLM_ERR_INVALID;
+    if (!h->P.record_awareness) {
+        h->err = "mlm_limits.record_awareness was not set";
+        return MLM_ERR_INVALID;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n = (size_t)h->stats.n_miss_cells;
+    if (n_out) *n_out = (int)n;
+    const size_t m = std::min<size_t>(n, (size_t)cap);
+    if (m && cell_idx) HIPCHK(h, hipMemcpy(cell_idx, h->P.ml_cell, m * 4, hipMemcpyDeviceToHost));
+    return MLM_OK;
+}
+
+int mlm_get_T_ls(mlm_handle *h, double q[4], double t[3]) {
+    if (!h || !q || !t) return MLM_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) q[i] = h->last.q_ls[i];
+    for (int i = 0; i < 3; ++i) t[i] = h->last.t_ls[i];
+    return MLM_OK;
+}
+
+int mlm_get_odds_table(mlm_handle *h, float *out) {
+    if (!h || !out) return MLM_ERR_INVALID;
+    std::memcpy(out, h->odds_table.data(), h->odds_table.size() * sizeof(float));
+    return MLM_OK;
+}
+
+int mlm_enable_kernel_timing(mlm_handle *h, int on) {
+    if (!h) return MLM_ERR_INVALID;
+    h->timing = on != 0;
+    return MLM_OK;
+}
+
+int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out) {
+    if (!h || cap < 0) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int n = (int)h->ktimes.size();
+    if (n_out) *n_out = n;
+    for (int i = 0; i < std::min(n, cap); ++i) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, h->ktimes[i].a, h->ktimes[i].b);
+        if (names) names[i] = h->ktimes[i].name;
+        if (ms) ms[i] = t;
+    }
+    return MLM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's ``mlmap`` class (include/mlmap.h:42-140) over the C ABI of
+``include/mlmap_hip.h``.
+
+Only the map-update path and its queries are mirrored: ``update_map``, ``getOccupancy``, ``getOdd``,
+``getOddGrad``, ``setFree_map_in_bound`` (+ ``getInflateOccupancy``, ``inflate_map``).  ROS plumbing
+(subscriptions, TF, RViz) is out of scope.
+
+This module is pure plumbing: ctypes calls into ``libmlmap_hip.so``.  There is no CPU fallback — if the
+library is missing or no MI355X is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .config import CConfig, MapConfig, to_c
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmlmap_hip.so")
+
+MLM_OK = 0
+STATUS = {0: "MLM_OK", -1: "MLM_ERR_INVALID", -2: "MLM_ERR_HIP", -3: "MLM_ERR_CAPACITY", -4: "MLM_ERR_UNSUPPORTED"}
+
+# every symbol include/mlmap_hip.h declares
+ABI_SYMBOLS = [
+    "mlm_create", "mlm_destroy", "mlm_last_error", "mlm_abi_version", "mlm_set_stream",
+    "mlm_integrate_depth_u16", "mlm_integrate_depth_u16_dev", "mlm_integrate_depth_batch_dev",
+    "mlm_integrate_points", "mlm_query_occupancy", "mlm_query_occupancy_inflate", "mlm_query_inflate_occupancy",
+    "mlm_query_odds", "mlm_query_odd_grad", "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
+    "mlm_export_blocks", "mlm_export_global_map", "mlm_sync", "mlm_get_frame_stats", "mlm_get_awareness_hits",
+    "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
+    "mlm_enable_kernel_timing",
+]
+
+
+class MlmError(RuntimeError):
+    pass
+
+
+class Limits(ctypes.Structure):
+    _fields_ = [("max_blocks", ctypes.c_int32), ("max_points", ctypes.c_int32), ("max_batch", ctypes.c_int32),
+                ("record_awareness", ctypes.c_int32)]
+
+
+class FrameStats(ctypes.Structure):
+    _fields_ = [("n_points", ctypes.c_int64), ("n_hit_cells", ctypes.c_int64), ("n_miss_cells", ctypes.c_int64),
+                ("n_out_of_range", ctypes.c_int64), ("n_blocks", ctypes.c_int64), ("n_rehash_epochs", ctypes.c_int64),
+                ("hit_bucket_count", ctypes.c_int64)]
+
+    def as_dict(self) -> Dict[str, int]:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libmlmap_hip.so and declare the prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MlmError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(p)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    L.mlm_create.argtypes = [vp, vp, i32, ctypes.POINTER(vp)]
+    L.mlm_destroy.argtypes = [vp]
+    L.mlm_last_error.argtypes = [vp]
+    L.mlm_last_error.restype = ctypes.c_char_p
+    L.mlm_set_stream.argtypes = [vp, vp]
+    L.mlm_integrate_depth_u16.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    L.mlm_integrate_depth_u16_dev.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
+    L.mlm_integrate_depth_batch_dev.argtypes = [vp, vp, i32, ctypes.c_size_t, i32, i32, i32, vp, vp]
+    L.mlm_integrate_points.argtypes = [vp, vp, i32, vp, vp]
+    L.mlm_query_occupancy.argtypes = [vp, vp, i32, vp]
+    L.mlm_query_occupancy_inflate.argtypes = [vp, vp, i32, ctypes.c_float, vp]
+    L.mlm_query_inflate_occupancy.argtypes = [vp, vp, i32, vp]
+    L.mlm_query_odds.argtypes = [vp, vp, i32, vp]
+    L.mlm_query_odd_grad.argtypes = [vp, vp, i32, i32, vp]
+    L.mlm_set_free_in_bound.argtypes = [vp, vp, vp]
+    L.mlm_inflate_map.argtypes = [vp, vp]
+    L.mlm_block_count.argtypes = [vp, vp]
+    L.mlm_export_blocks.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.mlm_export_global_map.argtypes = [vp, i32, vp, vp]
+    L.mlm_sync.argtypes = [vp]
+    L.mlm_get_frame_stats.argtypes = [vp, vp]
+    L.mlm_get_awareness_hits.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.mlm_get_awareness_misses.argtypes = [vp, i32, vp, vp]
+    L.mlm_get_T_ls.argtypes = [vp, vp, vp]
+    L.mlm_get_odds_table.argtypes = [vp, vp]
+    L.mlm_get_kernel_times.argtypes = [vp, i32, vp, vp, vp]
+    L.mlm_enable_kernel_timing.argtypes = [vp, i32]
+    if path is None:
+        _lib = L
+    return L
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class MLMap:
+    """One map on one MI355X (one handle = one device + one HIP stream)."""
+
+    FREE, OCCUPIED, UNKNOWN = 1, 0, -1  # mlmap.h:109-114
+
+    def __init__(self, cfg: MapConfig, device: int = 0, max_blocks: int = 0, max_points: int = 0,
+                 record_awareness: bool = False):
+        self.cfg = cfg
+        self.cells = cfg.cells_per_block
+        self._L = load_library()
+        self._c = to_c(cfg)
+        self._lim = Limits(max_blocks, max_points, 0, int(record_awareness))
+        self._h = ctypes.c_void_p()
+        rc = self._L.mlm_create(ctypes.byref(self._c), ctypes.byref(self._lim), device, ctypes.byref(self._h))
+        if rc != MLM_OK:
+            msg = self._L.mlm_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                self._L.mlm_destroy(self._h)
+                self._h = ctypes.c_void_p()
+            raise MlmError(f"mlm_create failed: {STATUS.get(rc, rc)} {msg}")
+
+    # ---- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mlm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc != MLM_OK:
+            raise MlmError(f"{what}: {STATUS.get(rc, rc)}: {self._L.mlm_last_error(self._h).decode()}")
+
+    def set_stream(self, stream_ptr: int):
+        self._chk(self._L.mlm_set_stream(self._h, ctypes.c_void_p(stream_ptr)), "mlm_set_stream")
+
+    def sync(self):
+        self._chk(self._L.mlm_sync(self._h), "mlm_sync")
+
+    # ---- update_map (mlmap.cpp:382-386) ---------------------------------------------------------
+    def update_map(self, depth_u16: np.ndarray, q_wb, t_wb, pixel_idx=None):
+        """project_depth + update_map on a host uint16 depth image (mm).  ``pixel_idx`` (v*W+u) reproduces a
+        sampler; None = dense."""
+        img = np.ascontiguousarray(depth_u16, dtype=np.uint16)
+        hgt, wid = img.shape
+        if pixel_idx is None:
+            pp, n = None, 0
+        else:
+            pix = np.ascontiguousarray(pixel_idx, dtype=np.int32)
+            pp, n = _p(pix), pix.size
+        self._chk(self._L.mlm_integrate_depth_u16(self._h, _p(img), wid, hgt, wid, pp, n, _p(_f64(q_wb)),
+                                                  _p(_f64(t_wb))), "mlm_integrate_depth_u16")
+
+    def update_map_dev(self, img_dev_ptr: int, width: int, height: int, q_wb, t_wb, row_stride: int = 0):
+        """Same with the image already in HBM (device pointer)."""
+        self._chk(self._L.mlm_integrate_depth_u16_dev(self._h, ctypes.c_void_p(img_dev_ptr), width, height,
+                                                      row_stride or width, None, 0, _p(_f64(q_wb)), _p(_f64(t_wb))),
+                  "mlm_integrate_depth_u16_dev")
+
+    def update_map_batch_dev(self, img_dev_ptr: int, n_frames: int, width: int, height: int, q_wb, t_wb,
+                             frame_stride: int = 0, row_stride: int = 0):
+        q = _f64(q_wb).reshape(n_frames, 4)
+        t = _f64(t_wb).reshape(n_frames, 3)
+        self._chk(self._L.mlm_integrate_depth_batch_dev(self._h, ctypes.c_void_p(img_dev_ptr), n_frames,
+                                                        frame_stride or width * height, width, height,
+                                                        row_stride or width, _p(q), _p(t)),
+                  "mlm_integrate_depth_batch_dev")
+
+    def update_map_points(self, xyz_s, q_wb, t_wb):
+        """input_pc_pose(PC_s, T_wb) + input_pc_pose_direct on explicit sensor-frame points."""
+        xyz = _f64(xyz_s).reshape(-1, 3)
+        self._chk(self._L.mlm_integrate_points(self._h, _p(xyz), xyz.shape[0], _p(_f64(q_wb)), _p(_f64(t_wb))),
+                  "mlm_integrate_points")
+
+    # ---- queries (mlmap.h:142-295) --------------------------------------------------------------
+    def getOccupancy(self, pos_w, inflate: Optional[float] = None) -> np.ndarray:
+        pos = _f64(pos_w).reshape(-1, 3)
+        out = np.empty(pos.shape[0], dtype=np.int8)
+        if inflate is None:
+            self._chk(self._L.mlm_query_occupancy(self._h, _p(pos), pos.shape[0], _p(out)), "mlm_query_occupancy")
+        else:
+            self._chk(self._L.mlm_query_occupancy_inflate(self._h, _p(pos), pos.shape[0], ctypes.c_float(inflate),
+                                                          _p(out)), "mlm_query_occupancy_inflate")
+        return out.astype(np.int32)
+
+    def getInflateOccupancy(self, pos_w) -> np.ndarray:
+        pos = _f64(pos_w).reshape(-1, 3)
+        out = np.empty(pos.shape[0], dtype=np.int8)
+        self._chk(self._L.mlm_query_inflate_occupancy(self._h, _p(pos), pos.shape[0], _p(out)),
+                  "mlm_query_inflate_occupancy")
+        return out.astype(np.int32)
+
+    def getOdd(self, pos_w) -> np.ndarray:
+        pos = _f64(pos_w).reshape(-1, 3)
+        out = np.empty(pos.shape[0], dtype=np.float32)
+        self._chk(self._L.mlm_query_odds(self._h, _p(pos), pos.shape[0], _p(out)), "mlm_query_odds")
+        return out
+
+    def getOddGrad(self, pos_w, max_iter: int = 5) -> np.ndarray:
+        pos = _f64(pos_w).reshape(-1, 3)
+        out = np.empty((pos.shape[0], 3), dtype=np.float64)
+        self._chk(self._L.mlm_query_odd_grad(self._h, _p(pos), pos.shape[0], max_iter, _p(out)), "mlm_query_odd_grad")
+        return out
+
+    def setFree_map_in_bound(self, box_min, box_max):
+        self._chk(self._L.mlm_set_free_in_bound(self._h, _p(_f64(box_min)), _p(_f64(box_max))),
+                  "mlm_set_free_in_bound")
+
+    def inflate_map(self, ct_pos):
+        self._chk(self._L.mlm_inflate_map(self._h, _p(_f64(ct_pos))), "mlm_inflate_map")
+
+    # ---- read-out -------------------------------------------------------------------------------
+    def frame_stats(self) -> Dict[str, int]:
+        s = FrameStats()
+        self._chk(self._L.mlm_get_frame_stats(self._h, ctypes.byref(s)), "mlm_get_frame_stats")
+        return s.as_dict()
+
+    def block_count(self) -> int:
+        n = ctypes.c_int32()
+        self._chk(self._L.mlm_block_count(self._h, ctypes.byref(n)), "mlm_block_count")
+        return n.value
+
+    def export_blocks(self) -> Dict[str, np.ndarray]:
+        """observed_group_map contents sorted by block key (same dict layout as the oracle binding)."""
+        n, C = self.block_count(), self.cells
+        keys = np.empty((n, 3), dtype=np.int32)
+        lo = np.empty((n, C), dtype=np.float32)
+        occ = np.empty((n, C), dtype=np.uint8)
+        infl = np.empty((n, C), dtype=np.uint8)
+        m = ctypes.c_int32()
+        self._chk(self._L.mlm_export_blocks(self._h, n, _p(keys), _p(lo), _p(occ), _p(infl), ctypes.byref(m)),
+                  "mlm_export_blocks")
+        o = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
+        return {"keys": keys[o], "collapsed": np.zeros(n, dtype=np.uint8), "log_odds": lo[o], "occ": occ[o],
+                "infl": infl[o]}
+
+    def class_counts(self) -> Dict[str, int]:
+        b = self.export_blocks()
+        return {"blocks": int(b["keys"].shape[0]), "o": int((b["occ"] == ord("o")).sum()),
+                "f": int((b["occ"] == ord("f")).sum())}
+
+    def awareness_hits(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(cell idx sorted, odds, first-touch time) of the last frame."""
+        n = self.frame_stats()["n_hit_cells"]
+        cell = np.empty(n, dtype=np.uint32)
+        odds = np.empty(n, dtype=np.float32)
+        t = np.empty(n, dtype=np.uint32)
+        m = ctypes.c_int32()
+        self._chk(self._L.mlm_get_awareness_hits(self._h, n, _p(cell), _p(odds), _p(t), ctypes.byref(m)),
+                  "mlm_get_awareness_hits")
+        o = np.argsort(cell, kind="stable")
+        return cell[o].astype(np.int64), odds[o], t[o]
+
+    def awareness_misses(self) -> np.ndarray:
+        n = self.frame_stats()["n_miss_cells"]
+        cell = np.empty(n, dtype=np.uint32)
+        m = ctypes.c_int32()
+        self._chk(self._L.mlm_get_awareness_misses(self._h, n, _p(cell), ctypes.byref(m)), "mlm_get_awareness_misses")
+        return np.sort(cell).astype(np.int64)
+
+    def T_ls(self):
+        q, t = np.empty(4), np.empty(3)
+        self._chk(self._L.mlm_get_T_ls(self._h, _p(q), _p(t)), "mlm_get_T_ls")
+        return q, t
+
+    def odds_table(self) -> np.ndarray:
+        out = np.empty((21, self.cfg.am_n_Rho), dtype=np.float32)
+        self._chk(self._L.mlm_get_odds_table(self._h, _p(out)), "mlm_get_odds_table")
+        return out
+
+    def enable_kernel_timing(self, on: bool = True):
+        self._chk(self._L.mlm_enable_kernel_timing(self._h, int(on)), "mlm_enable_kernel_timing")
+
+    def kernel_times(self) -> List[Tuple[str, float]]:
+        cap = 256
+        names = (ctypes.c_char_p * cap)()
+        ms = np.empty(cap, dtype=np.float32)
+        n = ctypes.c_int32()
+        self._chk(self._L.mlm_get_kernel_times(self._h, cap, names, _p(ms), ctypes.byref(n)), "mlm_get_kernel_times")
+        return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, cap))]

@@ -1,0 +1,175 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): hit/miss cell sets, block keys and occupancy classes bit-exact; odds within 1e-4.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from mlmapping_amd import synthetic as syn
+from mlmapping_amd.config import S1, S1_SIGMA0, S3, SDEF
+from tests.util import ODDS_TOL, compare_maps, voxel_centres
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mlmapping_amd.mlmap import MLMap
+    from oracle.binding import OracleMap
+
+    return MLMap, OracleMap
+
+
+def _awareness_equal(gpu, cpu):
+    gc, go, _ = gpu.awareness_hits()
+    cc, co = cpu.hit_cells_sorted()
+    assert np.array_equal(gc, cc), "hit cell sets differ"
+    assert np.abs(go.astype(np.float64) - co.astype(np.float64)).max() <= 1e-6, "hit odds differ"
+    assert np.array_equal(gpu.awareness_misses(), np.sort(cpu.misses()).astype(np.int64)), "miss cell sets differ"
+    st = gpu.frame_stats()
+    assert st["n_out_of_range"] == cpu.out_of_range_count()
+    assert st["hit_bucket_count"] == cpu.hit_bucket_count()
+
+
+def test_tables_and_pose(mods):
+    MLMap, OracleMap = mods
+    for cfg in (S1, SDEF):
+        gpu, cpu = MLMap(cfg, max_blocks=1024, record_awareness=True), OracleMap(cfg)
+        assert np.array_equal(gpu.odds_table().view(np.uint32), cpu.odds_table().view(np.uint32))
+        for q, t in syn.random_poses(5, seed=3):
+            gpu.update_map_points(np.array([[0.1, 0.2, 1.0]]), q, t)
+            cpu.awareness_points(np.array([[0.1, 0.2, 1.0]]), q, t)
+            gq, gt = gpu.T_ls()
+            cq, ct = cpu.T_ls()
+            assert np.array_equal(gq, cq) and np.array_equal(gt, ct)
+
+
+def test_config1_kat_and_awareness_sets(mods):
+    """BASELINE config 1: one 640x480 room frame, identity pose, 0.1 m — counts of SURVEY §8d and exact sets."""
+    MLMap, OracleMap = mods
+    gpu, cpu = MLMap(S1, max_blocks=4096, record_awareness=True), OracleMap(S1)
+    img = syn.room_depth(S1)
+    q, t = syn.static_pose()
+    gpu.update_map(img, q, t)
+    cpu.update_depth(img, q, t)
+    st = gpu.frame_stats()
+    assert (st["n_points"], st["n_hit_cells"], st["n_miss_cells"], st["n_blocks"]) == (307200, 14154, 74340, 116)
+    _awareness_equal(gpu, cpu)
+    d = compare_maps(gpu.export_blocks(), cpu.export_blocks(), "frame 0")
+    assert gpu.class_counts() == {"blocks": 116, "o": 7924, "f": 32960}
+    print(d)
+
+
+@pytest.mark.parametrize("scene,poses,cfg,frames", [
+    ("room", "static", S1, 20),
+    ("room_jitter", "smooth", S1, 12),
+    ("room_jitter", "random", S1, 8),
+    ("scatter", "static", S1, 4),
+    ("room", "translating", S1_SIGMA0, 8),
+    ("room", "translating", SDEF, 10),
+])
+def test_stream_parity(mods, scene, poses, cfg, frames):
+    """Multi-frame streams: the map must track the oracle frame after frame (iteration-order effects included)."""
+    MLMap, OracleMap = mods
+    gpu, cpu = MLMap(cfg, max_blocks=8192, record_awareness=True), OracleMap(cfg)
+    worst = {"max_dodd": 0.0, "bit_mismatch": 0}
+    for k, (img, (q, t)) in enumerate(syn.stream(cfg, scene, poses, frames)):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        _awareness_equal(gpu, cpu)
+        d = compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{scene}/{poses} frame {k}")
+        worst["max_dodd"] = max(worst["max_dodd"], d["max_dodd"])
+        worst["bit_mismatch"] = max(worst["bit_mismatch"], d["bit_mismatch"])
+    if scene == "room" and poses == "static" and cfg is S1:
+        c = gpu.class_counts()
+        assert (c["o"], c["f"]) == (9435, 32462)  # SURVEY §8d frame-19 KAT (iteration-order dependent)
+    print(scene, poses, worst)
+
+
+def test_config3_720p(mods):
+    """BASELINE config 3: 1280x720, 0.05 m voxels."""
+    MLMap, OracleMap = mods
+    gpu, cpu = MLMap(S3, max_blocks=8192, record_awareness=True), OracleMap(S3)
+    img = syn.room_depth(S3)
+    for k in range(2):
+        q, t = syn.translating_pose(k)
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"S3 frame {k}")
+        if k == 0:
+            st = gpu.frame_stats()
+            assert (st["n_hit_cells"], st["n_miss_cells"]) == (136766, 659944)
+
+
+def test_reference_sampler_via_pixel_list(mods):
+    """The reference's 500-sample rand() path: the host draws the pixel list, both sides integrate it."""
+    MLMap, OracleMap = mods
+    gpu, cpu = MLMap(SDEF, max_blocks=2048, record_awareness=True), OracleMap(SDEF)
+    img = syn.room_depth(SDEF)
+    rng = np.random.default_rng(1)
+    for k in range(10):
+        q, t = syn.translating_pose(k)
+        pix = (rng.integers(0, SDEF.height, 500) * SDEF.width + rng.integers(0, SDEF.width, 500)).astype(np.int32)
+        gpu.update_map(img, q, t, pixel_idx=pix)
+        cpu.update_depth_indexed(img, pix, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"sampled frame {k}")
+
+
+def test_edge_points(mods):
+    """SURVEY §8c G5 edge cases through the explicit point interface."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=4096, record_awareness=True), OracleMap(cfg)
+    q, t = syn.static_pose()
+    eps = 4.4e-16
+    # sensor frame: x right, y down, z forward (T_B_S of config_sim.yaml)
+    pts = np.array([
+        [eps, 0.0, 2.0],       # y_l = -eps -> phi_idx == nPhi drop
+        [0.0, 0.0, 2.0],       # on the optical axis
+        [0.0, 0.0, 30.0],      # rho >= nRho: clamp to the border then cast
+        [0.0, -5.0, 3.0],      # z above the map, ray cells in range
+        [0.0, 5.0, 3.0],       # z below
+        [0.0, 0.0, 0.05],      # cell rho = 1 (0.12 + 0.05 m): no miss cells
+        [0.0, 0.0, -0.12],     # x_l == 0 exactly: fast_atan2 quirk
+        [-0.12, 0.0, -0.12],   # somewhere behind
+        [0.0, 0.0, 0.0],
+        [3.0, 0.3, 6.3],
+    ])
+    gpu.update_map_points(pts, q, t)
+    cpu.update_points(pts, q, t)
+    _awareness_equal(gpu, cpu)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "edge points")
+    # empty input
+    gpu.update_map_points(np.zeros((0, 3)), q, t)
+    cpu.update_points(np.zeros((0, 3)), q, t)
+    assert gpu.frame_stats()["n_hit_cells"] == 0
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "after empty frame")
+
+
+def test_queries(mods):
+    MLMap, OracleMap = mods
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=8192), OracleMap(cfg)
+    for img, (q, t) in syn.stream(cfg, "room_jitter", "smooth", 6):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+    b = cpu.export_blocks()
+    rng = np.random.default_rng(5)
+    lo, hi = b["keys"].min(0) * 1.0 - 1.0, b["keys"].max(0) * 1.0 + 2.0
+    pos = np.concatenate([rng.uniform(lo, hi, size=(50000, 3)), voxel_centres(b, cfg, 100000)])
+    assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+    assert np.abs(gpu.getOdd(pos) - cpu.getOdd(pos)).max() <= ODDS_TOL
+    assert np.array_equal(gpu.getOccupancy(pos[:20000], inflate=0.15), cpu.getOccupancy(pos[:20000], inflate=0.15))
+    gg, cg = gpu.getOddGrad(pos[:30000]), cpu.getOddGrad(pos[:30000])
+    assert np.abs(gg - cg).max() <= 1e-4 * max(1.0, np.abs(cg).max())
+    # setFree_map_in_bound: idempotent, then everything must still agree
+    bmin, bmax = np.array([0.5, -1.0, 0.3]), np.array([2.5, 1.0, 2.0])
+    for _ in range(2):
+        gpu.setFree_map_in_bound(bmin, bmax)
+        cpu.setFree_map_in_bound(bmin, bmax)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "after setFree")
+    assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))

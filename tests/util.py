@@ -1,0 +1,40 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+ODDS_TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 on the float odds"
+
+
+def odds_of(log_odds: np.ndarray) -> np.ndarray:
+    """logit_inv (mlmap.h:40) in double, as getOdd computes before narrowing."""
+    p = np.power(10.0, log_odds.astype(np.float64))
+    return p / (1.0 + p)
+
+
+def compare_maps(g: dict, c: dict, what: str = "") -> dict:
+    """GPU block dump vs oracle block dump (both sorted by key).  Integer/byte facts must be identical; the float
+    log-odds are compared as odds with the 1e-4 tolerance of the north star.  Returns diagnostics."""
+    assert g["keys"].shape == c["keys"].shape, f"{what}: block count {g['keys'].shape[0]} vs {c['keys'].shape[0]}"
+    assert np.array_equal(g["keys"], c["keys"]), f"{what}: block key sets differ"
+    assert not c["collapsed"].any(), "collapsed blocks are not expected without frontier mode"
+    occ_bad = int((g["occ"] != c["occ"]).sum())
+    assert occ_bad == 0, f"{what}: {occ_bad} cells differ in occupancy class"
+    dodd = np.abs(odds_of(g["log_odds"]) - odds_of(c["log_odds"]))
+    assert dodd.max() <= ODDS_TOL, f"{what}: max |d odd| = {dodd.max():.3e}"
+    dl = np.abs(g["log_odds"].astype(np.float64) - c["log_odds"].astype(np.float64))
+    return {"blocks": int(g["keys"].shape[0]), "max_dodd": float(dodd.max()), "max_dL": float(dl.max()),
+            "bit_mismatch": int((g["log_odds"].view(np.uint32) != c["log_odds"].view(np.uint32)).sum()),
+            "cells": int(g["log_odds"].size)}
+
+
+def voxel_centres(b: dict, cfg, limit: int = 200000, seed: int = 0) -> np.ndarray:
+    """World centres of (a sample of) the allocated voxels: subbox_id2xyz_glb_vec (map_local.h:208-213)."""
+    n = cfg.subbox_n
+    keys = b["keys"].astype(np.float64)
+    ids = np.arange(cfg.cells_per_block)
+    cz, cy, cx = ids // (n * n), (ids // n) % n, ids % n
+    d = cfg.subbox_d_xyz
+    c = np.stack([cx, cy, cz], axis=1).astype(np.float64)
+    pos = (keys[:, None, :] * (d * n) + c[None, :, :] * d + d * 0.5).reshape(-1, 3)
+    if pos.shape[0] > limit:
+        pos = pos[np.random.default_rng(seed).choice(pos.shape[0], limit, replace=False)]
+    return pos
