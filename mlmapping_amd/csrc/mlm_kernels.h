@@ -2,7 +2,8 @@
 //
 // Stage A  (awareness_map_cylindrical::input_pc_pose, map_awareness.cpp:173-282)
 //   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions, de-duplicated ray walk
-//   k_collect_hits    dense sweep of the hit scratch -> unique-hit list (cell, first-touch time, odd, logit)
+//   k_collect_hits    dense sweep of the hit scratch -> unique-hit list + per-cell contribution segments
+//   k_scatter_contribs / k_noisy_or   point-order replay of the float noisy-OR chain -> odd, logit
 // Stage B  (iteration order of hit_idx_odds_hashmap, i.e. libstdc++ _Hashtable list order)
 //   k_bucket_min / k_make_keys (+ rank kernels on rehash frames)
 // Stage C  (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237)
@@ -13,12 +14,37 @@
 
 #define MLM_BLOCK 256
 
+__device__ __forceinline__ void mlm_cell_rpz(const MlmDev &P, uint32_t cell, int &rho, int &phi, int &z) {
+    z = (int)(cell / (uint32_t)P.nRhoPhi);
+    const int rem = (int)(cell % (uint32_t)P.nRhoPhi);
+    phi = rem / P.nRho;
+    rho = rem - phi * P.nRho;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Stage A
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mlm_contribute(const MlmDev &P, int cell, uint32_t t, int64_t lnq) {
+// A hit contribution is identified by its insertion time t = point*21 + sub, sub = 0 (centre), 2d-1 (+d
+// neighbour), 2d (-d neighbour): the order update_hits inserts them (map_awareness.cpp:146-168).
+__device__ __forceinline__ void mlm_count_contribution(const MlmDev &P, int cell, uint32_t t) {
     atomicMin(&P.hit_t[cell], t);
-    atomicAdd((unsigned long long *)&P.hit_lnq[cell], (unsigned long long)lnq);
+    atomicAdd(&P.hit_cnt[cell], 1u);
+}
+
+// Enumerate the contributions of one in-range point (update_hits, map_awareness.cpp:135-171).
+template <class F> __device__ __forceinline__ void mlm_for_each_contribution(const MlmDev &P, int rho, int phi, int zi,
+                                                                            uint32_t t0, F &&f) {
+    const int c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
+    f(c0, t0);
+    const float s3 = P.sigma3[rho];
+    if (!(1.0f < s3)) return;
+    const double slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0; // raycasting_z_over_rho, map_awareness.cpp:64-71
+    for (int d = 1; (float)d < s3 && (rho + d < P.nRho) && d <= MLM_DIFF_RANGE; ++d) {
+        int rz = mlm_cvt_int(round(zi + (d * slope)));
+        if (0 <= rz && rz < P.nZ) f(rz * P.nRhoPhi + phi * P.nRho + rho + d, t0 + 2 * d - 1);
+        rz = mlm_cvt_int(round(zi - (d * slope)));
+        if (0 <= rz && rz < P.nZ && rho - d >= 0) f(rz * P.nRhoPhi + phi * P.nRho + rho - d, t0 + 2 * d);
+    }
 }
 
 // ray walk, map_awareness.cpp:266-274: r = rho-1 .. 1, z' = round(z - (rho-r)*slope).  Bits of one (phi,z') row
@@ -57,7 +83,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
         const int v = pix / F.width;
         const int u = pix - v * F.width;
         const uint16_t raw = F.img[(size_t)v * F.row_stride + u];
-        if (raw == 0) return; // mlmap.cpp:338-341
+        if (raw == 0) { // mlmap.cpp:338-341
+            P.pt_cell[i] = -1;
+            return;
+        }
         // mlmap.cpp:329,344-346: (size_t u - float cx_) is a float subtraction, the rest is double
         const double depth = raw * P.inv_factor;
         xs = ((float)u - P.cx) * depth / P.fx;
@@ -79,23 +108,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
     const uint32_t t0 = (uint32_t)i * MLM_TIME_SLOTS;
     bool walk = false;
     double slope = 0;
+    int c0 = -1;
 
     if (inside) {
-        // update_hits, map_awareness.cpp:135-171
-        const int c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
-        slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0; // raycasting_z_over_rho, map_awareness.cpp:64-71
-        mlm_contribute(P, c0, t0, P.lnq_table[MLM_DIFF_RANGE * P.nRho + rho]);
-        const float s3 = P.sigma3[rho];
-        for (int d = 1; (float)d < s3 && (rho + d < P.nRho) && d <= MLM_DIFF_RANGE; ++d) {
-            int rz = mlm_cvt_int(round(zi + (d * slope)));
-            if (0 <= rz && rz < P.nZ)
-                mlm_contribute(P, rz * P.nRhoPhi + phi * P.nRho + rho + d, t0 + 2 * d - 1,
-                               P.lnq_table[(MLM_DIFF_RANGE + d) * P.nRho + rho]);
-            rz = mlm_cvt_int(round(zi - (d * slope)));
-            if (0 <= rz && rz < P.nZ && rho - d >= 0)
-                mlm_contribute(P, rz * P.nRhoPhi + phi * P.nRho + rho - d, t0 + 2 * d,
-                               P.lnq_table[(MLM_DIFF_RANGE - d) * P.nRho + rho]);
-        }
+        c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
+        slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0;
+        mlm_for_each_contribution(P, rho, phi, zi, t0, [&](int cell, uint32_t t) { mlm_count_contribution(P, cell, t); });
         if (P.visibility) {
             // every point of one (rho,phi,z) cell casts the identical ray: only the first one walks it
             const uint32_t bit = 1u << (c0 & 31);
@@ -111,33 +129,121 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
         }
         walk = true;
     }
+    P.pt_cell[i] = c0;
     if (!(can_do_cast && P.visibility)) atomicAdd(&P.ctr->n_oor, 1u); // map_awareness.cpp:277-278
     if (walk) mlm_walk_ray(P, rho, phi, zi, slope);
 }
 
-// One thread per awareness cell: emit the unique hit cells and reset the scratch for the next frame.
+// One thread per awareness cell: emit the unique hit cells, carve a segment of `contrib` for each, and reset
+// hit_t for the next frame (hit_cnt is consumed — and thereby zeroed — by k_scatter_contribs).
 __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t t = MLM_EMPTY_T;
     if (c < P.nCells) t = P.hit_t[c];
     const bool has = (t != MLM_EMPTY_T);
     const unsigned int pos = mlm_wave_append(&P.ctr->u_hit, has);
+    const uint32_t cnt = has ? P.hit_cnt[c] : 0u;
+    // wave-inclusive prefix sum of cnt, one atomic per wave for the segment space
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint32_t wave_base = 0;
+    if (lane == 63 && total) wave_base = atomicAdd(&P.ctr->n_contrib, total);
+    wave_base = __shfl(wave_base, 63, 64);
     if (!has) return;
-    const int64_t lnq = P.hit_lnq[c];
+    const uint32_t base = wave_base + incl - cnt;
     P.hit_t[c] = MLM_EMPTY_T;
-    P.hit_lnq[c] = 0;
-    // noisy-OR of all contributions (map_awareness.h:147-154) evaluated order-independently:
-    // 1 - prod(1 - odd_i) = 1 - exp(sum ln(1 - odd_i))
-    const double q = exp((double)lnq * (1.0 / MLM_LNQ_SCALE));
-    const float odd = (float)(1.0 - q);
-    // logit macro, map_local.h:8, on a float: log10f(x / (1 - x))
-    const float ratio = odd / (1.0f - odd);
-    const float inc = (float)log10((double)ratio);
+    P.seg_base[c] = base;
     P.hl_cell[pos] = (uint32_t)c;
     P.hl_t[pos] = t;
     P.hl_vt[pos] = t;
-    P.hl_odd[pos] = odd;
-    P.hl_inc[pos] = inc;
+    P.hl_base[pos] = base;
+    P.hl_cnt[pos] = cnt;
+}
+
+// Second sweep over the points: write each contribution's insertion time into its cell's segment.
+__global__ __launch_bounds__(MLM_BLOCK) void k_scatter_contribs(const MlmDev P, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c0 = P.pt_cell[i];
+    if (c0 < 0) return;
+    int rho, phi, zi;
+    mlm_cell_rpz(P, (uint32_t)c0, rho, phi, zi);
+    mlm_for_each_contribution(P, rho, phi, zi, (uint32_t)i * MLM_TIME_SLOTS, [&](int cell, uint32_t t) {
+        const uint32_t k = atomicSub(&P.hit_cnt[cell], 1u) - 1u;
+        const uint32_t slot = P.seg_base[cell] + k;
+        if (slot < P.contrib_cap) P.contrib[slot] = t;
+    });
+}
+
+__device__ __forceinline__ uint32_t mlm_wave_min_u32(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// One wave per unique hit cell: replay update_odds_hashmap (map_awareness.h:147-154) over the cell's contributions
+// in insertion-time order — the float noisy-OR chain is not associative, so the order is part of the result.
+// p == 1.0f is absorbing (1-(1-1)(1-a) == 1), which ends long chains after a few steps.
+__global__ __launch_bounds__(MLM_BLOCK) void k_noisy_or(const MlmDev P) {
+    const unsigned int n_cells = P.ctr->u_hit;
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned int w = wave; w < n_cells; w += n_waves) {
+        const uint32_t cell = P.hl_cell[w];
+        const uint32_t base = P.hl_base[w];
+        const uint32_t n = P.hl_cnt[w];
+        const int rho_c = (int)(cell % (uint32_t)P.nRho);
+        // keys of the first 64 contributions stay in registers
+        const uint32_t k0 = ((uint32_t)lane < n) ? P.contrib[base + lane] : 0xFFFFFFFFu;
+        float p = 0.0f;
+        bool first = true;
+        long long last = -1;
+        for (;;) {
+            uint32_t m = ((long long)k0 > last) ? k0 : 0xFFFFFFFFu;
+            for (uint32_t j = 64 + lane; j < n; j += 64) {
+                const uint32_t k = P.contrib[base + j];
+                if ((long long)k > last && k < m) m = k;
+            }
+            m = mlm_wave_min_u32(m);
+            if (m == 0xFFFFFFFFu) break;
+            // decode: sub 0 -> centre; 2d-1 -> "+d" neighbour of a point at rho_c-d; 2d -> "-d" neighbour of rho_c+d
+            const int sub = (int)(m % MLM_TIME_SLOTS);
+            int row = MLM_DIFF_RANGE, rho_s = rho_c;
+            if (sub > 0) {
+                const int d = (sub + 1) >> 1;
+                if (sub & 1) {
+                    row = MLM_DIFF_RANGE + d;
+                    rho_s = rho_c - d;
+                } else {
+                    row = MLM_DIFF_RANGE - d;
+                    rho_s = rho_c + d;
+                }
+            }
+            const float a = P.odds_table[row * P.nRho + rho_s];
+            if (first) {
+                p = a;
+                first = false;
+            } else {
+                p = 1 - (1 - p) * (1 - a);
+            }
+            last = (long long)m;
+            if (p == 1.0f) break;
+        }
+        if (lane == 0) {
+            // logit macro, map_local.h:8, on a float: log10f(x / (1 - x))
+            const float ratio = p / (1 - p);
+            P.hl_odd[w] = p;
+            P.hl_inc[w] = (float)log10((double)ratio);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -146,12 +252,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P) {
 // inside a chain later insertions sit nearer the head.  So "x is visited before y" <=> (first-insert time of x's
 // bucket, insert time of x) > (… y) lexicographically.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mlm_cell_rpz(const MlmDev &P, uint32_t cell, int &rho, int &phi, int &z) {
-    z = (int)(cell / (uint32_t)P.nRhoPhi);
-    const int rem = (int)(cell % (uint32_t)P.nRhoPhi);
-    phi = rem / P.nRho;
-    rho = rem - phi * P.nRho;
-}
 __global__ __launch_bounds__(MLM_BLOCK) void k_bucket_min(const MlmDev P, unsigned int n, unsigned long long n_bkt,
                                                           unsigned int arr_limit, int use_arr) {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;

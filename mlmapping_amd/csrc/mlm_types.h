@@ -6,7 +6,6 @@
 #define MLM_HT_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define MLM_TIME_SLOTS 21            // insertion slots per point: centre + (+d,-d) for d = 1..10
 #define MLM_DIFF_RANGE 10            // get_odds_table rows = 2*10+1 (map_awareness.cpp:36)
-#define MLM_LNQ_SCALE 274877906944.0 // 2^38: fixed-point scale of ln(1-odd) accumulators
 
 struct MlmCounters {
     // per-frame (zeroed at the start of every frame)
@@ -16,11 +15,13 @@ struct MlmCounters {
     unsigned int n_oor;       // "point out range"
     unsigned int n_miss_vox;  // voxels touched by misses this frame
     unsigned int n_miss_list; // entries of ml_cell (record_awareness only)
+    unsigned int n_contrib;   // hit contributions (centre + noise-spread neighbours) of this frame
+    unsigned int pad0;
     // persistent
     unsigned int n_blocks;    // allocated blocks
     unsigned int err;         // sticky error bits (1 = block pool / hash table full)
 };
-#define MLM_CTR_FRAME_BYTES 24
+#define MLM_CTR_FRAME_BYTES 32
 
 struct MlmDev {
     // ---- awareness map constants (map_awareness.cpp:19-82)
@@ -38,13 +39,17 @@ struct MlmDev {
     float cx, cy, fx, fy;
     double inv_factor;
     // ---- tables
-    const int64_t *lnq_table;  // [21*nRho] round(ln(1-odds_table)*2^38)
+    const float *odds_table;   // [21*nRho] get_odds_table (map_awareness.cpp:36-46)
     const float *sigma3;       // [nRho] 3*sigma_in_dr(rho)  (float, map_awareness.cpp:149)
     const double *cos_phi;     // [nPhi] cos/sin of the cell-centre azimuth (map_awareness.cpp:59-61)
     const double *sin_phi;
     // ---- per-frame awareness scratch
     uint32_t *hit_t;           // [nCells] first-touch time of a hit cell (min over contributions)
-    int64_t *hit_lnq;          // [nCells] sum of fixed-point ln(1-odd) over contributions
+    uint32_t *hit_cnt;         // [nCells] number of contributions; reused as the fill cursor of the segment
+    uint32_t *seg_base;        // [nCells] start of the cell's segment in `contrib`
+    uint32_t *contrib;         // [contrib_cap] insertion times of all contributions, grouped by cell
+    int32_t *pt_cell;          // [max_points] hit-centre cell of each point, -1 = none
+    unsigned int contrib_cap;
     uint32_t *start_bits;      // [ceil(nCells/32)] hit-centre cells whose ray has been walked
     uint32_t *miss_bits;       // [nMissWords] free cells, row-major (z,phi) rows of RW words, bit = rho
     // ---- unique-hit list (capacity nCells)
@@ -52,6 +57,8 @@ struct MlmDev {
     uint32_t *hl_t;            // first-touch time
     float *hl_odd;             // noisy-OR odd
     float *hl_inc;             // logit(odd), the log-odds increment
+    uint32_t *hl_base;         // segment start in `contrib`
+    uint32_t *hl_cnt;          // segment length
     uint32_t *hl_vt;           // virtual insertion time (== hl_t when no rehash happened this frame)
     uint32_t *hl_arr;          // arrival index (rank of hl_t), only valid on rehash frames
     uint64_t *hl_key;          // iteration-order key: (bucket_first << 32) | vt ; larger = earlier in iteration

@@ -322,6 +322,16 @@ int integrate_frame(mlm_handle *h, const MlmFrame &F, int mode) {
         Timed t(h, "k_collect_hits");
         hipLaunchKernelGGL(k_collect_hits, dim3(grid_for((size_t)P.nCells)), dim3(MLM_BLOCK), 0, h->stream, P);
     }
+    if (F.n > 0) {
+        {
+            Timed t(h, "k_scatter_contribs");
+            hipLaunchKernelGGL(k_scatter_contribs, dim3(grid_for((size_t)F.n)), dim3(MLM_BLOCK), 0, h->stream, P, F.n);
+        }
+        {
+            Timed t(h, "k_noisy_or");
+            hipLaunchKernelGGL(k_noisy_or, dim3(2048), dim3(MLM_BLOCK), 0, h->stream, P);
+        }
+    }
     int rc = read_counters(h);
     if (rc) return rc;
     const unsigned int U = h->h_ctr->u_hit;
@@ -447,7 +457,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         h->err = "awareness map too large";
         return MLM_ERR_UNSUPPORTED;
     }
-    if ((long long)h->lim.max_points * MLM_TIME_SLOTS > 0xFFFFFFF0ll) {
+    if ((long long)h->lim.max_points * MLM_TIME_SLOTS > 0x7FFFFFF0ll) {
         h->err = "max_points too large for 32-bit insertion times";
         return MLM_ERR_UNSUPPORTED;
     }
@@ -483,12 +493,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     // tables (host libm, uploaded once)
     OddsModel om{cfg->am_d_rho, cfg->depth_noise_coe};
     h->odds_table.resize((size_t)21 * P.nRho);
-    std::vector<int64_t> lnq((size_t)21 * P.nRho);
     for (int d = -MLM_DIFF_RANGE; d <= MLM_DIFF_RANGE; ++d)
         for (int r = 0; r < P.nRho; ++r) {
             const float a = om.get_odds(d, (size_t)r);
             h->odds_table[(size_t)(d + MLM_DIFF_RANGE) * P.nRho + r] = a;
-            lnq[(size_t)(d + MLM_DIFF_RANGE) * P.nRho + r] = std::llround(std::log(1.0 - (double)a) * MLM_LNQ_SCALE);
         }
     std::vector<float> sigma3(P.nRho);
     for (int r = 0; r < P.nRho; ++r) sigma3[r] = 3 * om.sigma_in_dr((size_t)r); // map_awareness.cpp:149
@@ -498,19 +506,19 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         cphi[p] = std::cos(center_phi);
         sphi[p] = std::sin(center_phi);
     }
-    int64_t *d_lnq;
+    float *d_odds;
     float *d_s3;
     double *d_c, *d_s;
     int rc;
-    if ((rc = dev_alloc(h, &d_lnq, lnq.size()))) return rc;
+    if ((rc = dev_alloc(h, &d_odds, h->odds_table.size()))) return rc;
     if ((rc = dev_alloc(h, &d_s3, sigma3.size()))) return rc;
     if ((rc = dev_alloc(h, &d_c, cphi.size()))) return rc;
     if ((rc = dev_alloc(h, &d_s, sphi.size()))) return rc;
-    HIPCHK(h, hipMemcpy(d_lnq, lnq.data(), lnq.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_odds, h->odds_table.data(), h->odds_table.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_s3, sigma3.data(), sigma3.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_c, cphi.data(), cphi.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_s, sphi.data(), sphi.size() * sizeof(double), hipMemcpyHostToDevice));
-    P.lnq_table = d_lnq;
+    P.odds_table = d_odds;
     P.sigma3 = d_s3;
     P.cos_phi = d_c;
     P.sin_phi = d_s;
@@ -518,7 +526,27 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     // awareness scratch + unique-hit list
     const size_t NC = (size_t)P.nCells;
     if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hit_lnq, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hit_cnt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.seg_base, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_base, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_cnt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.pt_cell, (size_t)h->lim.max_points))) return rc;
+    {
+        // most contributions one point can make: centre + (+d,-d) while d < 3*sigma(rho) (map_awareness.cpp:149)
+        int dmax = 0;
+        for (int r = 0; r < P.nRho; ++r) {
+            int d = 1;
+            while ((float)d < sigma3[r] && r + d < P.nRho && d <= MLM_DIFF_RANGE) ++d;
+            dmax = std::max(dmax, d - 1);
+        }
+        const size_t cap = (size_t)h->lim.max_points * (size_t)(1 + 2 * dmax);
+        if (cap > 0xFFFFFFF0ull) {
+            h->err = "contribution buffer too large";
+            return MLM_ERR_UNSUPPORTED;
+        }
+        P.contrib_cap = (unsigned int)cap;
+        if ((rc = dev_alloc(h, &P.contrib, cap))) return rc;
+    }
     if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
     if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
     if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
@@ -539,7 +567,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     }
     if ((rc = dev_alloc(h, &P.bkt_first, h->max_buckets))) return rc;
     HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.hit_lnq, 0, NC * sizeof(int64_t)));
+    HIPCHK(h, hipMemset(P.hit_cnt, 0, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
 

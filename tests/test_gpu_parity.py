@@ -26,7 +26,7 @@ def _awareness_equal(gpu, cpu):
     gc, go, _ = gpu.awareness_hits()
     cc, co = cpu.hit_cells_sorted()
     assert np.array_equal(gc, cc), "hit cell sets differ"
-    assert np.abs(go.astype(np.float64) - co.astype(np.float64)).max() <= 1e-6, "hit odds differ"
+    assert np.array_equal(go.view(np.uint32), co.view(np.uint32)), "hit odds differ (float bits)"
     assert np.array_equal(gpu.awareness_misses(), np.sort(cpu.misses()).astype(np.int64)), "miss cell sets differ"
     st = gpu.frame_stats()
     assert st["n_out_of_range"] == cpu.out_of_range_count()
