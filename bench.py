@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — depth frames/s integrated into the map on MI355X (BASELINE.json metric).
+
+A *step* is one batch of `--batch` synthetic depth frames of ONE stream pushed through the hot path
+(awareness raycast + log-odds block-map update) in order.  Inputs (uint16 depth frames + poses) are resident in
+HBM before the timed region starts.  Workload at N=1 = BASELINE config 2 (640x480 stream, 0.1 m local map,
+S1 parameters); `--workload cfg3` selects config 3 (1280x720, 0.05 m).
+
+Multi-GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): one independent depth
+stream + map per rank/GPU, no data-path collective (the path shards by stream: SURVEY.md §8e); the barrier and the
+max-over-ranks reduction of the elapsed time go through torch.distributed (RCCL).  "scaling": "weak".
+
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_inputs(cfg, n_distinct: int, n_total: int, seed: int):
+    """n_distinct jittered room frames (cycled) + n_total random SE(3) poses (north_star: synthetic VGA depth +
+    random SE(3) pose)."""
+    from mlmapping_amd import synthetic as syn
+
+    base = syn.room_depth(cfg)
+    frames = np.stack([syn.jitter_depth(base, k, seed=seed) for k in range(n_distinct)])
+    poses = syn.random_poses(n_total, seed=seed)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    return frames, q, t
+
+
+def cpu_baseline(cfg, frames, q, t, budget_s: float = 15.0):
+    """The CPU oracle (a port of the reference's map_awareness + map_local path: std::unordered_map/set, one thread)
+    timed on the same frames/poses, bounded to ~budget_s seconds."""
+    from oracle.binding import OracleMap
+
+    m = OracleMap(cfg)
+    n = 0
+    t0 = time.perf_counter()
+    while n < q.shape[0]:
+        m.update_depth(frames[n % frames.shape[0]], q[n], t[n])
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 3:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} frames of the same stream, {dt:.1f} s, oracle/libmlmap_oracle.so (1 thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--distinct", type=int, default=32, help="distinct depth frames kept in HBM (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+
+    from mlmapping_amd.config import S1, S3
+    from mlmapping_amd.mlmap import MLMap
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = S1 if args.workload == "cfg2" else S3
+    B, K, W = args.batch, args.steps, args.warmup
+    n_total = (K + W) * B
+    frames, q, t = make_inputs(cfg, args.distinct, n_total, seed=42 + rank)
+    # inputs resident in HBM: torch owns the buffer (uint16 payload viewed as int16 storage)
+    d_frames = torch.from_numpy(frames.view(np.int16)).cuda(local_rank)
+    torch.cuda.synchronize()
+    fsz = cfg.width * cfg.height
+
+    m = MLMap(cfg, device=local_rank, max_blocks=32768, max_points=cfg.width * cfg.height)
+    m.enable_kernel_timing(True)
+
+    ktime = {}
+    algo_bytes = []
+
+    def run_step(s: int, timed: bool):
+        for b in range(B):
+            k = s * B + b
+            ptr = d_frames.data_ptr() + (k % args.distinct) * fsz * 2
+            m.update_map_dev(ptr, cfg.width, cfg.height, q[k], t[k])
+            if timed:
+                for name, ms in m.kernel_times():
+                    a = ktime.setdefault(name, [0.0, 0])
+                    a[0] += ms
+                    a[1] += 1
+                st = m.frame_stats()
+                algo_bytes.append(2 * fsz + 10 * (st["n_hit_cells"] + st["n_miss_cells"]))
+
+    def barrier():
+        m.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for s in range(W):
+        run_step(s, False)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        run_step(s, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        fps = world * K * B / dt
+        # dominant kernel = largest summed device time
+        dom = max(ktime.items(), key=lambda kv: kv[1][0]) if ktime else None
+        mean_bytes = float(np.mean(algo_bytes)) if algo_bytes else 0.0
+        roof = None
+        if dom:
+            avg_ms = dom[1][0] / dom[1][1]
+            launches_per_frame = dom[1][1] / max(1, len(algo_bytes))
+            ach = mean_bytes / launches_per_frame / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom[0], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_ms * 1e3,
+                    "algorithmic_bytes_per_frame": mean_bytes,
+                    "kernels_us_per_frame": {k: v[0] * 1e3 / max(1, len(algo_bytes)) for k, v in ktime.items()}}
+        out = {
+            "metric": "depth frames/s into local map", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 index / f32 log-odds", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg2: 640x480 room+jitter stream, random SE(3) poses, S1 0.1 m map"
+                       if args.workload == "cfg2" else "BASELINE cfg3: 1280x720 room+jitter stream, S3 0.05 m map",
+                       "frames_per_step": B, "streams": world, "parallelism": f"{world} independent streams"},
+            "achieved_hbm_gbs_whole_path": fps * mean_bytes / 1e9,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, frames, q, t, args.cpu_budget)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
