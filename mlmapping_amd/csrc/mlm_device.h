@@ -188,3 +188,23 @@ __device__ __forceinline__ unsigned int mlm_wave_append(unsigned int *counter, b
     base = __shfl(base, leader, 64);
     return base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
 }
+
+// Block-aggregated append into one of MLM_RAY_LISTS sub-lists (chosen by blockIdx, so that blocks of different
+// XCDs hit different counter cache lines): one global atomic per block.  Every thread of the block must call it
+// at the same point.  s_cnt needs blockDim/64 entries.  Returns the position inside sub-list (blockIdx.x & 7).
+__device__ __forceinline__ unsigned int mlm_block_append(unsigned int (*ctr)[32], bool flag, unsigned int *s_cnt,
+                                                         unsigned int *s_base) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_cnt[wid] = (unsigned int)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int w = 0; w < nw; ++w) tot += s_cnt[w];
+        *s_base = tot ? atomicAdd(&ctr[blockIdx.x & 7][0], tot) : 0u;
+    }
+    __syncthreads();
+    unsigned int pos = *s_base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) pos += s_cnt[w];
+    return pos;
+}

@@ -3,7 +3,7 @@
 // Stage A  (awareness_map_cylindrical::input_pc_pose, map_awareness.cpp:173-282)
 //   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions, de-duplicated ray walk
 //   k_collect_hits    dense sweep of the hit scratch -> unique-hit list + per-cell contribution segments
-//   k_scatter_contribs / k_noisy_or   point-order replay of the float noisy-OR chain -> odd, logit
+//   k_scatter_contribs / k_sort_contribs / k_chain   point-order replay of the float noisy-OR chain -> odd, logit
 // Stage B  (iteration order of hit_idx_odds_hashmap, i.e. libstdc++ _Hashtable list order)
 //   k_bucket_min / k_make_keys (+ rank kernels on rehash frames)
 // Stage C  (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237)
@@ -13,6 +13,7 @@
 #include "mlm_device.h"
 
 #define MLM_BLOCK 256
+#define MLM_TOUCH_LDS 1536 // first-touch buffer of one k_bin_points block
 
 __device__ __forceinline__ void mlm_cell_rpz(const MlmDev &P, uint32_t cell, int &rho, int &phi, int &z) {
     z = (int)(cell / (uint32_t)P.nRhoPhi);
@@ -25,31 +26,57 @@ __device__ __forceinline__ void mlm_cell_rpz(const MlmDev &P, uint32_t cell, int
 // Stage A
 // ---------------------------------------------------------------------------------------------------------------
 // A hit contribution is identified by its insertion time t = point*21 + sub, sub = 0 (centre), 2d-1 (+d
-// neighbour), 2d (-d neighbour): the order update_hits inserts them (map_awareness.cpp:146-168).
-__device__ __forceinline__ void mlm_count_contribution(const MlmDev &P, int cell, uint32_t t) {
-    atomicMin(&P.hit_t[cell], t);
-    atomicAdd(&P.hit_cnt[cell], 1u);
-}
+// neighbour), 2d (-d neighbour): the order update_hits inserts them (map_awareness.cpp:146-168).  Its odd is
+// get_odds_table[row(sub)][rho of the point], so (cell, sub) fixes the value.
 
-// Enumerate the contributions of one in-range point (update_hits, map_awareness.cpp:135-171).
-template <class F> __device__ __forceinline__ void mlm_for_each_contribution(const MlmDev &P, int rho, int phi, int zi,
-                                                                            uint32_t t0, F &&f) {
-    const int c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
-    f(c0, t0);
-    const float s3 = P.sigma3[rho];
-    if (!(1.0f < s3)) return;
-    const double slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0; // raycasting_z_over_rho, map_awareness.cpp:64-71
-    for (int d = 1; (float)d < s3 && (rho + d < P.nRho) && d <= MLM_DIFF_RANGE; ++d) {
-        int rz = mlm_cvt_int(round(zi + (d * slope)));
-        if (0 <= rz && rz < P.nZ) f(rz * P.nRhoPhi + phi * P.nRho + rho + d, t0 + 2 * d - 1);
-        rz = mlm_cvt_int(round(zi - (d * slope)));
-        if (0 <= rz && rz < P.nZ && rho - d >= 0) f(rz * P.nRhoPhi + phi * P.nRho + rho - d, t0 + 2 * d);
+// Split the wave into groups of lanes holding the same key and run f(key, lane mask) on each group's lowest
+// lane.  Must be called by all 64 lanes.  Neighbouring pixels share awareness cells, so this turns ~64 global
+// atomics on a handful of addresses into a handful of atomics.
+template <class F> __device__ __forceinline__ void mlm_wave_groups(int key, bool valid, F &&f) {
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const unsigned long long m = __ballot(valid && key == k);
+        if (lane == leader) f(k, m);
+        todo &= ~m;
     }
 }
 
-// ray walk, map_awareness.cpp:266-274: r = rho-1 .. 1, z' = round(z - (rho-r)*slope).  Bits of one (phi,z') row
-// that fall into the same 32-bit word are OR-ed in registers and flushed with one atomic.
-__device__ __forceinline__ void mlm_walk_ray(const MlmDev &P, int rho, int phi, int z, double slope) {
+// One block = 4 waves; in dense mode a wave owns an 8x8 pixel tile (lanes row-major inside the tile, so a lower
+// lane always has the smaller pixel index = earlier insertion time) and the block a 32x8 strip.
+struct MlmTile {
+    int i;      // work item (pixel index / list position / point index), -1 = none
+    bool valid;
+};
+template <int MODE> __device__ __forceinline__ MlmTile mlm_tile_item(const MlmFrame &F) {
+    MlmTile t;
+    if (MODE == 0) {
+        const int tiles_x = (F.width + 31) >> 5;
+        const int by = blockIdx.x / tiles_x;
+        const int bx = blockIdx.x - by * tiles_x;
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const int px = bx * 32 + w * 8 + (l & 7);
+        const int py = by * 8 + (l >> 3);
+        t.valid = px < F.width && py < F.height;
+        t.i = py * F.width + px;
+    } else {
+        t.i = blockIdx.x * blockDim.x + threadIdx.x;
+        t.valid = t.i < F.n;
+    }
+    return t;
+}
+
+// ray walk, map_awareness.cpp:243-274, from the binned start (rho,phi,z) of a point (in range or not):
+// slope = (z - zc)/rho, clamp to the outer border, then r = rho-1 .. 1, z' = round(z - (rho-r)*slope).
+// Bits of one (phi,z') row that fall into the same 32-bit word are OR-ed in registers and flushed with one atomic.
+__device__ __forceinline__ void mlm_walk_ray(const MlmDev &P, int rho, int phi, int z) {
+    const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
+    if (rho >= P.nRho) {
+        z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
+        rho = P.nRho - 1;
+    }
     int cur_w = -1;
     uint32_t cur_m = 0;
     for (int r = rho - 1; r > 0; --r) {
@@ -68,181 +95,390 @@ __device__ __forceinline__ void mlm_walk_ray(const MlmDev &P, int rho, int phi, 
     if (cur_m) atomicOr(&P.miss_bits[cur_w], cur_m);
 }
 
+// neighbour cells of the noise spread (update_hits, map_awareness.cpp:149-168) for step d; -1 = none
+__device__ __forceinline__ void mlm_spread_cells(const MlmDev &P, int rho, int phi, int zi, int d, int &c_plus,
+                                                 int &c_minus) {
+    c_plus = -1;
+    c_minus = -1;
+    const double slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0; // raycasting_z_over_rho, map_awareness.cpp:64-71
+    int rz = mlm_cvt_int(round(zi + (d * slope)));
+    if (0 <= rz && rz < P.nZ) c_plus = rz * P.nRhoPhi + phi * P.nRho + rho + d;
+    rz = mlm_cvt_int(round(zi - (d * slope)));
+    if (0 <= rz && rz < P.nZ && rho - d >= 0) c_minus = rz * P.nRhoPhi + phi * P.nRho + rho - d;
+}
+__device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int d, float s3) {
+    return (float)d < s3 && (rho + d < P.nRho) && d <= MLM_DIFF_RANGE;
+}
+
 // MODE 0: dense depth image, 1: indexed depth pixels, 2: explicit sensor-frame points
 template <int MODE>
 __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const MlmFrame F) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= F.n) return;
-    double xs, ys, zs;
-    if (MODE == 2) {
-        xs = F.pts[3 * (size_t)i + 0];
-        ys = F.pts[3 * (size_t)i + 1];
-        zs = F.pts[3 * (size_t)i + 2];
-    } else {
-        const int pix = (MODE == 1) ? F.pix[i] : i;
-        const int v = pix / F.width;
-        const int u = pix - v * F.width;
-        const uint16_t raw = F.img[(size_t)v * F.row_stride + u];
-        if (raw == 0) { // mlmap.cpp:338-341
-            P.pt_cell[i] = -1;
-            return;
+    __shared__ unsigned int s_cnt[4];
+    __shared__ unsigned int s_base;
+    __shared__ unsigned int s_ntouch, s_tbase;
+    __shared__ uint32_t s_touch[MLM_TOUCH_LDS];
+    if (threadIdx.x == 0) s_ntouch = 0;
+    __syncthreads();
+    const MlmTile T = mlm_tile_item<MODE>(F);
+    const int i = T.i;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bool have = T.valid;
+    double xs = 0, ys = 0, zs = 0;
+    if (have) {
+        if (MODE == 2) {
+            xs = F.pts[3 * (size_t)i + 0];
+            ys = F.pts[3 * (size_t)i + 1];
+            zs = F.pts[3 * (size_t)i + 2];
+        } else {
+            const int pix = (MODE == 1) ? F.pix[i] : i;
+            const int v = pix / F.width;
+            const int u = pix - v * F.width;
+            const uint16_t raw = F.img[(size_t)v * F.row_stride + u];
+            if (raw == 0) { // mlmap.cpp:338-341
+                have = false;
+            } else {
+                // mlmap.cpp:329,344-346: (size_t u - float cx_) is a float subtraction, the rest is double
+                const double depth = raw * P.inv_factor;
+                xs = ((float)u - P.cx) * depth / P.fx;
+                ys = ((float)v - P.cy) * depth / P.fy;
+                zs = depth;
+            }
         }
-        // mlmap.cpp:329,344-346: (size_t u - float cx_) is a float subtraction, the rest is double
-        const double depth = raw * P.inv_factor;
-        xs = ((float)u - P.cx) * depth / P.fx;
-        ys = ((float)v - P.cy) * depth / P.fy;
-        zs = depth;
     }
-    atomicAdd(&P.ctr->n_points, 1u);
-
-    // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
-    double x, y, z;
-    mlm_quat_rot(F.q_ls, xs, ys, zs, x, y, z);
-    x = x + F.t_ls[0];
-    y = y + F.t_ls[1];
-    z = z + F.t_ls[2];
-
-    int rho, phi, zi;
-    bool can_do_cast;
-    const bool inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
+    int rho = 0, phi = 0, zi = 0, c0 = -1;
+    bool can_do_cast = false, inside = false;
+    if (have) {
+        // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
+        double x, y, z;
+        mlm_quat_rot(F.q_ls, xs, ys, zs, x, y, z);
+        x = x + F.t_ls[0];
+        y = y + F.t_ls[1];
+        z = z + F.t_ls[2];
+        inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
+        if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
+    }
+    if (T.valid) P.pt_cell[i] = c0;
     const uint32_t t0 = (uint32_t)i * MLM_TIME_SLOTS;
-    bool walk = false;
-    double slope = 0;
-    int c0 = -1;
 
-    if (inside) {
-        c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
-        slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0;
-        mlm_for_each_contribution(P, rho, phi, zi, t0, [&](int cell, uint32_t t) { mlm_count_contribution(P, cell, t); });
+    // ---- hit contributions: centre, then the +-d noise spread
+    bool emit_ray = false; // this lane queues a ray for (rho,phi,zi)
+    // the lane whose atomicMin finds the cell untouched queues it for k_collect_hits (block-local LDS buffer)
+    auto touch = [&](int cell, uint32_t t) {
+        if (atomicMin(&P.hit_t[cell], t) == MLM_EMPTY_T) {
+            const unsigned int k = atomicAdd(&s_ntouch, 1u);
+            if (k < MLM_TOUCH_LDS)
+                s_touch[k] = (uint32_t)cell;
+            else { // LDS buffer full: queue directly
+                const unsigned int g = atomicAdd(&P.ctr->touch_cnt[blockIdx.x & 7][0], 1u);
+                if (g < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + g] = (uint32_t)cell;
+            }
+        }
+    };
+    mlm_wave_groups(c0, inside, [&](int cell, unsigned long long m) {
+        touch(cell, t0);
+        atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
+        atomicOr(&P.hit_mask[cell], 1u);
         if (P.visibility) {
-            // every point of one (rho,phi,z) cell casts the identical ray: only the first one walks it
-            const uint32_t bit = 1u << (c0 & 31);
-            const uint32_t old = atomicOr(&P.start_bits[c0 >> 5], bit);
-            walk = (old & bit) == 0;
+            // every point of one (rho,phi,z) cell casts the identical ray: only the first one queues it
+            const uint32_t bit = 1u << (cell & 31);
+            const uint32_t old = atomicOr(&P.start_bits[cell >> 5], bit);
+            emit_ray = (old & bit) == 0;
         }
-    } else if (can_do_cast && P.visibility) {
-        // map_awareness.cpp:249-265: slope from the point's own (out-of-range) indices, clamp to the border
-        slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0;
-        if (rho >= P.nRho) {
-            zi = mlm_cvt_int(round(zi - ((rho - P.nRho + 1) * slope)));
-            rho = P.nRho - 1;
-        }
-        walk = true;
-    }
-    P.pt_cell[i] = c0;
-    if (!(can_do_cast && P.visibility)) atomicAdd(&P.ctr->n_oor, 1u); // map_awareness.cpp:277-278
-    if (walk) mlm_walk_ray(P, rho, phi, zi, slope);
-}
-
-// One thread per awareness cell: emit the unique hit cells, carve a segment of `contrib` for each, and reset
-// hit_t for the next frame (hit_cnt is consumed — and thereby zeroed — by k_scatter_contribs).
-__global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t t = MLM_EMPTY_T;
-    if (c < P.nCells) t = P.hit_t[c];
-    const bool has = (t != MLM_EMPTY_T);
-    const unsigned int pos = mlm_wave_append(&P.ctr->u_hit, has);
-    const uint32_t cnt = has ? P.hit_cnt[c] : 0u;
-    // wave-inclusive prefix sum of cnt, one atomic per wave for the segment space
-    const int lane = threadIdx.x & 63;
-    uint32_t incl = cnt;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    const uint32_t total = __shfl(incl, 63, 64);
-    uint32_t wave_base = 0;
-    if (lane == 63 && total) wave_base = atomicAdd(&P.ctr->n_contrib, total);
-    wave_base = __shfl(wave_base, 63, 64);
-    if (!has) return;
-    const uint32_t base = wave_base + incl - cnt;
-    P.hit_t[c] = MLM_EMPTY_T;
-    P.seg_base[c] = base;
-    P.hl_cell[pos] = (uint32_t)c;
-    P.hl_t[pos] = t;
-    P.hl_vt[pos] = t;
-    P.hl_base[pos] = base;
-    P.hl_cnt[pos] = cnt;
-}
-
-// Second sweep over the points: write each contribution's insertion time into its cell's segment.
-__global__ __launch_bounds__(MLM_BLOCK) void k_scatter_contribs(const MlmDev P, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c0 = P.pt_cell[i];
-    if (c0 < 0) return;
-    int rho, phi, zi;
-    mlm_cell_rpz(P, (uint32_t)c0, rho, phi, zi);
-    mlm_for_each_contribution(P, rho, phi, zi, (uint32_t)i * MLM_TIME_SLOTS, [&](int cell, uint32_t t) {
-        const uint32_t k = atomicSub(&P.hit_cnt[cell], 1u) - 1u;
-        const uint32_t slot = P.seg_base[cell] + k;
-        if (slot < P.contrib_cap) P.contrib[slot] = t;
     });
+    const float s3 = inside ? P.sigma3[rho] : 0.0f;
+    for (int d = 1; __any(inside && mlm_spread_active(P, rho, d, s3)); ++d) {
+        int cp = -1, cm = -1;
+        if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, cp, cm);
+        mlm_wave_groups(cp, cp >= 0, [&](int cell, unsigned long long m) {
+            touch(cell, t0 + 2 * d - 1);
+            atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
+            atomicOr(&P.hit_mask[cell], 1u << (2 * d - 1));
+        });
+        mlm_wave_groups(cm, cm >= 0, [&](int cell, unsigned long long m) {
+            touch(cell, t0 + 2 * d);
+            atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
+            atomicOr(&P.hit_mask[cell], 1u << (2 * d));
+        });
+    }
+    // ---- points outside the map that can still cast (map_awareness.cpp:241,249-265): identical starts inside
+    //      the wave are merged, across waves they are simply walked again (idempotent bit sets)
+    const bool outer = have && !inside && can_do_cast && P.visibility;
+    {
+        unsigned long long todo = __ballot(outer);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int kr = __shfl(rho, leader, 64), kp = __shfl(phi, leader, 64), kz = __shfl(zi, leader, 64);
+            const unsigned long long m = __ballot(outer && rho == kr && phi == kp && zi == kz);
+            if (lane == leader) emit_ray = true;
+            todo &= ~m;
+        }
+    }
+    // ---- statistics: per-block partial sums, no atomics
+    const unsigned int n_pts = (unsigned int)__popcll(__ballot(have));
+    const unsigned int n_oor = (unsigned int)__popcll(__ballot(have && !(can_do_cast && P.visibility)));
+    // ---- queue the rays: one global atomic per block, sub-list chosen by blockIdx so that the counters of
+    //      different XCDs live in different cache lines
+    const unsigned long long em = __ballot(emit_ray);
+    if (lane == 0) s_cnt[wid] = (unsigned int)__popcll(em) | (n_pts << 10) | (n_oor << 20);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int rays = 0, pts = 0, oor = 0;
+        for (int w = 0; w < 4; ++w) {
+            rays += s_cnt[w] & 1023u;
+            pts += (s_cnt[w] >> 10) & 1023u;
+            oor += s_cnt[w] >> 20;
+        }
+        P.blk_stats[2 * blockIdx.x] = pts;
+        P.blk_stats[2 * blockIdx.x + 1] = oor;
+        s_base = rays ? atomicAdd(&P.ctr->ray_cnt[blockIdx.x & 7][0], rays) : 0u;
+    }
+    __syncthreads();
+    if (emit_ray) {
+        unsigned int pos = s_base + (unsigned int)__popcll(em & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wid; ++w) pos += s_cnt[w] & 1023u;
+        if (pos < P.ray_cap) {
+            int32_t *r = P.rays + ((size_t)(blockIdx.x & 7) * P.ray_cap + pos) * 3;
+            r[0] = rho;
+            r[1] = phi;
+            r[2] = zi;
+        }
+    }
+    // ---- flush the first-touch buffer: one global atomic per block
+    const unsigned int nt = min(s_ntouch, (unsigned int)MLM_TOUCH_LDS); // all LDS atomics precede the barriers above
+    if (threadIdx.x == 0) s_tbase = nt ? atomicAdd(&P.ctr->touch_cnt[blockIdx.x & 7][0], nt) : 0u;
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
+        if (s_tbase + k < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + s_tbase + k] = s_touch[k];
 }
 
-__device__ __forceinline__ uint32_t mlm_wave_min_u32(uint32_t v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
+// one ray per lane
+__global__ __launch_bounds__(MLM_BLOCK) void k_walk_rays(const MlmDev P) {
+    const unsigned int k = blockIdx.y;
+    const unsigned int n = min(P.ctr->ray_cnt[k][0], P.ray_cap);
+    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const int32_t *q = P.rays + ((size_t)k * P.ray_cap + r) * 3;
+        mlm_walk_ray(P, q[0], q[1], q[2]);
+    }
+}
+
+__device__ __forceinline__ uint32_t mlm_wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
     }
     return v;
 }
 
-// One wave per unique hit cell: replay update_odds_hashmap (map_awareness.h:147-154) over the cell's contributions
-// in insertion-time order — the float noisy-OR chain is not associative, so the order is part of the result.
-// p == 1.0f is absorbing (1-(1-1)(1-a) == 1), which ends long chains after a few steps.
-__global__ __launch_bounds__(MLM_BLOCK) void k_noisy_or(const MlmDev P) {
-    const unsigned int n_cells = P.ctr->u_hit;
-    const int lane = threadIdx.x & 63;
-    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned int w = wave; w < n_cells; w += n_waves) {
-        const uint32_t cell = P.hl_cell[w];
-        const uint32_t base = P.hl_base[w];
-        const uint32_t n = P.hl_cnt[w];
-        const int rho_c = (int)(cell % (uint32_t)P.nRho);
-        // keys of the first 64 contributions stay in registers
-        const uint32_t k0 = ((uint32_t)lane < n) ? P.contrib[base + lane] : 0xFFFFFFFFu;
-        float p = 0.0f;
-        bool first = true;
-        long long last = -1;
-        for (;;) {
-            uint32_t m = ((long long)k0 > last) ? k0 : 0xFFFFFFFFu;
-            for (uint32_t j = 64 + lane; j < n; j += 64) {
-                const uint32_t k = P.contrib[base + j];
-                if ((long long)k > last && k < m) m = k;
-            }
-            m = mlm_wave_min_u32(m);
-            if (m == 0xFFFFFFFFu) break;
-            // decode: sub 0 -> centre; 2d-1 -> "+d" neighbour of a point at rho_c-d; 2d -> "-d" neighbour of rho_c+d
-            const int sub = (int)(m % MLM_TIME_SLOTS);
-            int row = MLM_DIFF_RANGE, rho_s = rho_c;
-            if (sub > 0) {
-                const int d = (sub + 1) >> 1;
-                if (sub & 1) {
-                    row = MLM_DIFF_RANGE + d;
-                    rho_s = rho_c - d;
-                } else {
-                    row = MLM_DIFF_RANGE - d;
-                    rho_s = rho_c + d;
-                }
-            }
-            const float a = P.odds_table[row * P.nRho + rho_s];
-            if (first) {
-                p = a;
-                first = false;
-            } else {
-                p = 1 - (1 - p) * (1 - a);
-            }
-            last = (long long)m;
-            if (p == 1.0f) break;
+// odd of the contribution kind `sub` into a cell at rho_c (see the top of this section)
+__device__ __forceinline__ float mlm_contribution_odd(const MlmDev &P, const float *table, int rho_c, int sub) {
+    int row = MLM_DIFF_RANGE, rho_s = rho_c;
+    if (sub > 0) {
+        const int d = (sub + 1) >> 1;
+        if (sub & 1) {
+            row = MLM_DIFF_RANGE + d;
+            rho_s = rho_c - d;
+        } else {
+            row = MLM_DIFF_RANGE - d;
+            rho_s = rho_c + d;
+        }
+    }
+    return table[row * P.nRho + rho_s];
+}
+// logit macro, map_local.h:8, on a float: log10f(x / (1 - x))
+__device__ __forceinline__ float mlm_logit(float p) {
+    const float ratio = p / (1 - p);
+    return (float)log10((double)ratio);
+}
+
+// One thread per first-touched cell (queued by k_bin_points): build the compact unique-hit list
+//  - cell, first-touch time;
+//  - cells with a single kind of contribution: odd (n applications of one value commute) and its logit;
+//  - cells with several kinds: a segment of `contrib` for the point-order replay (k_sort_contribs / k_chain);
+// and reset hit_t / hit_mask (and hit_cnt of single-kind cells) for the next frame.  gridDim.y = sub-list.
+__global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int n_stat_blocks) {
+    __shared__ uint32_t s_w[3][4];
+    __shared__ uint32_t s_base[3];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && wid == 0) { // fold the per-block statistics of k_bin_points
+        unsigned int a = 0, b = 0;
+        for (int j = lane; j < n_stat_blocks; j += 64) {
+            a += P.blk_stats[2 * j];
+            b += P.blk_stats[2 * j + 1];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, 64);
+            b += __shfl_xor(b, off, 64);
         }
         if (lane == 0) {
-            // logit macro, map_local.h:8, on a float: log10f(x / (1 - x))
-            const float ratio = p / (1 - p);
-            P.hl_odd[w] = p;
-            P.hl_inc[w] = (float)log10((double)ratio);
+            P.ctr->n_points = a;
+            P.ctr->n_oor = b;
         }
+    }
+    const unsigned int k = blockIdx.y;
+    const unsigned int n = min(P.ctr->touch_cnt[k][0], P.touch_cap);
+    for (unsigned int r0 = blockIdx.x * blockDim.x; r0 < n; r0 += gridDim.x * blockDim.x) { // uniform per block
+        const unsigned int r = r0 + threadIdx.x;
+        const bool has = r < n;
+        uint32_t c = 0, t = 0, mask = 0, cnt = 0;
+        if (has) {
+            c = P.touched[(size_t)k * P.touch_cap + r];
+            t = P.hit_t[c];
+            mask = P.hit_mask[c];
+            cnt = P.hit_cnt[c];
+        }
+        const bool multi = has && __popc(mask) > 1;
+        const unsigned long long bh = __ballot(has), bm = __ballot(multi);
+        const uint32_t cincl = mlm_wave_incl_scan(multi ? cnt : 0u);
+        if (lane == 63) {
+            s_w[0][wid] = (uint32_t)__popcll(bh);
+            s_w[1][wid] = (uint32_t)__popcll(bm);
+            s_w[2][wid] = cincl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 4; ++w) tot += s_w[threadIdx.x][w];
+            unsigned int *ctr = threadIdx.x == 0 ? &P.ctr->u_hit : (threadIdx.x == 1 ? &P.ctr->n_multi : &P.ctr->n_contrib);
+            s_base[threadIdx.x] = tot ? atomicAdd(ctr, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t off_h = s_base[0], off_m = s_base[1], off_c = s_base[2];
+        for (int w = 0; w < wid; ++w) {
+            off_h += s_w[0][w];
+            off_m += s_w[1][w];
+            off_c += s_w[2][w];
+        }
+        if (has) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const uint32_t pos = off_h + (uint32_t)__popcll(bh & below);
+            P.hit_t[c] = MLM_EMPTY_T;
+            P.hit_mask[c] = 0;
+            P.hl_cell[pos] = c;
+            P.hl_t[pos] = t;
+            P.hl_vt[pos] = t;
+            if (multi) {
+                const uint32_t base = off_c + cincl - cnt;
+                P.seg_base[c] = base;
+                P.hl_base[pos] = base;
+                P.hl_cnt[pos] = cnt;
+                P.mt_list[off_m + (uint32_t)__popcll(bm & below)] = pos;
+            } else {
+                // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
+                P.hit_cnt[c] = 0;
+                const int rho_c = (int)(c % (uint32_t)P.nRho);
+                const float a = mlm_contribution_odd(P, P.odds_table, rho_c, __ffs((int)mask) - 1);
+                float p = a;
+                for (uint32_t j = 1; j < cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
+                P.hl_odd[pos] = p;
+                P.hl_inc[pos] = mlm_logit(p);
+                P.hl_cnt[pos] = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Second sweep over the points: for cells that received several kinds of contribution, write each
+// contribution's insertion time into the cell's segment (hit_cnt counts down as the fill cursor).  Lanes of a
+// wave that feed the same cell share one atomic.
+__device__ __forceinline__ void mlm_scatter_put(const MlmDev &P, int cell, bool valid, uint32_t t) {
+    valid = valid && P.hit_cnt[cell] != 0; // single-kind cells were resolved (and zeroed) by k_collect_hits
+    unsigned long long todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(cell, leader, 64);
+        const bool mine = valid && cell == k;
+        const unsigned long long m = __ballot(mine);
+        uint32_t v = 0;
+        if (lane == leader) v = atomicSub(&P.hit_cnt[k], (unsigned int)__popcll(m));
+        v = __shfl(v, leader, 64);
+        if (mine) {
+            const uint32_t slot = P.seg_base[k] + v - 1u - (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (slot < P.contrib_cap) P.contrib[slot] = t;
+        }
+        todo &= ~m;
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(MLM_BLOCK) void k_scatter_contribs(const MlmDev P, const MlmFrame F) {
+    const MlmTile T = mlm_tile_item<MODE>(F);
+    const int c0 = T.valid ? P.pt_cell[T.i] : -1;
+    const bool inside = c0 >= 0;
+    int rho = 0, phi = 0, zi = 0;
+    if (inside) mlm_cell_rpz(P, (uint32_t)c0, rho, phi, zi);
+    const uint32_t t0 = (uint32_t)T.i * MLM_TIME_SLOTS;
+    mlm_scatter_put(P, c0, inside, t0);
+    const float s3 = inside ? P.sigma3[rho] : 0.0f;
+    for (int d = 1; __any(inside && mlm_spread_active(P, rho, d, s3)); ++d) {
+        int cp = -1, cm = -1;
+        if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, cp, cm);
+        mlm_scatter_put(P, cp, cp >= 0, t0 + 2 * d - 1);
+        mlm_scatter_put(P, cm, cm >= 0, t0 + 2 * d);
+    }
+}
+
+// One wave per multi-kind hit cell: order the cell's contributions by insertion time (rank by counting in LDS)
+// and store their kinds (`sub`) in that order.
+#define MLM_SORT_CAP 4096 // keys per wave held in LDS
+#define MLM_SORT_THREADS 128
+__global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev P) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_SORT_THREADS / 64][MLM_SORT_CAP];
+    const unsigned int n_cells = P.ctr->n_multi;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    volatile uint32_t *K = s_keys[wid];
+    for (unsigned int w = wave; w < n_cells; w += n_waves) {
+        const uint32_t pos = P.mt_list[w];
+        const uint32_t base = P.hl_base[pos];
+        const uint32_t n = P.hl_cnt[pos];
+        if (n <= MLM_SORT_CAP) {
+            const uint32_t n4 = (n + 3u) & ~3u;
+            for (uint32_t j = lane; j < n4; j += 64) K[j] = j < n ? P.contrib[base + j] : 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave execute in order
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < n; j += 64) {
+                const uint32_t my = K[j];
+                uint32_t r = 0;
+                for (uint32_t q = 0; q < n4; q += 4) {
+                    const uint4 v = *(const uint4 *)(const_cast<uint32_t *>(&s_keys[wid][q]));
+                    r += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
+                }
+                P.subs[base + r] = (uint8_t)(my % MLM_TIME_SLOTS);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // larger than the LDS window: same rank-by-counting straight from memory (rare, slow, exact)
+            for (uint32_t j = lane; j < n; j += 64) {
+                const uint32_t my = P.contrib[base + j];
+                uint32_t r = 0;
+                for (uint32_t q = 0; q < n; ++q) r += P.contrib[base + q] < my;
+                P.subs[base + r] = (uint8_t)(my % MLM_TIME_SLOTS);
+            }
+        }
+    }
+}
+
+// One lane per multi-kind hit cell: replay update_odds_hashmap (map_awareness.h:147-154) over the ordered kinds —
+// the float noisy-OR chain is not associative, so the order is part of the result.  p == 1.0f is absorbing
+// (1-(1-1)(1-a) == 1), which ends long chains early.
+__global__ __launch_bounds__(MLM_BLOCK) void k_chain(const MlmDev P) {
+    const unsigned int n_cells = P.ctr->n_multi;
+    for (unsigned int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_cells; w += gridDim.x * blockDim.x) {
+        const uint32_t pos = P.mt_list[w];
+        const uint32_t base = P.hl_base[pos];
+        const uint32_t n = P.hl_cnt[pos];
+        const int rho_c = (int)(P.hl_cell[pos] % (uint32_t)P.nRho);
+        float p = mlm_contribution_odd(P, P.odds_table, rho_c, P.subs[base]);
+        for (uint32_t j = 1; j < n && p != 1.0f; ++j) {
+            const float a = mlm_contribution_odd(P, P.odds_table, rho_c, P.subs[base + j]);
+            p = 1 - (1 - p) * (1 - a);
+        }
+        P.hl_odd[pos] = p;
+        P.hl_inc[pos] = mlm_logit(p);
     }
 }
 
@@ -358,46 +594,59 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_hits(const MlmDev P, unsign
     P.vox_head[v] = -1;
 }
 
-// One thread per word of the miss bit mask: count the frame's misses per voxel (their order is irrelevant:
-// every miss adds the same constant, map_local.cpp:188-192) and clear the word.
+// One thread per bit of the miss mask (= per awareness cell, in mask order): count the frame's misses per voxel
+// (their order is irrelevant: every miss adds the same constant, map_local.cpp:188-192) and clear the mask.
 __global__ __launch_bounds__(MLM_BLOCK) void k_misses_to_voxels(const MlmDev P, const MlmFrame F) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
+    __shared__ unsigned int s_base;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = (int)(g >> 5), b = (int)(g & 31);
     uint32_t bits = 0;
     if (w < P.nMissWords) bits = P.miss_bits[w];
-    if (bits == 0) return;
-    P.miss_bits[w] = 0;
-    atomicAdd(&P.ctr->u_miss, (unsigned int)__popc(bits));
-    const int row = w / P.RW;
-    const int wi = w - row * P.RW;
-    const int z = row / P.nPhi;
-    const int phi = row - z * P.nPhi;
-    while (bits) {
-        const int b = __ffs((int)bits) - 1;
-        bits &= bits - 1;
+    const bool set = (bits >> b) & 1u;
+    bool fresh = false; // first miss of its voxel this frame
+    int v = -1;
+    if (set) {
+        const int row = w / P.RW;
+        const int wi = w - row * P.RW;
+        const int z = row / P.nPhi;
+        const int phi = row - z * P.nPhi;
         const int rho = wi * 32 + b;
-        if (P.record_awareness) {
-            const unsigned int pos = atomicAdd(&P.ctr->n_miss_list, 1u);
-            P.ml_cell[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
-        }
         double wx, wy, wz;
         mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
         int gx, gy, gz, cid;
         mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-        const int slot = mlm_block_find_or_insert(P, gx, gy, gz);
-        if (slot < 0) continue;
-        const int v = slot * P.cells + cid;
-        const uint32_t old = atomicAdd(&P.vox_miss[v], 1u);
-        if (old == 0) {
-            const unsigned int pos = atomicAdd(&P.ctr->n_miss_vox, 1u);
-            P.miss_vox[pos] = v;
+        int slot = mlm_block_find(P, gx, gy, gz); // plain loads; blocks almost always exist already
+        if (slot == -1) slot = mlm_block_find_or_insert(P, gx, gy, gz);
+        if (slot >= 0) {
+            v = slot * P.cells + cid;
+            fresh = atomicAdd(&P.vox_miss[v], 1u) == 0;
+        }
+        if (P.record_awareness) {
+            const unsigned int pos = atomicAdd(&P.ctr->n_miss_list, 1u);
+            P.ml_cell[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
         }
     }
+    if (b == 0 && bits) P.miss_bits[w] = 0; // all 32 lanes of the word loaded it in the instruction above
+    const unsigned int pos = mlm_block_append(P.ctr->mvox_cnt, fresh, s_cnt, &s_base);
+    if (fresh && pos < P.mvox_cap) P.miss_vox[(size_t)(blockIdx.x & 7) * P.mvox_cap + pos] = v;
+    // statistics: unique miss cells, one atomic per block on a counter spread by blockIdx
+    __syncthreads();
+    const unsigned long long sm = __ballot(set);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(sm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int k = 0; k < MLM_BLOCK / 64; ++k) tot += s_cnt[k];
+        if (tot) atomicAdd(&P.ctr->umiss_part[blockIdx.x & 7][0], tot);
+    }
 }
-// map_local.cpp:188-203, k times
+// map_local.cpp:188-203, k times.  gridDim.y = sub-list.
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_misses(const MlmDev P) {
-    const unsigned int n = P.ctr->n_miss_vox;
+    const unsigned int sl = blockIdx.y;
+    const unsigned int n = min(P.ctr->mvox_cnt[sl][0], P.mvox_cap);
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int v = P.miss_vox[i];
+        const int v = P.miss_vox[(size_t)sl * P.mvox_cap + i];
         const uint32_t k = P.vox_miss[v];
         P.vox_miss[v] = 0;
         float L = P.log_odds[v];

@@ -15,13 +15,18 @@ struct MlmCounters {
     unsigned int n_oor;       // "point out range"
     unsigned int n_miss_vox;  // voxels touched by misses this frame
     unsigned int n_miss_list; // entries of ml_cell (record_awareness only)
-    unsigned int n_contrib;   // hit contributions (centre + noise-spread neighbours) of this frame
-    unsigned int pad0;
+    unsigned int n_contrib;   // contributions stored for multi-type cells (segments of `contrib`)
+    unsigned int n_multi;     // hit cells that received more than one kind of contribution
+    unsigned int ray_cnt[8][32]; // [k][0] = rays queued in sub-list k (one per blockIdx & 7), 128 B apart
+    unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
+    unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
+    unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
     // persistent
     unsigned int n_blocks;    // allocated blocks
     unsigned int err;         // sticky error bits (1 = block pool / hash table full)
 };
-#define MLM_CTR_FRAME_BYTES 32
+#define MLM_CTR_FRAME_BYTES (32 + 4 * 8 * 32 * 4)
+#define MLM_RAY_LISTS 8
 
 struct MlmDev {
     // ---- awareness map constants (map_awareness.cpp:19-82)
@@ -46,9 +51,17 @@ struct MlmDev {
     // ---- per-frame awareness scratch
     uint32_t *hit_t;           // [nCells] first-touch time of a hit cell (min over contributions)
     uint32_t *hit_cnt;         // [nCells] number of contributions; reused as the fill cursor of the segment
+    uint32_t *hit_mask;        // [nCells] bit s set = a contribution of insertion slot s (0 centre, 2d-1 "+d", 2d "-d")
     uint32_t *seg_base;        // [nCells] start of the cell's segment in `contrib`
     uint32_t *contrib;         // [contrib_cap] insertion times of all contributions, grouped by cell
     int32_t *pt_cell;          // [max_points] hit-centre cell of each point, -1 = none
+    int32_t *rays;             // [MLM_RAY_LISTS][ray_cap][3] queued rays: binned (rho,phi,z) of the start
+    unsigned int ray_cap;      // per sub-list
+    unsigned int *blk_stats;   // [2*max tiles] per-block partial sums: points fed, points out of range
+    uint32_t *mt_list;         // [nCells] indices into the hit list of the multi-type cells
+    uint32_t *touched;         // [MLM_RAY_LISTS][touch_cap] hit cells in first-touch order of the GPU (arbitrary)
+    unsigned int touch_cap;    // per sub-list
+    uint8_t *subs;             // [contrib_cap] per multi-kind cell: contribution kinds in insertion-time order
     unsigned int contrib_cap;
     uint32_t *start_bits;      // [ceil(nCells/32)] hit-centre cells whose ray has been walked
     uint32_t *miss_bits;       // [nMissWords] free cells, row-major (z,phi) rows of RW words, bit = rho
@@ -78,7 +91,8 @@ struct MlmDev {
     uint8_t *infl;             // [max_blocks*cells]
     int *vox_head;             // [max_blocks*cells] head of this frame's pending hit list, -1 = none
     uint32_t *vox_miss;        // [max_blocks*cells] miss count of this frame
-    int *miss_vox;             // [max_blocks*cells] list of voxels touched by misses
+    int *miss_vox;             // [MLM_RAY_LISTS][mvox_cap] voxels touched by misses this frame
+    unsigned int mvox_cap;
     MlmCounters *ctr;
 };
 

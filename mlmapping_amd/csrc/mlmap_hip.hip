@@ -308,28 +308,48 @@ int integrate_frame(mlm_handle *h, const MlmFrame &F, int mode) {
     h->last = F;
     HIPCHK(h, hipMemsetAsync(P.ctr, 0, MLM_CTR_FRAME_BYTES, h->stream));
     HIPCHK(h, hipMemsetAsync(P.start_bits, 0, ((size_t)P.nCells + 31) / 32 * sizeof(uint32_t), h->stream));
+    unsigned int nb = 0;
     if (F.n > 0) {
-        Timed t(h, "k_bin_points");
-        const unsigned int g = grid_for((size_t)F.n);
-        if (mode == 0)
-            hipLaunchKernelGGL(k_bin_points<0>, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, F);
-        else if (mode == 1)
-            hipLaunchKernelGGL(k_bin_points<1>, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, F);
-        else
-            hipLaunchKernelGGL(k_bin_points<2>, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, F);
+        nb = (mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
+        if ((size_t)(nb / MLM_RAY_LISTS + 1) * MLM_BLOCK > P.ray_cap || nb > h->lim.max_points / 64 + 1024) {
+            h->err = "frame geometry exceeds the ray queue sized from mlm_limits.max_points";
+            return MLM_ERR_CAPACITY;
+        }
+        {
+            Timed t(h, "k_bin_points");
+            if (mode == 0)
+                hipLaunchKernelGGL(k_bin_points<0>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
+            else if (mode == 1)
+                hipLaunchKernelGGL(k_bin_points<1>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
+            else
+                hipLaunchKernelGGL(k_bin_points<2>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
+        }
+        if (P.visibility) {
+            Timed t(h, "k_walk_rays");
+            hipLaunchKernelGGL(k_walk_rays, dim3(32, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P);
+        }
     }
     {
         Timed t(h, "k_collect_hits");
-        hipLaunchKernelGGL(k_collect_hits, dim3(grid_for((size_t)P.nCells)), dim3(MLM_BLOCK), 0, h->stream, P);
+        hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, (int)nb);
     }
     if (F.n > 0) {
         {
             Timed t(h, "k_scatter_contribs");
-            hipLaunchKernelGGL(k_scatter_contribs, dim3(grid_for((size_t)F.n)), dim3(MLM_BLOCK), 0, h->stream, P, F.n);
+            if (mode == 0)
+                hipLaunchKernelGGL(k_scatter_contribs<0>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
+            else if (mode == 1)
+                hipLaunchKernelGGL(k_scatter_contribs<1>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
+            else
+                hipLaunchKernelGGL(k_scatter_contribs<2>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
         }
         {
-            Timed t(h, "k_noisy_or");
-            hipLaunchKernelGGL(k_noisy_or, dim3(2048), dim3(MLM_BLOCK), 0, h->stream, P);
+            Timed t(h, "k_sort_contribs");
+            hipLaunchKernelGGL(k_sort_contribs, dim3(2048), dim3(MLM_SORT_THREADS), 0, h->stream, P);
+        }
+        {
+            Timed t(h, "k_chain");
+            hipLaunchKernelGGL(k_chain, dim3(256), dim3(MLM_BLOCK), 0, h->stream, P);
         }
     }
     int rc = read_counters(h);
@@ -349,19 +369,23 @@ int integrate_frame(mlm_handle *h, const MlmFrame &F, int mode) {
     }
     {
         Timed t(h, "k_misses_to_voxels");
-        hipLaunchKernelGGL(k_misses_to_voxels, dim3(grid_for((size_t)P.nMissWords)), dim3(MLM_BLOCK), 0, h->stream, P,
-                           F);
+        hipLaunchKernelGGL(k_misses_to_voxels, dim3(grid_for((size_t)P.nMissWords * 32)), dim3(MLM_BLOCK), 0,
+                           h->stream, P, F);
     }
     {
         Timed t(h, "k_apply_misses");
-        hipLaunchKernelGGL(k_apply_misses, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, P);
+        hipLaunchKernelGGL(k_apply_misses, dim3(16, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P);
     }
     HIPCHK(h, hipGetLastError());
     rc = read_counters(h);
     if (rc) return rc;
     h->stats.n_points = h->h_ctr->n_points;
     h->stats.n_hit_cells = h->h_ctr->u_hit;
-    h->stats.n_miss_cells = h->h_ctr->u_miss;
+    {
+        unsigned int um = 0;
+        for (int k = 0; k < MLM_RAY_LISTS; ++k) um += h->h_ctr->umiss_part[k][0];
+        h->stats.n_miss_cells = um;
+    }
     h->stats.n_out_of_range = h->h_ctr->n_oor;
     h->stats.n_blocks = std::min<unsigned int>(h->h_ctr->n_blocks, (unsigned int)P.max_blocks);
     if (h->h_ctr->err) {
@@ -528,6 +552,13 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hit_cnt, NC))) return rc;
     if ((rc = dev_alloc(h, &P.seg_base, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hit_mask, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
+    P.touch_cap = (unsigned int)NC;
+    if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
+    P.ray_cap = (unsigned int)h->lim.max_points / 4u + 4096u;
+    if ((rc = dev_alloc(h, &P.rays, (size_t)MLM_RAY_LISTS * P.ray_cap * 3))) return rc;
+    if ((rc = dev_alloc(h, &P.blk_stats, 2 * ((size_t)h->lim.max_points / 64 + 1024)))) return rc;
     if ((rc = dev_alloc(h, &P.hl_base, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_cnt, NC))) return rc;
     if ((rc = dev_alloc(h, &P.pt_cell, (size_t)h->lim.max_points))) return rc;
@@ -546,6 +577,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         }
         P.contrib_cap = (unsigned int)cap;
         if ((rc = dev_alloc(h, &P.contrib, cap))) return rc;
+        if ((rc = dev_alloc(h, &P.subs, cap))) return rc;
     }
     if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
     if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
@@ -568,6 +600,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &P.bkt_first, h->max_buckets))) return rc;
     HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.hit_cnt, 0, NC * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.hit_mask, 0, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
 
@@ -584,7 +617,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &P.infl, NV))) return rc;
     if ((rc = dev_alloc(h, &P.vox_head, NV))) return rc;
     if ((rc = dev_alloc(h, &P.vox_miss, NV))) return rc;
-    if ((rc = dev_alloc(h, &P.miss_vox, std::min(NV, NC)))) return rc;
+    P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
+    if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
     if ((rc = dev_alloc(h, &P.ctr, 1))) return rc;
     HIPCHK(h, hipMemset(P.ht_keys, 0xFF, ht * sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(P.ht_slot, 0xFF, ht * sizeof(int)));
