@@ -115,6 +115,9 @@ int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int widt
  * Frames are integrated in order (the update is order dependent). */
 int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_frames, size_t frame_stride,
                                   int width, int height, int row_stride, const double *q_wb, const double *t_wb);
+/* same with host-resident frames (frame k at img_host + k*frame_stride); uploads overlap with compute */
+int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_frames, size_t frame_stride, int width,
+                              int height, int row_stride, const double *q_wb, const double *t_wb);
 /* replaces awareness_map_cylindrical::input_pc_pose(PC_s, T_wb) + input_pc_pose_direct on an explicit
  * sensor-frame point list (include/map_awareness.h:74) */
 int mlm_integrate_points(mlm_handle *h, const double *xyz_s_host, int n, const double q_wb[4],

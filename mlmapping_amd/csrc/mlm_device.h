@@ -151,9 +151,9 @@ __device__ __forceinline__ int mlm_block_find_or_insert(const MlmDev &P, int gx,
         } else if (k == MLM_HT_EMPTY) {
             const unsigned long long prev = atomicCAS(&P.ht_keys[h], MLM_HT_EMPTY, key);
             if (prev == MLM_HT_EMPTY) {
-                int s = (int)atomicAdd(&P.ctr->n_blocks, 1u);
+                int s = (int)atomicAdd(&P.g->n_blocks, 1u);
                 if (s >= P.max_blocks) {
-                    atomicOr(&P.ctr->err, 1u);
+                    atomicOr(&P.g->err, 1u);
                     s = -2; // published as "pool full"
                 } else {
                     P.block_keys[3 * s + 0] = gx;
@@ -168,7 +168,7 @@ __device__ __forceinline__ int mlm_block_find_or_insert(const MlmDev &P, int gx,
         } else {
             h = (h + 1) & P.ht_mask;
             if (++probes > P.ht_mask) {
-                atomicOr(&P.ctr->err, 1u);
+                atomicOr(&P.g->err, 1u);
                 slot = -2;
                 done = true;
             }

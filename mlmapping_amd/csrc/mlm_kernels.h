@@ -3,7 +3,7 @@
 // Stage A  (awareness_map_cylindrical::input_pc_pose, map_awareness.cpp:173-282)
 //   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions, de-duplicated ray walk
 //   k_collect_hits    dense sweep of the hit scratch -> unique-hit list + per-cell contribution segments
-//   k_scatter_contribs / k_sort_contribs / k_chain   point-order replay of the float noisy-OR chain -> odd, logit
+//   k_sort_contribs / k_chain   point-order replay of the float noisy-OR chain -> odd, logit
 // Stage B  (iteration order of hit_idx_odds_hashmap, i.e. libstdc++ _Hashtable list order)
 //   k_bucket_min / k_make_keys (+ rank kernels on rehash frames)
 // Stage C  (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237)
@@ -70,29 +70,38 @@ template <int MODE> __device__ __forceinline__ MlmTile mlm_tile_item(const MlmFr
 
 // ray walk, map_awareness.cpp:243-274, from the binned start (rho,phi,z) of a point (in range or not):
 // slope = (z - zc)/rho, clamp to the outer border, then r = rho-1 .. 1, z' = round(z - (rho-r)*slope).
-// Bits of one (phi,z') row that fall into the same 32-bit word are OR-ed in registers and flushed with one atomic.
-__device__ __forceinline__ void mlm_walk_ray(const MlmDev &P, int rho, int phi, int z) {
+// One WAVE walks one ray: lane l takes the steps r = l+1, l+65, ...; lanes whose cells fall into the same 32-bit
+// word of the miss mask (consecutive r with equal z') are merged so that one atomicOr per word run is issued.
+__device__ __forceinline__ void mlm_walk_ray_wave(const MlmDev &P, int rho, int phi, int z) {
+    const int lane = threadIdx.x & 63;
     const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
     if (rho >= P.nRho) {
         z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
         rho = P.nRho - 1;
     }
-    int cur_w = -1;
-    uint32_t cur_m = 0;
-    for (int r = rho - 1; r > 0; --r) {
-        const int diff_r = rho - r;
-        const int zr = mlm_cvt_int(round(z - (diff_r * slope)));
-        if (0 <= zr && zr < P.nZ) {
-            const int w = (zr * P.nPhi + phi) * P.RW + (r >> 5);
-            if (w != cur_w) {
-                if (cur_m) atomicOr(&P.miss_bits[cur_w], cur_m);
-                cur_w = w;
-                cur_m = 0;
-            }
-            cur_m |= 1u << (r & 31);
+    for (int r0 = 1; r0 < rho; r0 += 64) {
+        const int r = r0 + lane;
+        int w = -1;
+        if (r < rho) {
+            const int diff_r = rho - r;
+            const int zr = mlm_cvt_int(round(z - (diff_r * slope)));
+            if (0 <= zr && zr < P.nZ) w = (zr * P.nPhi + phi) * P.RW + (r >> 5);
+        }
+        // run heads: lanes whose word differs from the previous lane's
+        const int w_prev = __shfl_up(w, 1, 64);
+        const bool head = w >= 0 && (lane == 0 || w_prev != w);
+        const unsigned long long valid = __ballot(w >= 0);
+        const unsigned long long heads = __ballot(head);
+        if (head) {
+            // the run ends before the next head or the next invalid lane
+            const unsigned long long above = ~((2ull << lane) - 1ull); // lanes > lane
+            const unsigned long long stop = (heads | ~valid) & above;
+            const int end = stop ? __ffsll((long long)stop) - 1 : 64; // exclusive
+            const int len = end - lane;                               // <= 32: a run stays inside one word
+            const uint32_t bits = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (r & 31);
+            atomicOr(&P.miss_bits[w], bits);
         }
     }
-    if (cur_m) atomicOr(&P.miss_bits[cur_w], cur_m);
 }
 
 // neighbour cells of the noise spread (update_hits, map_awareness.cpp:149-168) for step d; -1 = none
@@ -110,14 +119,25 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
     return (float)d < s3 && (rho + d < P.nRho) && d <= MLM_DIFF_RANGE;
 }
 
+struct MlmLdsNode {
+    uint32_t cell;
+    uint32_t i00_sub;
+    unsigned long long mask;
+};
+#define MLM_NODE_LDS 640 // contribution nodes buffered per k_bin_points block
+
 // MODE 0: dense depth image, 1: indexed depth pixels, 2: explicit sensor-frame points
 template <int MODE>
 __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const MlmFrame F) {
     __shared__ unsigned int s_cnt[4];
     __shared__ unsigned int s_base;
-    __shared__ unsigned int s_ntouch, s_tbase;
+    __shared__ unsigned int s_ntouch, s_tbase, s_nnode, s_nbase;
     __shared__ uint32_t s_touch[MLM_TOUCH_LDS];
-    if (threadIdx.x == 0) s_ntouch = 0;
+    __shared__ MlmLdsNode s_node[MLM_NODE_LDS];
+    if (threadIdx.x == 0) {
+        s_ntouch = 0;
+        s_nnode = 0;
+    }
     __syncthreads();
     const MlmTile T = mlm_tile_item<MODE>(F);
     const int i = T.i;
@@ -157,48 +177,57 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
         inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
         if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
     }
-    if (T.valid) P.pt_cell[i] = c0;
+    // work item of lane 0 of this wave (see MlmNode)
+    const uint32_t i00 = (uint32_t)__shfl(i, 0, 64);
     const uint32_t t0 = (uint32_t)i * MLM_TIME_SLOTS;
 
-    // ---- hit contributions: centre, then the +-d noise spread
-    bool emit_ray = false; // this lane queues a ray for (rho,phi,zi)
-    // the lane whose atomicMin finds the cell untouched queues it for k_collect_hits (block-local LDS buffer)
-    auto touch = [&](int cell, uint32_t t) {
-        if (atomicMin(&P.hit_t[cell], t) == MLM_EMPTY_T) {
+    // One group = the lanes of this wave that contribute kind `sub` to `cell`.  Its lowest lane (= earliest
+    // insertion time) posts the group: count, kind mask, first-touch time, and a node for the point-order replay.
+    // The returned atomics are only looked at after the grouping loop, so they are all in flight together.
+    auto post = [&](int key, bool valid, int sub, bool centre) -> bool {
+        uint32_t old_t = 0, old_start = ~0u;
+        int my_cell = -1;
+        mlm_wave_groups(key, valid, [&](int cell, unsigned long long m) {
+            my_cell = cell;
+            old_t = atomicMin(&P.hit_t[cell], t0 + (uint32_t)sub);
+            atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
+            atomicOr(&P.hit_mask[cell], 1u << sub);
+            if (centre && P.visibility) old_start = atomicOr(&P.start_bits[cell >> 5], 1u << (cell & 31));
+            const unsigned int k = atomicAdd(&s_nnode, 1u);
+            if (k < MLM_NODE_LDS) {
+                s_node[k].cell = (uint32_t)cell;
+                s_node[k].i00_sub = i00 | ((uint32_t)sub << 27);
+                s_node[k].mask = m;
+            } else { // LDS buffer full: link the node directly
+                const unsigned int reg = blockIdx.x & 7;
+                const unsigned int g = atomicAdd(&P.ctr->node_cnt[reg][0], 1u);
+                if (g < P.node_cap) {
+                    const uint32_t gi = reg * P.node_cap + g;
+                    P.nodes[gi].i00_sub = i00 | ((uint32_t)sub << 27);
+                    P.nodes[gi].mask = m;
+                    P.nodes[gi].next = atomicExch(&P.node_head[cell], gi);
+                }
+            }
+        });
+        if (my_cell >= 0 && old_t == MLM_EMPTY_T) { // first touch of the cell this frame: queue it for k_collect_hits
             const unsigned int k = atomicAdd(&s_ntouch, 1u);
             if (k < MLM_TOUCH_LDS)
-                s_touch[k] = (uint32_t)cell;
-            else { // LDS buffer full: queue directly
+                s_touch[k] = (uint32_t)my_cell;
+            else {
                 const unsigned int g = atomicAdd(&P.ctr->touch_cnt[blockIdx.x & 7][0], 1u);
-                if (g < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + g] = (uint32_t)cell;
+                if (g < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + g] = (uint32_t)my_cell;
             }
         }
+        // every point of one (rho,phi,z) cell casts the identical ray: only the first one queues it
+        return my_cell >= 0 && centre && P.visibility && (old_start & (1u << (my_cell & 31))) == 0;
     };
-    mlm_wave_groups(c0, inside, [&](int cell, unsigned long long m) {
-        touch(cell, t0);
-        atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
-        atomicOr(&P.hit_mask[cell], 1u);
-        if (P.visibility) {
-            // every point of one (rho,phi,z) cell casts the identical ray: only the first one queues it
-            const uint32_t bit = 1u << (cell & 31);
-            const uint32_t old = atomicOr(&P.start_bits[cell >> 5], bit);
-            emit_ray = (old & bit) == 0;
-        }
-    });
+    bool emit_ray = post(c0, inside, 0, true);
     const float s3 = inside ? P.sigma3[rho] : 0.0f;
     for (int d = 1; __any(inside && mlm_spread_active(P, rho, d, s3)); ++d) {
         int cp = -1, cm = -1;
         if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, cp, cm);
-        mlm_wave_groups(cp, cp >= 0, [&](int cell, unsigned long long m) {
-            touch(cell, t0 + 2 * d - 1);
-            atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
-            atomicOr(&P.hit_mask[cell], 1u << (2 * d - 1));
-        });
-        mlm_wave_groups(cm, cm >= 0, [&](int cell, unsigned long long m) {
-            touch(cell, t0 + 2 * d);
-            atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
-            atomicOr(&P.hit_mask[cell], 1u << (2 * d));
-        });
+        post(cp, cp >= 0, 2 * d - 1, false);
+        post(cm, cm >= 0, 2 * d, false);
     }
     // ---- points outside the map that can still cast (map_awareness.cpp:241,249-265): identical starts inside
     //      the wave are merged, across waves they are simply walked again (idempotent bit sets)
@@ -221,6 +250,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
     const unsigned long long em = __ballot(emit_ray);
     if (lane == 0) s_cnt[wid] = (unsigned int)__popcll(em) | (n_pts << 10) | (n_oor << 20);
     __syncthreads();
+    const unsigned int reg = blockIdx.x & 7;
+    const unsigned int nt = min(s_ntouch, (unsigned int)MLM_TOUCH_LDS);
+    const unsigned int nn = min(s_nnode, (unsigned int)MLM_NODE_LDS);
     if (threadIdx.x == 0) {
         unsigned int rays = 0, pts = 0, oor = 0;
         for (int w = 0; w < 4; ++w) {
@@ -230,34 +262,41 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
         }
         P.blk_stats[2 * blockIdx.x] = pts;
         P.blk_stats[2 * blockIdx.x + 1] = oor;
-        s_base = rays ? atomicAdd(&P.ctr->ray_cnt[blockIdx.x & 7][0], rays) : 0u;
+        s_base = rays ? atomicAdd(&P.ctr->ray_cnt[reg][0], rays) : 0u;
+        s_tbase = nt ? atomicAdd(&P.ctr->touch_cnt[reg][0], nt) : 0u;
+        s_nbase = nn ? atomicAdd(&P.ctr->node_cnt[reg][0], nn) : 0u;
     }
     __syncthreads();
     if (emit_ray) {
         unsigned int pos = s_base + (unsigned int)__popcll(em & ((1ull << lane) - 1ull));
         for (int w = 0; w < wid; ++w) pos += s_cnt[w] & 1023u;
         if (pos < P.ray_cap) {
-            int32_t *r = P.rays + ((size_t)(blockIdx.x & 7) * P.ray_cap + pos) * 3;
+            int32_t *r = P.rays + ((size_t)reg * P.ray_cap + pos) * 3;
             r[0] = rho;
             r[1] = phi;
             r[2] = zi;
         }
     }
-    // ---- flush the first-touch buffer: one global atomic per block
-    const unsigned int nt = min(s_ntouch, (unsigned int)MLM_TOUCH_LDS); // all LDS atomics precede the barriers above
-    if (threadIdx.x == 0) s_tbase = nt ? atomicAdd(&P.ctr->touch_cnt[blockIdx.x & 7][0], nt) : 0u;
-    __syncthreads();
     for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
-        if (s_tbase + k < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + s_tbase + k] = s_touch[k];
+        if (s_tbase + k < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + s_tbase + k] = s_touch[k];
+    for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x)
+        if (s_nbase + k < P.node_cap) {
+            const uint32_t gi = reg * P.node_cap + s_nbase + k;
+            P.nodes[gi].i00_sub = s_node[k].i00_sub;
+            P.nodes[gi].mask = s_node[k].mask;
+            P.nodes[gi].next = atomicExch(&P.node_head[s_node[k].cell], gi);
+        }
 }
 
-// one ray per lane
+// one ray per wave
 __global__ __launch_bounds__(MLM_BLOCK) void k_walk_rays(const MlmDev P) {
     const unsigned int k = blockIdx.y;
     const unsigned int n = min(P.ctr->ray_cnt[k][0], P.ray_cap);
-    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (unsigned int r = wave; r < n; r += n_waves) {
         const int32_t *q = P.rays + ((size_t)k * P.ray_cap + r) * 3;
-        mlm_walk_ray(P, q[0], q[1], q[2]);
+        mlm_walk_ray_wave(P, q[0], q[1], q[2]);
     }
 }
 
@@ -295,7 +334,7 @@ __device__ __forceinline__ float mlm_logit(float p) {
 //  - cell, first-touch time;
 //  - cells with a single kind of contribution: odd (n applications of one value commute) and its logit;
 //  - cells with several kinds: a segment of `contrib` for the point-order replay (k_sort_contribs / k_chain);
-// and reset hit_t / hit_mask (and hit_cnt of single-kind cells) for the next frame.  gridDim.y = sub-list.
+// and reset hit_t / hit_mask / hit_cnt (and node_head of single-kind cells) for the next frame.  gridDim.y = sub-list.
 __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int n_stat_blocks) {
     __shared__ uint32_t s_w[3][4];
     __shared__ uint32_t s_base[3];
@@ -354,18 +393,18 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int 
             const uint32_t pos = off_h + (uint32_t)__popcll(bh & below);
             P.hit_t[c] = MLM_EMPTY_T;
             P.hit_mask[c] = 0;
+            P.hit_cnt[c] = 0;
             P.hl_cell[pos] = c;
             P.hl_t[pos] = t;
             P.hl_vt[pos] = t;
             if (multi) {
                 const uint32_t base = off_c + cincl - cnt;
-                P.seg_base[c] = base;
                 P.hl_base[pos] = base;
                 P.hl_cnt[pos] = cnt;
                 P.mt_list[off_m + (uint32_t)__popcll(bm & below)] = pos;
             } else {
                 // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
-                P.hit_cnt[c] = 0;
+                P.node_head[c] = MLM_NIL;
                 const int rho_c = (int)(c % (uint32_t)P.nRho);
                 const float a = mlm_contribution_odd(P, P.odds_table, rho_c, __ffs((int)mask) - 1);
                 float p = a;
@@ -379,64 +418,43 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int 
     }
 }
 
-// Second sweep over the points: for cells that received several kinds of contribution, write each
-// contribution's insertion time into the cell's segment (hit_cnt counts down as the fill cursor).  Lanes of a
-// wave that feed the same cell share one atomic.
-__device__ __forceinline__ void mlm_scatter_put(const MlmDev &P, int cell, bool valid, uint32_t t) {
-    valid = valid && P.hit_cnt[cell] != 0; // single-kind cells were resolved (and zeroed) by k_collect_hits
-    unsigned long long todo = __ballot(valid);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(cell, leader, 64);
-        const bool mine = valid && cell == k;
-        const unsigned long long m = __ballot(mine);
-        uint32_t v = 0;
-        if (lane == leader) v = atomicSub(&P.hit_cnt[k], (unsigned int)__popcll(m));
-        v = __shfl(v, leader, 64);
-        if (mine) {
-            const uint32_t slot = P.seg_base[k] + v - 1u - (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (slot < P.contrib_cap) P.contrib[slot] = t;
-        }
-        todo &= ~m;
-    }
-}
-template <int MODE>
-__global__ __launch_bounds__(MLM_BLOCK) void k_scatter_contribs(const MlmDev P, const MlmFrame F) {
-    const MlmTile T = mlm_tile_item<MODE>(F);
-    const int c0 = T.valid ? P.pt_cell[T.i] : -1;
-    const bool inside = c0 >= 0;
-    int rho = 0, phi = 0, zi = 0;
-    if (inside) mlm_cell_rpz(P, (uint32_t)c0, rho, phi, zi);
-    const uint32_t t0 = (uint32_t)T.i * MLM_TIME_SLOTS;
-    mlm_scatter_put(P, c0, inside, t0);
-    const float s3 = inside ? P.sigma3[rho] : 0.0f;
-    for (int d = 1; __any(inside && mlm_spread_active(P, rho, d, s3)); ++d) {
-        int cp = -1, cm = -1;
-        if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, cp, cm);
-        mlm_scatter_put(P, cp, cp >= 0, t0 + 2 * d - 1);
-        mlm_scatter_put(P, cm, cm >= 0, t0 + 2 * d);
-    }
-}
-
-// One wave per multi-kind hit cell: order the cell's contributions by insertion time (rank by counting in LDS)
-// and store their kinds (`sub`) in that order.
+// One wave per multi-kind hit cell: expand the cell's contribution nodes into insertion times, order them (rank by
+// counting in LDS) and store their kinds (`sub`) in that order.  tile_w > 0: dense 8x8 tiles of an image of that
+// width; 0: linear work items.
 #define MLM_SORT_CAP 4096 // keys per wave held in LDS
 #define MLM_SORT_THREADS 128
-__global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev P) {
+__global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev P, int tile_w) {
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_SORT_THREADS / 64][MLM_SORT_CAP];
     const unsigned int n_cells = P.ctr->n_multi;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     volatile uint32_t *K = s_keys[wid];
+    const uint32_t lane_off = tile_w > 0 ? (uint32_t)((lane >> 3) * tile_w + (lane & 7)) : (uint32_t)lane;
     for (unsigned int w = wave; w < n_cells; w += n_waves) {
         const uint32_t pos = P.mt_list[w];
+        const uint32_t cell = P.hl_cell[pos];
         const uint32_t base = P.hl_base[pos];
         const uint32_t n = P.hl_cnt[pos];
-        if (n <= MLM_SORT_CAP) {
+        const bool in_lds = n <= MLM_SORT_CAP;
+        uint32_t filled = 0;
+        for (uint32_t node = P.node_head[cell]; node != MLM_NIL;) {
+            const MlmNode nd = P.nodes[node];
+            if ((nd.mask >> lane) & 1ull) {
+                const uint32_t key = ((nd.i00_sub & 0x07FFFFFFu) + lane_off) * MLM_TIME_SLOTS + (nd.i00_sub >> 27);
+                const uint32_t at = filled + (uint32_t)__popcll(nd.mask & ((1ull << lane) - 1ull));
+                if (in_lds)
+                    K[at] = key;
+                else if (base + at < P.contrib_cap)
+                    P.contrib[base + at] = key;
+            }
+            filled += (uint32_t)__popcll(nd.mask);
+            node = nd.next;
+        }
+        if (lane == 0) P.node_head[cell] = MLM_NIL;
+        if (in_lds) {
             const uint32_t n4 = (n + 3u) & ~3u;
-            for (uint32_t j = lane; j < n4; j += 64) K[j] = j < n ? P.contrib[base + j] : 0xFFFFFFFFu;
+            if (n + lane < n4) K[n + lane] = 0xFFFFFFFFu;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave execute in order
             __builtin_amdgcn_wave_barrier();
             for (uint32_t j = lane; j < n; j += 64) {
@@ -451,11 +469,13 @@ __global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         } else {
-            // larger than the LDS window: same rank-by-counting straight from memory (rare, slow, exact)
+            // larger than the LDS window: same rank-by-counting from the spill segment (rare, slow, exact)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
             for (uint32_t j = lane; j < n; j += 64) {
-                const uint32_t my = P.contrib[base + j];
+                const uint32_t my = __hip_atomic_load(&P.contrib[base + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t r = 0;
-                for (uint32_t q = 0; q < n; ++q) r += P.contrib[base + q] < my;
+                for (uint32_t q = 0; q < n; ++q)
+                    r += __hip_atomic_load(&P.contrib[base + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < my;
                 P.subs[base + r] = (uint8_t)(my % MLM_TIME_SLOTS);
             }
         }
@@ -465,17 +485,27 @@ __global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev
 // One lane per multi-kind hit cell: replay update_odds_hashmap (map_awareness.h:147-154) over the ordered kinds —
 // the float noisy-OR chain is not associative, so the order is part of the result.  p == 1.0f is absorbing
 // (1-(1-1)(1-a) == 1), which ends long chains early.
-__global__ __launch_bounds__(MLM_BLOCK) void k_chain(const MlmDev P) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_chain(const MlmDev P, int frame_idx, unsigned int rehash_threshold) {
+    // Stage B is launched assuming that this frame's unique hit cells fit the emulated container without a rehash
+    // (element count <= _M_next_resize).  If they do not, flag the frame: its Stage B/C kernels (and those of later
+    // frames) turn into no-ops and the host replays them with the exact rehash plan.
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.ctr->u_hit > rehash_threshold) atomicMin(&P.g->fail_frame, frame_idx);
     const unsigned int n_cells = P.ctr->n_multi;
     for (unsigned int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_cells; w += gridDim.x * blockDim.x) {
         const uint32_t pos = P.mt_list[w];
         const uint32_t base = P.hl_base[pos];
         const uint32_t n = P.hl_cnt[pos];
         const int rho_c = (int)(P.hl_cell[pos] % (uint32_t)P.nRho);
-        float p = mlm_contribution_odd(P, P.odds_table, rho_c, P.subs[base]);
-        for (uint32_t j = 1; j < n && p != 1.0f; ++j) {
+        float p = 0.0f;
+        bool first = true;
+        for (uint32_t j = 0; j < n && p != 1.0f; ++j) {
             const float a = mlm_contribution_odd(P, P.odds_table, rho_c, P.subs[base + j]);
-            p = 1 - (1 - p) * (1 - a);
+            if (first) {
+                p = a;
+                first = false;
+            } else {
+                p = 1 - (1 - p) * (1 - a);
+            }
         }
         P.hl_odd[pos] = p;
         P.hl_inc[pos] = mlm_logit(p);
@@ -488,23 +518,28 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain(const MlmDev P) {
 // inside a chain later insertions sit nearer the head.  So "x is visited before y" <=> (first-insert time of x's
 // bucket, insert time of x) > (… y) lexicographically.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MLM_BLOCK) void k_bucket_min(const MlmDev P, unsigned int n, unsigned long long n_bkt,
+#define MLM_SKIP_IF_FAILED(P, frame_idx)                                                                              \
+    if (__hip_atomic_load(&(P).g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= (frame_idx)) return;
+__global__ __launch_bounds__(MLM_BLOCK) void k_bucket_min(const MlmDev P, int frame_idx, unsigned long long n_bkt,
                                                           unsigned int arr_limit, int use_arr) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (use_arr && P.hl_arr[i] >= arr_limit) return;
-    int rho, phi, z;
-    mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
-    const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
-    atomicMin(&P.bkt_first[b], P.hl_vt[i]);
+    MLM_SKIP_IF_FAILED(P, frame_idx)
+    const unsigned int n = P.ctr->u_hit;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (use_arr && P.hl_arr[i] >= arr_limit) continue;
+        int rho, phi, z;
+        mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+        const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
+        atomicMin(&P.bkt_first[b], P.hl_vt[i]);
+    }
 }
 // final = 1: hl_key = (bucket_first<<32)|vt for every element.
 // final = 0: sort key for the re-densify pass: ~key for members (ascending sort = list order), all-ones otherwise.
-__global__ __launch_bounds__(MLM_BLOCK) void k_make_keys(const MlmDev P, unsigned int n, unsigned long long n_bkt,
+__global__ __launch_bounds__(MLM_BLOCK) void k_make_keys(const MlmDev P, int frame_idx, unsigned long long n_bkt,
                                                          unsigned int arr_limit, int use_arr, int final_pass,
                                                          unsigned long long *sort_keys, uint32_t *sort_vals) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    MLM_SKIP_IF_FAILED(P, frame_idx)
+    const unsigned int n = P.ctr->u_hit;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const bool member = !(use_arr && P.hl_arr[i] >= arr_limit);
     unsigned long long key = 0;
     if (member) {
@@ -519,53 +554,58 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_make_keys(const MlmDev P, unsigne
         sort_keys[i] = member ? ~key : ~0ull;
         sort_vals[i] = i;
     }
+    }
 }
 // after sorting (t, idx): arrival index of each element
 __global__ __launch_bounds__(MLM_BLOCK) void k_assign_rank(const MlmDev P, unsigned int n, const uint32_t *sorted_idx,
                                                            unsigned int limit, int to_arr) {
-    const unsigned int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n || r >= limit) return;
-    const uint32_t i = sorted_idx[r];
-    P.hl_vt[i] = r;
-    if (to_arr) P.hl_arr[i] = r;
+    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n && r < limit; r += gridDim.x * blockDim.x) {
+        const uint32_t i = sorted_idx[r];
+        P.hl_vt[i] = r;
+        if (to_arr) P.hl_arr[i] = r;
+    }
 }
 __global__ __launch_bounds__(MLM_BLOCK) void k_time_keys(const MlmDev P, unsigned int n, unsigned long long *sort_keys,
                                                          uint32_t *sort_vals) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    sort_keys[i] = P.hl_t[i];
-    sort_vals[i] = i;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        sort_keys[i] = P.hl_t[i];
+        sort_vals[i] = i;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Stage C
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MLM_BLOCK) void k_hits_to_voxels(const MlmDev P, const MlmFrame F, unsigned int n) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(MLM_BLOCK) void k_hits_to_voxels(const MlmDev P, const MlmFrame F, int frame_idx) {
+    MLM_SKIP_IF_FAILED(P, frame_idx)
+    const unsigned int n = P.ctr->u_hit;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     int rho, phi, z;
     mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
     double wx, wy, wz;
     mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
     int gx, gy, gz, cid;
     mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-    const int slot = mlm_block_find_or_insert(P, gx, gy, gz);
+    int slot = mlm_block_find(P, gx, gy, gz); // plain loads; blocks almost always exist already
+    if (slot == -1) slot = mlm_block_find_or_insert(P, gx, gy, gz);
     if (slot < 0) {
         P.hl_vox[i] = -1;
         P.hl_next[i] = -2;
-        return;
+        continue;
     }
     const int v = slot * P.cells + cid;
     P.hl_vox[i] = v;
     P.hl_next[i] = atomicExch(&P.vox_head[v], (int)i);
+    }
 }
 
 // The first-inserted node of each voxel list (next == -1) owns the voxel: it replays the voxel's hit
 // contributions in the reference's iteration order (descending hl_key) — map_local.cpp:157-171.
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_hits(const MlmDev P, unsigned int n) {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (P.hl_next[i] != -1) return;
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_hits(const MlmDev P, int frame_idx) {
+    MLM_SKIP_IF_FAILED(P, frame_idx)
+    const unsigned int n = P.ctr->u_hit;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (P.hl_next[i] != -1) continue;
     const int v = P.hl_vox[i];
     const int head = P.vox_head[v];
     float L = P.log_odds[v];
@@ -592,13 +632,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_hits(const MlmDev P, unsign
     P.log_odds[v] = L;
     P.occ[v] = o;
     P.vox_head[v] = -1;
+    }
 }
 
 // One thread per bit of the miss mask (= per awareness cell, in mask order): count the frame's misses per voxel
 // (their order is irrelevant: every miss adds the same constant, map_local.cpp:188-192) and clear the mask.
-__global__ __launch_bounds__(MLM_BLOCK) void k_misses_to_voxels(const MlmDev P, const MlmFrame F) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_misses_to_voxels(const MlmDev P, const MlmFrame F, int frame_idx) {
     __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
     __shared__ unsigned int s_base;
+    MLM_SKIP_IF_FAILED(P, frame_idx)
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int w = (int)(g >> 5), b = (int)(g & 31);
     uint32_t bits = 0;
@@ -642,7 +684,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_misses_to_voxels(const MlmDev P, 
     }
 }
 // map_local.cpp:188-203, k times.  gridDim.y = sub-list.
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_misses(const MlmDev P) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_misses(const MlmDev P, int frame_idx) {
+    MLM_SKIP_IF_FAILED(P, frame_idx)
     const unsigned int sl = blockIdx.y;
     const unsigned int n = min(P.ctr->mvox_cnt[sl][0], P.mvox_cap);
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -21,12 +21,28 @@ struct MlmCounters {
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
-    // persistent
-    unsigned int n_blocks;    // allocated blocks
-    unsigned int err;         // sticky error bits (1 = block pool / hash table full)
+    unsigned int node_cnt[8][32];  // [k][0] = contribution nodes allocated in region k
 };
-#define MLM_CTR_FRAME_BYTES (32 + 4 * 8 * 32 * 4)
+// map-wide state shared by all frame slots
+struct MlmGlobal {
+    unsigned int n_blocks;    // allocated blocks
+    unsigned int err;         // sticky error bits (1 = block pool / hash table full, 2 = a per-frame queue overflowed)
+    int fail_frame;           // first frame of the current submission whose hit container would rehash (speculation
+                              // miss); INT_MAX = none.  Stage B/C kernels of frames >= it do nothing.
+    unsigned int pad;
+};
+#define MLM_CTR_FRAME_BYTES (32 + 5 * 8 * 32 * 4)
 #define MLM_RAY_LISTS 8
+
+// The hit contributions one wave makes to one awareness cell with one kind (`sub`): lanes in `mask`, work items
+// i = i00 + lane (linear modes) or i00 + (lane>>3)*W + (lane&7) (dense 8x8 pixel tile).  Nodes of a cell are
+// linked through `next` from MlmDev::node_head.
+struct MlmNode {
+    uint32_t i00_sub; // i00 | sub << 27
+    uint32_t next;    // MLM_NIL terminates
+    unsigned long long mask;
+};
+#define MLM_NIL 0xFFFFFFFFu
 
 struct MlmDev {
     // ---- awareness map constants (map_awareness.cpp:19-82)
@@ -52,9 +68,10 @@ struct MlmDev {
     uint32_t *hit_t;           // [nCells] first-touch time of a hit cell (min over contributions)
     uint32_t *hit_cnt;         // [nCells] number of contributions; reused as the fill cursor of the segment
     uint32_t *hit_mask;        // [nCells] bit s set = a contribution of insertion slot s (0 centre, 2d-1 "+d", 2d "-d")
-    uint32_t *seg_base;        // [nCells] start of the cell's segment in `contrib`
-    uint32_t *contrib;         // [contrib_cap] insertion times of all contributions, grouped by cell
-    int32_t *pt_cell;          // [max_points] hit-centre cell of each point, -1 = none
+    uint32_t *node_head;       // [nCells] head of the cell's contribution-node list, MLM_NIL = empty
+    MlmNode *nodes;            // [MLM_RAY_LISTS][node_cap]
+    unsigned int node_cap;     // per region
+    uint32_t *contrib;         // [contrib_cap] spill space for cells with more contributions than the LDS window
     int32_t *rays;             // [MLM_RAY_LISTS][ray_cap][3] queued rays: binned (rho,phi,z) of the start
     unsigned int ray_cap;      // per sub-list
     unsigned int *blk_stats;   // [2*max tiles] per-block partial sums: points fed, points out of range
@@ -93,7 +110,8 @@ struct MlmDev {
     uint32_t *vox_miss;        // [max_blocks*cells] miss count of this frame
     int *miss_vox;             // [MLM_RAY_LISTS][mvox_cap] voxels touched by misses this frame
     unsigned int mvox_cap;
-    MlmCounters *ctr;
+    MlmCounters *ctr;          // this slot's per-frame counters
+    MlmGlobal *g;
 };
 
 struct MlmFrame {

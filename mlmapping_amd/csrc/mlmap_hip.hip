@@ -109,22 +109,34 @@ struct KernelTime {
 
 } // namespace
 
+// One frame in flight: private awareness scratch + unique-hit list, its own stream for Stage A.
+struct MlmSlot {
+    MlmDev P{};               // shared map pointers + this slot's scratch pointers
+    hipStream_t stream = nullptr;
+    hipEvent_t done_a = nullptr; // Stage A finished
+    MlmCounters *h_ctr = nullptr; // pinned mirror of P.ctr
+    MlmFrame F{};
+    int mode = 0;
+    unsigned int nb = 0;      // k_bin_points blocks
+    uint16_t *d_img = nullptr; // staging for host images
+    size_t img_cap = 0;
+    int32_t *d_pix = nullptr;
+    double *d_pts = nullptr;
+};
+
 struct mlm_handle {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; // main stream: Stage B/C (ordered across frames), queries
     bool own_stream = true;
     mlm_config cfg{};
     mlm_limits lim{};
-    MlmDev P{};
+    MlmDev P{};                   // template: constants + shared pointers
+    std::vector<MlmSlot> slots;
+    int last_slot = 0;
     Q4 q_bs{};
     D3 t_bs{};
     std::vector<float> odds_table;
     std::vector<void *> allocs;
-    // staging for host inputs
-    uint16_t *d_img = nullptr;
-    size_t img_cap = 0;
-    int32_t *d_pix = nullptr;
-    double *d_pts = nullptr;
     double *d_qpos = nullptr; // query positions
     void *d_qout = nullptr;
     size_t q_cap = 0;
@@ -133,19 +145,20 @@ struct mlm_handle {
     uint32_t *sv_in = nullptr, *sv_out = nullptr;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    MlmCounters *h_ctr = nullptr; // pinned
+    MlmGlobal *h_g = nullptr; // pinned mirror of P.g
     // emulated libstdc++ state of awareness_map->hit_idx_odds_hashmap: bucket count + rehash policy.
     // clear() (map_awareness.cpp:178) keeps both, so they persist across frames.
     size_t hit_n_bkt = 1;
     std::__detail::_Prime_rehash_policy hit_pol;
     size_t max_buckets = 0;
     mlm_frame_stats stats{};
-    MlmFrame last{};
     std::string err;
-    bool timing = false;
+    int timing = 0;
     std::vector<KernelTime> ktimes;
     std::vector<KernelTime> kpool;
     size_t kpool_used = 0;
+    hipEvent_t ev_main = nullptr; // recorded on the main stream, waited by the slot streams
+    long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
 };
 
 namespace {
@@ -167,11 +180,13 @@ template <class T> int dev_alloc(mlm_handle *h, T **p, size_t n) {
     return MLM_OK;
 }
 inline unsigned int grid_for(size_t n) { return (unsigned int)((n + MLM_BLOCK - 1) / MLM_BLOCK); }
+constexpr unsigned int kListGrid = 256; // blocks of the grid-stride kernels that walk a device-sized list
 
 struct Timed {
     mlm_handle *h;
+    hipStream_t s;
     KernelTime *kt = nullptr;
-    Timed(mlm_handle *hh, const char *name) : h(hh) {
+    Timed(mlm_handle *hh, hipStream_t st, const char *name) : h(hh), s(st) {
         if (!h->timing) return;
         if (h->kpool_used == h->kpool.size()) {
             KernelTime k{name, nullptr, nullptr};
@@ -181,11 +196,11 @@ struct Timed {
         }
         kt = &h->kpool[h->kpool_used++];
         kt->name = name;
-        hipEventRecord(kt->a, h->stream);
+        hipEventRecord(kt->a, s);
     }
     ~Timed() {
         if (kt) {
-            hipEventRecord(kt->b, h->stream);
+            hipEventRecord(kt->b, s);
             h->ktimes.push_back(*kt);
         }
     }
@@ -242,45 +257,36 @@ std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
     return ep;
 }
 
-int order_hits(mlm_handle *h, unsigned int U) {
-    const MlmDev &P = h->P;
+// Stage B for one frame whose unique-hit count U is known on the host: exact, with rehash epochs.
+int order_hits_exact(mlm_handle *h, MlmSlot &S, unsigned int U, int frame_idx) {
+    const MlmDev &P = S.P;
     const auto ep = plan_epochs(h, U);
     h->stats.n_rehash_epochs = (int64_t)ep.size();
-    h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
     if (h->hit_n_bkt > h->max_buckets) {
         h->err = "emulated bucket count exceeds capacity";
         return MLM_ERR_CAPACITY;
     }
     if (U == 0) return MLM_OK;
-    const unsigned int g = grid_for(U);
     const bool multi = ep.size() > 1;
     if (multi) {
         // arrival index = rank of the first-touch time
-        {
-            Timed t(h, "k_time_keys");
-            hipLaunchKernelGGL(k_time_keys, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
-        }
+        hipLaunchKernelGGL(k_time_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
         if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U,
                                    h->stream) != 0) {
             h->err = "radix sort failed";
             return MLM_ERR_HIP;
         }
-        hipLaunchKernelGGL(k_assign_rank, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
+        hipLaunchKernelGGL(k_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
     }
     for (size_t e = 0; e < ep.size(); ++e) {
         const unsigned int m = (unsigned int)ep[e].first;
         const unsigned long long nb = ep[e].second;
         const bool final_pass = (e + 1 == ep.size());
         HIPCHK(h, hipMemsetAsync(P.bkt_first, 0xFF, nb * sizeof(uint32_t), h->stream));
-        {
-            Timed t(h, "k_bucket_min");
-            hipLaunchKernelGGL(k_bucket_min, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0);
-        }
-        {
-            Timed t(h, "k_make_keys");
-            hipLaunchKernelGGL(k_make_keys, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0,
-                               final_pass ? 1 : 0, h->sk_in, h->sv_in);
-        }
+        hipLaunchKernelGGL(k_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, m,
+                           multi ? 1 : 0);
+        hipLaunchKernelGGL(k_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, m,
+                           multi ? 1 : 0, final_pass ? 1 : 0, h->sk_in, h->sv_in);
         if (!final_pass) {
             // list order of the epoch = descending key; the rehash re-inserts the nodes in that order
             if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U,
@@ -288,119 +294,207 @@ int order_hits(mlm_handle *h, unsigned int U) {
                 h->err = "radix sort failed";
                 return MLM_ERR_HIP;
             }
-            hipLaunchKernelGGL(k_assign_rank, dim3(g), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
+            hipLaunchKernelGGL(k_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
         }
     }
     return MLM_OK;
 }
 
-int read_counters(mlm_handle *h) {
-    HIPCHK(h, hipMemcpyAsync(h->h_ctr, h->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return MLM_OK;
-}
-
-// One frame: stage A -> (host: rehash plan) -> stage B -> stage C
-int integrate_frame(mlm_handle *h, const MlmFrame &F, int mode) {
-    const MlmDev &P = h->P;
-    h->ktimes.clear();
-    h->kpool_used = 0;
-    h->last = F;
-    HIPCHK(h, hipMemsetAsync(P.ctr, 0, MLM_CTR_FRAME_BYTES, h->stream));
-    HIPCHK(h, hipMemsetAsync(P.start_bits, 0, ((size_t)P.nCells + 31) / 32 * sizeof(uint32_t), h->stream));
-    unsigned int nb = 0;
+// Stage A of one frame on the slot's stream: awareness raycast -> unique hit list (+odds) and miss mask.
+int launch_stage_a(mlm_handle *h, MlmSlot &S, int frame_idx) {
+    const MlmDev &P = S.P;
+    const MlmFrame &F = S.F;
+    hipStream_t st = S.stream;
+    HIPCHK(h, hipMemsetAsync(P.ctr, 0, sizeof(MlmCounters), st));
+    HIPCHK(h, hipMemsetAsync(P.start_bits, 0, ((size_t)P.nCells + 31) / 32 * sizeof(uint32_t), st));
+    S.nb = 0;
     if (F.n > 0) {
-        nb = (mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
-        if ((size_t)(nb / MLM_RAY_LISTS + 1) * MLM_BLOCK > P.ray_cap || nb > h->lim.max_points / 64 + 1024) {
-            h->err = "frame geometry exceeds the ray queue sized from mlm_limits.max_points";
+        const unsigned int nb =
+            (S.mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
+        if ((size_t)(nb / MLM_RAY_LISTS + 1) * MLM_BLOCK > P.ray_cap || nb > (unsigned int)h->lim.max_points / 64 + 1024) {
+            h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
             return MLM_ERR_CAPACITY;
         }
+        S.nb = nb;
         {
-            Timed t(h, "k_bin_points");
-            if (mode == 0)
-                hipLaunchKernelGGL(k_bin_points<0>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
-            else if (mode == 1)
-                hipLaunchKernelGGL(k_bin_points<1>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
+            Timed t(h, st, "k_bin_points");
+            if (S.mode == 0)
+                hipLaunchKernelGGL(k_bin_points<0>, dim3(nb), dim3(MLM_BLOCK), 0, st, P, F);
+            else if (S.mode == 1)
+                hipLaunchKernelGGL(k_bin_points<1>, dim3(nb), dim3(MLM_BLOCK), 0, st, P, F);
             else
-                hipLaunchKernelGGL(k_bin_points<2>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
+                hipLaunchKernelGGL(k_bin_points<2>, dim3(nb), dim3(MLM_BLOCK), 0, st, P, F);
         }
         if (P.visibility) {
-            Timed t(h, "k_walk_rays");
-            hipLaunchKernelGGL(k_walk_rays, dim3(32, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P);
+            Timed t(h, st, "k_walk_rays");
+            hipLaunchKernelGGL(k_walk_rays, dim3(128, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P);
         }
     }
     {
-        Timed t(h, "k_collect_hits");
-        hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, (int)nb);
-    }
-    if (F.n > 0) {
-        {
-            Timed t(h, "k_scatter_contribs");
-            if (mode == 0)
-                hipLaunchKernelGGL(k_scatter_contribs<0>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
-            else if (mode == 1)
-                hipLaunchKernelGGL(k_scatter_contribs<1>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
-            else
-                hipLaunchKernelGGL(k_scatter_contribs<2>, dim3(nb), dim3(MLM_BLOCK), 0, h->stream, P, F);
-        }
-        {
-            Timed t(h, "k_sort_contribs");
-            hipLaunchKernelGGL(k_sort_contribs, dim3(2048), dim3(MLM_SORT_THREADS), 0, h->stream, P);
-        }
-        {
-            Timed t(h, "k_chain");
-            hipLaunchKernelGGL(k_chain, dim3(256), dim3(MLM_BLOCK), 0, h->stream, P);
-        }
-    }
-    int rc = read_counters(h);
-    if (rc) return rc;
-    const unsigned int U = h->h_ctr->u_hit;
-    rc = order_hits(h, U);
-    if (rc) return rc;
-    if (U > 0) {
-        {
-            Timed t(h, "k_hits_to_voxels");
-            hipLaunchKernelGGL(k_hits_to_voxels, dim3(grid_for(U)), dim3(MLM_BLOCK), 0, h->stream, P, F, U);
-        }
-        {
-            Timed t(h, "k_apply_hits");
-            hipLaunchKernelGGL(k_apply_hits, dim3(grid_for(U)), dim3(MLM_BLOCK), 0, h->stream, P, U);
-        }
+        Timed t(h, st, "k_collect_hits");
+        hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P, (int)S.nb);
     }
     {
-        Timed t(h, "k_misses_to_voxels");
-        hipLaunchKernelGGL(k_misses_to_voxels, dim3(grid_for((size_t)P.nMissWords * 32)), dim3(MLM_BLOCK), 0,
-                           h->stream, P, F);
+        Timed t(h, st, "k_sort_contribs");
+        hipLaunchKernelGGL(k_sort_contribs, dim3(2048), dim3(MLM_SORT_THREADS), 0, st, P, S.mode == 0 ? F.width : 0);
     }
     {
-        Timed t(h, "k_apply_misses");
-        hipLaunchKernelGGL(k_apply_misses, dim3(16, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P);
+        Timed t(h, st, "k_chain");
+        hipLaunchKernelGGL(k_chain, dim3(256), dim3(MLM_BLOCK), 0, st, P, frame_idx,
+                           (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
     }
-    HIPCHK(h, hipGetLastError());
-    rc = read_counters(h);
-    if (rc) return rc;
-    h->stats.n_points = h->h_ctr->n_points;
-    h->stats.n_hit_cells = h->h_ctr->u_hit;
+    HIPCHK(h, hipEventRecord(S.done_a, st));
+    return MLM_OK;
+}
+
+// Stage C of one frame on the main stream (after its ordering keys exist)
+void launch_stage_c(mlm_handle *h, MlmSlot &S, int frame_idx) {
+    const MlmDev &P = S.P;
     {
-        unsigned int um = 0;
-        for (int k = 0; k < MLM_RAY_LISTS; ++k) um += h->h_ctr->umiss_part[k][0];
-        h->stats.n_miss_cells = um;
+        Timed t(h, h->stream, "k_hits_to_voxels");
+        hipLaunchKernelGGL(k_hits_to_voxels, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, S.F, frame_idx);
     }
-    h->stats.n_out_of_range = h->h_ctr->n_oor;
-    h->stats.n_blocks = std::min<unsigned int>(h->h_ctr->n_blocks, (unsigned int)P.max_blocks);
-    if (h->h_ctr->err) {
+    {
+        Timed t(h, h->stream, "k_apply_hits");
+        hipLaunchKernelGGL(k_apply_hits, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx);
+    }
+    {
+        Timed t(h, h->stream, "k_misses_to_voxels");
+        hipLaunchKernelGGL(k_misses_to_voxels, dim3(grid_for((size_t)P.nMissWords * 32)), dim3(MLM_BLOCK), 0, h->stream,
+                           P, S.F, frame_idx);
+    }
+    {
+        Timed t(h, h->stream, "k_apply_misses");
+        hipLaunchKernelGGL(k_apply_misses, dim3(16, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx);
+    }
+}
+
+// Stage B (speculative: "no rehash this frame", i.e. one epoch with the current bucket count) + Stage C
+int launch_stage_bc_speculative(mlm_handle *h, MlmSlot &S, int frame_idx) {
+    const MlmDev &P = S.P;
+    const unsigned long long nb = h->hit_n_bkt;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, S.done_a, 0));
+    HIPCHK(h, hipMemsetAsync(P.bkt_first, 0xFF, nb * sizeof(uint32_t), h->stream));
+    {
+        Timed t(h, h->stream, "k_bucket_min");
+        hipLaunchKernelGGL(k_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, 0u, 0);
+    }
+    {
+        Timed t(h, h->stream, "k_make_keys");
+        hipLaunchKernelGGL(k_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, 0u, 0, 1,
+                           h->sk_in, h->sv_in);
+    }
+    launch_stage_c(h, S, frame_idx);
+    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+    return MLM_OK;
+}
+
+void fill_stats(mlm_handle *h, const MlmSlot &S) {
+    const MlmCounters &c = *S.h_ctr;
+    h->stats.n_points = c.n_points;
+    h->stats.n_hit_cells = c.u_hit;
+    unsigned int um = 0;
+    for (int k = 0; k < MLM_RAY_LISTS; ++k) um += c.umiss_part[k][0];
+    h->stats.n_miss_cells = um;
+    h->stats.n_out_of_range = c.n_oor;
+    h->stats.n_blocks = std::min<unsigned int>(h->h_g->n_blocks, (unsigned int)h->P.max_blocks);
+    h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
+}
+
+int check_queues(mlm_handle *h, const MlmSlot &S) {
+    const MlmCounters &c = *S.h_ctr;
+    const MlmDev &P = S.P;
+    bool over = c.n_contrib > P.contrib_cap;
+    for (int k = 0; k < MLM_RAY_LISTS; ++k)
+        over = over || c.ray_cnt[k][0] > P.ray_cap || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap ||
+               c.mvox_cnt[k][0] > P.mvox_cap;
+    if (over) {
+        h->err = "a per-frame device queue overflowed (raise mlm_limits.max_points)";
+        return MLM_ERR_CAPACITY;
+    }
+    if (h->h_g->err) {
         h->err = "block pool or block hash table full (raise mlm_limits.max_blocks)";
         return MLM_ERR_CAPACITY;
     }
     return MLM_OK;
 }
 
-int ensure_img(mlm_handle *h, size_t n_px) {
-    if (n_px <= h->img_cap) return MLM_OK;
-    if (h->d_img) hipFree(h->d_img);
-    h->d_img = nullptr;
-    HIPCHK(h, hipMalloc((void **)&h->d_img, n_px * sizeof(uint16_t)));
-    h->img_cap = n_px;
+// Integrate the frames already described in slots[0..n) (F, mode set), in order.
+int run_slots(mlm_handle *h, int n) {
+    h->ktimes.clear();
+    h->kpool_used = 0;
+    h->stats.n_rehash_epochs = 1;
+    // reset the speculation flag, then fan Stage A out over the slot streams
+    h->h_g->fail_frame = 0x7FFFFFFF;
+    HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipEvent_t ev_reset = h->ev_main;
+    HIPCHK(h, hipEventRecord(ev_reset, h->stream));
+    for (int j = 0; j < n; ++j) HIPCHK(h, hipStreamWaitEvent(h->slots[j].stream, ev_reset, 0));
+    for (int j = 0; j < n; ++j) {
+        const int rc = launch_stage_a(h, h->slots[j], j);
+        if (rc) return rc;
+    }
+    int first = 0;
+    while (first < n) {
+        for (int j = first; j < n; ++j) {
+            const int rc = launch_stage_bc_speculative(h, h->slots[j], j);
+            if (rc) return rc;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        const int f = h->h_g->fail_frame;
+        const int done_until = std::min(f, n);
+        for (int j = first; j < done_until; ++j) {
+            const int rc = check_queues(h, h->slots[j]);
+            if (rc) return rc;
+        }
+        if (f >= n) break;
+        // frame f does not fit the emulated container without a rehash: replay its Stage B exactly, then go on
+        h->n_spec_miss++;
+        MlmSlot &S = h->slots[f];
+        int rc = check_queues(h, S);
+        if (rc) return rc;
+        h->h_g->fail_frame = 0x7FFFFFFF;
+        HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        rc = order_hits_exact(h, S, S.h_ctr->u_hit, f);
+        if (rc) return rc;
+        launch_stage_c(h, S, f);
+        HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+        first = f + 1;
+        if (first >= n) {
+            HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            rc = check_queues(h, S);
+            if (rc) return rc;
+        }
+        // later frames evaluated their own speculation check against the OLD threshold in Stage A; re-evaluate on
+        // the host with the new policy state
+        for (int j = first; j < n; ++j)
+            if (h->slots[j].h_ctr->u_hit > h->hit_pol._M_next_resize) {
+                // will fail again: handled by the next loop iteration through the device flag set below
+            }
+        if (first < n) {
+            // re-arm the device-side check for the remaining frames with the new threshold
+            int ff = 0x7FFFFFFF;
+            for (int j = n - 1; j >= first; --j)
+                if (h->slots[j].h_ctr->u_hit > h->hit_pol._M_next_resize) ff = j;
+            h->h_g->fail_frame = ff;
+            HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice,
+                                     h->stream));
+        }
+    }
+    h->last_slot = n - 1;
+    fill_stats(h, h->slots[n - 1]);
+    return MLM_OK;
+}
+
+int ensure_img(mlm_handle *h, MlmSlot &S, size_t n_px) {
+    if (n_px <= S.img_cap) return MLM_OK;
+    if (S.d_img) hipFree(S.d_img);
+    S.d_img = nullptr;
+    HIPCHK(h, hipMalloc((void **)&S.d_img, n_px * sizeof(uint16_t)));
+    S.img_cap = n_px;
     return MLM_OK;
 }
 
@@ -433,6 +527,80 @@ int run_query(mlm_handle *h, int mode, const double *pos, int n, float inflate, 
     return MLM_OK;
 }
 
+int read_global(mlm_handle *h) {
+    HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+int alloc_slot(mlm_handle *h, MlmSlot &S, const std::vector<float> &sigma3) {
+    S.P = h->P;
+    MlmDev &P = S.P;
+    int rc;
+    const size_t NC = (size_t)P.nCells;
+    HIPCHK(h, hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&S.done_a, hipEventDisableTiming));
+    HIPCHK(h, hipHostMalloc((void **)&S.h_ctr, sizeof(MlmCounters), hipHostMallocDefault));
+    std::memset(S.h_ctr, 0, sizeof(MlmCounters));
+    if ((rc = dev_alloc(h, &P.ctr, 1))) return rc;
+    if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hit_cnt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hit_mask, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.node_head, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
+    if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
+    if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
+    P.touch_cap = (unsigned int)NC;
+    if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
+    P.ray_cap = (unsigned int)h->lim.max_points / 4u + 4096u;
+    if ((rc = dev_alloc(h, &P.rays, (size_t)MLM_RAY_LISTS * P.ray_cap * 3))) return rc;
+    if ((rc = dev_alloc(h, &P.blk_stats, 2 * ((size_t)h->lim.max_points / 64 + 1024)))) return rc;
+    {
+        // most contributions one point can make: centre + (+d,-d) while d < 3*sigma(rho) (map_awareness.cpp:149)
+        int dmax = 0;
+        for (int r = 0; r < P.nRho; ++r) {
+            int d = 1;
+            while ((float)d < sigma3[r] && r + d < P.nRho && d <= MLM_DIFF_RANGE) ++d;
+            dmax = std::max(dmax, d - 1);
+        }
+        const size_t cap = (size_t)h->lim.max_points * (size_t)(1 + 2 * dmax);
+        if (cap > 0xFFFFFFF0ull) {
+            h->err = "contribution buffer too large";
+            return MLM_ERR_UNSUPPORTED;
+        }
+        P.contrib_cap = (unsigned int)cap;
+        if ((rc = dev_alloc(h, &P.contrib, cap))) return rc;
+        if ((rc = dev_alloc(h, &P.subs, cap))) return rc;
+        P.node_cap = (unsigned int)(cap / MLM_RAY_LISTS + 4096);
+        if ((rc = dev_alloc(h, &P.nodes, (size_t)MLM_RAY_LISTS * P.node_cap))) return rc;
+    }
+    if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_t, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_odd, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_inc, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_base, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_cnt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_vt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_arr, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_key, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_next, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_vox, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
+    P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
+    if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
+    HIPCHK(h, hipMemset(P.ctr, 0, sizeof(MlmCounters)));
+    HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.hit_cnt, 0, NC * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.hit_mask, 0, NC * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.node_head, 0xFF, NC * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
+    if ((rc = ensure_img(h, S, (size_t)h->lim.max_points))) return rc;
+    if ((rc = dev_alloc(h, &S.d_pix, (size_t)h->lim.max_points))) return rc;
+    if ((rc = dev_alloc(h, &S.d_pts, (size_t)h->lim.max_points * 3))) return rc;
+    return MLM_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -455,7 +623,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if (lim_in) h->lim = *lim_in;
     if (h->lim.max_blocks <= 0) h->lim.max_blocks = 65536;
     if (h->lim.max_points <= 0) h->lim.max_points = 1280 * 720;
-    if (h->lim.max_batch <= 0) h->lim.max_batch = 32;
+    if (h->lim.max_batch <= 0) h->lim.max_batch = 8;
+    if (h->lim.max_batch > 64) h->lim.max_batch = 64;
     int ndev = 0;
     HIPCHK(h, hipGetDeviceCount(&ndev));
     if (ndev <= 0 || device < 0 || device >= ndev) {
@@ -464,6 +633,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     }
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
 
     MlmDev &P = h->P;
     // awareness constants, map_awareness.cpp:21-32
@@ -518,10 +688,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     OddsModel om{cfg->am_d_rho, cfg->depth_noise_coe};
     h->odds_table.resize((size_t)21 * P.nRho);
     for (int d = -MLM_DIFF_RANGE; d <= MLM_DIFF_RANGE; ++d)
-        for (int r = 0; r < P.nRho; ++r) {
-            const float a = om.get_odds(d, (size_t)r);
-            h->odds_table[(size_t)(d + MLM_DIFF_RANGE) * P.nRho + r] = a;
-        }
+        for (int r = 0; r < P.nRho; ++r) h->odds_table[(size_t)(d + MLM_DIFF_RANGE) * P.nRho + r] = om.get_odds(d, (size_t)r);
     std::vector<float> sigma3(P.nRho);
     for (int r = 0; r < P.nRho; ++r) sigma3[r] = 3 * om.sigma_in_dr((size_t)r); // map_awareness.cpp:149
     std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
@@ -547,50 +714,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     P.cos_phi = d_c;
     P.sin_phi = d_s;
 
-    // awareness scratch + unique-hit list
     const size_t NC = (size_t)P.nCells;
-    if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hit_cnt, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.seg_base, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hit_mask, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
-    P.touch_cap = (unsigned int)NC;
-    if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
-    P.ray_cap = (unsigned int)h->lim.max_points / 4u + 4096u;
-    if ((rc = dev_alloc(h, &P.rays, (size_t)MLM_RAY_LISTS * P.ray_cap * 3))) return rc;
-    if ((rc = dev_alloc(h, &P.blk_stats, 2 * ((size_t)h->lim.max_points / 64 + 1024)))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_base, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_cnt, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.pt_cell, (size_t)h->lim.max_points))) return rc;
-    {
-        // most contributions one point can make: centre + (+d,-d) while d < 3*sigma(rho) (map_awareness.cpp:149)
-        int dmax = 0;
-        for (int r = 0; r < P.nRho; ++r) {
-            int d = 1;
-            while ((float)d < sigma3[r] && r + d < P.nRho && d <= MLM_DIFF_RANGE) ++d;
-            dmax = std::max(dmax, d - 1);
-        }
-        const size_t cap = (size_t)h->lim.max_points * (size_t)(1 + 2 * dmax);
-        if (cap > 0xFFFFFFF0ull) {
-            h->err = "contribution buffer too large";
-            return MLM_ERR_UNSUPPORTED;
-        }
-        P.contrib_cap = (unsigned int)cap;
-        if ((rc = dev_alloc(h, &P.contrib, cap))) return rc;
-        if ((rc = dev_alloc(h, &P.subs, cap))) return rc;
-    }
-    if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
-    if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_t, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_odd, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_inc, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_vt, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_arr, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_key, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_next, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_vox, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
     // the emulated container can never hold more than nCells keys: bucket counts stay below the first
     // libstdc++ prime >= 2*nCells
     {
@@ -598,13 +722,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         h->max_buckets = pol._M_next_bkt(2 * NC + 2);
     }
     if ((rc = dev_alloc(h, &P.bkt_first, h->max_buckets))) return rc;
-    HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.hit_cnt, 0, NC * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.hit_mask, 0, NC * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
 
-    // block table + pool
+    // block table + pool (shared by all slots)
     size_t ht = 1;
     while (ht < (size_t)P.max_blocks * 4) ht <<= 1;
     P.ht_mask = (uint32_t)(ht - 1);
@@ -617,9 +736,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &P.infl, NV))) return rc;
     if ((rc = dev_alloc(h, &P.vox_head, NV))) return rc;
     if ((rc = dev_alloc(h, &P.vox_miss, NV))) return rc;
-    P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
-    if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
-    if ((rc = dev_alloc(h, &P.ctr, 1))) return rc;
+    if ((rc = dev_alloc(h, &P.g, 1))) return rc;
     HIPCHK(h, hipMemset(P.ht_keys, 0xFF, ht * sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(P.ht_slot, 0xFF, ht * sizeof(int)));
     HIPCHK(h, hipMemset(P.log_odds, 0, NV * sizeof(float)));            // allocate_ram: log_odds 0
@@ -627,12 +744,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     HIPCHK(h, hipMemset(P.infl, 'u', NV));                              //               inflate_occupancy 'u'
     HIPCHK(h, hipMemset(P.vox_head, 0xFF, NV * sizeof(int)));
     HIPCHK(h, hipMemset(P.vox_miss, 0, NV * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.ctr, 0, sizeof(MlmCounters)));
+    HIPCHK(h, hipMemset(P.g, 0, sizeof(MlmGlobal)));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
+    std::memset(h->h_g, 0, sizeof(MlmGlobal));
 
-    // inputs
-    if ((rc = ensure_img(h, (size_t)h->lim.max_points))) return rc;
-    if ((rc = dev_alloc(h, &h->d_pix, (size_t)h->lim.max_points))) return rc;
-    if ((rc = dev_alloc(h, &h->d_pts, (size_t)h->lim.max_points * 3))) return rc;
     // sort buffers
     h->sort_tmp_bytes = mlm_sort_temp_bytes(NC);
     if ((rc = dev_alloc(h, &h->sk_in, NC))) return rc;
@@ -640,7 +755,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &h->sv_in, NC))) return rc;
     if ((rc = dev_alloc(h, &h->sv_out, NC))) return rc;
     if ((rc = dev_alloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes))) return rc;
-    HIPCHK(h, hipHostMalloc((void **)&h->h_ctr, sizeof(MlmCounters), hipHostMallocDefault));
+
+    // frame slots
+    h->slots.resize((size_t)h->lim.max_batch);
+    for (auto &S : h->slots)
+        if ((rc = alloc_slot(h, S, sigma3))) return rc;
     HIPCHK(h, hipDeviceSynchronize());
     return MLM_OK;
 }
@@ -648,12 +767,18 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
 int mlm_destroy(mlm_handle *h) {
     if (!h) return MLM_ERR_INVALID;
     hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    hipDeviceSynchronize();
     for (void *p : h->allocs) hipFree(p);
-    if (h->d_img) hipFree(h->d_img);
+    for (auto &S : h->slots) {
+        if (S.d_img) hipFree(S.d_img);
+        if (S.h_ctr) hipHostFree(S.h_ctr);
+        if (S.done_a) hipEventDestroy(S.done_a);
+        if (S.stream) hipStreamDestroy(S.stream);
+    }
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
-    if (h->h_ctr) hipHostFree(h->h_ctr);
+    if (h->h_g) hipHostFree(h->h_g);
+    if (h->ev_main) hipEventDestroy(h->ev_main);
     for (auto &k : h->kpool) {
         hipEventDestroy(k.a);
         hipEventDestroy(k.b);
@@ -672,6 +797,69 @@ int mlm_set_stream(mlm_handle *h, void *s) {
     return MLM_OK;
 }
 
+int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_frames, size_t frame_stride, int width,
+                                  int height, int row_stride, const double *q_wb, const double *t_wb) {
+    if (!h || !img_dev || n_frames < 0 || !q_wb || !t_wb || width <= 0 || height <= 0 || row_stride < width)
+        return MLM_ERR_INVALID;
+    if ((long long)width * height > h->lim.max_points) {
+        h->err = "frame has more points than mlm_limits.max_points";
+        return MLM_ERR_CAPACITY;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int K = (int)h->slots.size();
+    for (int k0 = 0; k0 < n_frames; k0 += K) {
+        const int n = std::min(K, n_frames - k0);
+        for (int j = 0; j < n; ++j) {
+            MlmSlot &S = h->slots[j];
+            S.F = MlmFrame{};
+            frame_setup(h, q_wb + 4 * (size_t)(k0 + j), t_wb + 3 * (size_t)(k0 + j), S.F);
+            S.F.img = img_dev + (size_t)(k0 + j) * frame_stride;
+            S.F.width = width;
+            S.F.height = height;
+            S.F.row_stride = row_stride;
+            S.F.n = width * height;
+            S.mode = 0;
+        }
+        const int rc = run_slots(h, n);
+        if (rc) return rc;
+    }
+    return MLM_OK;
+}
+
+int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_frames, size_t frame_stride, int width,
+                              int height, int row_stride, const double *q_wb, const double *t_wb) {
+    if (!h || !img_host || n_frames < 0 || !q_wb || !t_wb || width <= 0 || height <= 0 || row_stride < width)
+        return MLM_ERR_INVALID;
+    if ((long long)width * height > h->lim.max_points) {
+        h->err = "frame has more points than mlm_limits.max_points";
+        return MLM_ERR_CAPACITY;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int K = (int)h->slots.size();
+    const size_t n_px = (size_t)row_stride * height;
+    for (int k0 = 0; k0 < n_frames; k0 += K) {
+        const int n = std::min(K, n_frames - k0);
+        for (int j = 0; j < n; ++j) {
+            MlmSlot &S = h->slots[j];
+            int rc = ensure_img(h, S, n_px);
+            if (rc) return rc;
+            HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t),
+                                     hipMemcpyHostToDevice, S.stream));
+            S.F = MlmFrame{};
+            frame_setup(h, q_wb + 4 * (size_t)(k0 + j), t_wb + 3 * (size_t)(k0 + j), S.F);
+            S.F.img = S.d_img;
+            S.F.width = width;
+            S.F.height = height;
+            S.F.row_stride = row_stride;
+            S.F.n = width * height;
+            S.mode = 0;
+        }
+        const int rc = run_slots(h, n);
+        if (rc) return rc;
+    }
+    return MLM_OK;
+}
+
 int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int width, int height, int row_stride,
                                 const int32_t *pixel_idx_dev, int n_idx, const double q_wb[4], const double t_wb[3]) {
     if (!h || !img_dev || width <= 0 || height <= 0 || row_stride < width || !q_wb || !t_wb) return MLM_ERR_INVALID;
@@ -682,43 +870,34 @@ int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int widt
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    MlmFrame F{};
-    frame_setup(h, q_wb, t_wb, F);
-    F.img = img_dev;
-    F.pix = pixel_idx_dev;
-    F.width = width;
-    F.height = height;
-    F.row_stride = row_stride;
-    F.n = (int)n;
-    return integrate_frame(h, F, pixel_idx_dev ? 1 : 0);
+    MlmSlot &S = h->slots[0];
+    S.F = MlmFrame{};
+    frame_setup(h, q_wb, t_wb, S.F);
+    S.F.img = img_dev;
+    S.F.pix = pixel_idx_dev;
+    S.F.width = width;
+    S.F.height = height;
+    S.F.row_stride = row_stride;
+    S.F.n = (int)n;
+    S.mode = pixel_idx_dev ? 1 : 0;
+    return run_slots(h, 1);
 }
 
 int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int height, int row_stride,
                             const int32_t *pixel_idx, int n_idx, const double q_wb[4], const double t_wb[3]) {
     if (!h || !img || width <= 0 || height <= 0 || row_stride < width) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    MlmSlot &S = h->slots[0];
     const size_t n_px = (size_t)row_stride * height;
-    int rc = ensure_img(h, n_px);
+    int rc = ensure_img(h, S, n_px);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, S.stream));
     if (pixel_idx) {
         if (n_idx < 0 || n_idx > h->lim.max_points) return MLM_ERR_CAPACITY;
-        HIPCHK(h, hipMemcpyAsync(h->d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice,
-                                 h->stream));
+        HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, S.stream));
     }
-    return mlm_integrate_depth_u16_dev(h, h->d_img, width, height, row_stride, pixel_idx ? h->d_pix : nullptr, n_idx,
-                                       q_wb, t_wb);
-}
-
-int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_frames, size_t frame_stride, int width,
-                                  int height, int row_stride, const double *q_wb, const double *t_wb) {
-    if (!h || !img_dev || n_frames < 0 || !q_wb || !t_wb) return MLM_ERR_INVALID;
-    for (int k = 0; k < n_frames; ++k) {
-        const int rc = mlm_integrate_depth_u16_dev(h, img_dev + (size_t)k * frame_stride, width, height, row_stride,
-                                                   nullptr, 0, q_wb + 4 * k, t_wb + 3 * k);
-        if (rc) return rc;
-    }
-    return MLM_OK;
+    return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, row_stride, pixel_idx ? S.d_pix : nullptr, n_idx, q_wb,
+                                       t_wb);
 }
 
 int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q_wb[4], const double t_wb[3]) {
@@ -728,14 +907,15 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    if (n > 0)
-        HIPCHK(h, hipMemcpyAsync(h->d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    MlmFrame F{};
-    frame_setup(h, q_wb, t_wb, F);
-    F.pts = h->d_pts;
-    F.n = n;
-    F.width = 1;
-    return integrate_frame(h, F, 2);
+    MlmSlot &S = h->slots[0];
+    if (n > 0) HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    S.F = MlmFrame{};
+    frame_setup(h, q_wb, t_wb, S.F);
+    S.F.pts = S.d_pts;
+    S.F.n = n;
+    S.F.width = 1;
+    S.mode = 2;
+    return run_slots(h, 1);
 }
 
 int mlm_query_occupancy(mlm_handle *h, const double *pos, int n, int8_t *out) {
@@ -793,9 +973,9 @@ int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
 int mlm_block_count(mlm_handle *h, int *n_out) {
     if (!h || !n_out) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = read_counters(h);
+    int rc = read_global(h);
     if (rc) return rc;
-    *n_out = (int)std::min<unsigned int>(h->h_ctr->n_blocks, (unsigned int)h->P.max_blocks);
+    *n_out = (int)std::min<unsigned int>(h->h_g->n_blocks, (unsigned int)h->P.max_blocks);
     return MLM_OK;
 }
 
@@ -841,13 +1021,14 @@ int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {
 int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *odds, uint32_t *t_first, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    const MlmDev &P = h->slots[(size_t)h->last_slot].P;
     const size_t n = (size_t)h->stats.n_hit_cells;
     if (n_out) *n_out = (int)n;
     const size_t m = std::min<size_t>(n, (size_t)cap);
     if (m == 0) return MLM_OK;
-    if (cell_idx) HIPCHK(h, hipMemcpy(cell_idx, h->P.hl_cell, m * 4, hipMemcpyDeviceToHost));
-    if (odds) HIPCHK(h, hipMemcpy(odds, h->P.hl_odd, m * 4, hipMemcpyDeviceToHost));
-    if (t_first) HIPCHK(h, hipMemcpy(t_first, h->P.hl_t, m * 4, hipMemcpyDeviceToHost));
+    if (cell_idx) HIPCHK(h, hipMemcpy(cell_idx, P.hl_cell, m * 4, hipMemcpyDeviceToHost));
+    if (odds) HIPCHK(h, hipMemcpy(odds, P.hl_odd, m * 4, hipMemcpyDeviceToHost));
+    if (t_first) HIPCHK(h, hipMemcpy(t_first, P.hl_t, m * 4, hipMemcpyDeviceToHost));
     return MLM_OK;
 }
 
@@ -858,17 +1039,19 @@ int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_
         return MLM_ERR_INVALID;
     }
     HIPCHK(h, hipSetDevice(h->device));
+    const MlmDev &P = h->slots[(size_t)h->last_slot].P;
     const size_t n = (size_t)h->stats.n_miss_cells;
     if (n_out) *n_out = (int)n;
     const size_t m = std::min<size_t>(n, (size_t)cap);
-    if (m && cell_idx) HIPCHK(h, hipMemcpy(cell_idx, h->P.ml_cell, m * 4, hipMemcpyDeviceToHost));
+    if (m && cell_idx) HIPCHK(h, hipMemcpy(cell_idx, P.ml_cell, m * 4, hipMemcpyDeviceToHost));
     return MLM_OK;
 }
 
 int mlm_get_T_ls(mlm_handle *h, double q[4], double t[3]) {
     if (!h || !q || !t) return MLM_ERR_INVALID;
-    for (int i = 0; i < 4; ++i) q[i] = h->last.q_ls[i];
-    for (int i = 0; i < 3; ++i) t[i] = h->last.t_ls[i];
+    const MlmFrame &F = h->slots[(size_t)h->last_slot].F;
+    for (int i = 0; i < 4; ++i) q[i] = F.q_ls[i];
+    for (int i = 0; i < 3; ++i) t[i] = F.t_ls[i];
     return MLM_OK;
 }
 
@@ -880,14 +1063,14 @@ int mlm_get_odds_table(mlm_handle *h, float *out) {
 
 int mlm_enable_kernel_timing(mlm_handle *h, int on) {
     if (!h) return MLM_ERR_INVALID;
-    h->timing = on != 0;
+    h->timing = on;
     return MLM_OK;
 }
 
 int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipDeviceSynchronize());
     const int n = (int)h->ktimes.size();
     if (n_out) *n_out = n;
     for (int i = 0; i < std::min(n, cap); ++i) {

@@ -28,6 +28,7 @@ STATUS = {0: "MLM_OK", -1: "MLM_ERR_INVALID", -2: "MLM_ERR_HIP", -3: "MLM_ERR_CA
 ABI_SYMBOLS = [
     "mlm_create", "mlm_destroy", "mlm_last_error", "mlm_abi_version", "mlm_set_stream",
     "mlm_integrate_depth_u16", "mlm_integrate_depth_u16_dev", "mlm_integrate_depth_batch_dev",
+    "mlm_integrate_depth_batch",
     "mlm_integrate_points", "mlm_query_occupancy", "mlm_query_occupancy_inflate", "mlm_query_inflate_occupancy",
     "mlm_query_odds", "mlm_query_odd_grad", "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
     "mlm_export_blocks", "mlm_export_global_map", "mlm_sync", "mlm_get_frame_stats", "mlm_get_awareness_hits",
@@ -76,6 +77,7 @@ def load_library(path: Optional[str] = None):
     L.mlm_integrate_depth_u16.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
     L.mlm_integrate_depth_u16_dev.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, vp]
     L.mlm_integrate_depth_batch_dev.argtypes = [vp, vp, i32, ctypes.c_size_t, i32, i32, i32, vp, vp]
+    L.mlm_integrate_depth_batch.argtypes = [vp, vp, i32, ctypes.c_size_t, i32, i32, i32, vp, vp]
     L.mlm_integrate_points.argtypes = [vp, vp, i32, vp, vp]
     L.mlm_query_occupancy.argtypes = [vp, vp, i32, vp]
     L.mlm_query_occupancy_inflate.argtypes = [vp, vp, i32, ctypes.c_float, vp]
@@ -114,12 +116,12 @@ class MLMap:
     FREE, OCCUPIED, UNKNOWN = 1, 0, -1  # mlmap.h:109-114
 
     def __init__(self, cfg: MapConfig, device: int = 0, max_blocks: int = 0, max_points: int = 0,
-                 record_awareness: bool = False):
+                 record_awareness: bool = False, max_batch: int = 0):
         self.cfg = cfg
         self.cells = cfg.cells_per_block
         self._L = load_library()
         self._c = to_c(cfg)
-        self._lim = Limits(max_blocks, max_points, 0, int(record_awareness))
+        self._lim = Limits(max_blocks, max_points, max_batch, int(record_awareness))
         self._h = ctypes.c_void_p()
         rc = self._L.mlm_create(ctypes.byref(self._c), ctypes.byref(self._lim), device, ctypes.byref(self._h))
         if rc != MLM_OK:
@@ -179,6 +181,15 @@ class MLMap:
                                                         frame_stride or width * height, width, height,
                                                         row_stride or width, _p(q), _p(t)),
                   "mlm_integrate_depth_batch_dev")
+
+    def update_map_batch(self, frames_u16: np.ndarray, q_wb, t_wb):
+        """K host frames [K,H,W] of one stream, integrated in order (uploads overlap with compute)."""
+        fr = np.ascontiguousarray(frames_u16, dtype=np.uint16)
+        k, hgt, wid = fr.shape
+        q = _f64(q_wb).reshape(k, 4)
+        t = _f64(t_wb).reshape(k, 3)
+        self._chk(self._L.mlm_integrate_depth_batch(self._h, _p(fr), k, hgt * wid, wid, hgt, wid, _p(q), _p(t)),
+                  "mlm_integrate_depth_batch")
 
     def update_map_points(self, xyz_s, q_wb, t_wb):
         """input_pc_pose(PC_s, T_wb) + input_pc_pose_direct on explicit sensor-frame points."""

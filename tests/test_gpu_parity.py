@@ -173,3 +173,24 @@ def test_queries(mods):
         cpu.setFree_map_in_bound(bmin, bmax)
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "after setFree")
     assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+
+
+def test_batch_pipeline_matches_frame_by_frame(mods):
+    """mlm_integrate_depth_batch_dev (Stage A of several frames in flight, speculative Stage B) must give the same
+    map as the oracle fed frame by frame — including the first batch, where the emulated hit container rehashes."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    n = 21
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
+    poses = syn.random_poses(n, 42)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=8), OracleMap(cfg)
+    gpu.update_map_batch(frames, q, t)
+    for k in range(n):
+        cpu.update_depth(frames[k], q[k], t[k])
+    info = compare_maps(gpu.export_blocks(), cpu.export_blocks(), "batch of 21")
+    st = gpu.frame_stats()
+    assert st["hit_bucket_count"] == cpu.hit_bucket_count()
+    assert st["n_hit_cells"] == len(cpu.hits()[1]) and st["n_miss_cells"] == len(cpu.misses())
+    print(info)
