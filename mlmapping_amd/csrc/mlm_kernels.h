@@ -3,7 +3,7 @@
 // Stage A  (awareness_map_cylindrical::input_pc_pose, map_awareness.cpp:173-282)
 //   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions, de-duplicated ray walk
 //   k_collect_hits    dense sweep of the hit scratch -> unique-hit list + per-cell contribution segments
-//   k_sort_contribs / k_chain   point-order replay of the float noisy-OR chain -> odd, logit
+//   k_expand_nodes / k_sort_contribs / k_chain   point-order replay of the float noisy-OR chain -> odd, logit
 // Stage B  (iteration order of hit_idx_odds_hashmap, i.e. libstdc++ _Hashtable list order)
 //   k_bucket_min / k_make_keys (+ rank kernels on rehash frames)
 // Stage C  (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237)
@@ -119,11 +119,7 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
     return (float)d < s3 && (rho + d < P.nRho) && d <= MLM_DIFF_RANGE;
 }
 
-struct MlmLdsNode {
-    uint32_t cell;
-    uint32_t i00_sub;
-    unsigned long long mask;
-};
+
 #define MLM_NODE_LDS 640 // contribution nodes buffered per k_bin_points block
 
 // MODE 0: dense depth image, 1: indexed depth pixels, 2: explicit sensor-frame points
@@ -133,7 +129,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
     __shared__ unsigned int s_base;
     __shared__ unsigned int s_ntouch, s_tbase, s_nnode, s_nbase;
     __shared__ uint32_t s_touch[MLM_TOUCH_LDS];
-    __shared__ MlmLdsNode s_node[MLM_NODE_LDS];
+    __shared__ MlmNode s_node[MLM_NODE_LDS];
     if (threadIdx.x == 0) {
         s_ntouch = 0;
         s_nnode = 0;
@@ -185,37 +181,40 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
     // insertion time) posts the group: count, kind mask, first-touch time, and a node for the point-order replay.
     // The returned atomics are only looked at after the grouping loop, so they are all in flight together.
     auto post = [&](int key, bool valid, int sub, bool centre) -> bool {
-        uint32_t old_t = 0, old_start = ~0u;
+        uint32_t old_t = 0, old_start = ~0u, pos = 0;
+        unsigned long long my_mask = 0;
         int my_cell = -1;
         mlm_wave_groups(key, valid, [&](int cell, unsigned long long m) {
             my_cell = cell;
+            my_mask = m;
             old_t = atomicMin(&P.hit_t[cell], t0 + (uint32_t)sub);
-            atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
+            pos = atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
             atomicOr(&P.hit_mask[cell], 1u << sub);
             if (centre && P.visibility) old_start = atomicOr(&P.start_bits[cell >> 5], 1u << (cell & 31));
+        });
+        if (my_cell >= 0) {
             const unsigned int k = atomicAdd(&s_nnode, 1u);
+            MlmNode nd;
+            nd.cell = (uint32_t)my_cell;
+            nd.pos = pos;
+            nd.i00_sub = i00 | ((uint32_t)sub << 27);
+            nd.pad = 0;
+            nd.mask = my_mask;
             if (k < MLM_NODE_LDS) {
-                s_node[k].cell = (uint32_t)cell;
-                s_node[k].i00_sub = i00 | ((uint32_t)sub << 27);
-                s_node[k].mask = m;
-            } else { // LDS buffer full: link the node directly
+                s_node[k] = nd;
+            } else { // LDS buffer full: store the node directly
                 const unsigned int reg = blockIdx.x & 7;
                 const unsigned int g = atomicAdd(&P.ctr->node_cnt[reg][0], 1u);
-                if (g < P.node_cap) {
-                    const uint32_t gi = reg * P.node_cap + g;
-                    P.nodes[gi].i00_sub = i00 | ((uint32_t)sub << 27);
-                    P.nodes[gi].mask = m;
-                    P.nodes[gi].next = atomicExch(&P.node_head[cell], gi);
-                }
+                if (g < P.node_cap) P.nodes[(size_t)reg * P.node_cap + g] = nd;
             }
-        });
-        if (my_cell >= 0 && old_t == MLM_EMPTY_T) { // first touch of the cell this frame: queue it for k_collect_hits
-            const unsigned int k = atomicAdd(&s_ntouch, 1u);
-            if (k < MLM_TOUCH_LDS)
-                s_touch[k] = (uint32_t)my_cell;
-            else {
-                const unsigned int g = atomicAdd(&P.ctr->touch_cnt[blockIdx.x & 7][0], 1u);
-                if (g < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + g] = (uint32_t)my_cell;
+            if (old_t == MLM_EMPTY_T) { // first touch of the cell this frame: queue it for k_collect_hits
+                const unsigned int kt = atomicAdd(&s_ntouch, 1u);
+                if (kt < MLM_TOUCH_LDS)
+                    s_touch[kt] = (uint32_t)my_cell;
+                else {
+                    const unsigned int g = atomicAdd(&P.ctr->touch_cnt[blockIdx.x & 7][0], 1u);
+                    if (g < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + g] = (uint32_t)my_cell;
+                }
             }
         }
         // every point of one (rho,phi,z) cell casts the identical ray: only the first one queues it
@@ -280,12 +279,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
     for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
         if (s_tbase + k < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + s_tbase + k] = s_touch[k];
     for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x)
-        if (s_nbase + k < P.node_cap) {
-            const uint32_t gi = reg * P.node_cap + s_nbase + k;
-            P.nodes[gi].i00_sub = s_node[k].i00_sub;
-            P.nodes[gi].mask = s_node[k].mask;
-            P.nodes[gi].next = atomicExch(&P.node_head[s_node[k].cell], gi);
-        }
+        if (s_nbase + k < P.node_cap) P.nodes[(size_t)reg * P.node_cap + s_nbase + k] = s_node[k];
 }
 
 // one ray per wave
@@ -334,7 +328,7 @@ __device__ __forceinline__ float mlm_logit(float p) {
 //  - cell, first-touch time;
 //  - cells with a single kind of contribution: odd (n applications of one value commute) and its logit;
 //  - cells with several kinds: a segment of `contrib` for the point-order replay (k_sort_contribs / k_chain);
-// and reset hit_t / hit_mask / hit_cnt (and node_head of single-kind cells) for the next frame.  gridDim.y = sub-list.
+// and reset hit_t / hit_mask / hit_cnt for the next frame.  gridDim.y = sub-list.
 __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int n_stat_blocks) {
     __shared__ uint32_t s_w[3][4];
     __shared__ uint32_t s_base[3];
@@ -368,7 +362,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int 
         }
         const bool multi = has && __popc(mask) > 1;
         const unsigned long long bh = __ballot(has), bm = __ballot(multi);
-        const uint32_t cincl = mlm_wave_incl_scan(multi ? cnt : 0u);
+        const uint32_t cpad = multi ? ((cnt + 15u) & ~15u) : 0u; // segments start 16-byte aligned in `subs`
+        const uint32_t cincl = mlm_wave_incl_scan(cpad);
         if (lane == 63) {
             s_w[0][wid] = (uint32_t)__popcll(bh);
             s_w[1][wid] = (uint32_t)__popcll(bm);
@@ -394,17 +389,19 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int 
             P.hit_t[c] = MLM_EMPTY_T;
             P.hit_mask[c] = 0;
             P.hit_cnt[c] = 0;
+            if (mask & 1u) atomicAnd(&P.start_bits[c >> 5], ~(1u << (c & 31))); // its ray was queued; reset for next frame
             P.hl_cell[pos] = c;
             P.hl_t[pos] = t;
             P.hl_vt[pos] = t;
             if (multi) {
-                const uint32_t base = off_c + cincl - cnt;
+                const uint32_t base = off_c + cincl - cpad;
+                P.seg_base[c] = base;
                 P.hl_base[pos] = base;
                 P.hl_cnt[pos] = cnt;
                 P.mt_list[off_m + (uint32_t)__popcll(bm & below)] = pos;
             } else {
                 // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
-                P.node_head[c] = MLM_NIL;
+                P.seg_base[c] = MLM_NIL;
                 const int rho_c = (int)(c % (uint32_t)P.nRho);
                 const float a = mlm_contribution_odd(P, P.odds_table, rho_c, __ffs((int)mask) - 1);
                 float p = a;
@@ -418,43 +415,57 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int 
     }
 }
 
-// One wave per multi-kind hit cell: expand the cell's contribution nodes into insertion times, order them (rank by
-// counting in LDS) and store their kinds (`sub`) in that order.  tile_w > 0: dense 8x8 tiles of an image of that
-// width; 0: linear work items.
-#define MLM_SORT_CAP 4096 // keys per wave held in LDS
-#define MLM_SORT_THREADS 128
-__global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev P, int tile_w) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_SORT_THREADS / 64][MLM_SORT_CAP];
+// One wave per contribution node: write the group's insertion times into its cell's segment of `contrib`
+// (multi-kind cells only).  tile_w > 0: dense 8x8 tiles of an image of that width; 0: linear work items.
+// gridDim.y = node region.
+__global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(const MlmDev P, int tile_w) {
+    const unsigned int reg = blockIdx.y;
+    const unsigned int n = min(P.ctr->node_cnt[reg][0], P.node_cap);
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t lane_off = tile_w > 0 ? (uint32_t)((lane >> 3) * tile_w + (lane & 7)) : (uint32_t)lane;
+    // a wave fetches 64 nodes at once (one per lane, coalesced) and then expands them one after the other
+    for (unsigned int k0 = wave * 64; k0 < n; k0 += n_waves * 64) {
+        MlmNode nd{};
+        uint32_t base = MLM_NIL;
+        if (k0 + lane < n) {
+            nd = P.nodes[(size_t)reg * P.node_cap + k0 + lane];
+            base = P.seg_base[nd.cell];
+        }
+        unsigned long long todo = __ballot(base != MLM_NIL);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t b = __shfl(base, src, 64), pos = __shfl(nd.pos, src, 64), is = __shfl(nd.i00_sub, src, 64);
+            const unsigned long long m = ((unsigned long long)__shfl((uint32_t)(nd.mask >> 32), src, 64) << 32) |
+                                         (unsigned long long)__shfl((uint32_t)nd.mask, src, 64);
+            if ((m >> lane) & 1ull) {
+                const uint32_t key = ((is & 0x07FFFFFFu) + lane_off) * MLM_TIME_SLOTS + (is >> 27);
+                const uint32_t at = b + pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (at < P.contrib_cap) P.contrib[at] = key;
+            }
+        }
+    }
+}
+
+// One wave per multi-kind hit cell: order the cell's contributions by insertion time (rank by counting, keys in
+// LDS) and store their kinds (`sub`) in that order.
+#define MLM_SORT_CAP 2048 // keys per wave held in LDS
+__global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(const MlmDev P) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_BLOCK / 64][MLM_SORT_CAP];
     const unsigned int n_cells = P.ctr->n_multi;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     volatile uint32_t *K = s_keys[wid];
-    const uint32_t lane_off = tile_w > 0 ? (uint32_t)((lane >> 3) * tile_w + (lane & 7)) : (uint32_t)lane;
     for (unsigned int w = wave; w < n_cells; w += n_waves) {
         const uint32_t pos = P.mt_list[w];
-        const uint32_t cell = P.hl_cell[pos];
         const uint32_t base = P.hl_base[pos];
         const uint32_t n = P.hl_cnt[pos];
-        const bool in_lds = n <= MLM_SORT_CAP;
-        uint32_t filled = 0;
-        for (uint32_t node = P.node_head[cell]; node != MLM_NIL;) {
-            const MlmNode nd = P.nodes[node];
-            if ((nd.mask >> lane) & 1ull) {
-                const uint32_t key = ((nd.i00_sub & 0x07FFFFFFu) + lane_off) * MLM_TIME_SLOTS + (nd.i00_sub >> 27);
-                const uint32_t at = filled + (uint32_t)__popcll(nd.mask & ((1ull << lane) - 1ull));
-                if (in_lds)
-                    K[at] = key;
-                else if (base + at < P.contrib_cap)
-                    P.contrib[base + at] = key;
-            }
-            filled += (uint32_t)__popcll(nd.mask);
-            node = nd.next;
-        }
-        if (lane == 0) P.node_head[cell] = MLM_NIL;
-        if (in_lds) {
+        if (n <= MLM_SORT_CAP) {
             const uint32_t n4 = (n + 3u) & ~3u;
-            if (n + lane < n4) K[n + lane] = 0xFFFFFFFFu;
+            for (uint32_t j = lane; j < n4; j += 64) K[j] = j < n ? P.contrib[base + j] : 0xFFFFFFFFu;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave execute in order
             __builtin_amdgcn_wave_barrier();
             for (uint32_t j = lane; j < n; j += 64) {
@@ -469,13 +480,11 @@ __global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         } else {
-            // larger than the LDS window: same rank-by-counting from the spill segment (rare, slow, exact)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+            // larger than the LDS window: same rank-by-counting straight from memory (rare, slow, exact)
             for (uint32_t j = lane; j < n; j += 64) {
-                const uint32_t my = __hip_atomic_load(&P.contrib[base + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t my = P.contrib[base + j];
                 uint32_t r = 0;
-                for (uint32_t q = 0; q < n; ++q)
-                    r += __hip_atomic_load(&P.contrib[base + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < my;
+                for (uint32_t q = 0; q < n; ++q) r += P.contrib[base + q] < my;
                 P.subs[base + r] = (uint8_t)(my % MLM_TIME_SLOTS);
             }
         }
@@ -486,6 +495,9 @@ __global__ __launch_bounds__(MLM_SORT_THREADS) void k_sort_contribs(const MlmDev
 // the float noisy-OR chain is not associative, so the order is part of the result.  p == 1.0f is absorbing
 // (1-(1-1)(1-a) == 1), which ends long chains early.
 __global__ __launch_bounds__(MLM_BLOCK) void k_chain(const MlmDev P, int frame_idx, unsigned int rehash_threshold) {
+    extern __shared__ float s_table[]; // get_odds_table, 21*nRho floats
+    for (int j = threadIdx.x; j < (2 * MLM_DIFF_RANGE + 1) * P.nRho; j += blockDim.x) s_table[j] = P.odds_table[j];
+    __syncthreads();
     // Stage B is launched assuming that this frame's unique hit cells fit the emulated container without a rehash
     // (element count <= _M_next_resize).  If they do not, flag the frame: its Stage B/C kernels (and those of later
     // frames) turn into no-ops and the host replays them with the exact rehash plan.
@@ -493,18 +505,31 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain(const MlmDev P, int frame_i
     const unsigned int n_cells = P.ctr->n_multi;
     for (unsigned int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_cells; w += gridDim.x * blockDim.x) {
         const uint32_t pos = P.mt_list[w];
-        const uint32_t base = P.hl_base[pos];
+        const uint32_t base = P.hl_base[pos]; // multiple of 16
         const uint32_t n = P.hl_cnt[pos];
         const int rho_c = (int)(P.hl_cell[pos] % (uint32_t)P.nRho);
         float p = 0.0f;
         bool first = true;
-        for (uint32_t j = 0; j < n && p != 1.0f; ++j) {
-            const float a = mlm_contribution_odd(P, P.odds_table, rho_c, P.subs[base + j]);
-            if (first) {
-                p = a;
-                first = false;
-            } else {
-                p = 1 - (1 - p) * (1 - a);
+        for (uint32_t j0 = 0; j0 < n && p != 1.0f; j0 += 16) {
+            const uint4 v = *(const uint4 *)(P.subs + base + j0); // 16 kinds
+            const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+            float a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int sub = (int)((word[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
+                if (j0 + q >= n) sub = 0; // padding bytes are not kinds
+                a[q] = mlm_contribution_odd(P, s_table, rho_c, sub);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (j0 + q < n) {
+                    if (first) {
+                        p = a[q];
+                        first = false;
+                    } else {
+                        p = 1 - (1 - p) * (1 - a[q]);
+                    }
+                }
             }
         }
         P.hl_odd[pos] = p;

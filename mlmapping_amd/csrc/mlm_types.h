@@ -35,11 +35,13 @@ struct MlmGlobal {
 #define MLM_RAY_LISTS 8
 
 // The hit contributions one wave makes to one awareness cell with one kind (`sub`): lanes in `mask`, work items
-// i = i00 + lane (linear modes) or i00 + (lane>>3)*W + (lane&7) (dense 8x8 pixel tile).  Nodes of a cell are
-// linked through `next` from MlmDev::node_head.
+// i = i00 + lane (linear modes) or i00 + (lane>>3)*W + (lane&7) (dense 8x8 pixel tile).  `pos` is where the group's
+// insertion times start inside the cell's segment of MlmDev::contrib.
 struct MlmNode {
+    uint32_t cell;
+    uint32_t pos;
     uint32_t i00_sub; // i00 | sub << 27
-    uint32_t next;    // MLM_NIL terminates
+    uint32_t pad;
     unsigned long long mask;
 };
 #define MLM_NIL 0xFFFFFFFFu
@@ -68,10 +70,10 @@ struct MlmDev {
     uint32_t *hit_t;           // [nCells] first-touch time of a hit cell (min over contributions)
     uint32_t *hit_cnt;         // [nCells] number of contributions; reused as the fill cursor of the segment
     uint32_t *hit_mask;        // [nCells] bit s set = a contribution of insertion slot s (0 centre, 2d-1 "+d", 2d "-d")
-    uint32_t *node_head;       // [nCells] head of the cell's contribution-node list, MLM_NIL = empty
+    uint32_t *seg_base;        // [nCells] start of the cell's segment in `contrib` (MLM_NIL for single-kind cells)
     MlmNode *nodes;            // [MLM_RAY_LISTS][node_cap]
     unsigned int node_cap;     // per region
-    uint32_t *contrib;         // [contrib_cap] spill space for cells with more contributions than the LDS window
+    uint32_t *contrib;         // [contrib_cap] insertion times of the contributions of multi-kind cells, by cell
     int32_t *rays;             // [MLM_RAY_LISTS][ray_cap][3] queued rays: binned (rho,phi,z) of the start
     unsigned int ray_cap;      // per sub-list
     unsigned int *blk_stats;   // [2*max tiles] per-block partial sums: points fed, points out of range
@@ -79,6 +81,7 @@ struct MlmDev {
     uint32_t *touched;         // [MLM_RAY_LISTS][touch_cap] hit cells in first-touch order of the GPU (arbitrary)
     unsigned int touch_cap;    // per sub-list
     uint8_t *subs;             // [contrib_cap] per multi-kind cell: contribution kinds in insertion-time order
+                               // (segments start 16-byte aligned; same offsets as `contrib`)
     unsigned int contrib_cap;
     uint32_t *start_bits;      // [ceil(nCells/32)] hit-centre cells whose ray has been walked
     uint32_t *miss_bits;       // [nMissWords] free cells, row-major (z,phi) rows of RW words, bit = rho

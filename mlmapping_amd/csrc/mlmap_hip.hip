@@ -306,7 +306,6 @@ int launch_stage_a(mlm_handle *h, MlmSlot &S, int frame_idx) {
     const MlmFrame &F = S.F;
     hipStream_t st = S.stream;
     HIPCHK(h, hipMemsetAsync(P.ctr, 0, sizeof(MlmCounters), st));
-    HIPCHK(h, hipMemsetAsync(P.start_bits, 0, ((size_t)P.nCells + 31) / 32 * sizeof(uint32_t), st));
     S.nb = 0;
     if (F.n > 0) {
         const unsigned int nb =
@@ -327,7 +326,7 @@ int launch_stage_a(mlm_handle *h, MlmSlot &S, int frame_idx) {
         }
         if (P.visibility) {
             Timed t(h, st, "k_walk_rays");
-            hipLaunchKernelGGL(k_walk_rays, dim3(128, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P);
+            hipLaunchKernelGGL(k_walk_rays, dim3(256, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P);
         }
     }
     {
@@ -335,12 +334,16 @@ int launch_stage_a(mlm_handle *h, MlmSlot &S, int frame_idx) {
         hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P, (int)S.nb);
     }
     {
+        Timed t(h, st, "k_expand_nodes");
+        hipLaunchKernelGGL(k_expand_nodes, dim3(64, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P, S.mode == 0 ? F.width : 0);
+    }
+    {
         Timed t(h, st, "k_sort_contribs");
-        hipLaunchKernelGGL(k_sort_contribs, dim3(2048), dim3(MLM_SORT_THREADS), 0, st, P, S.mode == 0 ? F.width : 0);
+        hipLaunchKernelGGL(k_sort_contribs, dim3(1024), dim3(MLM_BLOCK), 0, st, P);
     }
     {
         Timed t(h, st, "k_chain");
-        hipLaunchKernelGGL(k_chain, dim3(256), dim3(MLM_BLOCK), 0, st, P, frame_idx,
+        hipLaunchKernelGGL(k_chain, dim3(256), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st, P, frame_idx,
                            (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
     }
     HIPCHK(h, hipEventRecord(S.done_a, st));
@@ -546,7 +549,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, const std::vector<float> &sigma3) {
     if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hit_cnt, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hit_mask, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.node_head, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.seg_base, NC))) return rc;
     if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
     if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
     if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
@@ -568,9 +571,15 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, const std::vector<float> &sigma3) {
             h->err = "contribution buffer too large";
             return MLM_ERR_UNSUPPORTED;
         }
-        P.contrib_cap = (unsigned int)cap;
-        if ((rc = dev_alloc(h, &P.contrib, cap))) return rc;
-        if ((rc = dev_alloc(h, &P.subs, cap))) return rc;
+        // segments are padded to 16 entries; a multi-kind cell has >= 2 contributions
+        const size_t cap_pad = cap + 15 * std::min<size_t>(NC, cap / 2) + 64;
+        if (cap_pad > 0xFFFFFFF0ull) {
+            h->err = "contribution buffer too large";
+            return MLM_ERR_UNSUPPORTED;
+        }
+        P.contrib_cap = (unsigned int)cap_pad;
+        if ((rc = dev_alloc(h, &P.contrib, cap_pad))) return rc;
+        if ((rc = dev_alloc(h, &P.subs, cap_pad))) return rc;
         P.node_cap = (unsigned int)(cap / MLM_RAY_LISTS + 4096);
         if ((rc = dev_alloc(h, &P.nodes, (size_t)MLM_RAY_LISTS * P.node_cap))) return rc;
     }
@@ -592,7 +601,6 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, const std::vector<float> &sigma3) {
     HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.hit_cnt, 0, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.hit_mask, 0, NC * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.node_head, 0xFF, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
     if ((rc = ensure_img(h, S, (size_t)h->lim.max_points))) return rc;
