@@ -102,7 +102,7 @@ PRESETS = {"S1": S1, "S3": S3, "SDEF": SDEF, "S1_SIGMA0": S1_SIGMA0}
 
 
 class CConfig(ctypes.Structure):
-    """Binary layout shared by ``mlm_config`` (include/mlmap_hip.h) and ``mlo_config`` (oracle)."""
+    """Binary layout of ``mlm_config`` (include/mlmap_hip.h); the test-side checker uses the same layout."""
 
     _fields_ = [
         ("am_d_rho", ctypes.c_double),
