@@ -89,6 +89,12 @@ typedef struct mlm_frame_stats {
     int64_t n_blocks;      /* observed_group_map.size() */
     int64_t n_rehash_epochs; /* libstdc++ rehash epochs replayed for the hit container this frame (1 = none) */
     int64_t hit_bucket_count;/* emulated hit_idx_odds_hashmap.bucket_count() after this frame */
+    /* device-side work counters (no reference counterpart) */
+    int64_t n_multi_cells;   /* hit cells that received more than one kind of contribution (need the ordered replay) */
+    int64_t n_contrib_slots; /* 16-padded contribution slots reserved for those cells */
+    int64_t n_groups;        /* (wave, cell, kind) contribution groups = global atomics issued for hits */
+    int64_t n_rays;          /* rays walked after de-duplication */
+    int64_t n_spec_replays;  /* frames so far whose Stage B had to be replayed with a rehash plan */
 } mlm_frame_stats;
 
 /* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */
@@ -136,7 +142,8 @@ int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]);
 
 /* map read-out: what visualisers get by iterating local_map->observed_group_map (rviz_vis.cpp:280-321) */
 int mlm_block_count(mlm_handle *h, int *n_out);
-/* keys [cap*3], log_odds [cap*cells], occ / infl [cap*cells] ('u','f','o'); any pointer may be NULL */
+/* keys [cap*3], log_odds [cap*cells], occ / infl [cap*cells] ('u','f','o'); any pointer may be NULL; destinations may
+ * be host or device memory (the global-map merge exports straight into device tensors) */
 int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, uint8_t *occ, uint8_t *infl,
                       int *n_out);
 /* float xyz of inflated-'o' cell centres = PointCloud2 payload of /global_map (rviz_vis.cpp:296-327) */

@@ -402,6 +402,16 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_out_of_range = c.n_oor;
     h->stats.n_blocks = std::min<unsigned int>(h->h_g->n_blocks, (unsigned int)h->P.max_blocks);
     h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
+    h->stats.n_multi_cells = c.n_multi;
+    h->stats.n_contrib_slots = c.n_contrib;
+    int64_t ng = 0, nr = 0;
+    for (int k = 0; k < MLM_RAY_LISTS; ++k) {
+        ng += c.node_cnt[k][0];
+        nr += c.ray_cnt[k][0];
+    }
+    h->stats.n_groups = ng;
+    h->stats.n_rays = nr;
+    h->stats.n_spec_replays = h->n_spec_miss;
 }
 
 int check_queues(mlm_handle *h, const MlmSlot &S) {
@@ -996,10 +1006,10 @@ int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, ui
     const size_t m = (size_t)std::min(n, cap);
     const size_t C = (size_t)h->P.cells;
     if (m == 0) return MLM_OK;
-    if (keys) HIPCHK(h, hipMemcpyAsync(keys, h->P.block_keys, m * 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (log_odds) HIPCHK(h, hipMemcpyAsync(log_odds, h->P.log_odds, m * C * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (occ) HIPCHK(h, hipMemcpyAsync(occ, h->P.occ, m * C, hipMemcpyDeviceToHost, h->stream));
-    if (infl) HIPCHK(h, hipMemcpyAsync(infl, h->P.infl, m * C, hipMemcpyDeviceToHost, h->stream));
+    if (keys) HIPCHK(h, hipMemcpyAsync(keys, h->P.block_keys, m * 3 * sizeof(int), hipMemcpyDefault, h->stream));
+    if (log_odds) HIPCHK(h, hipMemcpyAsync(log_odds, h->P.log_odds, m * C * sizeof(float), hipMemcpyDefault, h->stream));
+    if (occ) HIPCHK(h, hipMemcpyAsync(occ, h->P.occ, m * C, hipMemcpyDefault, h->stream));
+    if (infl) HIPCHK(h, hipMemcpyAsync(infl, h->P.infl, m * C, hipMemcpyDefault, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MLM_OK;
 }
