@@ -150,6 +150,10 @@ int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, ui
 int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out);
 
 int mlm_sync(mlm_handle *h);
+/* async = 1: integrate calls return once the work is SUBMITTED (two batches may be in flight); errors of a batch and
+ * mlm_get_frame_stats lag by one call; mlm_sync, queries and exports wait for everything.  Default 0: integrate calls
+ * return when the map is updated. */
+int mlm_set_async(mlm_handle *h, int on);
 int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out);
 
 /* test hooks (need limits.record_awareness): unique hit cells (linear cell idx, odd, first-touch time) and

@@ -117,6 +117,7 @@ struct MlmSlot {
     MlmCounters *h_ctr = nullptr; // pinned mirror of P.ctr
     MlmFrame F{};
     int mode = 0;
+    int seq = 0;              // sequence number of the frame it currently holds
     unsigned int nb = 0;      // k_bin_points blocks
     uint16_t *d_img = nullptr; // staging for host images
     size_t img_cap = 0;
@@ -157,7 +158,14 @@ struct mlm_handle {
     std::vector<KernelTime> ktimes;
     std::vector<KernelTime> kpool;
     size_t kpool_used = 0;
-    hipEvent_t ev_main = nullptr; // recorded on the main stream, waited by the slot streams
+    // submission state (see submit_batch / drain)
+    std::vector<MlmSlot *> pending;
+    int next_seq = 0;
+    int cur_set = 0;
+    int set_pending[2] = {0, 0};
+    bool async_mode = false;
+    hipEvent_t batch_done[2] = {nullptr, nullptr};
+    MlmGlobal *h_gb[2] = {nullptr, nullptr}; // pinned snapshots of P.g taken at the end of each batch
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
 };
 
@@ -432,75 +440,125 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
     return MLM_OK;
 }
 
-// Integrate the frames already described in slots[0..n) (F, mode set), in order.
-int run_slots(mlm_handle *h, int n) {
-    h->ktimes.clear();
-    h->kpool_used = 0;
-    h->stats.n_rehash_epochs = 1;
-    // reset the speculation flag, then fan Stage A out over the slot streams
-    h->h_g->fail_frame = 0x7FFFFFFF;
-    HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-    hipEvent_t ev_reset = h->ev_main;
-    HIPCHK(h, hipEventRecord(ev_reset, h->stream));
-    for (int j = 0; j < n; ++j) HIPCHK(h, hipStreamWaitEvent(h->slots[j].stream, ev_reset, 0));
+// ---- submission / confirmation ---------------------------------------------------------------------------------
+// Frames carry a monotonically increasing sequence number.  Stage B/C of a frame is submitted speculatively; the
+// device flag g->fail_frame holds the first sequence number whose speculation did not hold (sticky), and every
+// Stage B/C kernel of a frame >= it is a no-op.  `pending` lists submitted-but-unconfirmed frames in order.
+
+int submit_batch(mlm_handle *h, int base, int n) {
     for (int j = 0; j < n; ++j) {
-        const int rc = launch_stage_a(h, h->slots[j], j);
+        MlmSlot &S = h->slots[(size_t)(base + j)];
+        S.seq = h->next_seq++;
+        const int rc = launch_stage_a(h, S, S.seq);
         if (rc) return rc;
     }
-    int first = 0;
-    while (first < n) {
-        for (int j = first; j < n; ++j) {
-            const int rc = launch_stage_bc_speculative(h, h->slots[j], j);
-            if (rc) return rc;
-        }
+    for (int j = 0; j < n; ++j) {
+        MlmSlot &S = h->slots[(size_t)(base + j)];
+        const int rc = launch_stage_bc_speculative(h, S, S.seq);
+        if (rc) return rc;
+        h->pending.push_back(&S);
+    }
+    const int set = base ? 1 : 0;
+    HIPCHK(h, hipMemcpyAsync(h->h_gb[set], h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipEventRecord(h->batch_done[set], h->stream));
+    h->set_pending[set] = n;
+    return MLM_OK;
+}
+
+int confirm_front(mlm_handle *h, int count) {
+    for (int j = 0; j < count; ++j) {
+        const int rc = check_queues(h, *h->pending[(size_t)j]);
+        if (rc) return rc;
+    }
+    if (count > 0) {
+        MlmSlot *last = h->pending[(size_t)count - 1];
+        h->last_slot = (int)(last - h->slots.data());
+        fill_stats(h, *last);
+    }
+    h->pending.erase(h->pending.begin(), h->pending.begin() + count);
+    return MLM_OK;
+}
+
+// Wait for everything submitted, replay frames whose speculation failed, leave nothing pending.
+int drain(mlm_handle *h) {
+    for (;;) {
         HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         const int f = h->h_g->fail_frame;
-        const int done_until = std::min(f, n);
-        for (int j = first; j < done_until; ++j) {
-            const int rc = check_queues(h, h->slots[j]);
-            if (rc) return rc;
-        }
-        if (f >= n) break;
-        // frame f does not fit the emulated container without a rehash: replay its Stage B exactly, then go on
+        size_t ok = 0;
+        while (ok < h->pending.size() && h->pending[ok]->seq < f) ++ok;
+        int rc = confirm_front(h, (int)ok);
+        if (rc) return rc;
+        if (h->pending.empty()) break;
+        // pending.front() does not fit the emulated container without a rehash: replay its Stage B exactly
         h->n_spec_miss++;
-        MlmSlot &S = h->slots[f];
-        int rc = check_queues(h, S);
+        MlmSlot &S = *h->pending.front();
+        rc = check_queues(h, S);
         if (rc) return rc;
         h->h_g->fail_frame = 0x7FFFFFFF;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        rc = order_hits_exact(h, S, S.h_ctr->u_hit, f);
+        rc = order_hits_exact(h, S, S.h_ctr->u_hit, S.seq);
         if (rc) return rc;
-        launch_stage_c(h, S, f);
+        launch_stage_c(h, S, S.seq);
         HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-        first = f + 1;
-        if (first >= n) {
-            HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            rc = check_queues(h, S);
+        // the later frames evaluated their device-side check against the OLD threshold: re-arm it from the host with
+        // the new policy state (their unique-hit counts are known), then resubmit their Stage B/C
+        int ff = 0x7FFFFFFF;
+        for (size_t j = h->pending.size(); j-- > 1;)
+            if (h->pending[j]->h_ctr->u_hit > h->hit_pol._M_next_resize) ff = h->pending[j]->seq;
+        HIPCHK(h, hipStreamSynchronize(h->stream)); // h_g is about to be rewritten
+        h->h_g->fail_frame = ff;
+        HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        for (size_t j = 1; j < h->pending.size(); ++j) {
+            rc = launch_stage_bc_speculative(h, *h->pending[j], h->pending[j]->seq);
             if (rc) return rc;
         }
-        // later frames evaluated their own speculation check against the OLD threshold in Stage A; re-evaluate on
-        // the host with the new policy state
-        for (int j = first; j < n; ++j)
-            if (h->slots[j].h_ctr->u_hit > h->hit_pol._M_next_resize) {
-                // will fail again: handled by the next loop iteration through the device flag set below
-            }
-        if (first < n) {
-            // re-arm the device-side check for the remaining frames with the new threshold
-            int ff = 0x7FFFFFFF;
-            for (int j = n - 1; j >= first; --j)
-                if (h->slots[j].h_ctr->u_hit > h->hit_pol._M_next_resize) ff = j;
-            h->h_g->fail_frame = ff;
-            HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice,
-                                     h->stream));
-        }
     }
-    h->last_slot = n - 1;
-    fill_stats(h, h->slots[n - 1]);
+    h->set_pending[0] = h->set_pending[1] = 0;
+    if (h->next_seq > 0x3FFFFFFF) h->next_seq = 0; // nothing in flight: sequence numbers may restart
     return MLM_OK;
 }
+
+// The batch submitted on slot set `set` is complete on the device?  Confirm it without draining the newer one.
+int finish_set(mlm_handle *h, int set) {
+    const int n = h->set_pending[set];
+    if (n == 0) return MLM_OK;
+    HIPCHK(h, hipEventSynchronize(h->batch_done[set]));
+    const int last_seq = h->pending[(size_t)n - 1]->seq;
+    if (h->h_gb[set]->fail_frame > last_seq && !h->h_gb[set]->err) {
+        h->h_g->n_blocks = h->h_gb[set]->n_blocks;
+        h->h_g->err = 0;
+        h->set_pending[set] = 0;
+        return confirm_front(h, n);
+    }
+    return drain(h);
+}
+
+// Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
+int run_slots(mlm_handle *h, int n) {
+    h->ktimes.clear();
+    h->kpool_used = 0;
+    h->stats.n_rehash_epochs = 1;
+    const int K = (int)h->slots.size() / 2;
+    const int set = h->cur_set;
+    int rc = submit_batch(h, set * K, n);
+    if (rc == MLM_OK) {
+        if (h->async_mode) {
+            rc = finish_set(h, set ^ 1); // the previous batch; this one keeps the GPU busy meanwhile
+            h->cur_set = set ^ 1;
+        } else {
+            rc = drain(h);
+        }
+    }
+    if (rc != MLM_OK) { // leave a defined state behind
+        hipDeviceSynchronize();
+        h->pending.clear();
+        h->set_pending[0] = h->set_pending[1] = 0;
+    }
+    return rc;
+}
+inline MlmSlot &cur_slot(mlm_handle *h, int j) { return h->slots[(size_t)(h->cur_set * ((int)h->slots.size() / 2) + j)]; }
 
 int ensure_img(mlm_handle *h, MlmSlot &S, size_t n_px) {
     if (n_px <= S.img_cap) return MLM_OK;
@@ -529,7 +587,9 @@ int run_query(mlm_handle *h, int mode, const double *pos, int n, float inflate, 
     if (!h || !pos || !out || n < 0) return MLM_ERR_INVALID;
     if (n == 0) return MLM_OK;
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = ensure_query(h, (size_t)n);
+    int rc = drain(h);
+    if (rc) return rc;
+    rc = ensure_query(h, (size_t)n);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_qpos, pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_query, dim3(grid_for((size_t)n)), dim3(MLM_BLOCK), 0, h->stream, h->P, mode, h->d_qpos, n,
@@ -541,6 +601,8 @@ int run_query(mlm_handle *h, int mode, const double *pos, int n, float inflate, 
 }
 
 int read_global(mlm_handle *h) {
+    const int rc = drain(h);
+    if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MLM_OK;
@@ -651,7 +713,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     }
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->batch_done[k], hipEventDisableTiming));
+        HIPCHK(h, hipHostMalloc((void **)&h->h_gb[k], sizeof(MlmGlobal), hipHostMallocDefault));
+        std::memset(h->h_gb[k], 0, sizeof(MlmGlobal));
+    }
 
     MlmDev &P = h->P;
     // awareness constants, map_awareness.cpp:21-32
@@ -762,7 +828,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     HIPCHK(h, hipMemset(P.infl, 'u', NV));                              //               inflate_occupancy 'u'
     HIPCHK(h, hipMemset(P.vox_head, 0xFF, NV * sizeof(int)));
     HIPCHK(h, hipMemset(P.vox_miss, 0, NV * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.g, 0, sizeof(MlmGlobal)));
+    {
+        MlmGlobal g0{};
+        g0.fail_frame = 0x7FFFFFFF;
+        HIPCHK(h, hipMemcpy(P.g, &g0, sizeof(MlmGlobal), hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
     std::memset(h->h_g, 0, sizeof(MlmGlobal));
 
@@ -775,7 +845,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes))) return rc;
 
     // frame slots
-    h->slots.resize((size_t)h->lim.max_batch);
+    h->slots.resize((size_t)h->lim.max_batch * 2); // two sets: one being filled while the other drains
     for (auto &S : h->slots)
         if ((rc = alloc_slot(h, S, sigma3))) return rc;
     HIPCHK(h, hipDeviceSynchronize());
@@ -796,7 +866,10 @@ int mlm_destroy(mlm_handle *h) {
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     if (h->h_g) hipHostFree(h->h_g);
-    if (h->ev_main) hipEventDestroy(h->ev_main);
+    for (int k = 0; k < 2; ++k) {
+        if (h->batch_done[k]) hipEventDestroy(h->batch_done[k]);
+        if (h->h_gb[k]) hipHostFree(h->h_gb[k]);
+    }
     for (auto &k : h->kpool) {
         hipEventDestroy(k.a);
         hipEventDestroy(k.b);
@@ -824,11 +897,11 @@ int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    const int K = (int)h->slots.size();
+    const int K = (int)h->slots.size() / 2;
     for (int k0 = 0; k0 < n_frames; k0 += K) {
         const int n = std::min(K, n_frames - k0);
         for (int j = 0; j < n; ++j) {
-            MlmSlot &S = h->slots[j];
+            MlmSlot &S = cur_slot(h, j);
             S.F = MlmFrame{};
             frame_setup(h, q_wb + 4 * (size_t)(k0 + j), t_wb + 3 * (size_t)(k0 + j), S.F);
             S.F.img = img_dev + (size_t)(k0 + j) * frame_stride;
@@ -853,12 +926,12 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    const int K = (int)h->slots.size();
+    const int K = (int)h->slots.size() / 2;
     const size_t n_px = (size_t)row_stride * height;
     for (int k0 = 0; k0 < n_frames; k0 += K) {
         const int n = std::min(K, n_frames - k0);
         for (int j = 0; j < n; ++j) {
-            MlmSlot &S = h->slots[j];
+            MlmSlot &S = cur_slot(h, j);
             int rc = ensure_img(h, S, n_px);
             if (rc) return rc;
             HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t),
@@ -888,7 +961,7 @@ int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int widt
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    MlmSlot &S = h->slots[0];
+    MlmSlot &S = cur_slot(h, 0);
     S.F = MlmFrame{};
     frame_setup(h, q_wb, t_wb, S.F);
     S.F.img = img_dev;
@@ -905,7 +978,7 @@ int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int h
                             const int32_t *pixel_idx, int n_idx, const double q_wb[4], const double t_wb[3]) {
     if (!h || !img || width <= 0 || height <= 0 || row_stride < width) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    MlmSlot &S = h->slots[0];
+    MlmSlot &S = cur_slot(h, 0);
     const size_t n_px = (size_t)row_stride * height;
     int rc = ensure_img(h, S, n_px);
     if (rc) return rc;
@@ -925,7 +998,7 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    MlmSlot &S = h->slots[0];
+    MlmSlot &S = cur_slot(h, 0);
     if (n > 0) HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
     S.F = MlmFrame{};
     frame_setup(h, q_wb, t_wb, S.F);
@@ -967,7 +1040,9 @@ int mlm_set_free_in_bound(mlm_handle *h, const double bmin[3], const double bmax
     }
     const size_t total = ax[0].size() * ax[1].size() * ax[2].size();
     const size_t na = ax[0].size() + ax[1].size() + ax[2].size();
-    int rc = ensure_query(h, (na + 2) / 3 + 1);
+    int rc = drain(h);
+    if (rc) return rc;
+    rc = ensure_query(h, (na + 2) / 3 + 1);
     if (rc) return rc;
     double *d = h->d_qpos;
     HIPCHK(h, hipMemcpyAsync(d, ax[0].data(), ax[0].size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -1026,8 +1101,15 @@ int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out)
 int mlm_sync(mlm_handle *h) {
     if (!h) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return MLM_OK;
+    return drain(h);
+}
+
+int mlm_set_async(mlm_handle *h, int on) {
+    if (!h) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = drain(h);
+    h->async_mode = on != 0;
+    return rc;
 }
 
 int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {
@@ -1039,6 +1121,10 @@ int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {
 int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *odds, uint32_t *t_first, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    {
+        const int rc = drain(h);
+        if (rc) return rc;
+    }
     const MlmDev &P = h->slots[(size_t)h->last_slot].P;
     const size_t n = (size_t)h->stats.n_hit_cells;
     if (n_out) *n_out = (int)n;

@@ -31,7 +31,8 @@ ABI_SYMBOLS = [
     "mlm_integrate_depth_batch",
     "mlm_integrate_points", "mlm_query_occupancy", "mlm_query_occupancy_inflate", "mlm_query_inflate_occupancy",
     "mlm_query_odds", "mlm_query_odd_grad", "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
-    "mlm_export_blocks", "mlm_export_global_map", "mlm_sync", "mlm_get_frame_stats", "mlm_get_awareness_hits",
+    "mlm_export_blocks", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
+    "mlm_get_awareness_hits",
     "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
     "mlm_enable_kernel_timing",
 ]
@@ -92,6 +93,7 @@ def load_library(path: Optional[str] = None):
     L.mlm_export_blocks.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.mlm_export_global_map.argtypes = [vp, i32, vp, vp]
     L.mlm_sync.argtypes = [vp]
+    L.mlm_set_async.argtypes = [vp, i32]
     L.mlm_get_frame_stats.argtypes = [vp, vp]
     L.mlm_get_awareness_hits.argtypes = [vp, i32, vp, vp, vp, vp]
     L.mlm_get_awareness_misses.argtypes = [vp, i32, vp, vp]
@@ -154,6 +156,10 @@ class MLMap:
 
     def sync(self):
         self._chk(self._L.mlm_sync(self._h), "mlm_sync")
+
+    def set_async(self, on: bool = True):
+        """Integrate calls return after submission (two batches in flight); sync()/queries wait for everything."""
+        self._chk(self._L.mlm_set_async(self._h, int(on)), "mlm_set_async")
 
     # ---- update_map (mlmap.cpp:382-386) ---------------------------------------------------------
     def update_map(self, depth_u16: np.ndarray, q_wb, t_wb, pixel_idx=None):

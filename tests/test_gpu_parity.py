@@ -194,3 +194,23 @@ def test_batch_pipeline_matches_frame_by_frame(mods):
     assert st["hit_bucket_count"] == cpu.hit_bucket_count()
     assert st["n_hit_cells"] == len(cpu.hits()[1]) and st["n_miss_cells"] == len(cpu.misses())
     print(info)
+
+
+def test_async_submission_matches(mods):
+    """Asynchronous mode (two batches in flight, confirmation one call late) must end in the same map."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    n = 30
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "smooth", n)])
+    poses = syn.smooth_trajectory(n, 42)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=4), OracleMap(cfg)
+    gpu.set_async(True)
+    for k0 in range(0, n, 5):  # batches of 5 > max_batch 4: also splits inside a call
+        gpu.update_map_batch(frames[k0:k0 + 5], q[k0:k0 + 5], t[k0:k0 + 5])
+    gpu.sync()
+    for k in range(n):
+        cpu.update_depth(frames[k], q[k], t[k])
+    print(compare_maps(gpu.export_blocks(), cpu.export_blocks(), "async 30 frames"))
+    assert gpu.frame_stats()["n_hit_cells"] == len(cpu.hits()[1])
