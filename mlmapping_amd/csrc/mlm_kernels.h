@@ -7,7 +7,7 @@
 // Stage B  (iteration order of hit_idx_odds_hashmap, i.e. libstdc++ _Hashtable list order)
 //   k_bucket_min / k_make_keys (+ rank kernels on rehash frames)
 // Stage C  (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237)
-//   k_hits_to_voxels / k_apply_hits / k_misses_to_voxels / k_apply_misses
+//   k_voxelize / k_apply_hits / k_apply_misses
 // Queries  (mlmap.h:142-295, mlmap.cpp:388-407)
 #pragma once
 #include "mlm_device.h"
@@ -123,16 +123,28 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
 #define MLM_NODE_LDS 640 // contribution nodes buffered per k_bin_points block
 
 // MODE 0: dense depth image, 1: indexed depth pixels, 2: explicit sensor-frame points
+// Stage A kernels are launched once per BATCH: blockIdx.z selects the frame slot (its MlmDev and MlmFrame live in
+// device memory), so one launch covers all frames in flight.
+#define MLM_SLOT_ARGS const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot_base
+#define MLM_SLOT_SETUP                                                                                                \
+    const MlmDev &P = slot_tab[slot_base + blockIdx.z];                                                               \
+    const MlmFrame &F = frame_tab[slot_base + blockIdx.z];                                                            \
+    (void)F;
+
+#define MLM_RAY_LDS 320 // rays buffered per k_bin_points block (256 in-range starts + merged outer starts)
 template <int MODE>
-__global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const MlmFrame F) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
     __shared__ unsigned int s_cnt[4];
-    __shared__ unsigned int s_base;
+    __shared__ unsigned int s_nray;
+    __shared__ int s_ray[MLM_RAY_LDS][3];
     __shared__ unsigned int s_ntouch, s_tbase, s_nnode, s_nbase;
     __shared__ uint32_t s_touch[MLM_TOUCH_LDS];
     __shared__ MlmNode s_node[MLM_NODE_LDS];
     if (threadIdx.x == 0) {
         s_ntouch = 0;
         s_nnode = 0;
+        s_nray = 0;
     }
     __syncthreads();
     const MlmTile T = mlm_tile_item<MODE>(F);
@@ -244,54 +256,39 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(const MlmDev P, const 
     // ---- statistics: per-block partial sums, no atomics
     const unsigned int n_pts = (unsigned int)__popcll(__ballot(have));
     const unsigned int n_oor = (unsigned int)__popcll(__ballot(have && !(can_do_cast && P.visibility)));
-    // ---- queue the rays: one global atomic per block, sub-list chosen by blockIdx so that the counters of
-    //      different XCDs live in different cache lines
-    const unsigned long long em = __ballot(emit_ray);
-    if (lane == 0) s_cnt[wid] = (unsigned int)__popcll(em) | (n_pts << 10) | (n_oor << 20);
+    // ---- rays are walked by the block that queued them (LDS queue, one ray per wave at a time)
+    if (emit_ray) {
+        const unsigned int k = atomicAdd(&s_nray, 1u);
+        if (k < MLM_RAY_LDS) {
+            s_ray[k][0] = rho;
+            s_ray[k][1] = phi;
+            s_ray[k][2] = zi;
+        }
+    }
+    if (lane == 0) s_cnt[wid] = n_pts | (n_oor << 10);
     __syncthreads();
     const unsigned int reg = blockIdx.x & 7;
     const unsigned int nt = min(s_ntouch, (unsigned int)MLM_TOUCH_LDS);
     const unsigned int nn = min(s_nnode, (unsigned int)MLM_NODE_LDS);
+    const unsigned int nr = min(s_nray, (unsigned int)MLM_RAY_LDS);
     if (threadIdx.x == 0) {
-        unsigned int rays = 0, pts = 0, oor = 0;
+        unsigned int pts = 0, oor = 0;
         for (int w = 0; w < 4; ++w) {
-            rays += s_cnt[w] & 1023u;
-            pts += (s_cnt[w] >> 10) & 1023u;
-            oor += s_cnt[w] >> 20;
+            pts += s_cnt[w] & 1023u;
+            oor += s_cnt[w] >> 10;
         }
         P.blk_stats[2 * blockIdx.x] = pts;
         P.blk_stats[2 * blockIdx.x + 1] = oor;
-        s_base = rays ? atomicAdd(&P.ctr->ray_cnt[reg][0], rays) : 0u;
         s_tbase = nt ? atomicAdd(&P.ctr->touch_cnt[reg][0], nt) : 0u;
         s_nbase = nn ? atomicAdd(&P.ctr->node_cnt[reg][0], nn) : 0u;
+        if (nr) atomicAdd(&P.ctr->ray_cnt[reg][0], nr); // statistic only
     }
+    for (unsigned int r = wid; r < nr; r += MLM_BLOCK / 64) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
     __syncthreads();
-    if (emit_ray) {
-        unsigned int pos = s_base + (unsigned int)__popcll(em & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wid; ++w) pos += s_cnt[w] & 1023u;
-        if (pos < P.ray_cap) {
-            int32_t *r = P.rays + ((size_t)reg * P.ray_cap + pos) * 3;
-            r[0] = rho;
-            r[1] = phi;
-            r[2] = zi;
-        }
-    }
     for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
         if (s_tbase + k < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + s_tbase + k] = s_touch[k];
     for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x)
         if (s_nbase + k < P.node_cap) P.nodes[(size_t)reg * P.node_cap + s_nbase + k] = s_node[k];
-}
-
-// one ray per wave
-__global__ __launch_bounds__(MLM_BLOCK) void k_walk_rays(const MlmDev P) {
-    const unsigned int k = blockIdx.y;
-    const unsigned int n = min(P.ctr->ray_cnt[k][0], P.ray_cap);
-    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (unsigned int r = wave; r < n; r += n_waves) {
-        const int32_t *q = P.rays + ((size_t)k * P.ray_cap + r) * 3;
-        mlm_walk_ray_wave(P, q[0], q[1], q[2]);
-    }
 }
 
 __device__ __forceinline__ uint32_t mlm_wave_incl_scan(uint32_t v) {
@@ -329,7 +326,8 @@ __device__ __forceinline__ float mlm_logit(float p) {
 //  - cells with a single kind of contribution: odd (n applications of one value commute) and its logit;
 //  - cells with several kinds: a segment of `contrib` for the point-order replay (k_sort_contribs / k_chain);
 // and reset hit_t / hit_mask / hit_cnt for the next frame.  gridDim.y = sub-list.
-__global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int n_stat_blocks) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n_stat_blocks) {
+    MLM_SLOT_SETUP
     __shared__ uint32_t s_w[3][4];
     __shared__ uint32_t s_base[3];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -418,7 +416,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(const MlmDev P, int 
 // One wave per contribution node: write the group's insertion times into its cell's segment of `contrib`
 // (multi-kind cells only).  tile_w > 0: dense 8x8 tiles of an image of that width; 0: linear work items.
 // gridDim.y = node region.
-__global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(const MlmDev P, int tile_w) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int tile_w) {
+    MLM_SLOT_SETUP
     const unsigned int reg = blockIdx.y;
     const unsigned int n = min(P.ctr->node_cnt[reg][0], P.node_cap);
     const int lane = threadIdx.x & 63;
@@ -452,7 +451,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(const MlmDev P, int 
 // One wave per multi-kind hit cell: order the cell's contributions by insertion time (rank by counting, keys in
 // LDS) and store their kinds (`sub`) in that order.
 #define MLM_SORT_CAP 2048 // keys per wave held in LDS
-__global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(const MlmDev P) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_BLOCK / 64][MLM_SORT_CAP];
     const unsigned int n_cells = P.ctr->n_multi;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -494,7 +494,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(const MlmDev P) {
 // One lane per multi-kind hit cell: replay update_odds_hashmap (map_awareness.h:147-154) over the ordered kinds —
 // the float noisy-OR chain is not associative, so the order is part of the result.  p == 1.0f is absorbing
 // (1-(1-1)(1-a) == 1), which ends long chains early.
-__global__ __launch_bounds__(MLM_BLOCK) void k_chain(const MlmDev P, int frame_idx, unsigned int rehash_threshold) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_chain(MLM_SLOT_ARGS, unsigned int rehash_threshold) {
+    MLM_SLOT_SETUP
+    const int frame_idx = F.seq;
     extern __shared__ float s_table[]; // get_odds_table, 21*nRho floats
     for (int j = threadIdx.x; j < (2 * MLM_DIFF_RANGE + 1) * P.nRho; j += blockDim.x) s_table[j] = P.odds_table[j];
     __syncthreads();
@@ -601,72 +603,51 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_time_keys(const MlmDev P, unsigne
 // ---------------------------------------------------------------------------------------------------------------
 // Stage C
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MLM_BLOCK) void k_hits_to_voxels(const MlmDev P, const MlmFrame F, int frame_idx) {
-    MLM_SKIP_IF_FAILED(P, frame_idx)
-    const unsigned int n = P.ctr->u_hit;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    int rho, phi, z;
-    mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
-    double wx, wy, wz;
-    mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-    int gx, gy, gz, cid;
-    mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-    int slot = mlm_block_find(P, gx, gy, gz); // plain loads; blocks almost always exist already
-    if (slot == -1) slot = mlm_block_find_or_insert(P, gx, gy, gz);
-    if (slot < 0) {
-        P.hl_vox[i] = -1;
-        P.hl_next[i] = -2;
-        continue;
-    }
-    const int v = slot * P.cells + cid;
-    P.hl_vox[i] = v;
-    P.hl_next[i] = atomicExch(&P.vox_head[v], (int)i);
-    }
+// bucket-first table of the speculative path: entry = (~seq << 32) | first insertion time.  atomicMin keeps the
+// newest frame's smallest time, so the table never needs clearing between frames.
+__device__ __forceinline__ unsigned long long mlm_bkt_entry(int seq, uint32_t t) {
+    return ((unsigned long long)(0xFFFFFFFFu - (uint32_t)seq) << 32) | (unsigned long long)t;
 }
 
-// The first-inserted node of each voxel list (next == -1) owns the voxel: it replays the voxel's hit
-// contributions in the reference's iteration order (descending hl_key) — map_local.cpp:157-171.
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_hits(const MlmDev P, int frame_idx) {
-    MLM_SKIP_IF_FAILED(P, frame_idx)
-    const unsigned int n = P.ctr->u_hit;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (P.hl_next[i] != -1) continue;
-    const int v = P.hl_vox[i];
-    const int head = P.vox_head[v];
-    float L = P.log_odds[v];
-    uint8_t o = P.occ[v];
-    unsigned long long last = ~0ull;
-    for (;;) {
-        int best = -1;
-        unsigned long long bestkey = 0;
-        for (int j = head; j >= 0; j = P.hl_next[j]) {
-            const unsigned long long k = P.hl_key[j];
-            if (k < last && (best < 0 || k > bestkey)) {
-                best = j;
-                bestkey = k;
-            }
-        }
-        if (best < 0) break;
-        if (L < P.lo_max) {
-            L = L + P.hl_inc[best];
-            L = L > P.lo_max ? P.lo_max : L;
-        }
-        if (L > P.lo_sh && o != 'o') o = 'o';
-        last = bestkey;
-    }
-    P.log_odds[v] = L;
-    P.occ[v] = o;
-    P.vox_head[v] = -1;
-    }
-}
-
-// One thread per bit of the miss mask (= per awareness cell, in mask order): count the frame's misses per voxel
-// (their order is irrelevant: every miss adds the same constant, map_local.cpp:188-192) and clear the mask.
-__global__ __launch_bounds__(MLM_BLOCK) void k_misses_to_voxels(const MlmDev P, const MlmFrame F, int frame_idx) {
+// Stage B+C, kernel 1 of 3.  Blocks [0, hit_blocks): one unique hit per lane — bucket-first time of the emulated
+// container (speculative single epoch; n_bkt == 0 on the exact path where hl_key is already final), world voxel of
+// the cell centre, push on the voxel's pending list.  Blocks [hit_blocks, ...): one bit of the miss mask per lane —
+// count the frame's misses per voxel (their order is irrelevant: every miss adds the same constant,
+// map_local.cpp:188-192) and clear the mask.
+__global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const MlmFrame F, unsigned int hit_blocks,
+                                                        unsigned long long n_bkt) {
     __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
     __shared__ unsigned int s_base;
+    const int frame_idx = F.seq;
     MLM_SKIP_IF_FAILED(P, frame_idx)
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x < hit_blocks) {
+        const unsigned int n = P.ctr->u_hit;
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += hit_blocks * blockDim.x) {
+            int rho, phi, z;
+            mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+            if (n_bkt) {
+                const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
+                atomicMin(&P.bkt64[b], mlm_bkt_entry(frame_idx, P.hl_vt[i]));
+                P.hl_bkt[i] = (uint32_t)b;
+            }
+            double wx, wy, wz;
+            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+            int gx, gy, gz, cid;
+            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
+            int slot = mlm_block_find(P, gx, gy, gz); // plain loads; blocks almost always exist already
+            if (slot == -1) slot = mlm_block_find_or_insert(P, gx, gy, gz);
+            if (slot < 0) {
+                P.hl_vox[i] = -1;
+                P.hl_next[i] = -2;
+                continue;
+            }
+            const int v = slot * P.cells + cid;
+            P.hl_vox[i] = v;
+            P.hl_next[i] = atomicExch(&P.vox_head[v], (int)i);
+        }
+        return;
+    }
+    const long long g = (long long)(blockIdx.x - hit_blocks) * blockDim.x + threadIdx.x;
     const int w = (int)(g >> 5), b = (int)(g & 31);
     uint32_t bits = 0;
     if (w < P.nMissWords) bits = P.miss_bits[w];
@@ -683,7 +664,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_misses_to_voxels(const MlmDev P, 
         mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
         int gx, gy, gz, cid;
         mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-        int slot = mlm_block_find(P, gx, gy, gz); // plain loads; blocks almost always exist already
+        int slot = mlm_block_find(P, gx, gy, gz);
         if (slot == -1) slot = mlm_block_find_or_insert(P, gx, gy, gz);
         if (slot >= 0) {
             v = slot * P.cells + cid;
@@ -708,7 +689,59 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_misses_to_voxels(const MlmDev P, 
         if (tot) atomicAdd(&P.ctr->umiss_part[blockIdx.x & 7][0], tot);
     }
 }
-// map_local.cpp:188-203, k times.  gridDim.y = sub-list.
+
+// iteration-order key of unique hit j: larger = visited earlier by the reference's container walk
+__device__ __forceinline__ unsigned long long mlm_order_key(const MlmDev &P, int j, int explicit_keys) {
+    if (explicit_keys) return P.hl_key[j];
+    const unsigned long long first = P.bkt64[P.hl_bkt[j]] & 0xFFFFFFFFull;
+    return ((first + 1ull) << 32) | (unsigned long long)P.hl_vt[j];
+}
+
+// Kernel 2 of 3.  The first-pushed entry of each voxel list (next == -1) owns the voxel: it replays the voxel's
+// hit contributions in the reference's iteration order (descending key) — map_local.cpp:157-171.
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_hits(const MlmDev P, int frame_idx, int explicit_keys) {
+    MLM_SKIP_IF_FAILED(P, frame_idx)
+    const unsigned int n = P.ctr->u_hit;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (P.hl_next[i] != -1) continue;
+        const int v = P.hl_vox[i];
+        const int head = P.vox_head[v];
+        float L = P.log_odds[v];
+        uint8_t o = P.occ[v];
+        if (head == (int)i) { // the common case: a single contribution
+            if (L < P.lo_max) {
+                L = L + P.hl_inc[i];
+                L = L > P.lo_max ? P.lo_max : L;
+            }
+            if (L > P.lo_sh && o != 'o') o = 'o';
+        } else {
+            unsigned long long last = ~0ull;
+            for (;;) {
+                int best = -1;
+                unsigned long long bestkey = 0;
+                for (int j = head; j >= 0; j = P.hl_next[j]) {
+                    const unsigned long long k = mlm_order_key(P, j, explicit_keys);
+                    if (k < last && (best < 0 || k > bestkey)) {
+                        best = j;
+                        bestkey = k;
+                    }
+                }
+                if (best < 0) break;
+                if (L < P.lo_max) {
+                    L = L + P.hl_inc[best];
+                    L = L > P.lo_max ? P.lo_max : L;
+                }
+                if (L > P.lo_sh && o != 'o') o = 'o';
+                last = bestkey;
+            }
+        }
+        P.log_odds[v] = L;
+        P.occ[v] = o;
+        P.vox_head[v] = -1;
+    }
+}
+
+// Kernel 3 of 3: map_local.cpp:188-203, k times per touched voxel.  gridDim.y = sub-list.
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_misses(const MlmDev P, int frame_idx) {
     MLM_SKIP_IF_FAILED(P, frame_idx)
     const unsigned int sl = blockIdx.y;

@@ -17,7 +17,7 @@ struct MlmCounters {
     unsigned int n_miss_list; // entries of ml_cell (record_awareness only)
     unsigned int n_contrib;   // contributions stored for multi-type cells (segments of `contrib`)
     unsigned int n_multi;     // hit cells that received more than one kind of contribution
-    unsigned int ray_cnt[8][32]; // [k][0] = rays queued in sub-list k (one per blockIdx & 7), 128 B apart
+    unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
@@ -74,8 +74,6 @@ struct MlmDev {
     MlmNode *nodes;            // [MLM_RAY_LISTS][node_cap]
     unsigned int node_cap;     // per region
     uint32_t *contrib;         // [contrib_cap] insertion times of the contributions of multi-kind cells, by cell
-    int32_t *rays;             // [MLM_RAY_LISTS][ray_cap][3] queued rays: binned (rho,phi,z) of the start
-    unsigned int ray_cap;      // per sub-list
     unsigned int *blk_stats;   // [2*max tiles] per-block partial sums: points fed, points out of range
     uint32_t *mt_list;         // [nCells] indices into the hit list of the multi-type cells
     uint32_t *touched;         // [MLM_RAY_LISTS][touch_cap] hit cells in first-touch order of the GPU (arbitrary)
@@ -97,7 +95,9 @@ struct MlmDev {
     uint64_t *hl_key;          // iteration-order key: (bucket_first << 32) | vt ; larger = earlier in iteration
     int *hl_next;              // per-voxel pending list link
     int *hl_vox;               // voxel address (slot*cells + cell id)
-    uint32_t *bkt_first;       // [max buckets] min vt per hash bucket
+    uint32_t *bkt_first;       // [max buckets] min vt per hash bucket (exact path on rehash frames)
+    unsigned long long *bkt64; // [max buckets] (~seq << 32 | min vt): speculative path, never cleared
+    uint32_t *hl_bkt;          // bucket index of each unique hit (speculative path)
     uint32_t *ml_cell;         // unique-miss list (only with record_awareness)
     int record_awareness;
     // ---- hashed block table + pool
@@ -127,4 +127,6 @@ struct MlmFrame {
     const double *pts;     // device or null
     int width, height, row_stride;
     int n;                 // work items: pixels (dense), list length (indexed) or points
+    int seq;               // sequence number of the frame (speculation bookkeeping)
+    int pad;
 };

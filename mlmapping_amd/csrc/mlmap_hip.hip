@@ -112,9 +112,7 @@ struct KernelTime {
 // One frame in flight: private awareness scratch + unique-hit list, its own stream for Stage A.
 struct MlmSlot {
     MlmDev P{};               // shared map pointers + this slot's scratch pointers
-    hipStream_t stream = nullptr;
-    hipEvent_t done_a = nullptr; // Stage A finished
-    MlmCounters *h_ctr = nullptr; // pinned mirror of P.ctr
+    MlmCounters *h_ctr = nullptr; // pinned mirror of P.ctr (points into mlm_handle::h_ctr_all)
     MlmFrame F{};
     int mode = 0;
     int seq = 0;              // sequence number of the frame it currently holds
@@ -164,6 +162,14 @@ struct mlm_handle {
     int cur_set = 0;
     int set_pending[2] = {0, 0};
     bool async_mode = false;
+    hipStream_t stream_a = nullptr;          // Stage A of whole batches (overlaps Stage B/C of the previous batch)
+    hipEvent_t stage_a_done[2] = {nullptr, nullptr};
+    hipEvent_t set_free[2] = {nullptr, nullptr}; // main stream finished reading the set's Stage A outputs
+    MlmDev *d_slot_tab = nullptr;            // [2K] device copies of the slots' MlmDev
+    MlmFrame *d_frame_tab = nullptr;         // [2K] per-frame parameters of the frames in flight
+    MlmFrame *h_frame_tab = nullptr;         // pinned staging of d_frame_tab
+    MlmCounters *d_ctr_all = nullptr;        // [2K] contiguous per-slot counters
+    MlmCounters *h_ctr_all = nullptr;        // pinned mirror
     hipEvent_t batch_done[2] = {nullptr, nullptr};
     MlmGlobal *h_gb[2] = {nullptr, nullptr}; // pinned snapshots of P.g taken at the end of each batch
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
@@ -308,96 +314,79 @@ int order_hits_exact(mlm_handle *h, MlmSlot &S, unsigned int U, int frame_idx) {
     return MLM_OK;
 }
 
-// Stage A of one frame on the slot's stream: awareness raycast -> unique hit list (+odds) and miss mask.
-int launch_stage_a(mlm_handle *h, MlmSlot &S, int frame_idx) {
-    const MlmDev &P = S.P;
-    const MlmFrame &F = S.F;
-    hipStream_t st = S.stream;
-    HIPCHK(h, hipMemsetAsync(P.ctr, 0, sizeof(MlmCounters), st));
-    S.nb = 0;
+// Stage A of a whole batch (slots base..base+n, same mode and image geometry) on stream_a: awareness raycast ->
+// unique hit lists (+odds) and miss masks.  One launch per kernel covers all n frames (blockIdx.z = slot).
+int launch_stage_a_batch(mlm_handle *h, int base, int n) {
+    const MlmSlot &S0 = h->slots[(size_t)base];
+    const MlmDev &P = S0.P;
+    const MlmFrame &F = S0.F;
+    const int mode = S0.mode;
+    hipStream_t st = h->stream_a;
+    const int set = base ? 1 : 0;
+    // the previous user of this slot set must have been consumed by the main stream
+    HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
+    for (int j = 0; j < n; ++j) h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
+    HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));
+    unsigned int nb = 0;
     if (F.n > 0) {
-        const unsigned int nb =
-            (S.mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
-        if ((size_t)(nb / MLM_RAY_LISTS + 1) * MLM_BLOCK > P.ray_cap || nb > (unsigned int)h->lim.max_points / 64 + 1024) {
+        nb = (mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
+        if (nb > (unsigned int)h->lim.max_points / 64 + 1024) {
             h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
             return MLM_ERR_CAPACITY;
         }
-        S.nb = nb;
-        {
-            Timed t(h, st, "k_bin_points");
-            if (S.mode == 0)
-                hipLaunchKernelGGL(k_bin_points<0>, dim3(nb), dim3(MLM_BLOCK), 0, st, P, F);
-            else if (S.mode == 1)
-                hipLaunchKernelGGL(k_bin_points<1>, dim3(nb), dim3(MLM_BLOCK), 0, st, P, F);
-            else
-                hipLaunchKernelGGL(k_bin_points<2>, dim3(nb), dim3(MLM_BLOCK), 0, st, P, F);
-        }
-        if (P.visibility) {
-            Timed t(h, st, "k_walk_rays");
-            hipLaunchKernelGGL(k_walk_rays, dim3(256, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P);
-        }
+        Timed t(h, st, "k_bin_points");
+        if (mode == 0)
+            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        else if (mode == 1)
+            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        else
+            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     {
         Timed t(h, st, "k_collect_hits");
-        hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P, (int)S.nb);
+        hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+                           h->d_frame_tab, base, (int)nb);
     }
     {
         Timed t(h, st, "k_expand_nodes");
-        hipLaunchKernelGGL(k_expand_nodes, dim3(64, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, st, P, S.mode == 0 ? F.width : 0);
+        hipLaunchKernelGGL(k_expand_nodes, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+                           h->d_frame_tab, base, mode == 0 ? F.width : 0);
     }
     {
         Timed t(h, st, "k_sort_contribs");
-        hipLaunchKernelGGL(k_sort_contribs, dim3(1024), dim3(MLM_BLOCK), 0, st, P);
+        hipLaunchKernelGGL(k_sort_contribs, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+                           h->d_frame_tab, base);
     }
     {
         Timed t(h, st, "k_chain");
-        hipLaunchKernelGGL(k_chain, dim3(256), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st, P, frame_idx,
+        hipLaunchKernelGGL(k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st,
+                           h->d_slot_tab, h->d_frame_tab, base,
                            (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
     }
-    HIPCHK(h, hipEventRecord(S.done_a, st));
+    HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
 }
 
-// Stage C of one frame on the main stream (after its ordering keys exist)
-void launch_stage_c(mlm_handle *h, MlmSlot &S, int frame_idx) {
+// Stage B+C of one frame on the main stream.  n_bkt != 0: speculative single-epoch ordering inside k_voxelize;
+// n_bkt == 0: hl_key was produced by order_hits_exact.
+void launch_stage_bc(mlm_handle *h, MlmSlot &S, unsigned long long n_bkt) {
     const MlmDev &P = S.P;
+    const unsigned int miss_blocks = grid_for((size_t)P.nMissWords * 32);
     {
-        Timed t(h, h->stream, "k_hits_to_voxels");
-        hipLaunchKernelGGL(k_hits_to_voxels, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, S.F, frame_idx);
+        Timed t(h, h->stream, "k_voxelize");
+        hipLaunchKernelGGL(k_voxelize, dim3(kListGrid + miss_blocks), dim3(MLM_BLOCK), 0, h->stream, P, S.F, kListGrid,
+                           n_bkt);
     }
     {
         Timed t(h, h->stream, "k_apply_hits");
-        hipLaunchKernelGGL(k_apply_hits, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx);
-    }
-    {
-        Timed t(h, h->stream, "k_misses_to_voxels");
-        hipLaunchKernelGGL(k_misses_to_voxels, dim3(grid_for((size_t)P.nMissWords * 32)), dim3(MLM_BLOCK), 0, h->stream,
-                           P, S.F, frame_idx);
+        hipLaunchKernelGGL(k_apply_hits, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq, n_bkt ? 0 : 1);
     }
     {
         Timed t(h, h->stream, "k_apply_misses");
-        hipLaunchKernelGGL(k_apply_misses, dim3(16, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx);
+        hipLaunchKernelGGL(k_apply_misses, dim3(16, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq);
     }
-}
-
-// Stage B (speculative: "no rehash this frame", i.e. one epoch with the current bucket count) + Stage C
-int launch_stage_bc_speculative(mlm_handle *h, MlmSlot &S, int frame_idx) {
-    const MlmDev &P = S.P;
-    const unsigned long long nb = h->hit_n_bkt;
-    HIPCHK(h, hipStreamWaitEvent(h->stream, S.done_a, 0));
-    HIPCHK(h, hipMemsetAsync(P.bkt_first, 0xFF, nb * sizeof(uint32_t), h->stream));
-    {
-        Timed t(h, h->stream, "k_bucket_min");
-        hipLaunchKernelGGL(k_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, 0u, 0);
-    }
-    {
-        Timed t(h, h->stream, "k_make_keys");
-        hipLaunchKernelGGL(k_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, 0u, 0, 1,
-                           h->sk_in, h->sv_in);
-    }
-    launch_stage_c(h, S, frame_idx);
-    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-    return MLM_OK;
 }
 
 void fill_stats(mlm_handle *h, const MlmSlot &S) {
@@ -427,8 +416,7 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
     const MlmDev &P = S.P;
     bool over = c.n_contrib > P.contrib_cap;
     for (int k = 0; k < MLM_RAY_LISTS; ++k)
-        over = over || c.ray_cnt[k][0] > P.ray_cap || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap ||
-               c.mvox_cnt[k][0] > P.mvox_cap;
+        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mvox_cnt[k][0] > P.mvox_cap;
     if (over) {
         h->err = "a per-frame device queue overflowed (raise mlm_limits.max_points)";
         return MLM_ERR_CAPACITY;
@@ -446,21 +434,29 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
 // Stage B/C kernel of a frame >= it is a no-op.  `pending` lists submitted-but-unconfirmed frames in order.
 
 int submit_batch(mlm_handle *h, int base, int n) {
+    if (h->hit_n_bkt > h->max_buckets) {
+        h->err = "emulated bucket count exceeds capacity";
+        return MLM_ERR_CAPACITY;
+    }
+    const int set = base ? 1 : 0;
     for (int j = 0; j < n; ++j) {
         MlmSlot &S = h->slots[(size_t)(base + j)];
         S.seq = h->next_seq++;
-        const int rc = launch_stage_a(h, S, S.seq);
-        if (rc) return rc;
+        S.F.seq = S.seq;
     }
+    int rc = launch_stage_a_batch(h, base, n);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
     for (int j = 0; j < n; ++j) {
         MlmSlot &S = h->slots[(size_t)(base + j)];
-        const int rc = launch_stage_bc_speculative(h, S, S.seq);
-        if (rc) return rc;
+        launch_stage_bc(h, S, h->hit_n_bkt);
         h->pending.push_back(&S);
     }
-    const int set = base ? 1 : 0;
+    HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters),
+                             hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_gb[set], h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipEventRecord(h->batch_done[set], h->stream));
+    HIPCHK(h, hipEventRecord(h->set_free[set], h->stream));
     h->set_pending[set] = n;
     return MLM_OK;
 }
@@ -500,7 +496,7 @@ int drain(mlm_handle *h) {
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
         rc = order_hits_exact(h, S, S.h_ctr->u_hit, S.seq);
         if (rc) return rc;
-        launch_stage_c(h, S, S.seq);
+        launch_stage_bc(h, S, 0);
         HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
         // the later frames evaluated their device-side check against the OLD threshold: re-arm it from the host with
         // the new policy state (their unique-hit counts are known), then resubmit their Stage B/C
@@ -511,12 +507,16 @@ int drain(mlm_handle *h) {
         h->h_g->fail_frame = ff;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
         for (size_t j = 1; j < h->pending.size(); ++j) {
-            rc = launch_stage_bc_speculative(h, *h->pending[j], h->pending[j]->seq);
-            if (rc) return rc;
+            MlmSlot &R = *h->pending[j];
+            launch_stage_bc(h, R, h->hit_n_bkt);
+            HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
         }
     }
     h->set_pending[0] = h->set_pending[1] = 0;
-    if (h->next_seq > 0x3FFFFFFF) h->next_seq = 0; // nothing in flight: sequence numbers may restart
+    if (h->next_seq > 0x3FFFFFFF) { // nothing in flight: sequence numbers restart, so the bucket table must forget them
+        h->next_seq = 0;
+        HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, h->max_buckets * sizeof(unsigned long long), h->stream));
+    }
     return MLM_OK;
 }
 
@@ -608,16 +608,13 @@ int read_global(mlm_handle *h) {
     return MLM_OK;
 }
 
-int alloc_slot(mlm_handle *h, MlmSlot &S, const std::vector<float> &sigma3) {
+int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float> &sigma3) {
     S.P = h->P;
     MlmDev &P = S.P;
     int rc;
     const size_t NC = (size_t)P.nCells;
-    HIPCHK(h, hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&S.done_a, hipEventDisableTiming));
-    HIPCHK(h, hipHostMalloc((void **)&S.h_ctr, sizeof(MlmCounters), hipHostMallocDefault));
-    std::memset(S.h_ctr, 0, sizeof(MlmCounters));
-    if ((rc = dev_alloc(h, &P.ctr, 1))) return rc;
+    S.h_ctr = h->h_ctr_all + index;
+    P.ctr = h->d_ctr_all + index;
     if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hit_cnt, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hit_mask, NC))) return rc;
@@ -627,8 +624,6 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, const std::vector<float> &sigma3) {
     if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
     P.touch_cap = (unsigned int)NC;
     if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
-    P.ray_cap = (unsigned int)h->lim.max_points / 4u + 4096u;
-    if ((rc = dev_alloc(h, &P.rays, (size_t)MLM_RAY_LISTS * P.ray_cap * 3))) return rc;
     if ((rc = dev_alloc(h, &P.blk_stats, 2 * ((size_t)h->lim.max_points / 64 + 1024)))) return rc;
     {
         // most contributions one point can make: centre + (+d,-d) while d < 3*sigma(rho) (map_awareness.cpp:149)
@@ -666,10 +661,10 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, const std::vector<float> &sigma3) {
     if ((rc = dev_alloc(h, &P.hl_key, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_next, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_vox, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_bkt, NC))) return rc;
     if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
     P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
     if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
-    HIPCHK(h, hipMemset(P.ctr, 0, sizeof(MlmCounters)));
     HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.hit_cnt, 0, NC * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.hit_mask, 0, NC * sizeof(uint32_t)));
@@ -806,6 +801,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         h->max_buckets = pol._M_next_bkt(2 * NC + 2);
     }
     if ((rc = dev_alloc(h, &P.bkt_first, h->max_buckets))) return rc;
+    if ((rc = dev_alloc(h, &P.bkt64, h->max_buckets))) return rc;
+    HIPCHK(h, hipMemset(P.bkt64, 0xFF, h->max_buckets * sizeof(unsigned long long)));
 
     // block table + pool (shared by all slots)
     size_t ht = 1;
@@ -845,9 +842,28 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes))) return rc;
 
     // frame slots
-    h->slots.resize((size_t)h->lim.max_batch * 2); // two sets: one being filled while the other drains
-    for (auto &S : h->slots)
-        if ((rc = alloc_slot(h, S, sigma3))) return rc;
+    const size_t NS = (size_t)h->lim.max_batch * 2; // two sets: one being filled while the other drains
+    h->slots.resize(NS);
+    if ((rc = dev_alloc(h, &h->d_ctr_all, NS))) return rc;
+    if ((rc = dev_alloc(h, &h->d_slot_tab, NS))) return rc;
+    if ((rc = dev_alloc(h, &h->d_frame_tab, NS))) return rc;
+    HIPCHK(h, hipMemset(h->d_ctr_all, 0, NS * sizeof(MlmCounters)));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ctr_all, NS * sizeof(MlmCounters), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_frame_tab, NS * sizeof(MlmFrame), hipHostMallocDefault));
+    std::memset(h->h_ctr_all, 0, NS * sizeof(MlmCounters));
+    std::memset(h->h_frame_tab, 0, NS * sizeof(MlmFrame));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream_a, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->stage_a_done[k], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->set_free[k], hipEventDisableTiming));
+    }
+    for (size_t i = 0; i < NS; ++i)
+        if ((rc = alloc_slot(h, h->slots[i], i, sigma3))) return rc;
+    {
+        std::vector<MlmDev> tab(NS);
+        for (size_t i = 0; i < NS; ++i) tab[i] = h->slots[i].P;
+        HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), NS * sizeof(MlmDev), hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipDeviceSynchronize());
     return MLM_OK;
 }
@@ -857,12 +873,15 @@ int mlm_destroy(mlm_handle *h) {
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     for (void *p : h->allocs) hipFree(p);
-    for (auto &S : h->slots) {
+    for (auto &S : h->slots)
         if (S.d_img) hipFree(S.d_img);
-        if (S.h_ctr) hipHostFree(S.h_ctr);
-        if (S.done_a) hipEventDestroy(S.done_a);
-        if (S.stream) hipStreamDestroy(S.stream);
+    if (h->h_ctr_all) hipHostFree(h->h_ctr_all);
+    if (h->h_frame_tab) hipHostFree(h->h_frame_tab);
+    for (int k = 0; k < 2; ++k) {
+        if (h->stage_a_done[k]) hipEventDestroy(h->stage_a_done[k]);
+        if (h->set_free[k]) hipEventDestroy(h->set_free[k]);
     }
+    if (h->stream_a) hipStreamDestroy(h->stream_a);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     if (h->h_g) hipHostFree(h->h_g);
@@ -935,7 +954,7 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
             int rc = ensure_img(h, S, n_px);
             if (rc) return rc;
             HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t),
-                                     hipMemcpyHostToDevice, S.stream));
+                                     hipMemcpyHostToDevice, h->stream_a));
             S.F = MlmFrame{};
             frame_setup(h, q_wb + 4 * (size_t)(k0 + j), t_wb + 3 * (size_t)(k0 + j), S.F);
             S.F.img = S.d_img;
@@ -982,10 +1001,10 @@ int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int h
     const size_t n_px = (size_t)row_stride * height;
     int rc = ensure_img(h, S, n_px);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, S.stream));
+    HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_a));
     if (pixel_idx) {
         if (n_idx < 0 || n_idx > h->lim.max_points) return MLM_ERR_CAPACITY;
-        HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, S.stream));
+        HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_a));
     }
     return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, row_stride, pixel_idx ? S.d_pix : nullptr, n_idx, q_wb,
                                        t_wb);
@@ -999,7 +1018,7 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
     }
     HIPCHK(h, hipSetDevice(h->device));
     MlmSlot &S = cur_slot(h, 0);
-    if (n > 0) HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    if (n > 0) HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream_a));
     S.F = MlmFrame{};
     frame_setup(h, q_wb, t_wb, S.F);
     S.F.pts = S.d_pts;
