@@ -1,7 +1,8 @@
 // mlm_kernels.h — HIP kernels of the per-frame map update (gfx950, wave64).
 //
 // Stage A  (awareness_map_cylindrical::input_pc_pose, map_awareness.cpp:173-282)
-//   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions, de-duplicated ray walk
+//   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions as wave groups, de-duplicated ray walk
+//   k_assign_nodes    per group: first-touch time / kind mask / count of its cell, position inside the cell
 //   k_collect_hits    dense sweep of the hit scratch -> unique-hit list + per-cell contribution segments
 //   k_expand_nodes / k_sort_contribs / k_chain   point-order replay of the float noisy-OR chain -> odd, logit
 // Stage B  (iteration order of hit_idx_odds_hashmap, i.e. libstdc++ _Hashtable list order)
@@ -13,7 +14,6 @@
 #include "mlm_device.h"
 
 #define MLM_BLOCK 256
-#define MLM_TOUCH_LDS 1536 // first-touch buffer of one k_bin_points block
 
 __device__ __forceinline__ void mlm_cell_rpz(const MlmDev &P, uint32_t cell, int &rho, int &phi, int &z) {
     z = (int)(cell / (uint32_t)P.nRhoPhi);
@@ -138,11 +138,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     __shared__ unsigned int s_cnt[4];
     __shared__ unsigned int s_nray;
     __shared__ int s_ray[MLM_RAY_LDS][3];
-    __shared__ unsigned int s_ntouch, s_tbase, s_nnode, s_nbase;
-    __shared__ uint32_t s_touch[MLM_TOUCH_LDS];
+    __shared__ unsigned int s_nnode, s_nbase;
     __shared__ MlmNode s_node[MLM_NODE_LDS];
     if (threadIdx.x == 0) {
-        s_ntouch = 0;
         s_nnode = 0;
         s_nray = 0;
     }
@@ -190,25 +188,22 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     const uint32_t t0 = (uint32_t)i * MLM_TIME_SLOTS;
 
     // One group = the lanes of this wave that contribute kind `sub` to `cell`.  Its lowest lane (= earliest
-    // insertion time) posts the group: count, kind mask, first-touch time, and a node for the point-order replay.
-    // The returned atomics are only looked at after the grouping loop, so they are all in flight together.
+    // insertion time) records the group as a node; all bookkeeping on the cell (first-touch time, kind mask, count,
+    // position) is done later by k_assign_nodes, 64 independent atomics at a time.
     auto post = [&](int key, bool valid, int sub, bool centre) -> bool {
-        uint32_t old_t = 0, old_start = ~0u, pos = 0;
+        uint32_t old_start = ~0u;
         unsigned long long my_mask = 0;
         int my_cell = -1;
         mlm_wave_groups(key, valid, [&](int cell, unsigned long long m) {
             my_cell = cell;
             my_mask = m;
-            old_t = atomicMin(&P.hit_t[cell], t0 + (uint32_t)sub);
-            pos = atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
-            atomicOr(&P.hit_mask[cell], 1u << sub);
             if (centre && P.visibility) old_start = atomicOr(&P.start_bits[cell >> 5], 1u << (cell & 31));
         });
         if (my_cell >= 0) {
             const unsigned int k = atomicAdd(&s_nnode, 1u);
             MlmNode nd;
             nd.cell = (uint32_t)my_cell;
-            nd.pos = pos;
+            nd.pos = 0;
             nd.i00_sub = i00 | ((uint32_t)sub << 27);
             nd.pad = 0;
             nd.mask = my_mask;
@@ -218,15 +213,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
                 const unsigned int reg = blockIdx.x & 7;
                 const unsigned int g = atomicAdd(&P.ctr->node_cnt[reg][0], 1u);
                 if (g < P.node_cap) P.nodes[(size_t)reg * P.node_cap + g] = nd;
-            }
-            if (old_t == MLM_EMPTY_T) { // first touch of the cell this frame: queue it for k_collect_hits
-                const unsigned int kt = atomicAdd(&s_ntouch, 1u);
-                if (kt < MLM_TOUCH_LDS)
-                    s_touch[kt] = (uint32_t)my_cell;
-                else {
-                    const unsigned int g = atomicAdd(&P.ctr->touch_cnt[blockIdx.x & 7][0], 1u);
-                    if (g < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + g] = (uint32_t)my_cell;
-                }
             }
         }
         // every point of one (rho,phi,z) cell casts the identical ray: only the first one queues it
@@ -268,7 +254,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     if (lane == 0) s_cnt[wid] = n_pts | (n_oor << 10);
     __syncthreads();
     const unsigned int reg = blockIdx.x & 7;
-    const unsigned int nt = min(s_ntouch, (unsigned int)MLM_TOUCH_LDS);
     const unsigned int nn = min(s_nnode, (unsigned int)MLM_NODE_LDS);
     const unsigned int nr = min(s_nray, (unsigned int)MLM_RAY_LDS);
     if (threadIdx.x == 0) {
@@ -279,14 +264,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         }
         P.blk_stats[2 * blockIdx.x] = pts;
         P.blk_stats[2 * blockIdx.x + 1] = oor;
-        s_tbase = nt ? atomicAdd(&P.ctr->touch_cnt[reg][0], nt) : 0u;
         s_nbase = nn ? atomicAdd(&P.ctr->node_cnt[reg][0], nn) : 0u;
         if (nr) atomicAdd(&P.ctr->ray_cnt[reg][0], nr); // statistic only
     }
     for (unsigned int r = wid; r < nr; r += MLM_BLOCK / 64) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
     __syncthreads();
-    for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
-        if (s_tbase + k < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + s_tbase + k] = s_touch[k];
     for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x)
         if (s_nbase + k < P.node_cap) P.nodes[(size_t)reg * P.node_cap + s_nbase + k] = s_node[k];
 }
@@ -321,7 +303,40 @@ __device__ __forceinline__ float mlm_logit(float p) {
     return (float)log10((double)ratio);
 }
 
-// One thread per first-touched cell (queued by k_bin_points): build the compact unique-hit list
+// One lane per contribution node: book the group on its cell — first-touch time (min), kind mask (or), count (add).
+// The add returns the group's position inside the cell's segment; the node that finds the count at 0 is the cell's
+// first and queues the cell for k_collect_hits.  gridDim.y = node region, blockIdx.z = slot.
+__global__ __launch_bounds__(MLM_BLOCK) void k_assign_nodes(MLM_SLOT_ARGS, int tile_w) {
+    MLM_SLOT_SETUP
+    __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
+    __shared__ unsigned int s_base;
+    const unsigned int reg = blockIdx.y;
+    const unsigned int n = min(P.ctr->node_cnt[reg][0], P.node_cap);
+    for (unsigned int k0 = blockIdx.x * blockDim.x; k0 < n; k0 += gridDim.x * blockDim.x) { // uniform per block
+        const unsigned int k = k0 + threadIdx.x;
+        bool first = false;
+        uint32_t cell = 0;
+        if (k < n) {
+            MlmNode *nd = &P.nodes[(size_t)reg * P.node_cap + k];
+            cell = nd->cell;
+            const unsigned long long m = nd->mask;
+            const int l0 = __ffsll((long long)m) - 1; // lowest lane = earliest insertion time of the group
+            const uint32_t off = tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0;
+            const uint32_t is = nd->i00_sub;
+            const uint32_t t = ((is & 0x07FFFFFFu) + off) * MLM_TIME_SLOTS + (is >> 27);
+            atomicMin(&P.hit_t[cell], t);
+            atomicOr(&P.hit_mask[cell], 1u << (is >> 27));
+            const uint32_t pos = atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
+            nd->pos = pos;
+            first = pos == 0;
+        }
+        const unsigned int at = mlm_block_append(P.ctr->touch_cnt, first, s_cnt, &s_base);
+        if (first && at < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + at] = cell;
+        __syncthreads();
+    }
+}
+
+// One thread per first-touched cell (queued by k_assign_nodes): build the compact unique-hit list
 //  - cell, first-touch time;
 //  - cells with a single kind of contribution: odd (n applications of one value commute) and its logit;
 //  - cells with several kinds: a segment of `contrib` for the point-order replay (k_sort_contribs / k_chain);

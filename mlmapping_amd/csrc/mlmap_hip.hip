@@ -345,6 +345,11 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
             hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     {
+        Timed t(h, st, "k_assign_nodes");
+        hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+                           h->d_frame_tab, base, mode == 0 ? F.width : 0);
+    }
+    {
         Timed t(h, st, "k_collect_hits");
         hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, (int)nb);
@@ -707,7 +712,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         return MLM_ERR_HIP;
     }
     HIPCHK(h, hipSetDevice(device));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0; // numerically lower = higher priority
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi));
+    }
     for (int k = 0; k < 2; ++k) {
         HIPCHK(h, hipEventCreateWithFlags(&h->batch_done[k], hipEventDisableTiming));
         HIPCHK(h, hipHostMalloc((void **)&h->h_gb[k], sizeof(MlmGlobal), hipHostMallocDefault));
