@@ -120,9 +120,13 @@ __device__ __forceinline__ uint32_t mlm_mix(unsigned long long k) {
     k ^= k >> 33;
     return (uint32_t)k;
 }
+__device__ __forceinline__ void mlm_unpack_key(unsigned long long key, int &gx, int &gy, int &gz) {
+    gx = (int)((key >> 42) & 0x1FFFFFu) - (1 << 20);
+    gy = (int)((key >> 21) & 0x1FFFFFu) - (1 << 20);
+    gz = (int)(key & 0x1FFFFFu) - (1 << 20);
+}
 // lookup only; -1 if absent
-__device__ __forceinline__ int mlm_block_find(const MlmDev &P, int gx, int gy, int gz) {
-    const unsigned long long key = mlm_pack_key(gx, gy, gz);
+__device__ __forceinline__ int mlm_block_find_k(const MlmDev &P, unsigned long long key) {
     uint32_t h = mlm_mix(key) & P.ht_mask;
     for (uint32_t probe = 0; probe <= P.ht_mask; ++probe) {
         const unsigned long long k = P.ht_keys[h];
@@ -132,10 +136,12 @@ __device__ __forceinline__ int mlm_block_find(const MlmDev &P, int gx, int gy, i
     }
     return -1;
 }
+__device__ __forceinline__ int mlm_block_find(const MlmDev &P, int gx, int gy, int gz) {
+    return mlm_block_find_k(P, mlm_pack_key(gx, gy, gz));
+}
 // allocate_ram (map_local.h:215-231): find or create.  One loop whose divergent arms reconverge every
 // iteration, so a lane waiting for another lane's slot publication can never starve it.
-__device__ __forceinline__ int mlm_block_find_or_insert(const MlmDev &P, int gx, int gy, int gz) {
-    const unsigned long long key = mlm_pack_key(gx, gy, gz);
+__device__ __forceinline__ int mlm_block_find_or_insert_k(const MlmDev &P, unsigned long long key) {
     uint32_t h = mlm_mix(key) & P.ht_mask;
     int slot = -1;
     bool done = false;
@@ -156,6 +162,8 @@ __device__ __forceinline__ int mlm_block_find_or_insert(const MlmDev &P, int gx,
                     atomicOr(&P.g->err, 1u);
                     s = -2; // published as "pool full"
                 } else {
+                    int gx, gy, gz;
+                    mlm_unpack_key(key, gx, gy, gz);
                     P.block_keys[3 * s + 0] = gx;
                     P.block_keys[3 * s + 1] = gy;
                     P.block_keys[3 * s + 2] = gz;
@@ -174,6 +182,12 @@ __device__ __forceinline__ int mlm_block_find_or_insert(const MlmDev &P, int gx,
             }
         }
     }
+    return slot;
+}
+// block of a packed key: plain-load lookup first (blocks almost always exist already), CAS insert otherwise
+__device__ __forceinline__ int mlm_block_slot(const MlmDev &P, unsigned long long key) {
+    int slot = mlm_block_find_k(P, key);
+    if (slot == -1) slot = mlm_block_find_or_insert_k(P, key);
     return slot;
 }
 

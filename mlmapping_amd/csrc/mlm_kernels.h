@@ -8,7 +8,7 @@
 // Stage B  (iteration order of hit_idx_odds_hashmap, i.e. libstdc++ _Hashtable list order)
 //   k_bucket_min / k_make_keys (+ rank kernels on rehash frames)
 // Stage C  (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237)
-//   k_voxelize / k_apply_hits / k_apply_misses
+//   k_prepare_voxels (Stage A, map independent) / k_voxelize / k_apply
 // Queries  (mlmap.h:142-295, mlmap.cpp:388-407)
 #pragma once
 #include "mlm_device.h"
@@ -618,91 +618,126 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_time_keys(const MlmDev P, unsigne
 // ---------------------------------------------------------------------------------------------------------------
 // Stage C
 // ---------------------------------------------------------------------------------------------------------------
+// Last Stage A kernel (batched): everything about Stage C that does not depend on the map — the world voxel
+// (packed block key + cell id) of every unique hit cell and of every unique miss cell.  blockIdx.y == 0: one unique
+// hit per lane.  blockIdx.y == 1: one bit of the miss mask per lane -> compact miss-cell list; clears the mask.
+__global__ __launch_bounds__(MLM_BLOCK) void k_prepare_voxels(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
+    __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
+    __shared__ unsigned int s_base;
+    if (blockIdx.y == 0) {
+        const unsigned int n = P.ctr->u_hit;
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            int rho, phi, z;
+            mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+            double wx, wy, wz;
+            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+            int gx, gy, gz, cid;
+            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
+            P.hl_bkey[i] = mlm_pack_key(gx, gy, gz);
+            P.hl_cid[i] = (uint32_t)cid;
+        }
+        return;
+    }
+    const long long total = (long long)P.nMissWords * 32;
+    for (long long g0 = (long long)blockIdx.x * blockDim.x; g0 < total; g0 += (long long)gridDim.x * blockDim.x) {
+        const long long g = g0 + threadIdx.x;
+        const int w = (int)(g >> 5), b = (int)(g & 31);
+        uint32_t bits = 0;
+        if (w < P.nMissWords) bits = P.miss_bits[w];
+        const bool set = (bits >> b) & 1u;
+        unsigned long long bkey = 0;
+        uint32_t cid = 0;
+        if (set) {
+            const int row = w / P.RW;
+            const int wi = w - row * P.RW;
+            const int z = row / P.nPhi;
+            const int phi = row - z * P.nPhi;
+            const int rho = wi * 32 + b;
+            double wx, wy, wz;
+            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+            int gx, gy, gz, c;
+            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, c);
+            bkey = mlm_pack_key(gx, gy, gz);
+            cid = (uint32_t)c;
+            if (P.record_awareness) {
+                const unsigned int pos = atomicAdd(&P.ctr->n_miss_list, 1u);
+                P.ml_cell[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+            }
+        }
+        if (b == 0 && bits) P.miss_bits[w] = 0; // all 32 lanes of the word loaded it in the instruction above
+        const unsigned int pos = mlm_block_append(P.ctr->mc_cnt, set, s_cnt, &s_base);
+        if (set && pos < P.mc_cap) {
+            P.mc_bkey[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = bkey;
+            P.mc_cid[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = cid;
+        }
+        __syncthreads();
+    }
+}
+
+#define MLM_HAS_HITS 0x80000000u // flag in vox_miss: the voxel has pending hit contributions this frame
+
 // bucket-first table of the speculative path: entry = (~seq << 32) | first insertion time.  atomicMin keeps the
 // newest frame's smallest time, so the table never needs clearing between frames.
 __device__ __forceinline__ unsigned long long mlm_bkt_entry(int seq, uint32_t t) {
     return ((unsigned long long)(0xFFFFFFFFu - (uint32_t)seq) << 32) | (unsigned long long)t;
 }
 
-// Stage B+C, kernel 1 of 3.  Blocks [0, hit_blocks): one unique hit per lane — bucket-first time of the emulated
-// container (speculative single epoch; n_bkt == 0 on the exact path where hl_key is already final), world voxel of
-// the cell centre, push on the voxel's pending list.  Blocks [hit_blocks, ...): one bit of the miss mask per lane —
-// count the frame's misses per voxel (their order is irrelevant: every miss adds the same constant,
-// map_local.cpp:188-192) and clear the mask.
-__global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const MlmFrame F, unsigned int hit_blocks,
-                                                        unsigned long long n_bkt) {
+// Stage B+C, kernel 1 of 2 (the part that needs the map, in frame order).  blockIdx.y == 0: one unique hit per lane —
+// bucket-first time of the emulated container (speculative single epoch; n_bkt == 0 on the exact path where hl_key
+// is already final), block lookup/creation (allocate_ram, map_local.h:215-231), push on the voxel's pending list.
+// blockIdx.y == 1 + k: miss-cell sub-list k — count the frame's misses per voxel (their order is irrelevant: every
+// miss adds the same constant, map_local.cpp:188-192).
+__global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const MlmFrame F, unsigned long long n_bkt) {
     __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
     __shared__ unsigned int s_base;
     const int frame_idx = F.seq;
     MLM_SKIP_IF_FAILED(P, frame_idx)
-    if (blockIdx.x < hit_blocks) {
+    if (blockIdx.y == 0) {
         const unsigned int n = P.ctr->u_hit;
-        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += hit_blocks * blockDim.x) {
-            int rho, phi, z;
-            mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
             if (n_bkt) {
+                int rho, phi, z;
+                mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
                 const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
                 atomicMin(&P.bkt64[b], mlm_bkt_entry(frame_idx, P.hl_vt[i]));
                 P.hl_bkt[i] = (uint32_t)b;
             }
-            double wx, wy, wz;
-            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-            int gx, gy, gz, cid;
-            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-            int slot = mlm_block_find(P, gx, gy, gz); // plain loads; blocks almost always exist already
-            if (slot == -1) slot = mlm_block_find_or_insert(P, gx, gy, gz);
+            const int slot = mlm_block_slot(P, P.hl_bkey[i]);
             if (slot < 0) {
                 P.hl_vox[i] = -1;
                 P.hl_next[i] = -2;
                 continue;
             }
-            const int v = slot * P.cells + cid;
+            const int v = slot * P.cells + (int)P.hl_cid[i];
             P.hl_vox[i] = v;
             P.hl_next[i] = atomicExch(&P.vox_head[v], (int)i);
+            atomicOr(&P.vox_miss[v], MLM_HAS_HITS); // tells k_apply's miss side that a hit owner exists
         }
         return;
     }
-    const long long g = (long long)(blockIdx.x - hit_blocks) * blockDim.x + threadIdx.x;
-    const int w = (int)(g >> 5), b = (int)(g & 31);
-    uint32_t bits = 0;
-    if (w < P.nMissWords) bits = P.miss_bits[w];
-    const bool set = (bits >> b) & 1u;
-    bool fresh = false; // first miss of its voxel this frame
-    int v = -1;
-    if (set) {
-        const int row = w / P.RW;
-        const int wi = w - row * P.RW;
-        const int z = row / P.nPhi;
-        const int phi = row - z * P.nPhi;
-        const int rho = wi * 32 + b;
-        double wx, wy, wz;
-        mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-        int gx, gy, gz, cid;
-        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-        int slot = mlm_block_find(P, gx, gy, gz);
-        if (slot == -1) slot = mlm_block_find_or_insert(P, gx, gy, gz);
-        if (slot >= 0) {
-            v = slot * P.cells + cid;
-            fresh = atomicAdd(&P.vox_miss[v], 1u) == 0;
+    const unsigned int sl = blockIdx.y - 1;
+    const unsigned int n = min(P.ctr->mc_cnt[sl][0], P.mc_cap);
+    unsigned int n_here = 0;
+    for (unsigned int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) { // uniform per block
+        const unsigned int i = i0 + threadIdx.x;
+        bool fresh = false; // first miss of its voxel this frame
+        int v = -1;
+        if (i < n) {
+            ++n_here;
+            const int slot = mlm_block_slot(P, P.mc_bkey[(size_t)sl * P.mc_cap + i]);
+            if (slot >= 0) {
+                v = slot * P.cells + (int)P.mc_cid[(size_t)sl * P.mc_cap + i];
+                fresh = (atomicAdd(&P.vox_miss[v], 1u) & ~MLM_HAS_HITS) == 0;
+            }
         }
-        if (P.record_awareness) {
-            const unsigned int pos = atomicAdd(&P.ctr->n_miss_list, 1u);
-            P.ml_cell[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
-        }
+        const unsigned int pos = mlm_block_append(P.ctr->mvox_cnt, fresh, s_cnt, &s_base);
+        if (fresh && pos < P.mvox_cap) P.miss_vox[(size_t)(blockIdx.x & 7) * P.mvox_cap + pos] = v;
+        __syncthreads();
     }
-    if (b == 0 && bits) P.miss_bits[w] = 0; // all 32 lanes of the word loaded it in the instruction above
-    const unsigned int pos = mlm_block_append(P.ctr->mvox_cnt, fresh, s_cnt, &s_base);
-    if (fresh && pos < P.mvox_cap) P.miss_vox[(size_t)(blockIdx.x & 7) * P.mvox_cap + pos] = v;
-    // statistics: unique miss cells, one atomic per block on a counter spread by blockIdx
-    __syncthreads();
-    const unsigned long long sm = __ballot(set);
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(sm);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int tot = 0;
-        for (int k = 0; k < MLM_BLOCK / 64; ++k) tot += s_cnt[k];
-        if (tot) atomicAdd(&P.ctr->umiss_part[blockIdx.x & 7][0], tot);
-    }
+    // statistics: unique miss cells
+    for (int off = 32; off > 0; off >>= 1) n_here += __shfl_xor(n_here, off, 64);
+    if ((threadIdx.x & 63) == 0 && n_here) atomicAdd(&P.ctr->umiss_part[blockIdx.x & 7][0], n_here);
 }
 
 // iteration-order key of unique hit j: larger = visited earlier by the reference's container walk
@@ -712,68 +747,79 @@ __device__ __forceinline__ unsigned long long mlm_order_key(const MlmDev &P, int
     return ((first + 1ull) << 32) | (unsigned long long)P.hl_vt[j];
 }
 
-// Kernel 2 of 3.  The first-pushed entry of each voxel list (next == -1) owns the voxel: it replays the voxel's
-// hit contributions in the reference's iteration order (descending key) — map_local.cpp:157-171.
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_hits(const MlmDev P, int frame_idx, int explicit_keys) {
-    MLM_SKIP_IF_FAILED(P, frame_idx)
-    const unsigned int n = P.ctr->u_hit;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (P.hl_next[i] != -1) continue;
-        const int v = P.hl_vox[i];
-        const int head = P.vox_head[v];
-        float L = P.log_odds[v];
-        uint8_t o = P.occ[v];
-        if (head == (int)i) { // the common case: a single contribution
-            if (L < P.lo_max) {
-                L = L + P.hl_inc[i];
-                L = L > P.lo_max ? P.lo_max : L;
-            }
-            if (L > P.lo_sh && o != 'o') o = 'o';
-        } else {
-            unsigned long long last = ~0ull;
-            for (;;) {
-                int best = -1;
-                unsigned long long bestkey = 0;
-                for (int j = head; j >= 0; j = P.hl_next[j]) {
-                    const unsigned long long k = mlm_order_key(P, j, explicit_keys);
-                    if (k < last && (best < 0 || k > bestkey)) {
-                        best = j;
-                        bestkey = k;
-                    }
-                }
-                if (best < 0) break;
-                if (L < P.lo_max) {
-                    L = L + P.hl_inc[best];
-                    L = L > P.lo_max ? P.lo_max : L;
-                }
-                if (L > P.lo_sh && o != 'o') o = 'o';
-                last = bestkey;
-            }
+// map_local.cpp:188-203: k misses on one voxel
+__device__ __forceinline__ void mlm_apply_misses(const MlmDev &P, float &L, uint8_t &o, uint32_t k) {
+    for (uint32_t j = 0; j < k; ++j) {
+        if (L >= P.lo_min) {
+            L = L + P.lo_miss;
+            L = L < P.lo_min ? P.lo_min : L;
         }
-        P.log_odds[v] = L;
-        P.occ[v] = o;
-        P.vox_head[v] = -1;
+        if (L < P.lo_sh && o != 'f') o = 'f';
     }
 }
 
-// Kernel 3 of 3: map_local.cpp:188-203, k times per touched voxel.  gridDim.y = sub-list.
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_misses(const MlmDev P, int frame_idx) {
+// Kernel 2 of 2.  blockIdx.y == 0: the first-pushed entry of each voxel list (next == -1) owns the voxel: it replays
+// the voxel's hit contributions in the reference's iteration order (descending key, map_local.cpp:157-171), then the
+// voxel's misses of this frame (the reference runs all hits before all misses, map_local.cpp:147,176).
+// blockIdx.y == 1 + k: voxels touched by misses, sub-list k — those that also have hits are left to the hit owner
+// (the MLM_HAS_HITS flag in the miss counter tells the two sides apart, so each voxel's misses are applied once).
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_idx, int explicit_keys) {
     MLM_SKIP_IF_FAILED(P, frame_idx)
-    const unsigned int sl = blockIdx.y;
+    if (blockIdx.y == 0) {
+        const unsigned int n = P.ctr->u_hit;
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+            if (P.hl_next[i] != -1) continue;
+            const int v = P.hl_vox[i];
+            const int head = P.vox_head[v];
+            float L = P.log_odds[v];
+            uint8_t o = P.occ[v];
+            if (head == (int)i) { // the common case: a single contribution
+                if (L < P.lo_max) {
+                    L = L + P.hl_inc[i];
+                    L = L > P.lo_max ? P.lo_max : L;
+                }
+                if (L > P.lo_sh && o != 'o') o = 'o';
+            } else {
+                unsigned long long last = ~0ull;
+                for (;;) {
+                    int best = -1;
+                    unsigned long long bestkey = 0;
+                    for (int j = head; j >= 0; j = P.hl_next[j]) {
+                        const unsigned long long k = mlm_order_key(P, j, explicit_keys);
+                        if (k < last && (best < 0 || k > bestkey)) {
+                            best = j;
+                            bestkey = k;
+                        }
+                    }
+                    if (best < 0) break;
+                    if (L < P.lo_max) {
+                        L = L + P.hl_inc[best];
+                        L = L > P.lo_max ? P.lo_max : L;
+                    }
+                    if (L > P.lo_sh && o != 'o') o = 'o';
+                    last = bestkey;
+                }
+            }
+            const uint32_t km = atomicExch(&P.vox_miss[v], 0u) & ~MLM_HAS_HITS;
+            mlm_apply_misses(P, L, o, km);
+            P.log_odds[v] = L;
+            P.occ[v] = o;
+            P.vox_head[v] = -1;
+        }
+        return;
+    }
+    const unsigned int sl = blockIdx.y - 1;
     const unsigned int n = min(P.ctr->mvox_cnt[sl][0], P.mvox_cap);
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int v = P.miss_vox[(size_t)sl * P.mvox_cap + i];
-        const uint32_t k = P.vox_miss[v];
+        // vox_miss[v]: 0 = a hit owner already applied the misses; MLM_HAS_HITS set = a hit owner will; else the
+        // voxel has misses only and this lane is the only one that touches it
+        const uint32_t k = __hip_atomic_load(&P.vox_miss[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == 0 || (k & MLM_HAS_HITS)) continue;
         P.vox_miss[v] = 0;
         float L = P.log_odds[v];
         uint8_t o = P.occ[v];
-        for (uint32_t j = 0; j < k; ++j) {
-            if (L >= P.lo_min) {
-                L = L + P.lo_miss;
-                L = L < P.lo_min ? P.lo_min : L;
-            }
-            if (L < P.lo_sh && o != 'f') o = 'f';
-        }
+        mlm_apply_misses(P, L, o, k);
         P.log_odds[v] = L;
         P.occ[v] = o;
     }

@@ -22,6 +22,7 @@ struct MlmCounters {
     unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
     unsigned int node_cnt[8][32];  // [k][0] = contribution nodes allocated in region k
+    unsigned int mc_cnt[8][32];    // [k][0] = unique miss cells queued in sub-list k
 };
 // map-wide state shared by all frame slots
 struct MlmGlobal {
@@ -31,7 +32,7 @@ struct MlmGlobal {
                               // miss); INT_MAX = none.  Stage B/C kernels of frames >= it do nothing.
     unsigned int pad;
 };
-#define MLM_CTR_FRAME_BYTES (32 + 5 * 8 * 32 * 4)
+#define MLM_CTR_FRAME_BYTES (32 + 6 * 8 * 32 * 4)
 #define MLM_RAY_LISTS 8
 
 // The hit contributions one wave makes to one awareness cell with one kind (`sub`): lanes in `mask`, work items
@@ -98,6 +99,11 @@ struct MlmDev {
     uint32_t *bkt_first;       // [max buckets] min vt per hash bucket (exact path on rehash frames)
     unsigned long long *bkt64; // [max buckets] (~seq << 32 | min vt): speculative path, never cleared
     uint32_t *hl_bkt;          // bucket index of each unique hit (speculative path)
+    unsigned long long *hl_bkey; // packed block key of the cell centre's world voxel
+    uint32_t *hl_cid;          // cell id inside that block
+    unsigned long long *mc_bkey; // [MLM_RAY_LISTS][mc_cap] unique miss cells: packed block key ...
+    uint32_t *mc_cid;          //                              ... and cell id
+    unsigned int mc_cap;       // per sub-list
     uint32_t *ml_cell;         // unique-miss list (only with record_awareness)
     int record_awareness;
     // ---- hashed block table + pool

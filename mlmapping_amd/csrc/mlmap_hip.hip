@@ -370,6 +370,11 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
                            h->d_slot_tab, h->d_frame_tab, base,
                            (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
     }
+    {
+        Timed t(h, st, "k_prepare_voxels");
+        const unsigned int pb = std::min<unsigned int>(grid_for((size_t)P.nMissWords * 32), n > 4 ? 1024u : 4096u);
+        hipLaunchKernelGGL(k_prepare_voxels, dim3(pb, 2, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+    }
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
 }
@@ -378,19 +383,13 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
 // n_bkt == 0: hl_key was produced by order_hits_exact.
 void launch_stage_bc(mlm_handle *h, MlmSlot &S, unsigned long long n_bkt) {
     const MlmDev &P = S.P;
-    const unsigned int miss_blocks = grid_for((size_t)P.nMissWords * 32);
     {
         Timed t(h, h->stream, "k_voxelize");
-        hipLaunchKernelGGL(k_voxelize, dim3(kListGrid + miss_blocks), dim3(MLM_BLOCK), 0, h->stream, P, S.F, kListGrid,
-                           n_bkt);
+        hipLaunchKernelGGL(k_voxelize, dim3(64, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F, n_bkt);
     }
     {
-        Timed t(h, h->stream, "k_apply_hits");
-        hipLaunchKernelGGL(k_apply_hits, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq, n_bkt ? 0 : 1);
-    }
-    {
-        Timed t(h, h->stream, "k_apply_misses");
-        hipLaunchKernelGGL(k_apply_misses, dim3(16, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq);
+        Timed t(h, h->stream, "k_apply");
+        hipLaunchKernelGGL(k_apply, dim3(64, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq, n_bkt ? 0 : 1);
     }
 }
 
@@ -421,7 +420,8 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
     const MlmDev &P = S.P;
     bool over = c.n_contrib > P.contrib_cap;
     for (int k = 0; k < MLM_RAY_LISTS; ++k)
-        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mvox_cnt[k][0] > P.mvox_cap;
+        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mvox_cnt[k][0] > P.mvox_cap ||
+               c.mc_cnt[k][0] > P.mc_cap;
     if (over) {
         h->err = "a per-frame device queue overflowed (raise mlm_limits.max_points)";
         return MLM_ERR_CAPACITY;
@@ -667,6 +667,11 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = dev_alloc(h, &P.hl_next, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_vox, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_bkt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_bkey, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_cid, NC))) return rc;
+    P.mc_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 4096);
+    if ((rc = dev_alloc(h, &P.mc_bkey, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
+    if ((rc = dev_alloc(h, &P.mc_cid, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
     if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
     P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
     if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
