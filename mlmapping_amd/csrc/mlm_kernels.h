@@ -970,6 +970,101 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_set_free(const MlmDev P, const do
     P.log_odds[(size_t)slot * P.cells + cid] = 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Inflation (mlmap::inflate_map, mlmap.cpp:286-309; local_map_cartesian::inflate_atpos, map_local.h:233-264)
+// ---------------------------------------------------------------------------------------------------------------
+// The reference visits the (2G+1)^3 blocks around the vehicle in x-outer/z-inner order; visiting a block first wipes
+// its inflate_occupancy and then dilates its own 'o' cells (L1 ball of radius inflate_n) — also into neighbouring
+// blocks.  A neighbour that is visited LATER is wiped after that write, so a write from block Bs into block Bt inside
+// the cube survives iff rank(Bs) >= rank(Bt); blocks outside the cube are never wiped and only accumulate.  That rule
+// is order free, which is what the two kernels below implement.
+__device__ __forceinline__ int mlm_cube_rank(int ox, int oy, int oz, int G) {
+    const int w = 2 * G + 1;
+    return ((ox + G) * w + (oy + G)) * w + (oz + G);
+}
+// one thread per (cube block, cell): wipe
+__global__ __launch_bounds__(MLM_BLOCK) void k_inflate_reset(const MlmDev P, int cgx, int cgy, int cgz, int G) {
+    const int w = 2 * G + 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)w * w * w * P.cells) return;
+    const int c = (int)(i % P.cells);
+    const int b = (int)(i / P.cells);
+    const int oz = b % w - G, oy = (b / w) % w - G, ox = b / (w * w) - G;
+    const int slot = mlm_block_find(P, cgx + ox, cgy + oy, cgz + oz);
+    if (slot >= 0) P.infl[(size_t)slot * P.cells + c] = 'u';
+}
+// one thread per (cube block, cell): dilate the 'o' cells above flate_height
+__global__ __launch_bounds__(MLM_BLOCK) void k_inflate_spread(const MlmDev P, int cgx, int cgy, int cgz, int G, int R,
+                                                              double flate_height) {
+    const int w = 2 * G + 1;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)w * w * w * P.cells) return;
+    const int c = (int)(i % P.cells);
+    const int b = (int)(i / P.cells);
+    const int oz = b % w - G, oy = (b / w) % w - G, ox = b / (w * w) - G;
+    const int gx = cgx + ox, gy = cgy + oy, gz = cgz + oz;
+    const int slot = mlm_block_find(P, gx, gy, gz);
+    if (slot < 0) return;
+    if (P.occ[(size_t)slot * P.cells + c] != 'o') return;
+    const int cz = c / (P.n * P.n), cy = (c - cz * P.n * P.n) / P.n, cx = c - cz * P.n * P.n - cy * P.n;
+    // subbox_id2xyz_glb_vec(temp_glb, it)(2) > flate_height, mlmap.cpp:303 / map_local.h:208-213
+    if (!(gz * P.d_glb + cz * P.d_sub + P.d_sub_half > flate_height)) return;
+    const int my_rank = mlm_cube_rank(ox, oy, oz, G);
+    for (int dx = -R; dx <= R; ++dx)
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dz = -R; dz <= R; ++dz) {
+                if (abs(dx) + abs(dy) + abs(dz) > R) continue;
+                int tx = cx + dx, ty = cy + dy, tz = cz + dz;
+                int bx = 0, by = 0, bz = 0; // block displacement (one wrap: inflate_n < subbox_n)
+                if (tx >= P.n) { bx = 1; tx -= P.n; } else if (tx < 0) { bx = -1; tx += P.n; }
+                if (ty >= P.n) { by = 1; ty -= P.n; } else if (ty < 0) { by = -1; ty += P.n; }
+                if (tz >= P.n) { bz = 1; tz -= P.n; } else if (tz < 0) { bz = -1; tz += P.n; }
+                int tslot = slot;
+                if (bx | by | bz) {
+                    const int tox = ox + bx, toy = oy + by, toz = oz + bz;
+                    const bool in_cube = abs(tox) <= G && abs(toy) <= G && abs(toz) <= G;
+                    tslot = mlm_block_slot(P, mlm_pack_key(gx + bx, gy + by, gz + bz)); // allocate_ram happens anyway
+                    if (tslot < 0) continue;
+                    if (in_cube && mlm_cube_rank(tox, toy, toz, G) > my_rank) continue; // wiped later by the reference
+                }
+                P.infl[(size_t)tslot * P.cells + (tz * P.n * P.n + ty * P.n + tx)] = 'o';
+            }
+}
+// /global_map payload (rviz_vis.cpp:296-327): float centres (PointXYZ) of the cells whose inflate_occupancy is 'o'
+__global__ __launch_bounds__(MLM_BLOCK) void k_export_global(const MlmDev P, unsigned int n_blocks, float *xyz,
+                                                             unsigned int cap, unsigned int *counter) {
+    __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
+    __shared__ unsigned int s_base;
+    const long long total = (long long)n_blocks * P.cells;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < total; i0 += (long long)gridDim.x * blockDim.x) {
+        const long long i = i0 + threadIdx.x;
+        const bool on = i < total && P.infl[i] == 'o';
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const unsigned long long m = __ballot(on);
+        if (lane == 0) s_cnt[wid] = (unsigned int)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int tot = 0;
+            for (int k = 0; k < MLM_BLOCK / 64; ++k) tot += s_cnt[k];
+            s_base = tot ? atomicAdd(counter, tot) : 0u;
+        }
+        __syncthreads();
+        if (on) {
+            unsigned int pos = s_base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+            for (int k = 0; k < wid; ++k) pos += s_cnt[k];
+            if (pos < cap) {
+                const int slot = (int)(i / P.cells), c = (int)(i % P.cells);
+                const int cz = c / (P.n * P.n), cy = (c - cz * P.n * P.n) / P.n, cx = c - cz * P.n * P.n - cy * P.n;
+                // subbox_id2xyz_glb (map_local.h:201-206): doubles narrowed by PointXYZ(float,float,float)
+                xyz[3 * (size_t)pos + 0] = (float)(P.block_keys[3 * slot + 0] * P.d_glb + cx * P.d_sub + P.d_sub_half);
+                xyz[3 * (size_t)pos + 1] = (float)(P.block_keys[3 * slot + 1] * P.d_glb + cy * P.d_sub + P.d_sub_half);
+                xyz[3 * (size_t)pos + 2] = (float)(P.block_keys[3 * slot + 2] * P.d_glb + cz * P.d_sub + P.d_sub_half);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(MLM_BLOCK) void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

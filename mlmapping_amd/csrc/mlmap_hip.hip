@@ -1090,10 +1090,30 @@ int mlm_set_free_in_bound(mlm_handle *h, const double bmin[3], const double bmax
 }
 
 int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
-    (void)ct_pos;
-    if (!h) return MLM_ERR_INVALID;
-    h->err = "inflate_map not implemented yet (SURVEY §8f rank 2)";
-    return MLM_ERR_UNSUPPORTED;
+    if (!h || !ct_pos) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int R = h->cfg.inflate_n, G = h->cfg.inflate_global_n;
+    if (R < 0 || G < 0 || R >= h->P.n || G > 16) {
+        h->err = "inflate_n must be < subbox_n and inflate_global_n <= 16";
+        return MLM_ERR_UNSUPPORTED;
+    }
+    int rc = drain(h);
+    if (rc) return rc;
+    // get_global_idx(ct_pos) (mlmap.cpp:289, map_local.h:148-152)
+    const int cgx = (int)std::floor(ct_pos[0] / h->P.d_glb), cgy = (int)std::floor(ct_pos[1] / h->P.d_glb),
+              cgz = (int)std::floor(ct_pos[2] / h->P.d_glb);
+    const size_t total = (size_t)(2 * G + 1) * (2 * G + 1) * (2 * G + 1) * (size_t)h->P.cells;
+    hipLaunchKernelGGL(k_inflate_reset, dim3(grid_for(total)), dim3(MLM_BLOCK), 0, h->stream, h->P, cgx, cgy, cgz, G);
+    hipLaunchKernelGGL(k_inflate_spread, dim3(grid_for(total)), dim3(MLM_BLOCK), 0, h->stream, h->P, cgx, cgy, cgz, G, R,
+                       0.1 /* flate_height, map_local.h:65 */);
+    HIPCHK(h, hipGetLastError());
+    rc = read_global(h);
+    if (rc) return rc;
+    if (h->h_g->err) {
+        h->err = "block pool or block hash table full (raise mlm_limits.max_blocks)";
+        return MLM_ERR_CAPACITY;
+    }
+    return MLM_OK;
 }
 
 int mlm_block_count(mlm_handle *h, int *n_out) {
@@ -1123,12 +1143,33 @@ int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, ui
 }
 
 int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out) {
-    (void)cap_points;
-    (void)xyz;
-    if (!h) return MLM_ERR_INVALID;
-    if (n_out) *n_out = 0;
-    h->err = "global map export not implemented yet (SURVEY §8f rank 4)";
-    return MLM_ERR_UNSUPPORTED;
+    if (!h || cap_points < 0 || (cap_points > 0 && !xyz)) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int nb = 0;
+    int rc = mlm_block_count(h, &nb);
+    if (rc) return rc;
+    float *d_xyz = nullptr;
+    unsigned int *d_cnt = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d_xyz, std::max<size_t>((size_t)cap_points * 3 * sizeof(float), 16)));
+    HIPCHK(h, hipMalloc((void **)&d_cnt, sizeof(unsigned int)));
+    HIPCHK(h, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), h->stream));
+    if (nb > 0)
+        hipLaunchKernelGGL(k_export_global, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, h->P, (unsigned int)nb, d_xyz,
+                           (unsigned int)cap_points, d_cnt);
+    unsigned int cnt = 0;
+    hipError_t e = hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && cnt && cap_points)
+        e = hipMemcpy(xyz, d_xyz, (size_t)std::min<unsigned int>(cnt, (unsigned int)cap_points) * 3 * sizeof(float),
+                      hipMemcpyDefault);
+    hipFree(d_xyz);
+    hipFree(d_cnt);
+    if (e != hipSuccess) {
+        h->err = std::string("mlm_export_global_map: ") + hipGetErrorString(e);
+        return MLM_ERR_HIP;
+    }
+    if (n_out) *n_out = (int)cnt;
+    return MLM_OK;
 }
 
 int mlm_sync(mlm_handle *h) {

@@ -272,6 +272,15 @@ class MLMap:
         return {"blocks": int(b["keys"].shape[0]), "o": int((b["occ"] == ord("o")).sum()),
                 "f": int((b["occ"] == ord("f")).sum())}
 
+    def global_map_points(self) -> np.ndarray:
+        """float32 [n,3] centres of the inflated-'o' cells: the PointCloud2 payload of /global_map."""
+        n = ctypes.c_int32()
+        self._chk(self._L.mlm_export_global_map(self._h, 0, None, ctypes.byref(n)), "mlm_export_global_map")
+        out = np.empty((n.value, 3), dtype=np.float32)
+        if n.value:
+            self._chk(self._L.mlm_export_global_map(self._h, n.value, _p(out), ctypes.byref(n)), "mlm_export_global_map")
+        return out
+
     def awareness_hits(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """(cell idx sorted, odds, first-touch time) of the last frame."""
         n = self.frame_stats()["n_hit_cells"]

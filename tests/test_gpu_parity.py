@@ -214,3 +214,32 @@ def test_async_submission_matches(mods):
         cpu.update_depth(frames[k], q[k], t[k])
     print(compare_maps(gpu.export_blocks(), cpu.export_blocks(), "async 30 frames"))
     assert gpu.frame_stats()["n_hit_cells"] == len(cpu.hits()[1])
+
+
+def test_inflation_and_global_map(mods):
+    """§8f rank 2/4: inflate_map (incl. the reference's visiting-order wipe rule and block allocation by inflation),
+    getInflateOccupancy, getOccupancy(pos, inflate) and the /global_map point payload."""
+    MLMap, OracleMap = mods
+    for cfg in (S1, SDEF):
+        gpu, cpu = MLMap(cfg, max_blocks=8192), OracleMap(cfg)
+        pose = None
+        for k, (img, (q, t)) in enumerate(syn.stream(cfg, "room_jitter", "smooth", 5)):
+            gpu.update_map(img, q, t)
+            cpu.update_depth(img, q, t)
+            pose = t
+            if k in (2, 4):  # the 5 Hz timer fires between frames; repeated inflation accumulates outside the cube
+                gpu.inflate_map(pose)
+                cpu.inflate_map(pose)
+        g, c = gpu.export_blocks(), cpu.export_blocks()
+        compare_maps(g, c, "after inflation")
+        assert np.array_equal(g["infl"], c["infl"]), f"{int((g['infl'] != c['infl']).sum())} inflate cells differ"
+        assert (c["infl"] == ord("o")).sum() > 0
+        gp, cp = gpu.global_map_points(), cpu.global_map_points()
+        assert gp.shape == cp.shape
+        key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        assert np.array_equal(key(gp).view(np.uint32), key(cp).view(np.uint32)), "global map points differ"
+        rng = np.random.default_rng(9)
+        pos = np.concatenate([rng.uniform(c["keys"].min(0) * cfg.subbox_d_xyz * cfg.subbox_n - 1,
+                                          (c["keys"].max(0) + 1) * cfg.subbox_d_xyz * cfg.subbox_n + 1, size=(40000, 3)),
+                              voxel_centres(c, cfg, 60000)])
+        assert np.array_equal(gpu.getInflateOccupancy(pos), cpu.getInflateOccupancy(pos))
