@@ -63,8 +63,8 @@ def cpu_baseline(cfg, frames, q, t, budget_s: float = 15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="frames per step")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--distinct", type=int, default=32, help="distinct depth frames kept in HBM (cycled)")
@@ -174,12 +174,24 @@ def main():
         dom = max(ktime.items(), key=lambda kv: kv[1][0]) if ktime else None
         mean_bytes = float(np.mean(algo_bytes)) if algo_bytes else 0.0
         roof = None
+        # HBM-side bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot be
+        # driven from inside this process; tools/pmc_workload.py + tools/pmc_summary.py regenerate the file)
+        pmc = None
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            if files and args.workload == "cfg2":
+                pmc = json.load(open(files[-1]))
+        except Exception:
+            pmc = None
         if dom:
             avg_ms = dom[1][0] / dom[1][1]
             launches_per_frame = dom[1][1] / max(1, n_inst)
             ach = mean_bytes / launches_per_frame / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_ms * 1e3,
+                    "frac": ach / HBM_PEAK_GBS,
+                    "traffic": (pmc["kernels"].get(dom[0], {}).get("total_bytes") if pmc else None),
+                    "traffic_source": (os.path.basename(files[-1]) if pmc else None), "avg_launch_us": avg_ms * 1e3,
                     "algorithmic_bytes_per_frame": mean_bytes,
                     "kernels_us_per_frame": {k: v[0] * 1e3 / max(1, n_inst) for k, v in ktime.items()}}
         out = {
