@@ -146,6 +146,11 @@ int mlm_block_count(mlm_handle *h, int *n_out);
  * be host or device memory (the global-map merge exports straight into device tensors) */
 int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, uint8_t *occ, uint8_t *infl,
                       int *n_out);
+/* collapsed [cap]: 1 for blocks the release scan (map_local.cpp:208-232) froze — their vectors have size 1 in the
+ * reference, element 0 answers queries; always 0 unless use_exploration_frontiers */
+int mlm_export_block_flags(mlm_handle *h, int cap, uint8_t *collapsed, int *n_out);
+/* frontier cells as (gx,gy,gz,cell id) quadruples = the /frontier cloud before centre conversion (rviz_vis.cpp:267-293) */
+int mlm_export_frontier(mlm_handle *h, int cap, int32_t *keys_cell, int *n_out);
 /* float xyz of inflated-'o' cell centres = PointCloud2 payload of /global_map (rviz_vis.cpp:296-327) */
 int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out);
 

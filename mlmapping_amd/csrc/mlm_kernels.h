@@ -137,7 +137,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
     __shared__ unsigned int s_cnt[4];
     __shared__ unsigned int s_nray;
-    __shared__ int s_ray[MLM_RAY_LDS][3];
+    __shared__ int s_ray[MLM_RAY_LDS][4];
+    __shared__ unsigned int s_nbase2;
     __shared__ unsigned int s_nnode, s_nbase;
     __shared__ MlmNode s_node[MLM_NODE_LDS];
     if (threadIdx.x == 0) {
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
             s_ray[k][0] = rho;
             s_ray[k][1] = phi;
             s_ray[k][2] = zi;
+            s_ray[k][3] = inside ? -1 : i; // explore mode: in-range starts take the cell's first point later
         }
     }
     if (lane == 0) s_cnt[wid] = n_pts | (n_oor << 10);
@@ -267,7 +269,21 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         s_nbase = nn ? atomicAdd(&P.ctr->node_cnt[reg][0], nn) : 0u;
         if (nr) atomicAdd(&P.ctr->ray_cnt[reg][0], nr); // statistic only
     }
-    for (unsigned int r = wid; r < nr; r += MLM_BLOCK / 64) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
+    if (!P.explore) {
+        for (unsigned int r = wid; r < nr; r += MLM_BLOCK / 64) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
+    } else if (nr) {
+        // frontier mode needs each miss cell's insertion time, which depends on the FIRST point of a start cell; that
+        // is only known after k_assign_nodes, so the rays are queued and walked by k_ex_walk_rays
+        if (threadIdx.x == 0) s_nbase2 = atomicAdd(&P.ctr->n_ex_rays, nr);
+        __syncthreads();
+        for (unsigned int r = threadIdx.x; r < nr; r += blockDim.x) {
+            int32_t *q = P.ex_rays + 4 * (size_t)(s_nbase2 + r);
+            q[0] = s_ray[r][0];
+            q[1] = s_ray[r][1];
+            q[2] = s_ray[r][2];
+            q[3] = s_ray[r][3];
+        }
+    }
     __syncthreads();
     for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x)
         if (s_nbase + k < P.node_cap) P.nodes[(size_t)reg * P.node_cap + s_nbase + k] = s_node[k];
@@ -326,6 +342,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_assign_nodes(MLM_SLOT_ARGS, int t
             const uint32_t t = ((is & 0x07FFFFFFu) + off) * MLM_TIME_SLOTS + (is >> 27);
             atomicMin(&P.hit_t[cell], t);
             atomicOr(&P.hit_mask[cell], 1u << (is >> 27));
+            if (P.explore && (is >> 27) == 0) atomicMin(&P.start_t[cell], (is & 0x07FFFFFFu) + off);
             const uint32_t pos = atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
             nd->pos = pos;
             first = pos == 0;
@@ -402,7 +419,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
             P.hit_t[c] = MLM_EMPTY_T;
             P.hit_mask[c] = 0;
             P.hit_cnt[c] = 0;
-            if (mask & 1u) atomicAnd(&P.start_bits[c >> 5], ~(1u << (c & 31))); // its ray was queued; reset for next frame
+            if (mask & 1u) {
+                atomicAnd(&P.start_bits[c >> 5], ~(1u << (c & 31))); // its ray was queued; reset for next frame
+                if (P.explore) P.start_t[c] = MLM_EMPTY_T; // (k_ex_walk_rays runs before this kernel)
+            }
             P.hl_cell[pos] = c;
             P.hl_t[pos] = t;
             P.hl_vt[pos] = t;
@@ -703,7 +723,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
                 atomicMin(&P.bkt64[b], mlm_bkt_entry(frame_idx, P.hl_vt[i]));
                 P.hl_bkt[i] = (uint32_t)b;
             }
-            const int slot = mlm_block_slot(P, P.hl_bkey[i]);
+            int slot = mlm_block_slot(P, P.hl_bkey[i]);
+            if (P.explore && slot >= 0 && P.blk_collapsed[slot]) slot = -3; // released block: allocate_ram() is false
             if (slot < 0) {
                 P.hl_vox[i] = -1;
                 P.hl_next[i] = -2;
@@ -712,7 +733,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
             const int v = slot * P.cells + (int)P.hl_cid[i];
             P.hl_vox[i] = v;
             P.hl_next[i] = atomicExch(&P.vox_head[v], (int)i);
-            atomicOr(&P.vox_miss[v], MLM_HAS_HITS); // tells k_apply's miss side that a hit owner exists
+            if (!P.explore) atomicOr(&P.vox_miss[v], MLM_HAS_HITS); // tells k_apply's miss side that a hit owner exists
         }
         return;
     }
@@ -773,6 +794,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
             const int head = P.vox_head[v];
             float L = P.log_odds[v];
             uint8_t o = P.occ[v];
+            const uint8_t o0 = o;
             if (head == (int)i) { // the common case: a single contribution
                 if (L < P.lo_max) {
                     L = L + P.hl_inc[i];
@@ -800,8 +822,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
                     last = bestkey;
                 }
             }
-            const uint32_t km = atomicExch(&P.vox_miss[v], 0u) & ~MLM_HAS_HITS;
-            mlm_apply_misses(P, L, o, km);
+            if (!P.explore) {
+                const uint32_t km = atomicExch(&P.vox_miss[v], 0u) & ~MLM_HAS_HITS;
+                mlm_apply_misses(P, L, o, km);
+            } else if (o == 'o' && o0 != 'o') {
+                P.frnt[v] = 0; // frontier.erase(subbox_id), map_local.cpp:167-168
+            }
             P.log_odds[v] = L;
             P.occ[v] = o;
             P.vox_head[v] = -1;
@@ -834,6 +860,7 @@ __device__ __forceinline__ int mlm_get_occupancy(const MlmDev &P, double x, doub
     mlm_voxel_of(P, x, y, z, gx, gy, gz, cid);
     const int slot = mlm_block_find(P, gx, gy, gz);
     if (slot < 0) return -1;
+    if (P.explore && P.blk_collapsed[slot]) cid = 0; // occupancy.size() == 1 -> occupancy[0], mlmap.h:183-184
     const uint8_t r = P.occ[(size_t)slot * P.cells + cid];
     return r == 'o' ? 0 : (r == 'f' ? 1 : -1);
 }
@@ -846,6 +873,7 @@ __device__ __forceinline__ float mlm_logit_inv(float L) {
 __device__ __forceinline__ float mlm_get_odd_at(const MlmDev &P, int gx, int gy, int gz, int cid) {
     const int slot = mlm_block_find(P, gx, gy, gz);
     if (slot < 0) return 0.5f;
+    if (P.explore && P.blk_collapsed[slot]) cid = 0; // log_odds.size() == 1 -> log_odds[0], mlmap.h:221-222
     return mlm_logit_inv(P.log_odds[(size_t)slot * P.cells + cid]);
 }
 // 6-neighbour step of subbox_neighbors (map_local.cpp:77-120): order +z,-z,+y,-y,+x,-x
@@ -901,7 +929,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_query(const MlmDev P, int mode, c
         mlm_voxel_of(P, x, y, z, gx, gy, gz, cid);
         const int slot = mlm_block_find(P, gx, gy, gz);
         int res = -1;
-        if (slot >= 0 && P.infl[(size_t)slot * P.cells + cid] == 'o') res = 0;
+        if (slot >= 0 && !(P.explore && P.blk_collapsed[slot]) && P.infl[(size_t)slot * P.cells + cid] == 'o') res = 0;
         out_i8[i] = (int8_t)res;
     } else if (mode == 3) {
         int gx, gy, gz, cid;
@@ -965,7 +993,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_set_free(const MlmDev P, const do
     int gx, gy, gz, cid;
     mlm_voxel_of(P, xs[ix], ys[iy], zs[iz], gx, gy, gz, cid);
     const int slot = mlm_block_find(P, gx, gy, gz);
-    if (slot < 0) return;
+    if (slot < 0 || (P.explore && P.blk_collapsed[slot])) return; // only blocks with occupancy.size() > 1, mlmap.cpp:399
     P.occ[(size_t)slot * P.cells + cid] = 'f';
     P.log_odds[(size_t)slot * P.cells + cid] = 0.0f;
 }
@@ -991,7 +1019,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_inflate_reset(const MlmDev P, int
     const int b = (int)(i / P.cells);
     const int oz = b % w - G, oy = (b / w) % w - G, ox = b / (w * w) - G;
     const int slot = mlm_block_find(P, cgx + ox, cgy + oy, cgz + oz);
-    if (slot >= 0) P.infl[(size_t)slot * P.cells + c] = 'u';
+    if (slot >= 0 && !(P.explore && P.blk_collapsed[slot])) P.infl[(size_t)slot * P.cells + c] = 'u';
 }
 // one thread per (cube block, cell): dilate the 'o' cells above flate_height
 __global__ __launch_bounds__(MLM_BLOCK) void k_inflate_spread(const MlmDev P, int cgx, int cgy, int cgz, int G, int R,
@@ -1004,7 +1032,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_inflate_spread(const MlmDev P, in
     const int oz = b % w - G, oy = (b / w) % w - G, ox = b / (w * w) - G;
     const int gx = cgx + ox, gy = cgy + oy, gz = cgz + oz;
     const int slot = mlm_block_find(P, gx, gy, gz);
-    if (slot < 0) return;
+    if (slot < 0 || (P.explore && P.blk_collapsed[slot])) return;
     if (P.occ[(size_t)slot * P.cells + c] != 'o') return;
     const int cz = c / (P.n * P.n), cy = (c - cz * P.n * P.n) / P.n, cx = c - cz * P.n * P.n - cy * P.n;
     // subbox_id2xyz_glb_vec(temp_glb, it)(2) > flate_height, mlmap.cpp:303 / map_local.h:208-213
@@ -1024,7 +1052,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_inflate_spread(const MlmDev P, in
                     const int tox = ox + bx, toy = oy + by, toz = oz + bz;
                     const bool in_cube = abs(tox) <= G && abs(toy) <= G && abs(toz) <= G;
                     tslot = mlm_block_slot(P, mlm_pack_key(gx + bx, gy + by, gz + bz)); // allocate_ram happens anyway
-                    if (tslot < 0) continue;
+                    if (tslot < 0 || (P.explore && P.blk_collapsed[tslot])) continue;
                     if (in_cube && mlm_cube_rank(tox, toy, toz, G) > my_rank) continue; // wiped later by the reference
                 }
                 P.infl[(size_t)tslot * P.cells + (tz * P.n * P.n + ty * P.n + tx)] = 'o';

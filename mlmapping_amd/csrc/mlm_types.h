@@ -17,6 +17,10 @@ struct MlmCounters {
     unsigned int n_miss_list; // entries of ml_cell (record_awareness only)
     unsigned int n_contrib;   // contributions stored for multi-type cells (segments of `contrib`)
     unsigned int n_multi;     // hit cells that received more than one kind of contribution
+    unsigned int n_ex_rays;   // explore mode: queued rays
+    unsigned int n_ex_miss;   // explore mode: unique miss cells
+    unsigned int n_ex_vox;    // explore mode: voxels touched by misses
+    unsigned int pad_ex;
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
@@ -32,7 +36,7 @@ struct MlmGlobal {
                               // miss); INT_MAX = none.  Stage B/C kernels of frames >= it do nothing.
     unsigned int pad;
 };
-#define MLM_CTR_FRAME_BYTES (32 + 6 * 8 * 32 * 4)
+#define MLM_CTR_FRAME_BYTES (48 + 6 * 8 * 32 * 4)
 #define MLM_RAY_LISTS 8
 
 // The hit contributions one wave makes to one awareness cell with one kind (`sub`): lanes in `mask`, work items
@@ -119,6 +123,22 @@ struct MlmDev {
     uint32_t *vox_miss;        // [max_blocks*cells] miss count of this frame
     int *miss_vox;             // [MLM_RAY_LISTS][mvox_cap] voxels touched by misses this frame
     unsigned int mvox_cap;
+    // ---- exploration-frontier mode (use_exploration_frontiers: true) — map_local.cpp:7-33,208-232
+    int explore;
+    uint8_t *frnt;             // [max_blocks*cells] 1 = the cell is in its block's frontier set
+    uint8_t *blk_collapsed;    // [max_blocks] 1 = block was "released" (vectors resized to 1: frozen, element 0 answers)
+    uint8_t *blk_observed;     // [max_blocks] observed_subboxes of the current frame
+    unsigned long long *vox_tau; // [max_blocks*cells] iteration-order key of the voxel's first miss this frame
+    uint32_t *start_t;         // [nCells] first point whose hit centre is this cell (its ray's insertion time base)
+    uint32_t *miss_t;          // [nCells] first insertion time of a miss cell: point*256 + ray step
+    int32_t *ex_rays;          // [max_points][4] queued rays: rho, phi, z, point (-1: take start_t of the cell)
+    uint32_t *ex_cell;         // unique miss cells of the frame (capacity nCells) ...
+    uint32_t *ex_t;            // ... first insertion time
+    uint32_t *ex_vt;           // ... virtual insertion time (rehash replay)
+    uint32_t *ex_arr;          // ... arrival rank
+    unsigned long long *ex_key;// ... iteration-order key (larger = earlier)
+    int *ex_vox;               // ... voxel address or -1
+    uint32_t *bktm_first;      // [max buckets of the miss container] min vt per bucket
     MlmCounters *ctr;          // this slot's per-frame counters
     MlmGlobal *g;
 };

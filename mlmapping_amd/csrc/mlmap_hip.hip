@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "../../include/mlmap_hip.h"
-#include "mlm_kernels.h"
+#include "mlm_kernels_explore.h"
 
 extern "C" size_t mlm_sort_temp_bytes(size_t n);
 extern "C" int mlm_sort_pairs_u64_u32(void *temp, size_t temp_bytes, const unsigned long long *kin,
@@ -150,6 +150,9 @@ struct mlm_handle {
     size_t hit_n_bkt = 1;
     std::__detail::_Prime_rehash_policy hit_pol;
     size_t max_buckets = 0;
+    // the same for awareness_map->miss_idx_set (only tracked in frontier mode, where its iteration order matters)
+    size_t miss_n_bkt = 1;
+    std::__detail::_Prime_rehash_policy miss_pol;
     mlm_frame_stats stats{};
     std::string err;
     int timing = 0;
@@ -251,24 +254,27 @@ void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb
 // Replay the rehash policy of libstdc++'s _Hashtable for `U` unique insertions into a cleared container.
 // Returns the epochs: (number of elements present when the epoch ends, bucket count during the epoch).
 // Uses the very policy object std::unordered_map uses, so it follows whatever libstdc++ this library is linked to.
-std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
+std::vector<std::pair<size_t, size_t>> plan_epochs_for(std::__detail::_Prime_rehash_policy &pol, size_t &n_bkt, size_t U) {
     std::vector<std::pair<size_t, size_t>> ep;
-    size_t n = h->hit_n_bkt;
+    size_t n = n_bkt;
     size_t i = 0;
     while (i < U) {
         // _M_insert_unique_node: _M_need_rehash(bucket_count, element_count, 1) before linking the node
-        const auto r = h->hit_pol._M_need_rehash(n, i, 1);
+        const auto r = pol._M_need_rehash(n, i, 1);
         if (r.first) {
             if (i > 0) ep.emplace_back(i, n);
             n = r.second;
         }
         // the policy is inert while element_count + 1 <= _M_next_resize
-        const size_t next = std::max<size_t>(i + 1, h->hit_pol._M_next_resize);
+        const size_t next = std::max<size_t>(i + 1, pol._M_next_resize);
         i = std::min(U, next);
     }
     ep.emplace_back(U, n);
-    h->hit_n_bkt = n;
+    n_bkt = n;
     return ep;
+}
+std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
+    return plan_epochs_for(h->hit_pol, h->hit_n_bkt, U);
 }
 
 // Stage B for one frame whose unique-hit count U is known on the host: exact, with rehash epochs.
@@ -433,6 +439,110 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
     return MLM_OK;
 }
 
+// ---- frontier mode (use_exploration_frontiers: true): one frame at a time, exact ordering of BOTH containers ------
+// Iteration-order keys of miss_idx_set (std::unordered_set<size_t>) into ex_key; same scheme as order_hits_exact.
+int order_misses_exact(mlm_handle *h, MlmSlot &S, unsigned int U) {
+    const MlmDev &P = S.P;
+    const auto ep = plan_epochs_for(h->miss_pol, h->miss_n_bkt, U);
+    if (h->miss_n_bkt > h->max_buckets) {
+        h->err = "emulated bucket count exceeds capacity";
+        return MLM_ERR_CAPACITY;
+    }
+    if (U == 0) return MLM_OK;
+    const bool multi = ep.size() > 1;
+    if (multi) {
+        hipLaunchKernelGGL(k_ex_time_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
+        if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U, h->stream) != 0) {
+            h->err = "radix sort failed";
+            return MLM_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_ex_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
+    }
+    for (size_t e = 0; e < ep.size(); ++e) {
+        const unsigned int m = (unsigned int)ep[e].first;
+        const unsigned long long nb = ep[e].second;
+        const bool final_pass = (e + 1 == ep.size());
+        HIPCHK(h, hipMemsetAsync(P.bktm_first, 0xFF, nb * sizeof(uint32_t), h->stream));
+        hipLaunchKernelGGL(k_ex_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0);
+        hipLaunchKernelGGL(k_ex_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0,
+                           final_pass ? 1 : 0, h->sk_in, h->sv_in);
+        if (!final_pass) {
+            if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U, h->stream) != 0) {
+                h->err = "radix sort failed";
+                return MLM_ERR_HIP;
+            }
+            hipLaunchKernelGGL(k_ex_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
+        }
+    }
+    return MLM_OK;
+}
+
+int run_frame_explore(mlm_handle *h, int slot_index) {
+    MlmSlot &S = h->slots[(size_t)slot_index];
+    const MlmDev &P = S.P;
+    hipStream_t st = h->stream;
+    h->ktimes.clear();
+    h->kpool_used = 0;
+    S.seq = 0;
+    S.F.seq = 0;
+    h->h_frame_tab[slot_index] = S.F;
+    HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + slot_index, h->h_frame_tab + slot_index, sizeof(MlmFrame), hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemsetAsync(P.ctr, 0, sizeof(MlmCounters), st));
+    const MlmFrame &F = S.F;
+    unsigned int nb = 0;
+    const dim3 blk(MLM_BLOCK);
+    if (F.n > 0) {
+        nb = (S.mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
+        if (nb > (unsigned int)h->lim.max_points / 64 + 1024) {
+            h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
+            return MLM_ERR_CAPACITY;
+        }
+        if (S.mode == 0)
+            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+        else if (S.mode == 1)
+            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+        else
+            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+    }
+    const int tile_w = S.mode == 0 ? F.width : 0;
+    hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
+    hipLaunchKernelGGL(k_ex_walk_rays, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+    hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, (int)nb);
+    hipLaunchKernelGGL(k_expand_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
+    hipLaunchKernelGGL(k_sort_contribs, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+    hipLaunchKernelGGL(k_chain, dim3(256, 1, 1), blk, (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
+                       slot_index, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(k_prepare_voxels, dim3(256, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index); // hits only
+    hipLaunchKernelGGL(k_ex_collect_misses, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipGetLastError());
+    const unsigned int U = S.h_ctr->u_hit, UM = S.h_ctr->n_ex_miss;
+    int rc = order_hits_exact(h, S, U, 0);
+    if (rc) return rc;
+    rc = order_misses_exact(h, S, UM);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_voxelize, dim3(64, 1), blk, 0, st, P, S.F, 0ull);   // hits: push on voxel lists (explicit keys)
+    hipLaunchKernelGGL(k_apply, dim3(64, 1), blk, 0, st, P, 0, 1);           // hits: ordered replay, frontier erase on 'o'
+    hipLaunchKernelGGL(k_ex_miss_tau, dim3(kListGrid), blk, 0, st, P, S.F);
+    hipLaunchKernelGGL(k_ex_observe, dim3(kListGrid), blk, 0, st, P, S.F);
+    hipLaunchKernelGGL(k_ex_apply_misses, dim3(kListGrid), blk, 0, st, P);
+    HIPCHK(h, hipMemcpyAsync(h->h_g, P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    const unsigned int n_blocks = std::min<unsigned int>(h->h_g->n_blocks, (unsigned int)P.max_blocks);
+    if (n_blocks) hipLaunchKernelGGL(k_ex_release, dim3(std::min(n_blocks, 1024u)), blk, 0, st, P, n_blocks);
+    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipGetLastError());
+    rc = check_queues(h, S);
+    if (rc) return rc;
+    h->last_slot = slot_index;
+    fill_stats(h, S);
+    h->stats.n_miss_cells = UM;
+    h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
+    return MLM_OK;
+}
+
 // ---- submission / confirmation ---------------------------------------------------------------------------------
 // Frames carry a monotonically increasing sequence number.  Stage B/C of a frame is submitted speculatively; the
 // device flag g->fail_frame holds the first sequence number whose speculation did not hold (sticky), and every
@@ -542,6 +652,14 @@ int finish_set(mlm_handle *h, int set) {
 
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
 int run_slots(mlm_handle *h, int n) {
+    if (h->P.explore) { // frontier mode: frame by frame, exact
+        const int K = (int)h->slots.size() / 2;
+        for (int j = 0; j < n; ++j) {
+            const int rc = run_frame_explore(h, h->cur_set * K + j);
+            if (rc) return rc;
+        }
+        return MLM_OK;
+    }
     h->ktimes.clear();
     h->kpool_used = 0;
     h->stats.n_rehash_epochs = 1;
@@ -673,6 +791,19 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = dev_alloc(h, &P.mc_bkey, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
     if ((rc = dev_alloc(h, &P.mc_cid, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
     if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
+    if (P.explore) {
+        if ((rc = dev_alloc(h, &P.start_t, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.miss_t, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_rays, (size_t)h->lim.max_points * 4 + 4096))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_cell, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_t, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_vt, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_arr, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_key, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_vox, NC))) return rc;
+        HIPCHK(h, hipMemset(P.start_t, 0xFF, NC * sizeof(uint32_t)));
+        HIPCHK(h, hipMemset(P.miss_t, 0xFF, NC * sizeof(uint32_t)));
+    }
     P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
     if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
     HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
@@ -700,7 +831,6 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if (cfg->am_n_rho <= 1 || cfg->am_d_rho <= 0 || cfg->am_d_phi_deg <= 0 || cfg->am_d_z <= 0 || cfg->subbox_n <= 0 ||
         cfg->subbox_d_xyz <= 0 || cfg->am_n_z_below < 0 || cfg->am_n_z_over < 0)
         return MLM_ERR_INVALID;
-    if (cfg->use_exploration_frontiers) return MLM_ERR_UNSUPPORTED; // frontier bookkeeping: SURVEY §8f rank 1
     mlm_handle *h = new mlm_handle();
     *out = h; // returned even on failure so that mlm_last_error can be read; caller must mlm_destroy it
     h->device = device;
@@ -710,6 +840,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if (h->lim.max_points <= 0) h->lim.max_points = 1280 * 720;
     if (h->lim.max_batch <= 0) h->lim.max_batch = 8;
     if (h->lim.max_batch > 64) h->lim.max_batch = 64;
+    if (cfg->use_exploration_frontiers) h->lim.max_batch = 1; // frontier mode integrates frame by frame
+    if ((long long)h->lim.max_points * 256 > 0xFFFFFFF0ll && cfg->use_exploration_frontiers) {
+        h->err = "max_points too large for 32-bit miss insertion times";
+        return MLM_ERR_UNSUPPORTED;
+    }
     int ndev = 0;
     HIPCHK(h, hipGetDeviceCount(&ndev));
     if (ndev <= 0 || device < 0 || device >= ndev) {
@@ -769,6 +904,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     P.fy = (float)cfg->cam_fy;
     P.inv_factor = 1.0 / 1000.0;
     P.record_awareness = h->lim.record_awareness;
+    P.explore = cfg->use_exploration_frontiers != 0;
     P.max_blocks = h->lim.max_blocks;
 
     // T_bs, mlmap.cpp:22-25
@@ -832,6 +968,17 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &P.vox_head, NV))) return rc;
     if ((rc = dev_alloc(h, &P.vox_miss, NV))) return rc;
     if ((rc = dev_alloc(h, &P.g, 1))) return rc;
+    if (P.explore) {
+        if ((rc = dev_alloc(h, &P.frnt, NV))) return rc;
+        if ((rc = dev_alloc(h, &P.vox_tau, NV))) return rc;
+        if ((rc = dev_alloc(h, &P.blk_collapsed, (size_t)P.max_blocks))) return rc;
+        if ((rc = dev_alloc(h, &P.blk_observed, (size_t)P.max_blocks))) return rc;
+        if ((rc = dev_alloc(h, &P.bktm_first, h->max_buckets))) return rc;
+        HIPCHK(h, hipMemset(P.frnt, 0, NV));
+        HIPCHK(h, hipMemset(P.vox_tau, 0, NV * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(P.blk_collapsed, 0, (size_t)P.max_blocks));
+        HIPCHK(h, hipMemset(P.blk_observed, 0, (size_t)P.max_blocks));
+    }
     HIPCHK(h, hipMemset(P.ht_keys, 0xFF, ht * sizeof(unsigned long long)));
     HIPCHK(h, hipMemset(P.ht_slot, 0xFF, ht * sizeof(int)));
     HIPCHK(h, hipMemset(P.log_odds, 0, NV * sizeof(float)));            // allocate_ram: log_odds 0
@@ -1142,6 +1289,51 @@ int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, ui
     return MLM_OK;
 }
 
+int mlm_export_block_flags(mlm_handle *h, int cap, uint8_t *collapsed, int *n_out) {
+    if (!h || cap < 0) return MLM_ERR_INVALID;
+    int n = 0;
+    int rc = mlm_block_count(h, &n);
+    if (rc) return rc;
+    if (n_out) *n_out = n;
+    const size_t m = (size_t)std::min(n, cap);
+    if (!m || !collapsed) return MLM_OK;
+    if (h->P.explore)
+        HIPCHK(h, hipMemcpy(collapsed, h->P.blk_collapsed, m, hipMemcpyDefault));
+    else
+        std::memset(collapsed, 0, m);
+    return MLM_OK;
+}
+
+int mlm_export_frontier(mlm_handle *h, int cap, int32_t *keys_cell, int *n_out) {
+    if (!h || cap < 0 || (cap > 0 && !keys_cell)) return MLM_ERR_INVALID;
+    if (n_out) *n_out = 0;
+    if (!h->P.explore) return MLM_OK;
+    int nb = 0;
+    int rc = mlm_block_count(h, &nb);
+    if (rc) return rc;
+    int32_t *d_out = nullptr;
+    unsigned int *d_cnt = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d_out, std::max<size_t>((size_t)cap * 4 * sizeof(int32_t), 16)));
+    HIPCHK(h, hipMalloc((void **)&d_cnt, sizeof(unsigned int)));
+    HIPCHK(h, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), h->stream));
+    if (nb > 0)
+        hipLaunchKernelGGL(k_ex_export_frontier, dim3(512), dim3(MLM_BLOCK), 0, h->stream, h->P, (unsigned int)nb, d_out,
+                           (unsigned int)cap, d_cnt);
+    unsigned int cnt = 0;
+    hipError_t e = hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && cnt && cap)
+        e = hipMemcpy(keys_cell, d_out, (size_t)std::min<unsigned int>(cnt, (unsigned int)cap) * 4 * sizeof(int32_t), hipMemcpyDefault);
+    hipFree(d_out);
+    hipFree(d_cnt);
+    if (e != hipSuccess) {
+        h->err = std::string("mlm_export_frontier: ") + hipGetErrorString(e);
+        return MLM_ERR_HIP;
+    }
+    if (n_out) *n_out = (int)cnt;
+    return MLM_OK;
+}
+
 int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out) {
     if (!h || cap_points < 0 || (cap_points > 0 && !xyz)) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1212,7 +1404,7 @@ int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *od
 
 int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
-    if (!h->P.record_awareness) {
+    if (!h->P.record_awareness && !h->P.explore) {
         h->err = "mlm_limits.record_awareness was not set";
         return MLM_ERR_INVALID;
     }
@@ -1221,7 +1413,7 @@ int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_
     const size_t n = (size_t)h->stats.n_miss_cells;
     if (n_out) *n_out = (int)n;
     const size_t m = std::min<size_t>(n, (size_t)cap);
-    if (m && cell_idx) HIPCHK(h, hipMemcpy(cell_idx, P.ml_cell, m * 4, hipMemcpyDeviceToHost));
+    if (m && cell_idx) HIPCHK(h, hipMemcpy(cell_idx, P.explore ? P.ex_cell : P.ml_cell, m * 4, hipMemcpyDeviceToHost));
     return MLM_OK;
 }
 

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mlm_integrate_depth_batch",
     "mlm_integrate_points", "mlm_query_occupancy", "mlm_query_occupancy_inflate", "mlm_query_inflate_occupancy",
     "mlm_query_odds", "mlm_query_odd_grad", "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
-    "mlm_export_blocks", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
+    "mlm_export_blocks", "mlm_export_block_flags", "mlm_export_frontier", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
     "mlm_get_awareness_hits",
     "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
     "mlm_enable_kernel_timing",
@@ -92,6 +92,8 @@ def load_library(path: Optional[str] = None):
     L.mlm_block_count.argtypes = [vp, vp]
     L.mlm_export_blocks.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.mlm_export_global_map.argtypes = [vp, i32, vp, vp]
+    L.mlm_export_block_flags.argtypes = [vp, i32, vp, vp]
+    L.mlm_export_frontier.argtypes = [vp, i32, vp, vp]
     L.mlm_sync.argtypes = [vp]
     L.mlm_set_async.argtypes = [vp, i32]
     L.mlm_get_frame_stats.argtypes = [vp, vp]
@@ -263,9 +265,19 @@ class MLMap:
         m = ctypes.c_int32()
         self._chk(self._L.mlm_export_blocks(self._h, n, _p(keys), _p(lo), _p(occ), _p(infl), ctypes.byref(m)),
                   "mlm_export_blocks")
+        col = np.zeros(n, dtype=np.uint8)
+        self._chk(self._L.mlm_export_block_flags(self._h, n, _p(col), ctypes.byref(m)), "mlm_export_block_flags")
         o = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))
-        return {"keys": keys[o], "collapsed": np.zeros(n, dtype=np.uint8), "log_odds": lo[o], "occ": occ[o],
-                "infl": infl[o]}
+        return {"keys": keys[o], "collapsed": col[o], "log_odds": lo[o], "occ": occ[o], "infl": infl[o]}
+
+    def export_frontier(self) -> np.ndarray:
+        """[n,4] int32 (gx,gy,gz,cell id) of the frontier cells, sorted."""
+        n = ctypes.c_int32()
+        self._chk(self._L.mlm_export_frontier(self._h, 0, None, ctypes.byref(n)), "mlm_export_frontier")
+        out = np.empty((n.value, 4), dtype=np.int32)
+        if n.value:
+            self._chk(self._L.mlm_export_frontier(self._h, n.value, _p(out), ctypes.byref(n)), "mlm_export_frontier")
+        return out[np.lexsort((out[:, 3], out[:, 2], out[:, 1], out[:, 0]))]
 
     def class_counts(self) -> Dict[str, int]:
         b = self.export_blocks()

@@ -243,3 +243,35 @@ def test_inflation_and_global_map(mods):
                                           (c["keys"].max(0) + 1) * cfg.subbox_d_xyz * cfg.subbox_n + 1, size=(40000, 3)),
                               voxel_centres(c, cfg, 60000)])
         assert np.array_equal(gpu.getInflateOccupancy(pos), cpu.getInflateOccupancy(pos))
+
+
+@pytest.mark.parametrize("name", ["S1-n5", "SDEF"])
+def test_exploration_frontiers(mods, name):
+    """§8f rank 1: use_exploration_frontiers: true (config2.yaml:36) — frontier sets (order dependent through the
+    iteration order of miss_idx_set), released/frozen blocks, and everything else as before."""
+    MLMap, OracleMap = mods
+    cfg = (S1.with_(use_exploration_frontiers=True, subbox_n=5) if name == "S1-n5"
+           else SDEF.with_(use_exploration_frontiers=True, lm_occupied_sh=2.0, depth_noise_coe=0.00375))
+    gpu, cpu = MLMap(cfg, max_blocks=16384, record_awareness=True), OracleMap(cfg)
+    for k, (img, (q, t)) in enumerate(syn.stream(cfg, "room_jitter", "smooth", 8)):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"explore {name} frame {k}")
+        gf, cf = gpu.export_frontier(), cpu.export_frontier()
+        assert gf.shape == cf.shape and np.array_equal(gf, cf), f"frontier sets differ at frame {k}: {gf.shape} vs {cf.shape}"
+    b = cpu.export_blocks()
+    if name == "S1-n5":
+        assert b["collapsed"].sum() > 50  # the release path is really exercised
+    pos = np.concatenate([np.random.default_rng(3).uniform(-4, 6, size=(40000, 3)), voxel_centres(b, cfg, 60000)])
+    assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+    assert np.abs(gpu.getOdd(pos) - cpu.getOdd(pos)).max() <= ODDS_TOL
+    gpu.setFree_map_in_bound([0.0, -1.0, 0.5], [2.0, 1.0, 1.5])
+    cpu.setFree_map_in_bound([0.0, -1.0, 0.5], [2.0, 1.0, 1.5])
+    gpu.inflate_map([0.0, 0.0, 1.5])
+    cpu.inflate_map([0.0, 0.0, 1.5])
+    g2, c2 = gpu.export_blocks(), cpu.export_blocks()
+    compare_maps(g2, c2, "explore after setFree+inflate")
+    col = c2["collapsed"].astype(bool)
+    assert np.array_equal(g2["infl"][~col], c2["infl"][~col])
+    assert np.array_equal(gpu.getInflateOccupancy(pos), cpu.getInflateOccupancy(pos))
