@@ -124,6 +124,16 @@ int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_
 /* same with host-resident frames (frame k at img_host + k*frame_stride); uploads overlap with compute */
 int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_frames, size_t frame_stride, int width,
                               int height, int row_stride, const double *q_wb, const double *t_wb);
+/* replaces the body of mlmap::depth_odom_input_callback (src/mlmap.cpp:463-532) for a ROS-free host: depth is the
+ * sensor_msgs/Image payload (encoding 32FC1 metres -> converted x1000 to 16UC1 on the device, mlmap.cpp:480-483; or
+ * 16UC1 millimetres), odom_* / imu_w the nav_msgs/Odometry pose+twist and sensor_msgs/Imu angular velocity, stamps in
+ * seconds; the pose is forwarded to the image stamp by the reference's linear model (mlmap.cpp:485-498).
+ * sampled != 0: project_depth's rand() sampler (<= sample_cnt pixels, glibc rand(), v first, mlmap.cpp:322-327);
+ * 0: dense.  T_wb_out (optional): compensated pose, q (w,x,y,z) then t. */
+int mlm_integrate_callback(mlm_handle *h, const void *depth_host, int is_f32, int width, int height, double t_img,
+                           const double odom_p[3], const double odom_q[4], const double odom_v[3], double t_odom,
+                           const double imu_w[3], double t_imu, double camera2odom_latency, int sampled,
+                           double T_wb_out[7]);
 /* replaces awareness_map_cylindrical::input_pc_pose(PC_s, T_wb) + input_pc_pose_direct on an explicit
  * sensor-frame point list (include/map_awareness.h:74) */
 int mlm_integrate_points(mlm_handle *h, const double *xyz_s_host, int n, const double q_wb[4],

@@ -1093,6 +1093,17 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_export_global(const MlmDev P, uns
     }
 }
 
+// cv::Mat::convertTo(CV_16UC1, 1000) of the 32FC1 depth image (mlmap.cpp:482): float product, round half to even,
+// saturate
+__global__ __launch_bounds__(MLM_BLOCK) void k_convert_f32_u16(const float *src, uint16_t *dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = src[i] * 1000.0f;
+        int r = 0;
+        if (s == s) r = (int)fminf(fmaxf(rintf(s), 0.0f), 65535.0f);
+        dst[i] = (uint16_t)r;
+    }
+}
+
 __global__ __launch_bounds__(MLM_BLOCK) void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -1171,6 +1171,108 @@ int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int h
                                        t_wb);
 }
 
+int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int width, int height, double t_img,
+                           const double odom_p[3], const double odom_q[4], const double odom_v[3], double t_odom,
+                           const double imu_w[3], double t_imu, double latency, int sampled, double T_wb_out[7]) {
+    if (!h || !depth || width <= 0 || height <= 0 || !odom_p || !odom_q || !odom_v || !imu_w) return MLM_ERR_INVALID;
+    const size_t n_px = (size_t)width * height;
+    if ((long long)n_px > h->lim.max_points) {
+        h->err = "frame has more points than mlm_limits.max_points";
+        return MLM_ERR_CAPACITY;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    // ---- pose latency compensation, mlmap.cpp:470-498 (Sophus so3.cpp:127-197, Eigen toRotationMatrix)
+    const double gap_odom = t_img - t_odom, gap_imu = t_img - t_imu;
+    const double time_gap = gap_imu - latency;
+    const Q4 q = q_norm(Q4{odom_q[0], odom_q[1], odom_q[2], odom_q[3]});
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx,
+                         txz - twy, tyz + twx, 1 - (txx + tyy)};
+    const D3 rot_dot{(R[0] * imu_w[0] + R[1] * imu_w[1]) + R[2] * imu_w[2], (R[3] * imu_w[0] + R[4] * imu_w[1]) + R[5] * imu_w[2],
+                     (R[6] * imu_w[0] + R[7] * imu_w[1]) + R[8] * imu_w[2]};
+    D3 lg;
+    {
+        const double EPS = 1e-10; // SMALL_EPS, so3.h:35
+        const double n = std::sqrt((q.x * q.x + q.y * q.y) + q.z * q.z), w = q.w;
+        double f;
+        if (n < EPS)
+            f = 2. / w - 2. * (n * n) / (w * (w * w));
+        else
+            f = 2 * std::atan(n / w) / n;
+        lg = D3{f * q.x, f * q.y, f * q.z};
+    }
+    const D3 rot_cp{lg.x + time_gap * rot_dot.x, lg.y + time_gap * rot_dot.y, lg.z + time_gap * rot_dot.z};
+    Q4 q_wb;
+    {
+        const double EPS = 1e-10;
+        const double theta = std::sqrt((rot_cp.x * rot_cp.x + rot_cp.y * rot_cp.y) + rot_cp.z * rot_cp.z);
+        const double half = 0.5 * theta, re = std::cos(half);
+        double im;
+        if (theta < EPS) {
+            const double t2 = theta * theta, t4 = t2 * t2;
+            im = 0.5 - 0.0208333 * t2 + 0.000260417 * t4;
+        } else {
+            im = std::sin(half) / theta;
+        }
+        q_wb = q_norm(Q4{re, im * rot_cp.x, im * rot_cp.y, im * rot_cp.z});
+    }
+    const double dtv = gap_odom - latency;
+    const double qa[4] = {q_wb.w, q_wb.x, q_wb.y, q_wb.z};
+    const double ta[3] = {odom_p[0] + dtv * odom_v[0], odom_p[1] + dtv * odom_v[1], odom_p[2] + dtv * odom_v[2]};
+    if (T_wb_out) {
+        for (int i = 0; i < 4; ++i) T_wb_out[i] = qa[i];
+        for (int i = 0; i < 3; ++i) T_wb_out[4 + i] = ta[i];
+    }
+    // ---- depth image: upload (and convert 32FC1 -> 16UC1 on the device)
+    int rc = drain(h);
+    if (rc) return rc;
+    MlmSlot &S = cur_slot(h, 0);
+    rc = ensure_img(h, S, n_px);
+    if (rc) return rc;
+    std::vector<uint16_t> host_u16; // needed only by the sampler when the input is float
+    if (is_f32) {
+        float *d_f = nullptr;
+        HIPCHK(h, hipMalloc((void **)&d_f, n_px * sizeof(float)));
+        hipError_t e = hipMemcpyAsync(d_f, depth, n_px * sizeof(float), hipMemcpyHostToDevice, h->stream_a);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_convert_f32_u16, dim3(grid_for(n_px)), dim3(MLM_BLOCK), 0, h->stream_a, d_f, S.d_img, n_px);
+            if (sampled) {
+                host_u16.resize(n_px);
+                e = hipMemcpyAsync(host_u16.data(), S.d_img, n_px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream_a);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream_a);
+        hipFree(d_f);
+        if (e != hipSuccess) {
+            h->err = std::string("mlm_integrate_callback: ") + hipGetErrorString(e);
+            return MLM_ERR_HIP;
+        }
+    } else {
+        HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_a));
+    }
+    std::vector<int32_t> pix;
+    if (sampled) {
+        // project_depth, mlmap.cpp:311-349: the sampler needs the raw values to skip zeros
+        const uint16_t *img = is_f32 ? host_u16.data() : (const uint16_t *)depth;
+        const size_t want = (size_t)h->cfg.sample_cnt;
+        int cnt = 0;
+        const int max_iter = 2 * h->cfg.sample_cnt;
+        while (pix.size() < want && cnt < max_iter) {
+            cnt++;
+            const size_t v = static_cast<size_t>(rand() % height);
+            const size_t u = static_cast<size_t>(rand() % width);
+            if (img[v * (size_t)width + u] == 0) continue;
+            pix.push_back((int32_t)(v * (size_t)width + u));
+        }
+        if (!pix.empty())
+            HIPCHK(h, hipMemcpyAsync(S.d_pix, pix.data(), pix.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_a));
+        HIPCHK(h, hipStreamSynchronize(h->stream_a)); // pix is a local
+    }
+    return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, width, sampled ? S.d_pix : nullptr, (int)pix.size(), qa, ta);
+}
+
 int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q_wb[4], const double t_wb[3]) {
     if (!h || (!xyz && n > 0) || n < 0 || !q_wb || !t_wb) return MLM_ERR_INVALID;
     if (n > h->lim.max_points) {

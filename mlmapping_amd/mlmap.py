@@ -28,7 +28,7 @@ STATUS = {0: "MLM_OK", -1: "MLM_ERR_INVALID", -2: "MLM_ERR_HIP", -3: "MLM_ERR_CA
 ABI_SYMBOLS = [
     "mlm_create", "mlm_destroy", "mlm_last_error", "mlm_abi_version", "mlm_set_stream",
     "mlm_integrate_depth_u16", "mlm_integrate_depth_u16_dev", "mlm_integrate_depth_batch_dev",
-    "mlm_integrate_depth_batch",
+    "mlm_integrate_depth_batch", "mlm_integrate_callback",
     "mlm_integrate_points", "mlm_query_occupancy", "mlm_query_occupancy_inflate", "mlm_query_inflate_occupancy",
     "mlm_query_odds", "mlm_query_odd_grad", "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
     "mlm_export_blocks", "mlm_export_block_flags", "mlm_export_frontier", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
@@ -82,6 +82,8 @@ def load_library(path: Optional[str] = None):
     L.mlm_integrate_depth_batch_dev.argtypes = [vp, vp, i32, ctypes.c_size_t, i32, i32, i32, vp, vp]
     L.mlm_integrate_depth_batch.argtypes = [vp, vp, i32, ctypes.c_size_t, i32, i32, i32, vp, vp]
     L.mlm_integrate_points.argtypes = [vp, vp, i32, vp, vp]
+    L.mlm_integrate_callback.argtypes = [vp, vp, i32, i32, i32, ctypes.c_double, vp, vp, vp, ctypes.c_double, vp,
+                                         ctypes.c_double, ctypes.c_double, i32, vp]
     L.mlm_query_occupancy.argtypes = [vp, vp, i32, vp]
     L.mlm_query_occupancy_inflate.argtypes = [vp, vp, i32, ctypes.c_float, vp]
     L.mlm_query_inflate_occupancy.argtypes = [vp, vp, i32, vp]
@@ -200,6 +202,20 @@ class MLMap:
         t = _f64(t_wb).reshape(k, 3)
         self._chk(self._L.mlm_integrate_depth_batch(self._h, _p(fr), k, hgt * wid, wid, hgt, wid, _p(q), _p(t)),
                   "mlm_integrate_depth_batch")
+
+    def depth_odom_callback(self, depth, t_img, odom_p, odom_q, odom_v, t_odom, imu_w, t_imu, latency, sampled=True):
+        """mlmap::depth_odom_input_callback (mlmap.cpp:463-532) without ROS; depth float32 metres (32FC1) or uint16 mm.
+        Returns the latency-compensated T_wb as (q (w,x,y,z), t) in one array of 7."""
+        d = np.ascontiguousarray(depth)
+        is_f32 = int(d.dtype == np.float32)
+        if not is_f32:
+            d = d.astype(np.uint16)
+        out = np.empty(7)
+        self._chk(self._L.mlm_integrate_callback(self._h, _p(d), is_f32, d.shape[1], d.shape[0], float(t_img),
+                                                 _p(_f64(odom_p)), _p(_f64(odom_q)), _p(_f64(odom_v)), float(t_odom),
+                                                 _p(_f64(imu_w)), float(t_imu), float(latency), int(sampled), _p(out)),
+                  "mlm_integrate_callback")
+        return out
 
     def update_map_points(self, xyz_s, q_wb, t_wb):
         """input_pc_pose(PC_s, T_wb) + input_pc_pose_direct on explicit sensor-frame points."""

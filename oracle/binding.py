@@ -45,6 +45,9 @@ def lib():
             getattr(L, name).argtypes = [vp, vp, i32, i32, vp, vp]
         L.mlo_update_depth_indexed.restype = i32
         L.mlo_update_depth_indexed.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
+        L.mlo_callback.restype = i32
+        L.mlo_callback.argtypes = [vp, vp, i32, i32, i32, ctypes.c_double, vp, vp, vp, ctypes.c_double, vp, ctypes.c_double,
+                                   ctypes.c_double, i32, vp]
         L.mlo_project_dense.restype = i32
         L.mlo_project_dense.argtypes = [vp, vp, i32, i32, vp]
         L.mlo_local_from_awareness.argtypes = [vp]
@@ -132,6 +135,18 @@ class OracleMap:
     def update_depth_sampled(self, img, q_wb, t_wb) -> int:
         img = np.ascontiguousarray(img, dtype=np.uint16)
         return lib().mlo_update_depth_sampled(self._h, _p(img), img.shape[0], img.shape[1], _p(_f64(q_wb)), _p(_f64(t_wb)))
+
+    def depth_odom_callback(self, depth, t_img, odom_p, odom_q, odom_v, t_odom, imu_w, t_imu, latency, sampled=True):
+        """depth_odom_input_callback (mlmap.cpp:463-532); depth float32 metres (32FC1) or uint16 mm.  Returns T_wb (7)."""
+        d = np.ascontiguousarray(depth)
+        is_f32 = int(d.dtype == np.float32)
+        if not is_f32:
+            d = d.astype(np.uint16)
+        out = np.empty(7)
+        lib().mlo_callback(self._h, _p(d), is_f32, d.shape[0], d.shape[1], float(t_img), _p(_f64(odom_p)), _p(_f64(odom_q)),
+                           _p(_f64(odom_v)), float(t_odom), _p(_f64(imu_w)), float(t_imu), float(latency), int(sampled),
+                           _p(out))
+        return out
 
     def project_dense(self, img) -> np.ndarray:
         img = np.ascontiguousarray(img, dtype=np.uint16)

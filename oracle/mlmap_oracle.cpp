@@ -726,6 +726,60 @@ struct mlo_handle {
     }
 };
 
+/* Eigen QuaternionBase::toRotationMatrix */
+static void quat_to_R(const Quat &q, double R[9]) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0] = 1 - (tyy + tzz);
+    R[1] = txy - twz;
+    R[2] = txz + twy;
+    R[3] = txy + twz;
+    R[4] = 1 - (txx + tzz);
+    R[5] = tyz - twx;
+    R[6] = txz - twy;
+    R[7] = tyz + twx;
+    R[8] = 1 - (txx + tyy);
+}
+/* SO3::logAndTheta, so3.cpp:127-165 (SMALL_EPS = 1e-10, so3.h:35) */
+static V3 so3_log(const Quat &q) {
+    const double SMALL_EPS = 1e-10;
+    double n = std::sqrt((q.x * q.x + q.y * q.y) + q.z * q.z);
+    double w = q.w;
+    double squared_w = w * w;
+    double two_atan_nbyw_by_n;
+    if (n < SMALL_EPS) {
+        two_atan_nbyw_by_n = 2. / w - 2. * (n * n) / (w * squared_w);
+    } else {
+        if (std::fabs(w) < SMALL_EPS) {
+            if (w > 0)
+                two_atan_nbyw_by_n = M_PI / n;
+            else
+                two_atan_nbyw_by_n = -M_PI / n;
+        }
+        two_atan_nbyw_by_n = 2 * std::atan(n / w) / n; /* (overwrites the branch above, as in the reference) */
+    }
+    return V3{two_atan_nbyw_by_n * q.x, two_atan_nbyw_by_n * q.y, two_atan_nbyw_by_n * q.z};
+}
+/* SO3::expAndTheta, so3.cpp:175-197; SO3(Quaterniond) normalises */
+static Quat so3_exp(const V3 &omega) {
+    const double SMALL_EPS = 1e-10;
+    double theta = std::sqrt((omega.x * omega.x + omega.y * omega.y) + omega.z * omega.z);
+    double half_theta = 0.5 * theta;
+    double imag_factor;
+    double real_factor = std::cos(half_theta);
+    if (theta < SMALL_EPS) {
+        double theta_sq = theta * theta;
+        double theta_po4 = theta_sq * theta_sq;
+        imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+    } else {
+        double sin_half_theta = std::sin(half_theta);
+        imag_factor = sin_half_theta / theta;
+    }
+    return quat_normalized(Quat{real_factor, imag_factor * omega.x, imag_factor * omega.y, imag_factor * omega.z});
+}
+
 static SE3 make_T_wb(const double q_wb[4], const double t_wb[3]) {
     /* mlmap.cpp:494: SE3(SO3, Vec3); SO3::exp returns a unit quaternion — the harness supplies q_wb
      * directly and it is normalised once as SO3(Quaterniond) does (so3.cpp:43-47). */
@@ -832,6 +886,77 @@ int mlo_update_depth_sampled(mlo_handle *h, const uint16_t *img, int rows, int c
         h->pc_eigen.emplace_back(h->backproject(u, v, raw));
     }
     h->update_map(make_T_wb(q_wb, t_wb));
+    return (int)h->pc_eigen.size();
+}
+
+/* cv::Mat::convertTo(CV_16UC1, 1000) on a 32FC1 image (mlmap.cpp:482).  OpenCV is not in the reference tree; its
+ * documented rule is dst = saturate_cast<ushort>(src*alpha) with the product in float and round-half-to-even. */
+static inline uint16_t cv_f32_to_u16(float v) {
+    const float s = v * 1000.0f;
+    if (!(s == s)) return 0;
+    const long r = std::lrintf(s);
+    return (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
+}
+
+int mlo_callback(mlo_handle *h, const void *depth, int is_f32, int rows, int cols, double t_img, const double odom_p[3],
+                 const double odom_q[4], const double odom_v[3], double t_odom, const double imu_w[3], double t_imu,
+                 double camera2odom_latency, int sampled, double *T_wb_out) {
+    /* mlmap.cpp:470-473 */
+    double ros_time_gap_odom = t_img - t_odom;
+    double ros_time_gap_imu = t_img - t_imu;
+    double time_gap = ros_time_gap_imu - camera2odom_latency;
+    std::vector<uint16_t> img((size_t)rows * cols);
+    if (is_f32) {
+        const float *f = (const float *)depth;
+        for (size_t i = 0; i < img.size(); i++) img[i] = cv_f32_to_u16(f[i]);
+    } else {
+        std::memcpy(img.data(), depth, img.size() * sizeof(uint16_t));
+    }
+    /* mlmap.cpp:485-498 */
+    V3 ct_pos{odom_p[0], odom_p[1], odom_p[2]};
+    Quat rot_og = quat_normalized(Quat{odom_q[0], odom_q[1], odom_q[2], odom_q[3]});
+    double R[9];
+    quat_to_R(rot_og, R);
+    V3 rot_dot{(R[0] * imu_w[0] + R[1] * imu_w[1]) + R[2] * imu_w[2], (R[3] * imu_w[0] + R[4] * imu_w[1]) + R[5] * imu_w[2],
+               (R[6] * imu_w[0] + R[7] * imu_w[1]) + R[8] * imu_w[2]};
+    V3 lg = so3_log(rot_og);
+    V3 rot_cp{lg.x + time_gap * rot_dot.x, lg.y + time_gap * rot_dot.y, lg.z + time_gap * rot_dot.z};
+    SE3 T_wb;
+    T_wb.q = so3_exp(rot_cp);
+    const double dtv = ros_time_gap_odom - camera2odom_latency;
+    T_wb.t = V3{ct_pos.x + dtv * odom_v[0], ct_pos.y + dtv * odom_v[1], ct_pos.z + dtv * odom_v[2]};
+    if (T_wb_out) {
+        T_wb_out[0] = T_wb.q.w;
+        T_wb_out[1] = T_wb.q.x;
+        T_wb_out[2] = T_wb.q.y;
+        T_wb_out[3] = T_wb.q.z;
+        T_wb_out[4] = T_wb.t.x;
+        T_wb_out[5] = T_wb.t.y;
+        T_wb_out[6] = T_wb.t.z;
+    }
+    /* project_depth + update_map, mlmap.cpp:504-507 (pc_eigen cleared at :469) */
+    h->pc_eigen.clear();
+    if (sampled) {
+        size_t u, v;
+        int cnt = 0;
+        int max_iter = 2 * h->pc_sample_cnt;
+        while (h->pc_eigen.size() < h->pc_sample_cnt && cnt < max_iter) {
+            cnt++;
+            v = static_cast<size_t>(rand() % rows);
+            u = static_cast<size_t>(rand() % cols);
+            uint16_t raw = img[v * cols + u];
+            if (raw == 0) continue;
+            h->pc_eigen.emplace_back(h->backproject(u, v, raw));
+        }
+    } else {
+        for (int v = 0; v < rows; v++)
+            for (int u = 0; u < cols; u++) {
+                uint16_t raw = img[(size_t)v * cols + u];
+                if (raw == 0) continue;
+                h->pc_eigen.emplace_back(h->backproject((size_t)u, (size_t)v, raw));
+            }
+    }
+    h->update_map(T_wb);
     return (int)h->pc_eigen.size();
 }
 

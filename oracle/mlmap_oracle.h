@@ -83,6 +83,13 @@ void mlo_local_from_awareness(mlo_handle *h);
 /* back-projection alone: writes up to rows*cols points (xyz), returns count */
 int mlo_project_dense(mlo_handle *h, const uint16_t *img, int rows, int cols, double *xyz_out);
 
+/* mlmap::depth_odom_input_callback (mlmap.cpp:463-532) without ROS: 32FC1->16UC1 conversion (:480-483), pose latency
+ * compensation (:485-498, Sophus SO3 log/exp so3.cpp:127-202), project_depth (rand() sampler, or dense when sampled=0),
+ * update_map.  Stamps in seconds.  odom_q = (w,x,y,z).  T_wb_out (optional): q(4) + t(3) of the compensated pose. */
+int mlo_callback(mlo_handle *h, const void *depth, int is_f32, int rows, int cols, double t_img, const double odom_p[3],
+                 const double odom_q[4], const double odom_v[3], double t_odom, const double imu_w[3], double t_imu,
+                 double camera2odom_latency, int sampled, double *T_wb_out);
+
 /* awareness results of the last frame, in container iteration order */
 size_t mlo_hit_count(mlo_handle *h);
 size_t mlo_miss_count(mlo_handle *h);

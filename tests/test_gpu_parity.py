@@ -275,3 +275,29 @@ def test_exploration_frontiers(mods, name):
     col = c2["collapsed"].astype(bool)
     assert np.array_equal(g2["infl"][~col], c2["infl"][~col])
     assert np.array_equal(gpu.getInflateOccupancy(pos), cpu.getInflateOccupancy(pos))
+
+
+def test_ros_free_callback(mods):
+    """§8f rank 3: depth_odom_input_callback without ROS — 32FC1 conversion, pose latency compensation
+    (SO3 log/exp), the 500-sample rand() sampler and the dense variant."""
+    MLMap, OracleMap = mods
+    libc = ctypes.CDLL("libc.so.6")
+    cfg = SDEF
+    base = syn.room_depth(cfg).astype(np.float32) / 1000.0  # metres
+    rng = np.random.default_rng(11)
+    for sampled in (True, False):
+        gpu, cpu = MLMap(cfg, max_blocks=4096, record_awareness=True), OracleMap(cfg)
+        for k in range(6):
+            depth = base + rng.uniform(0, 0.05, size=base.shape).astype(np.float32)
+            depth[rng.integers(0, cfg.height, 50), rng.integers(0, cfg.width, 50)] = 0.0  # invalid pixels
+            q, t = syn.smooth_trajectory(6, 5)[k]
+            args = dict(t_img=10.0 + k / 30.0, odom_p=t, odom_q=q, odom_v=[0.3, -0.1, 0.02], t_odom=10.0 + k / 30.0 - 0.004,
+                        imu_w=[0.05, -0.2, 0.4], t_imu=10.0 + k / 30.0 - 0.002, latency=0.085, sampled=sampled)
+            libc.srand(100 + k)
+            tg = gpu.depth_odom_callback(depth, **args)
+            libc.srand(100 + k)
+            tc = cpu.depth_odom_callback(depth, **args)
+            assert np.array_equal(tg, tc), "compensated T_wb differs"
+            _awareness_equal(gpu, cpu)
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"callback sampled={sampled} frame {k}")
+        assert gpu.frame_stats()["n_points"] == (500 if sampled else gpu.frame_stats()["n_points"])
