@@ -301,3 +301,70 @@ def test_ros_free_callback(mods):
             _awareness_equal(gpu, cpu)
             compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"callback sampled={sampled} frame {k}")
         assert gpu.frame_stats()["n_points"] == (500 if sampled else gpu.frame_stats()["n_points"])
+
+
+def test_gpu_against_golden_digests(mods):
+    """The HIP path against the committed golden fixtures (tests/golden/oracle_digests.json): every integer/byte output
+    must hash to the recorded digest (log-odds are float and compared by tolerance elsewhere)."""
+    import importlib.util
+    import json
+    import os
+
+    MLMap, _ = mods
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(root, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(root, "tests", "golden", "oracle_digests.json")))
+    for name, (cfg, scene, poses, frames) in mg.CASES.items():
+        gpu = MLMap(cfg, max_blocks=16384, record_awareness=True)
+        for k, (img, (q, t)) in enumerate(syn.stream(cfg, scene, poses, max(frames) + 1)):
+            gpu.update_map(img, q, t)
+            if k in frames:
+                cells, odds, _ = gpu.awareness_hits()
+                miss = gpu.awareness_misses().astype(np.uint64)
+            if k == max(frames):
+                gpu.inflate_map(t)
+            if k in frames:
+                w = want[f"{name}/{k}"]
+                assert mg.h(cells, odds) == w["hits"], f"{name}/{k}: hit cells/odds"
+                assert mg.h(miss) == w["misses"], f"{name}/{k}: miss cells"
+                b = gpu.export_blocks()
+                col = b["collapsed"].astype(bool)
+                for key in ("occ", "infl"):
+                    b[key][col, 1:] = 0  # a released block keeps element 0 only in the reference
+                assert mg.h(b["keys"], b["collapsed"]) == w["blocks"], f"{name}/{k}: block keys"
+                assert mg.h(b["occ"]) == w["occ"], f"{name}/{k}: occupancy"
+                assert mg.h(b["infl"]) == w["infl"], f"{name}/{k}: inflate occupancy"
+                assert mg.h(gpu.export_frontier()) == w["frontier"], f"{name}/{k}: frontier"
+
+
+def test_determinism_and_properties_full_size(mods):
+    """Size-independent properties at BASELINE's full sizes: two handles fed the same stream end bit-identical
+    (no dependence on GPU scheduling), batch == frame-by-frame, setFree is idempotent, an empty frame is a no-op."""
+    MLMap, _ = mods
+    for cfg, n in ((S1, 12), (S3, 3)):
+        frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
+        poses = syn.random_poses(n, 42)
+        q = np.stack([p[0] for p in poses])
+        t = np.stack([p[1] for p in poses])
+        a = MLMap(cfg, max_blocks=32768, max_batch=4)
+        b = MLMap(cfg, max_blocks=32768, max_batch=1)
+        a.update_map_batch(frames, q, t)
+        for k in range(n):
+            b.update_map(frames[k], q[k], t[k])
+        ea, eb = a.export_blocks(), b.export_blocks()
+        for key in ("keys", "occ", "infl"):
+            assert np.array_equal(ea[key], eb[key])
+        assert np.array_equal(ea["log_odds"].view(np.uint32), eb["log_odds"].view(np.uint32)), "log-odds bits differ"
+        before = a.export_blocks()
+        a.update_map_points(np.zeros((0, 3)), q[0], t[0])
+        after = a.export_blocks()
+        assert all(np.array_equal(before[k], after[k]) for k in ("keys", "occ", "log_odds"))
+        a.setFree_map_in_bound([-1, -1, 0.5], [1, 1, 1.5])
+        once = a.export_blocks()
+        a.setFree_map_in_bound([-1, -1, 0.5], [1, 1, 1.5])
+        twice = a.export_blocks()
+        assert np.array_equal(once["occ"], twice["occ"]) and np.array_equal(once["log_odds"], twice["log_odds"])
+        a.close()
+        b.close()
