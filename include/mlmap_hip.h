@@ -179,8 +179,10 @@ int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_
 int mlm_get_T_ls(mlm_handle *h, double q[4], double t[3]);
 int mlm_get_odds_table(mlm_handle *h, float *out);
 
-/* device-time of the kernels launched by the last integrate call, measured with HIP events on the handle's
- * stream (milliseconds); names are static strings.  Used by bench.py's roofline leg. */
+/* Device time of the launches of the integrate calls, measured with HIP events on the streams the kernels run on
+ * (milliseconds); names are static strings.  on = 1: the list describes the last call only; on = 2: it accumulates over
+ * calls until read (mlm_get_kernel_times with cap >= n consumes it) — bench.py uses this over its timed region.
+ * Stage A kernels are launched once per batch, so one entry of theirs covers all frames of that batch. */
 int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out);
 int mlm_enable_kernel_timing(mlm_handle *h, int on);
 

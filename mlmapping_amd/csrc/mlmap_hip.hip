@@ -165,6 +165,7 @@ struct mlm_handle {
     int cur_set = 0;
     int set_pending[2] = {0, 0};
     bool async_mode = false;
+    int cu_split = 0;
     hipStream_t stream_a = nullptr;          // Stage A of whole batches (overlaps Stage B/C of the previous batch)
     hipEvent_t stage_a_done[2] = {nullptr, nullptr};
     hipEvent_t set_free[2] = {nullptr, nullptr}; // main stream finished reading the set's Stage A outputs
@@ -481,8 +482,6 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     MlmSlot &S = h->slots[(size_t)slot_index];
     const MlmDev &P = S.P;
     hipStream_t st = h->stream;
-    h->ktimes.clear();
-    h->kpool_used = 0;
     S.seq = 0;
     S.F.seq = 0;
     h->h_frame_tab[slot_index] = S.F;
@@ -652,6 +651,11 @@ int finish_set(mlm_handle *h, int set) {
 
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
 int run_slots(mlm_handle *h, int n) {
+    (void)hipGetLastError(); // a stale error of unrelated HIP calls in this thread is not ours
+    if (h->timing == 1) { // per-call mode: the list describes the last call only
+        h->ktimes.clear();
+        h->kpool_used = 0;
+    }
     if (h->P.explore) { // frontier mode: frame by frame, exact
         const int K = (int)h->slots.size() / 2;
         for (int j = 0; j < n; ++j) {
@@ -660,8 +664,6 @@ int run_slots(mlm_handle *h, int n) {
         }
         return MLM_OK;
     }
-    h->ktimes.clear();
-    h->kpool_used = 0;
     h->stats.n_rehash_epochs = 1;
     const int K = (int)h->slots.size() / 2;
     const int set = h->cur_set;
@@ -853,9 +855,24 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     }
     HIPCHK(h, hipSetDevice(device));
     {
+        // Stage B+C (main stream) is the serial per-frame chain of short, latency-bound kernels; Stage A floods the
+        // chip with wide kernels.  MLM_CU_SPLIT=k (default 0 = off) reserves the first k CUs for the main stream and
+        // leaves the rest to Stage A, so that the chain is not stretched by queueing behind Stage A's waves.
         int lo = 0, hi = 0; // numerically lower = higher priority
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi));
+        const char *env = getenv("MLM_CU_SPLIT");
+        h->cu_split = env ? atoi(env) : 0;
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount;
+        if (h->cu_split > 0 && h->cu_split < ncu) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int c = 0; c < h->cu_split; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+            HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream, (uint32_t)mask.size(), mask.data()));
+        } else {
+            h->cu_split = 0;
+            HIPCHK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi));
+        }
     }
     for (int k = 0; k < 2; ++k) {
         HIPCHK(h, hipEventCreateWithFlags(&h->batch_done[k], hipEventDisableTiming));
@@ -1013,7 +1030,16 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     HIPCHK(h, hipHostMalloc((void **)&h->h_frame_tab, NS * sizeof(MlmFrame), hipHostMallocDefault));
     std::memset(h->h_ctr_all, 0, NS * sizeof(MlmCounters));
     std::memset(h->h_frame_tab, 0, NS * sizeof(MlmFrame));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream_a, hipStreamNonBlocking));
+    if (h->cu_split > 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int c = h->cu_split; c < ncu; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+        HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream_a, (uint32_t)mask.size(), mask.data()));
+    } else {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream_a, hipStreamNonBlocking));
+    }
     for (int k = 0; k < 2; ++k) {
         HIPCHK(h, hipEventCreateWithFlags(&h->stage_a_done[k], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->set_free[k], hipEventDisableTiming));
@@ -1031,6 +1057,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
 
 int mlm_destroy(mlm_handle *h) {
     if (!h) return MLM_ERR_INVALID;
+    if (!h->stream) { // creation failed before the device was touched
+        delete h;
+        return MLM_OK;
+    }
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     for (void *p : h->allocs) hipFree(p);
@@ -1535,13 +1565,21 @@ int mlm_get_odds_table(mlm_handle *h, float *out) {
 
 int mlm_enable_kernel_timing(mlm_handle *h, int on) {
     if (!h) return MLM_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = drain(h);
     h->timing = on;
-    return MLM_OK;
+    h->ktimes.clear();
+    h->kpool_used = 0;
+    return rc;
 }
 
 int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
+    {
+        const int rc = drain(h);
+        if (rc) return rc;
+    }
     HIPCHK(h, hipDeviceSynchronize());
     const int n = (int)h->ktimes.size();
     if (n_out) *n_out = n;
@@ -1550,6 +1588,10 @@ int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, 
         hipEventElapsedTime(&t, h->ktimes[i].a, h->ktimes[i].b);
         if (names) names[i] = h->ktimes[i].name;
         if (ms) ms[i] = t;
+    }
+    if (h->timing == 2 && cap >= n) { // accumulate mode: reading the list consumes it
+        h->ktimes.clear();
+        h->kpool_used = 0;
     }
     return MLM_OK;
 }

@@ -338,11 +338,11 @@ class MLMap:
         self._chk(self._L.mlm_get_odds_table(self._h, _p(out)), "mlm_get_odds_table")
         return out
 
-    def enable_kernel_timing(self, on: bool = True):
+    def enable_kernel_timing(self, on=True):
+        """True/1: per call; 2: accumulate over calls until kernel_times() is read; False/0: off."""
         self._chk(self._L.mlm_enable_kernel_timing(self._h, int(on)), "mlm_enable_kernel_timing")
 
-    def kernel_times(self) -> List[Tuple[str, float]]:
-        cap = 256
+    def kernel_times(self, cap: int = 1 << 16) -> List[Tuple[str, float]]:
         names = (ctypes.c_char_p * cap)()
         ms = np.empty(cap, dtype=np.float32)
         n = ctypes.c_int32()

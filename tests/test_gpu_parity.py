@@ -368,3 +368,46 @@ def test_determinism_and_properties_full_size(mods):
         assert np.array_equal(once["occ"], twice["occ"]) and np.array_equal(once["log_odds"], twice["log_odds"])
         a.close()
         b.close()
+
+
+def test_heavy_cell_beyond_lds_window(mods):
+    """A multi-kind cell with more contributions than the LDS sort window (2048) takes the from-memory ranking path."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=2048, record_awareness=True), OracleMap(cfg)
+    q, t = syn.static_pose()
+    rng = np.random.default_rng(21)
+    # sensor frame z forward: two adjacent range cells around 6 m (3*sigma > 1 there, so they spread into each other)
+    n = 6000
+    z = np.where(rng.random(n) < 0.5, 5.93, 6.03) + rng.uniform(-0.004, 0.004, n)
+    pts = np.stack([rng.uniform(-0.003, 0.003, n), rng.uniform(-0.003, 0.003, n), z], axis=1)
+    gpu.update_map_points(pts, q, t)
+    cpu.update_points(pts, q, t)
+    st = gpu.frame_stats()
+    assert st["n_contrib_slots"] > 2 * 2048, st
+    _awareness_equal(gpu, cpu)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "heavy cell")
+
+
+def test_argument_and_capacity_errors(mods):
+    """Error behaviour of the boundary: statuses, never exceptions or silent corruption."""
+    import ctypes as C
+
+    from mlmapping_amd.mlmap import MlmError, load_library
+
+    MLMap, _ = mods
+    L = load_library()
+    assert L.mlm_create(None, None, 0, C.byref(C.c_void_p())) == -1  # MLM_ERR_INVALID
+    bad = S1.with_(am_n_Rho=0)
+    with pytest.raises(MlmError):
+        MLMap(bad)
+    with pytest.raises(MlmError):
+        MLMap(S1, device=99)
+    m = MLMap(S1, max_blocks=8, max_points=640 * 480)  # block pool far too small
+    with pytest.raises(MlmError, match="CAPACITY"):
+        m.update_map(syn.room_depth(S1), *syn.static_pose())
+    m2 = MLMap(SDEF, max_blocks=1024, max_points=1000)
+    with pytest.raises(MlmError, match="CAPACITY"):
+        m2.update_map(syn.room_depth(SDEF), *syn.static_pose())  # 230 400 pixels > max_points
+    m2.update_map(syn.room_depth(SDEF), *syn.static_pose(), pixel_idx=np.arange(0, 230400, 400))  # 576 pixels: fine
+    assert m2.frame_stats()["n_points"] == 576
