@@ -120,7 +120,16 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
 }
 
 
-#define MLM_NODE_LDS 640 // contribution nodes buffered per k_bin_points block
+#define MLM_NODE_LDS 448 // contribution nodes buffered per k_bin_points block
+#define MLM_AGG_LDS 256  // block-local table that merges the block's groups per awareness cell (power of two)
+struct MlmCellAgg {
+    uint32_t cell;      // MLM_NIL = empty
+    uint32_t tmin;      // earliest insertion time of the block's contributions to the cell
+    uint32_t kmask;     // kinds
+    uint32_t cnt;       // contributions
+    uint32_t base;      // position of the block's first contribution inside the cell's segment
+    uint32_t start_min; // explore mode: first point whose hit centre is the cell
+};
 
 // MODE 0: dense depth image, 1: indexed depth pixels, 2: explicit sensor-frame points
 // Stage A kernels are launched once per BATCH: blockIdx.z selects the frame slot (its MlmDev and MlmFrame live in
@@ -131,7 +140,7 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
     const MlmFrame &F = frame_tab[slot_base + blockIdx.z];                                                            \
     (void)F;
 
-#define MLM_RAY_LDS 320 // rays buffered per k_bin_points block (256 in-range starts + merged outer starts)
+#define MLM_RAY_LDS 256 // rays buffered per k_bin_points block (every lane queues at most one)
 template <int MODE>
 __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
@@ -139,11 +148,21 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     __shared__ unsigned int s_nray;
     __shared__ int s_ray[MLM_RAY_LDS][4];
     __shared__ unsigned int s_nbase2;
-    __shared__ unsigned int s_nnode, s_nbase;
+    __shared__ unsigned int s_nnode, s_nbase, s_ntouch, s_tbase;
     __shared__ MlmNode s_node[MLM_NODE_LDS];
+    __shared__ MlmCellAgg s_agg[MLM_AGG_LDS];
+    __shared__ uint32_t s_touch[MLM_AGG_LDS];
     if (threadIdx.x == 0) {
         s_nnode = 0;
         s_nray = 0;
+        s_ntouch = 0;
+    }
+    for (int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
+        s_agg[e].cell = MLM_NIL;
+        s_agg[e].tmin = MLM_EMPTY_T;
+        s_agg[e].kmask = 0;
+        s_agg[e].cnt = 0;
+        s_agg[e].start_min = MLM_EMPTY_T;
     }
     __syncthreads();
     const MlmTile T = mlm_tile_item<MODE>(F);
@@ -210,10 +229,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
             nd.mask = my_mask;
             if (k < MLM_NODE_LDS) {
                 s_node[k] = nd;
-            } else { // LDS buffer full: store the node directly
+            } else { // LDS buffer full: store the node directly; k_assign_nodes books it
                 const unsigned int reg = blockIdx.x & 7;
                 const unsigned int g = atomicAdd(&P.ctr->node_cnt[reg][0], 1u);
+                nd.pad = 1;
                 if (g < P.node_cap) P.nodes[(size_t)reg * P.node_cap + g] = nd;
+                atomicAdd(&P.ctr->n_unassigned, 1u);
             }
         }
         // every point of one (rho,phi,z) cell casts the identical ray: only the first one queues it
@@ -285,8 +306,69 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         }
     }
     __syncthreads();
-    for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x)
-        if (s_nbase + k < P.node_cap) P.nodes[(size_t)reg * P.node_cap + s_nbase + k] = s_node[k];
+    // ---- book the block's groups on their cells.  The groups are first merged per cell in an LDS table, so that a
+    //      cell costs three device-scope atomics per BLOCK (first-touch time min, kind mask or, count add -> position)
+    //      instead of three per (wave, kind) group.
+    const int tile_w = (MODE == 0) ? F.width : 0;
+    for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x) {
+        const MlmNode nd = s_node[k];
+        const int sub = (int)(nd.i00_sub >> 27);
+        const int l0 = __ffsll((long long)nd.mask) - 1; // lowest lane = earliest insertion time of the group
+        const uint32_t i_first = (nd.i00_sub & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
+        const uint32_t t = i_first * MLM_TIME_SLOTS + (uint32_t)sub;
+        const uint32_t cnt = (uint32_t)__popcll(nd.mask);
+        uint32_t e = (nd.cell * 2654435761u) >> 24; // 8 bits
+        bool placed = false;
+        for (int probe = 0; probe < MLM_AGG_LDS; ++probe) {
+            const uint32_t prev = atomicCAS(&s_agg[e].cell, MLM_NIL, nd.cell);
+            if (prev == MLM_NIL || prev == nd.cell) {
+                placed = true;
+                break;
+            }
+            e = (e + 1) & (MLM_AGG_LDS - 1);
+        }
+        if (placed) {
+            atomicMin(&s_agg[e].tmin, t);
+            atomicOr(&s_agg[e].kmask, 1u << sub);
+            s_node[k].pos = atomicAdd(&s_agg[e].cnt, cnt);
+            if (sub == 0) atomicMin(&s_agg[e].start_min, i_first);
+            s_node[k].pad = e;
+        } else { // table full (never seen): book the group on its own
+            atomicMin(&P.hit_t[nd.cell], t);
+            atomicOr(&P.hit_mask[nd.cell], 1u << sub);
+            const uint32_t pos = atomicAdd(&P.hit_cnt[nd.cell], cnt);
+            if (P.explore && sub == 0) atomicMin(&P.start_t[nd.cell], i_first);
+            s_node[k].pos = pos;
+            s_node[k].pad = MLM_NIL;
+            if (pos == 0) {
+                const unsigned int g = atomicAdd(&P.ctr->touch_cnt[reg][0], 1u);
+                if (g < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + g] = nd.cell;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
+        const uint32_t cell = s_agg[e].cell;
+        if (cell == MLM_NIL) continue;
+        atomicMin(&P.hit_t[cell], s_agg[e].tmin);
+        atomicOr(&P.hit_mask[cell], s_agg[e].kmask);
+        const uint32_t base = atomicAdd(&P.hit_cnt[cell], s_agg[e].cnt);
+        if (P.explore && s_agg[e].start_min != MLM_EMPTY_T) atomicMin(&P.start_t[cell], s_agg[e].start_min);
+        s_agg[e].base = base;
+        if (base == 0) s_touch[atomicAdd(&s_ntouch, 1u)] = cell; // first contributions of the cell this frame
+    }
+    __syncthreads();
+    const unsigned int nt = s_ntouch;
+    if (threadIdx.x == 0) s_tbase = nt ? atomicAdd(&P.ctr->touch_cnt[reg][0], nt) : 0u;
+    for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x) {
+        MlmNode nd = s_node[k];
+        if (nd.pad != MLM_NIL) nd.pos += s_agg[nd.pad].base;
+        nd.pad = 0;
+        if (s_nbase + k < P.node_cap) P.nodes[(size_t)reg * P.node_cap + s_nbase + k] = nd;
+    }
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
+        if (s_tbase + k < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + s_tbase + k] = s_touch[k];
 }
 
 __device__ __forceinline__ uint32_t mlm_wave_incl_scan(uint32_t v) {
@@ -319,21 +401,23 @@ __device__ __forceinline__ float mlm_logit(float p) {
     return (float)log10((double)ratio);
 }
 
-// One lane per contribution node: book the group on its cell — first-touch time (min), kind mask (or), count (add).
-// The add returns the group's position inside the cell's segment; the node that finds the count at 0 is the cell's
-// first and queues the cell for k_collect_hits.  gridDim.y = node region, blockIdx.z = slot.
+// Groups that overflowed a k_bin_points block's LDS buffer (flag pad == 1; normally none): book each on its cell —
+// first-touch time (min), kind mask (or), count (add -> position); the one that finds the count at 0 queues the cell
+// for k_collect_hits.  gridDim.y = node region, blockIdx.z = slot.
 __global__ __launch_bounds__(MLM_BLOCK) void k_assign_nodes(MLM_SLOT_ARGS, int tile_w) {
     MLM_SLOT_SETUP
     __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
     __shared__ unsigned int s_base;
     const unsigned int reg = blockIdx.y;
+    if (P.ctr->n_unassigned == 0) return; // the common case: every group was booked by its block
     const unsigned int n = min(P.ctr->node_cnt[reg][0], P.node_cap);
     for (unsigned int k0 = blockIdx.x * blockDim.x; k0 < n; k0 += gridDim.x * blockDim.x) { // uniform per block
         const unsigned int k = k0 + threadIdx.x;
         bool first = false;
         uint32_t cell = 0;
-        if (k < n) {
+        if (k < n && P.nodes[(size_t)reg * P.node_cap + k].pad == 1) {
             MlmNode *nd = &P.nodes[(size_t)reg * P.node_cap + k];
+            nd->pad = 0;
             cell = nd->cell;
             const unsigned long long m = nd->mask;
             const int l0 = __ffsll((long long)m) - 1; // lowest lane = earliest insertion time of the group
@@ -483,10 +567,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int t
     }
 }
 
-// One wave per multi-kind hit cell: order the cell's contributions by insertion time (rank by counting, keys in
+// One wave per multi-kind hit cell: order the cell's contributions by insertion time (bitonic sort of the keys in
 // LDS) and store their kinds (`sub`) in that order.
-#define MLM_SORT_CAP 2048 // keys per wave held in LDS
-__global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS) {
+// Launched twice per batch: CAP = 1024 (5 KB of LDS per wave, full occupancy) takes the cells with n <= 1024, CAP = 4096
+// the few larger ones (n_lo = 1024); cells beyond 4096 contributions are ranked from memory.
+template <int MLM_SORT_CAP>
+__global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsigned int n_lo) {
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_BLOCK / 64][MLM_SORT_CAP];
     const unsigned int n_cells = P.ctr->n_multi;
@@ -498,11 +584,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS) {
         const uint32_t pos = P.mt_list[w];
         const uint32_t base = P.hl_base[pos];
         const uint32_t n = P.hl_cnt[pos];
-        if (n <= MLM_SORT_CAP) {
+        if (n <= n_lo || (n > MLM_SORT_CAP && MLM_SORT_CAP < 4096)) continue; // the other launch's cells
+        if (n <= 320) {
+            // small cells (the bulk): rank by counting — every lane counts the keys below its own with 16-byte
+            // broadcast reads; the ordered kinds are staged in the unused upper part of the wave's LDS window
             const uint32_t n4 = (n + 3u) & ~3u;
             for (uint32_t j = lane; j < n4; j += 64) K[j] = j < n ? P.contrib[base + j] : 0xFFFFFFFFu;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave execute in order
             __builtin_amdgcn_wave_barrier();
+            volatile uint8_t *S = (volatile uint8_t *)(s_keys[wid] + 640);
             for (uint32_t j = lane; j < n; j += 64) {
                 const uint32_t my = K[j];
                 uint32_t r = 0;
@@ -510,7 +600,48 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS) {
                     const uint4 v = *(const uint4 *)(const_cast<uint32_t *>(&s_keys[wid][q]));
                     r += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
                 }
-                P.subs[base + r] = (uint8_t)(my % MLM_TIME_SLOTS);
+                S[r] = (uint8_t)(my % MLM_TIME_SLOTS);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < n4 / 4; j += 64)
+                ((uint32_t *)(P.subs + base))[j] = ((volatile uint32_t *)(s_keys[wid] + 640))[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if (n <= MLM_SORT_CAP) {
+            // bitonic sort of the keys in LDS by one wave (padding keys 0xFFFFFFFF sink to the end)
+            uint32_t N = 64;
+            while (N < n) N <<= 1;
+            for (uint32_t j = lane; j < N; j += 64) K[j] = j < n ? P.contrib[base + j] : 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS ops of one wave execute in order
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = 2; k <= N; k <<= 1) {
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = lane; t < (N >> 1); t += 64) {
+                        const uint32_t i = 2u * t - (t & (j - 1u));
+                        const uint32_t l = i + j;
+                        const uint32_t a = K[i], b = K[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) {
+                            K[i] = b;
+                            K[l] = a;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            // kinds in insertion-time order, 4 per lane per step, written as whole dwords (the segment is 16-byte
+            // aligned and padded to 16)
+            const uint32_t n4 = (n + 3u) & ~3u;
+            for (uint32_t j = lane; j < n4 / 4; j += 64) {
+                uint32_t w4 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t key = K[4 * j + q]; // beyond n: padding, never read back as a kind
+                    w4 |= (key % MLM_TIME_SLOTS) << (8 * q);
+                }
+                ((uint32_t *)(P.subs + base))[j] = w4;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -654,8 +785,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_prepare_voxels(MLM_SLOT_ARGS) {
             mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
             int gx, gy, gz, cid;
             mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-            P.hl_bkey[i] = mlm_pack_key(gx, gy, gz);
+            const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+            P.hl_bkey[i] = bkey;
             P.hl_cid[i] = (uint32_t)cid;
+            // blocks are only ever added and keep their slot, so a block found now stays valid; a block that does not
+            // exist yet (or is being inserted by an earlier frame's Stage C right now) is resolved by k_voxelize
+            P.hl_slot[i] = mlm_block_find_k(P, bkey);
         }
         return;
     }
@@ -690,11 +825,13 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_prepare_voxels(MLM_SLOT_ARGS) {
         if (set && pos < P.mc_cap) {
             P.mc_bkey[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = bkey;
             P.mc_cid[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = cid;
+            P.mc_slot[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = mlm_block_find_k(P, bkey);
         }
         __syncthreads();
     }
 }
 
+#define MLM_APPLY_REGS 12 // hit contributions of one voxel ordered in registers by k_apply
 #define MLM_HAS_HITS 0x80000000u // flag in vox_miss: the voxel has pending hit contributions this frame
 
 // bucket-first table of the speculative path: entry = (~seq << 32) | first insertion time.  atomicMin keeps the
@@ -709,8 +846,6 @@ __device__ __forceinline__ unsigned long long mlm_bkt_entry(int seq, uint32_t t)
 // blockIdx.y == 1 + k: miss-cell sub-list k — count the frame's misses per voxel (their order is irrelevant: every
 // miss adds the same constant, map_local.cpp:188-192).
 __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const MlmFrame F, unsigned long long n_bkt) {
-    __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
-    __shared__ unsigned int s_base;
     const int frame_idx = F.seq;
     MLM_SKIP_IF_FAILED(P, frame_idx)
     if (blockIdx.y == 0) {
@@ -723,7 +858,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
                 atomicMin(&P.bkt64[b], mlm_bkt_entry(frame_idx, P.hl_vt[i]));
                 P.hl_bkt[i] = (uint32_t)b;
             }
-            int slot = mlm_block_slot(P, P.hl_bkey[i]);
+            int slot = P.hl_slot[i];
+            if (slot < 0) slot = mlm_block_slot(P, P.hl_bkey[i]);
             if (P.explore && slot >= 0 && P.blk_collapsed[slot]) slot = -3; // released block: allocate_ram() is false
             if (slot < 0) {
                 P.hl_vox[i] = -1;
@@ -740,21 +876,18 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
     const unsigned int sl = blockIdx.y - 1;
     const unsigned int n = min(P.ctr->mc_cnt[sl][0], P.mc_cap);
     unsigned int n_here = 0;
-    for (unsigned int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) { // uniform per block
-        const unsigned int i = i0 + threadIdx.x;
-        bool fresh = false; // first miss of its voxel this frame
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        ++n_here;
+        const size_t at = (size_t)sl * P.mc_cap + i;
+        int slot = P.mc_slot[at];
+        if (slot < 0) slot = mlm_block_slot(P, P.mc_bkey[at]);
         int v = -1;
-        if (i < n) {
-            ++n_here;
-            const int slot = mlm_block_slot(P, P.mc_bkey[(size_t)sl * P.mc_cap + i]);
-            if (slot >= 0) {
-                v = slot * P.cells + (int)P.mc_cid[(size_t)sl * P.mc_cap + i];
-                fresh = (atomicAdd(&P.vox_miss[v], 1u) & ~MLM_HAS_HITS) == 0;
-            }
+        if (slot >= 0) {
+            v = slot * P.cells + (int)P.mc_cid[at];
+            // the first miss of a voxel this frame owns it in k_apply; the others only count
+            if ((atomicAdd(&P.vox_miss[v], 1u) & ~MLM_HAS_HITS) != 0) v = -1;
         }
-        const unsigned int pos = mlm_block_append(P.ctr->mvox_cnt, fresh, s_cnt, &s_base);
-        if (fresh && pos < P.mvox_cap) P.miss_vox[(size_t)(blockIdx.x & 7) * P.mvox_cap + pos] = v;
-        __syncthreads();
+        P.mc_vox[at] = v;
     }
     // statistics: unique miss cells
     for (int off = 32; off > 0; off >>= 1) n_here += __shfl_xor(n_here, off, 64);
@@ -782,7 +915,7 @@ __device__ __forceinline__ void mlm_apply_misses(const MlmDev &P, float &L, uint
 // Kernel 2 of 2.  blockIdx.y == 0: the first-pushed entry of each voxel list (next == -1) owns the voxel: it replays
 // the voxel's hit contributions in the reference's iteration order (descending key, map_local.cpp:157-171), then the
 // voxel's misses of this frame (the reference runs all hits before all misses, map_local.cpp:147,176).
-// blockIdx.y == 1 + k: voxels touched by misses, sub-list k — those that also have hits are left to the hit owner
+// blockIdx.y == 1 + k: miss cells of sub-list k that were their voxel's first miss — voxels that also have hits are left to the hit owner
 // (the MLM_HAS_HITS flag in the miss counter tells the two sides apart, so each voxel's misses are applied once).
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_idx, int explicit_keys) {
     MLM_SKIP_IF_FAILED(P, frame_idx)
@@ -802,24 +935,64 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
                 }
                 if (L > P.lo_sh && o != 'o') o = 'o';
             } else {
-                unsigned long long last = ~0ull;
-                for (;;) {
-                    int best = -1;
-                    unsigned long long bestkey = 0;
-                    for (int j = head; j >= 0; j = P.hl_next[j]) {
-                        const unsigned long long k = mlm_order_key(P, j, explicit_keys);
-                        if (k < last && (best < 0 || k > bestkey)) {
-                            best = j;
-                            bestkey = k;
+                // one walk over the list collects (key, increment) into a register-resident array kept in descending
+                // key order (static indexing: fully unrolled compare-exchange insertion); lists longer than the array
+                // fall back to repeated selection straight from memory
+                unsigned long long ks[MLM_APPLY_REGS];
+                float vs[MLM_APPLY_REGS];
+#pragma unroll
+                for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                    ks[q] = 0; // real keys are never 0
+                    vs[q] = 0.0f;
+                }
+                int cnt = 0;
+                for (int j = head; j >= 0; j = P.hl_next[j]) {
+                    unsigned long long k = mlm_order_key(P, j, explicit_keys);
+                    float inc = P.hl_inc[j];
+                    ++cnt;
+#pragma unroll
+                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                        if (k > ks[q]) {
+                            const unsigned long long tk = ks[q];
+                            const float tv = vs[q];
+                            ks[q] = k;
+                            vs[q] = inc;
+                            k = tk;
+                            inc = tv;
                         }
                     }
-                    if (best < 0) break;
-                    if (L < P.lo_max) {
-                        L = L + P.hl_inc[best];
-                        L = L > P.lo_max ? P.lo_max : L;
+                }
+                if (cnt <= MLM_APPLY_REGS) {
+#pragma unroll
+                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                        if (q < cnt) {
+                            if (L < P.lo_max) {
+                                L = L + vs[q];
+                                L = L > P.lo_max ? P.lo_max : L;
+                            }
+                            if (L > P.lo_sh && o != 'o') o = 'o';
+                        }
                     }
-                    if (L > P.lo_sh && o != 'o') o = 'o';
-                    last = bestkey;
+                } else {
+                    unsigned long long last = ~0ull;
+                    for (;;) {
+                        int best = -1;
+                        unsigned long long bestkey = 0;
+                        for (int j = head; j >= 0; j = P.hl_next[j]) {
+                            const unsigned long long k = mlm_order_key(P, j, explicit_keys);
+                            if (k < last && (best < 0 || k > bestkey)) {
+                                best = j;
+                                bestkey = k;
+                            }
+                        }
+                        if (best < 0) break;
+                        if (L < P.lo_max) {
+                            L = L + P.hl_inc[best];
+                            L = L > P.lo_max ? P.lo_max : L;
+                        }
+                        if (L > P.lo_sh && o != 'o') o = 'o';
+                        last = bestkey;
+                    }
                 }
             }
             if (!P.explore) {
@@ -835,9 +1008,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
         return;
     }
     const unsigned int sl = blockIdx.y - 1;
-    const unsigned int n = min(P.ctr->mvox_cnt[sl][0], P.mvox_cap);
+    const unsigned int n = min(P.ctr->mc_cnt[sl][0], P.mc_cap);
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int v = P.miss_vox[(size_t)sl * P.mvox_cap + i];
+        const int v = P.mc_vox[(size_t)sl * P.mc_cap + i];
+        if (v < 0) continue; // not the voxel's first miss (or no block)
         // vox_miss[v]: 0 = a hit owner already applied the misses; MLM_HAS_HITS set = a hit owner will; else the
         // voxel has misses only and this lane is the only one that touches it
         const uint32_t k = __hip_atomic_load(&P.vox_miss[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -20,7 +20,7 @@ struct MlmCounters {
     unsigned int n_ex_rays;   // explore mode: queued rays
     unsigned int n_ex_miss;   // explore mode: unique miss cells
     unsigned int n_ex_vox;    // explore mode: voxels touched by misses
-    unsigned int pad_ex;
+    unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
@@ -105,6 +105,9 @@ struct MlmDev {
     uint32_t *hl_bkt;          // bucket index of each unique hit (speculative path)
     unsigned long long *hl_bkey; // packed block key of the cell centre's world voxel
     uint32_t *hl_cid;          // cell id inside that block
+    int *hl_slot;              // pool slot of that block if it already existed when Stage A looked, else -1
+    int *mc_slot;              // same for the miss cells
+    int *mc_vox;               // voxel address if the miss cell is its voxel's first miss of the frame, else -1
     unsigned long long *mc_bkey; // [MLM_RAY_LISTS][mc_cap] unique miss cells: packed block key ...
     uint32_t *mc_cid;          //                              ... and cell id
     unsigned int mc_cap;       // per sub-list

@@ -368,8 +368,10 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     }
     {
         Timed t(h, st, "k_sort_contribs");
-        hipLaunchKernelGGL(k_sort_contribs, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
-                           h->d_frame_tab, base);
+        hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+                           h->d_frame_tab, base, 0u);
+        hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(n > 4 ? 32 : 128, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+                           h->d_frame_tab, base, 1024u);
     }
     {
         Timed t(h, st, "k_chain");
@@ -392,11 +394,11 @@ void launch_stage_bc(mlm_handle *h, MlmSlot &S, unsigned long long n_bkt) {
     const MlmDev &P = S.P;
     {
         Timed t(h, h->stream, "k_voxelize");
-        hipLaunchKernelGGL(k_voxelize, dim3(64, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F, n_bkt);
+        hipLaunchKernelGGL(k_voxelize, dim3(160, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F, n_bkt);
     }
     {
         Timed t(h, h->stream, "k_apply");
-        hipLaunchKernelGGL(k_apply, dim3(64, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq, n_bkt ? 0 : 1);
+        hipLaunchKernelGGL(k_apply, dim3(160, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq, n_bkt ? 0 : 1);
     }
 }
 
@@ -427,8 +429,7 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
     const MlmDev &P = S.P;
     bool over = c.n_contrib > P.contrib_cap;
     for (int k = 0; k < MLM_RAY_LISTS; ++k)
-        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mvox_cnt[k][0] > P.mvox_cap ||
-               c.mc_cnt[k][0] > P.mc_cap;
+        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mc_cnt[k][0] > P.mc_cap;
     if (over) {
         h->err = "a per-frame device queue overflowed (raise mlm_limits.max_points)";
         return MLM_ERR_CAPACITY;
@@ -508,7 +509,8 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     hipLaunchKernelGGL(k_ex_walk_rays, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, (int)nb);
     hipLaunchKernelGGL(k_expand_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
-    hipLaunchKernelGGL(k_sort_contribs, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+    hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 0u);
+    hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(128, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 1024u);
     hipLaunchKernelGGL(k_chain, dim3(256, 1, 1), blk, (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
                        slot_index, 0xFFFFFFFFu);
     hipLaunchKernelGGL(k_prepare_voxels, dim3(256, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index); // hits only
@@ -789,9 +791,12 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = dev_alloc(h, &P.hl_bkt, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_bkey, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_cid, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_slot, NC))) return rc;
     P.mc_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 4096);
     if ((rc = dev_alloc(h, &P.mc_bkey, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
     if ((rc = dev_alloc(h, &P.mc_cid, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
+    if ((rc = dev_alloc(h, &P.mc_slot, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
+    if ((rc = dev_alloc(h, &P.mc_vox, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
     if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
     if (P.explore) {
         if ((rc = dev_alloc(h, &P.start_t, NC))) return rc;
