@@ -120,8 +120,8 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
 }
 
 
-#define MLM_NODE_LDS 448 // contribution nodes buffered per k_bin_points block
-#define MLM_AGG_LDS 256  // block-local table that merges the block's groups per awareness cell (power of two)
+// MlmDev::node_lds contribution nodes are buffered per k_bin_points block; MlmDev::agg_lds (a power of two) entries of
+// a block-local table merge the block's groups per awareness cell
 struct MlmCellAgg {
     uint32_t cell;      // MLM_NIL = empty
     uint32_t tmin;      // earliest insertion time of the block's contributions to the cell
@@ -146,18 +146,22 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
     __shared__ unsigned int s_cnt[4];
     __shared__ unsigned int s_nray;
-    __shared__ int s_ray[MLM_RAY_LDS][4];
     __shared__ unsigned int s_nbase2;
     __shared__ unsigned int s_nnode, s_nbase, s_ntouch, s_tbase;
-    __shared__ MlmNode s_node[MLM_NODE_LDS];
-    __shared__ MlmCellAgg s_agg[MLM_AGG_LDS];
-    __shared__ uint32_t s_touch[MLM_AGG_LDS];
+    // dynamic LDS, sized by the host from the configuration (how many kinds a point can spread into):
+    // [node_lds nodes][agg_lds cell aggregates][agg_lds first-touched cells][MLM_RAY_LDS rays]
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const unsigned int MLM_NODE_LDS = P.node_lds, MLM_AGG_LDS = P.agg_lds;
+    MlmNode *s_node = (MlmNode *)s_dyn;
+    MlmCellAgg *s_agg = (MlmCellAgg *)(s_node + MLM_NODE_LDS);
+    uint32_t *s_touch = (uint32_t *)(s_agg + MLM_AGG_LDS);
+    int(*s_ray)[4] = (int(*)[4])(s_touch + MLM_AGG_LDS);
     if (threadIdx.x == 0) {
         s_nnode = 0;
         s_nray = 0;
         s_ntouch = 0;
     }
-    for (int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
+    for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
         s_agg[e].cell = MLM_NIL;
         s_agg[e].tmin = MLM_EMPTY_T;
         s_agg[e].kmask = 0;
@@ -317,9 +321,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         const uint32_t i_first = (nd.i00_sub & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
         const uint32_t t = i_first * MLM_TIME_SLOTS + (uint32_t)sub;
         const uint32_t cnt = (uint32_t)__popcll(nd.mask);
-        uint32_t e = (nd.cell * 2654435761u) >> 24; // 8 bits
+        uint32_t e = (nd.cell * 2654435761u) >> P.agg_shift; // log2(agg_lds) bits
         bool placed = false;
-        for (int probe = 0; probe < MLM_AGG_LDS; ++probe) {
+        for (unsigned int probe = 0; probe < MLM_AGG_LDS; ++probe) {
             const uint32_t prev = atomicCAS(&s_agg[e].cell, MLM_NIL, nd.cell);
             if (prev == MLM_NIL || prev == nd.cell) {
                 placed = true;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
+    for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
         const uint32_t cell = s_agg[e].cell;
         if (cell == MLM_NIL) continue;
         atomicMin(&P.hit_t[cell], s_agg[e].tmin);

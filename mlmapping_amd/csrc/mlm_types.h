@@ -128,6 +128,8 @@ struct MlmDev {
     unsigned int mvox_cap;
     // ---- exploration-frontier mode (use_exploration_frontiers: true) — map_local.cpp:7-33,208-232
     int explore;
+    // LDS sizing of k_bin_points (host-chosen from the noise spread of the configuration)
+    unsigned int node_lds, agg_lds, agg_shift, bin_lds_bytes;
     uint8_t *frnt;             // [max_blocks*cells] 1 = the cell is in its block's frontier set
     uint8_t *blk_collapsed;    // [max_blocks] 1 = block was "released" (vectors resized to 1: frozen, element 0 answers)
     uint8_t *blk_observed;     // [max_blocks] observed_subboxes of the current frame

@@ -345,11 +345,11 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         }
         Timed t(h, st, "k_bin_points");
         if (mode == 0)
-            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, n), dim3(MLM_BLOCK), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
         else if (mode == 1)
-            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, n), dim3(MLM_BLOCK), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
         else
-            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(MLM_BLOCK), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     {
         Timed t(h, st, "k_assign_nodes");
@@ -370,7 +370,7 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         Timed t(h, st, "k_sort_contribs");
         hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 0u);
-        hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(n > 4 ? 32 : 128, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 1024u);
     }
     {
@@ -498,11 +498,11 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
             return MLM_ERR_CAPACITY;
         }
         if (S.mode == 0)
-            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, 1), blk, P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
         else if (S.mode == 1)
-            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, 1), blk, P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
         else
-            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), blk, P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     }
     const int tile_w = S.mode == 0 ? F.width : 0;
     hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
@@ -926,6 +926,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     P.fy = (float)cfg->cam_fy;
     P.inv_factor = 1.0 / 1000.0;
     P.record_awareness = h->lim.record_awareness;
+    P.node_lds = 448;
+    P.agg_lds = 256;
     P.explore = cfg->use_exploration_frontiers != 0;
     P.max_blocks = h->lim.max_blocks;
 
@@ -942,6 +944,24 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         for (int r = 0; r < P.nRho; ++r) h->odds_table[(size_t)(d + MLM_DIFF_RANGE) * P.nRho + r] = om.get_odds(d, (size_t)r);
     std::vector<float> sigma3(P.nRho);
     for (int r = 0; r < P.nRho; ++r) sigma3[r] = 3 * om.sigma_in_dr((size_t)r); // map_awareness.cpp:149
+    {
+        // a point spreads into 1 + 2*dmax cells; the wider the spread, the more groups and distinct cells a block produces
+        int dmax = 0;
+        for (int r = 0; r < P.nRho; ++r) {
+            int d = 1;
+            while ((float)d < sigma3[r] && r + d < P.nRho && d <= MLM_DIFF_RANGE) ++d;
+            dmax = std::max(dmax, d - 1);
+        }
+        if (dmax > 4) {
+            P.node_lds = 1024;
+            P.agg_lds = 512;
+        }
+        unsigned int lg = 0;
+        while ((1u << lg) < P.agg_lds) ++lg;
+        P.agg_shift = 32 - lg;
+        P.bin_lds_bytes = P.node_lds * (unsigned int)sizeof(MlmNode) + P.agg_lds * (unsigned int)(sizeof(MlmCellAgg) + 4) +
+                          MLM_RAY_LDS * 16;
+    }
     std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
     for (int p = 0; p < P.nPhi; ++p) {
         const double center_phi = P.dPhi / 2 + (p * P.dPhi); // map_awareness.cpp:59
