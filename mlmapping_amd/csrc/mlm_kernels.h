@@ -520,6 +520,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
                 P.hl_base[pos] = base;
                 P.hl_cnt[pos] = cnt;
                 P.mt_list[off_m + (uint32_t)__popcll(bm & below)] = pos;
+                if (cnt > 1024u) P.mt_big[atomicAdd(&P.ctr->n_big, 1u)] = pos; // few: second k_sort_contribs launch
             } else {
                 // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
                 P.seg_base[c] = MLM_NIL;
@@ -579,16 +580,18 @@ template <int MLM_SORT_CAP>
 __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsigned int n_lo) {
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_BLOCK / 64][MLM_SORT_CAP];
-    const unsigned int n_cells = P.ctr->n_multi;
+    const bool big = MLM_SORT_CAP > 1024;
+    const unsigned int n_cells = big ? P.ctr->n_big : P.ctr->n_multi;
+    const uint32_t *list = big ? P.mt_big : P.mt_list;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     volatile uint32_t *K = s_keys[wid];
     for (unsigned int w = wave; w < n_cells; w += n_waves) {
-        const uint32_t pos = P.mt_list[w];
+        const uint32_t pos = list[w];
         const uint32_t base = P.hl_base[pos];
         const uint32_t n = P.hl_cnt[pos];
-        if (n <= n_lo || (n > MLM_SORT_CAP && MLM_SORT_CAP < 4096)) continue; // the other launch's cells
+        if (n <= n_lo || (n > MLM_SORT_CAP && !big)) continue; // the other launch's cells
         if (n <= 320) {
             // small cells (the bulk): rank by counting — every lane counts the keys below its own with 16-byte
             // broadcast reads; the ordered kinds are staged in the unused upper part of the wave's LDS window

@@ -20,6 +20,8 @@ struct MlmCounters {
     unsigned int n_ex_rays;   // explore mode: queued rays
     unsigned int n_ex_miss;   // explore mode: unique miss cells
     unsigned int n_ex_vox;    // explore mode: voxels touched by misses
+    unsigned int n_big;       // multi-kind cells with more than 1024 contributions
+    unsigned int pad_b[3];
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
@@ -36,7 +38,7 @@ struct MlmGlobal {
                               // miss); INT_MAX = none.  Stage B/C kernels of frames >= it do nothing.
     unsigned int pad;
 };
-#define MLM_CTR_FRAME_BYTES (48 + 6 * 8 * 32 * 4)
+#define MLM_CTR_FRAME_BYTES (64 + 6 * 8 * 32 * 4)
 #define MLM_RAY_LISTS 8
 
 // The hit contributions one wave makes to one awareness cell with one kind (`sub`): lanes in `mask`, work items
@@ -81,6 +83,7 @@ struct MlmDev {
     uint32_t *contrib;         // [contrib_cap] insertion times of the contributions of multi-kind cells, by cell
     unsigned int *blk_stats;   // [2*max tiles] per-block partial sums: points fed, points out of range
     uint32_t *mt_list;         // [nCells] indices into the hit list of the multi-type cells
+    uint32_t *mt_big;          // [nCells] those with more than 1024 contributions
     uint32_t *touched;         // [MLM_RAY_LISTS][touch_cap] hit cells in first-touch order of the GPU (arbitrary)
     unsigned int touch_cap;    // per sub-list
     uint8_t *subs;             // [contrib_cap] per multi-kind cell: contribution kinds in insertion-time order
