@@ -411,3 +411,41 @@ def test_argument_and_capacity_errors(mods):
         m2.update_map(syn.room_depth(SDEF), *syn.static_pose())  # 230 400 pixels > max_points
     m2.update_map(syn.room_depth(SDEF), *syn.static_pose(), pixel_idx=np.arange(0, 230400, 400))  # 576 pixels: fine
     assert m2.frame_stats()["n_points"] == 576
+
+
+def test_random_configurations(mods):
+    """Fuzz: random map geometries, noise levels, thresholds and camera models — the HIP path must track the oracle on
+    all of them (sets and classes exact, odds within 1e-4)."""
+    MLMap, OracleMap = mods
+    rng = np.random.default_rng(2024)
+    for trial in range(30):
+        d = float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.25]))
+        cfg = S1.with_(
+            am_d_Rho=d, am_d_Phi_deg=float(rng.choice([0.5, 1.0, 2.0, 3.0, 5.0])), am_d_Z=float(rng.choice([d, 2 * d, 0.5 * d])),
+            am_n_Rho=int(rng.integers(20, 100)), am_n_Z_below=int(rng.integers(5, 30)), am_n_Z_over=int(rng.integers(5, 30)),
+            depth_noise_coe=float(rng.choice([1e-6, 0.001, 0.00375, 0.008])),
+            subbox_d_xyz=float(rng.choice([d, 2 * d, 0.5 * d])), subbox_n=int(rng.choice([4, 5, 8, 10, 16])),
+            lm_log_odds_min=float(rng.uniform(-3, -1)), lm_log_odds_max=float(rng.uniform(3, 5)),
+            lm_measurement_miss=float(rng.uniform(-1.2, -0.3)), lm_occupied_sh=float(rng.uniform(1.0, 3.0)),
+            use_exploration_frontiers=bool(trial % 3 == 2),
+            cam_fx=float(rng.uniform(150, 400)), cam_fy=float(rng.uniform(150, 400)), cam_cx=163.3, cam_cy=117.9,
+            width=320, height=240)
+        # keep the noise spread inside the reference's 21-row odds table (3*sigma <= 10, SURVEY App. B)
+        if 3 * cfg.depth_noise_coe * (cfg.am_n_Rho * cfg.am_d_Rho) ** 2 / cfg.am_d_Rho > 10:
+            cfg = cfg.with_(depth_noise_coe=1e-6)
+        gpu, cpu = MLMap(cfg, max_blocks=32768, max_points=320 * 240, record_awareness=True), OracleMap(cfg)
+        for k in range(3):
+            depth = rng.integers(300, int(1000 * cfg.am_n_Rho * cfg.am_d_Rho * 1.3), size=(240, 320)).astype(np.uint16)
+            depth[rng.random((240, 320)) < 0.02] = 0
+            if k == 1:  # a smooth surface as well as speckle
+                depth[:] = (1000 * 0.6 * cfg.am_n_Rho * cfg.am_d_Rho + 200 * np.sin(np.arange(320) / 25.0)[None, :]).astype(np.uint16)
+            q, t = syn.random_poses(3, seed=trial)[k]
+            gpu.update_map(depth, q, t)
+            cpu.update_depth(depth, q, t)
+            _awareness_equal(gpu, cpu)
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"fuzz trial {trial} frame {k} cfg {cfg}")
+            if cfg.use_exploration_frontiers:
+                assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"fuzz trial {trial}: frontier"
+        pos = rng.uniform(-8, 8, size=(20000, 3))
+        assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+        gpu.close()
