@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--distinct", type=int, default=32, help="distinct depth frames kept in HBM (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -131,8 +132,12 @@ def main():
     for s in range(W):
         run_step(s, False)
     barrier()
-    # HIP events around every launch of the timed region, on the streams the kernels run on (accumulate mode)
-    m.enable_kernel_timing(2)
+    # HIP events over the timed region, on the stream the kernels run on: mode 3 brackets the dominant kernel's
+    # launches only (k_bin_points, one launch per batch => two events per batch).  Bracketing every kernel costs ~19 %
+    # throughput (measured: 19.3k -> 16.3k frames/s, the per-frame Stage C chain is latency bound), so the other
+    # kernels' times come from a few extra fully instrumented batches after the region.
+    if not args.no_kernel_timing:
+        m.enable_kernel_timing(3)
     t0 = time.perf_counter()
     for s in range(W, W + K):
         run_step(s, True)
@@ -146,8 +151,20 @@ def main():
         a = ktime.setdefault(name, [0.0, 0])
         a[0] += ms
         a[1] += 1
+    n_inst = K * B  # frames covered by the launches recorded in the timed region
+    ktime_c = {}
+    n_c = min(K, 6)
+    if not args.no_kernel_timing:
+        m.enable_kernel_timing(2)
+        for s in range(n_c):
+            run_step(s, False)
+        m.sync()
+        for name, ms in m.kernel_times():
+            if name not in ktime:
+                a = ktime_c.setdefault(name, [0.0, 0])
+                a[0] += ms
+                a[1] += 1
     m.enable_kernel_timing(0)
-    n_inst = K * B  # frames covered by the recorded launches
     # PCIe-inclusive rate: the same batches handed over as HOST buffers (uploads overlap with compute); reported, never
     # `value`
     n_host = min(K, 5)
@@ -187,7 +204,9 @@ def main():
                                 if pmc and dom[0] in pmc["kernels"] else None),
                     "traffic_source": (os.path.basename(files[-1]) if pmc else None), "avg_launch_us": avg_ms * 1e3,
                     "algorithmic_bytes_per_frame": mean_bytes,
-                    "kernels_us_per_frame": {k: v[0] * 1e3 / max(1, n_inst) for k, v in ktime.items()}}
+                    "kernels_us_per_frame": {**{k: v[0] * 1e3 / max(1, n_inst) for k, v in ktime.items()},
+                                             **{k + " (extra instrumented batches)": v[0] * 1e3 / max(1, n_c * B)
+                                                for k, v in ktime_c.items()}}}
         out = {
             "metric": "depth frames/s into local map", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -338,9 +338,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
             if (sub == 0) atomicMin(&s_agg[e].start_min, i_first);
             s_node[k].pad = e;
         } else { // table full (never seen): book the group on its own
-            atomicMin(&P.hit_t[nd.cell], t);
-            atomicOr(&P.hit_mask[nd.cell], 1u << sub);
-            const uint32_t pos = atomicAdd(&P.hit_cnt[nd.cell], cnt);
+            atomicMin(&P.cs[nd.cell].t, t);
+            atomicOr(&P.cs[nd.cell].mask, 1u << sub);
+            const uint32_t pos = atomicAdd(&P.cs[nd.cell].cnt, cnt);
             if (P.explore && sub == 0) atomicMin(&P.start_t[nd.cell], i_first);
             s_node[k].pos = pos;
             s_node[k].pad = MLM_NIL;
@@ -354,9 +354,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
         const uint32_t cell = s_agg[e].cell;
         if (cell == MLM_NIL) continue;
-        atomicMin(&P.hit_t[cell], s_agg[e].tmin);
-        atomicOr(&P.hit_mask[cell], s_agg[e].kmask);
-        const uint32_t base = atomicAdd(&P.hit_cnt[cell], s_agg[e].cnt);
+        atomicMin(&P.cs[cell].t, s_agg[e].tmin);
+        atomicOr(&P.cs[cell].mask, s_agg[e].kmask);
+        const uint32_t base = atomicAdd(&P.cs[cell].cnt, s_agg[e].cnt);
         if (P.explore && s_agg[e].start_min != MLM_EMPTY_T) atomicMin(&P.start_t[cell], s_agg[e].start_min);
         s_agg[e].base = base;
         if (base == 0) s_touch[atomicAdd(&s_ntouch, 1u)] = cell; // first contributions of the cell this frame
@@ -428,10 +428,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_assign_nodes(MLM_SLOT_ARGS, int t
             const uint32_t off = tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0;
             const uint32_t is = nd->i00_sub;
             const uint32_t t = ((is & 0x07FFFFFFu) + off) * MLM_TIME_SLOTS + (is >> 27);
-            atomicMin(&P.hit_t[cell], t);
-            atomicOr(&P.hit_mask[cell], 1u << (is >> 27));
+            atomicMin(&P.cs[cell].t, t);
+            atomicOr(&P.cs[cell].mask, 1u << (is >> 27));
             if (P.explore && (is >> 27) == 0) atomicMin(&P.start_t[cell], (is & 0x07FFFFFFu) + off);
-            const uint32_t pos = atomicAdd(&P.hit_cnt[cell], (unsigned int)__popcll(m));
+            const uint32_t pos = atomicAdd(&P.cs[cell].cnt, (unsigned int)__popcll(m));
             nd->pos = pos;
             first = pos == 0;
         }
@@ -474,9 +474,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
         uint32_t c = 0, t = 0, mask = 0, cnt = 0;
         if (has) {
             c = P.touched[(size_t)k * P.touch_cap + r];
-            t = P.hit_t[c];
-            mask = P.hit_mask[c];
-            cnt = P.hit_cnt[c];
+            const uint4 st = *(const uint4 *)&P.cs[c]; // t, cnt, mask, seg in one 16-byte load
+            t = st.x;
+            cnt = st.y;
+            mask = st.z;
         }
         const bool multi = has && __popc(mask) > 1;
         const unsigned long long bh = __ballot(has), bm = __ballot(multi);
@@ -504,9 +505,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
         if (has) {
             const unsigned long long below = (1ull << lane) - 1ull;
             const uint32_t pos = off_h + (uint32_t)__popcll(bh & below);
-            P.hit_t[c] = MLM_EMPTY_T;
-            P.hit_mask[c] = 0;
-            P.hit_cnt[c] = 0;
+            P.cs[c].t = MLM_EMPTY_T;
+            P.cs[c].mask = 0;
+            P.cs[c].cnt = 0;
             if (mask & 1u) {
                 atomicAnd(&P.start_bits[c >> 5], ~(1u << (c & 31))); // its ray was queued; reset for next frame
                 if (P.explore) P.start_t[c] = MLM_EMPTY_T; // (k_ex_walk_rays runs before this kernel)
@@ -516,14 +517,14 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
             P.hl_vt[pos] = t;
             if (multi) {
                 const uint32_t base = off_c + cincl - cpad;
-                P.seg_base[c] = base;
+                P.cs[c].seg = base;
                 P.hl_base[pos] = base;
                 P.hl_cnt[pos] = cnt;
                 P.mt_list[off_m + (uint32_t)__popcll(bm & below)] = pos;
                 if (cnt > 1024u) P.mt_big[atomicAdd(&P.ctr->n_big, 1u)] = pos; // few: second k_sort_contribs launch
             } else {
                 // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
-                P.seg_base[c] = MLM_NIL;
+                P.cs[c].seg = MLM_NIL;
                 const int rho_c = (int)(c % (uint32_t)P.nRho);
                 const float a = mlm_contribution_odd(P, P.odds_table, rho_c, __ffs((int)mask) - 1);
                 float p = a;
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int t
         uint32_t base = MLM_NIL;
         if (k0 + lane < n) {
             nd = P.nodes[(size_t)reg * P.node_cap + k0 + lane];
-            base = P.seg_base[nd.cell];
+            base = P.cs[nd.cell].seg;
         }
         unsigned long long todo = __ballot(base != MLM_NIL);
         while (todo) {

@@ -53,6 +53,15 @@ struct MlmNode {
 };
 #define MLM_NIL 0xFFFFFFFFu
 
+// Per-frame state of one awareness cell, 16 bytes so that the three atomics that book a group on a cell and the
+// reads of k_collect_hits touch ONE cache line.
+struct MlmCell {
+    uint32_t t;    // first-touch time of a hit cell (min over contributions), MLM_EMPTY_T = not hit this frame
+    uint32_t cnt;  // number of contributions
+    uint32_t mask; // bit s set = a contribution of insertion slot s (0 centre, 2d-1 "+d", 2d "-d")
+    uint32_t seg;  // start of the cell's segment in `contrib` (MLM_NIL for single-kind cells)
+};
+
 struct MlmDev {
     // ---- awareness map constants (map_awareness.cpp:19-82)
     double dRho, dPhi, dZ, z_border_min;
@@ -74,10 +83,7 @@ struct MlmDev {
     const double *cos_phi;     // [nPhi] cos/sin of the cell-centre azimuth (map_awareness.cpp:59-61)
     const double *sin_phi;
     // ---- per-frame awareness scratch
-    uint32_t *hit_t;           // [nCells] first-touch time of a hit cell (min over contributions)
-    uint32_t *hit_cnt;         // [nCells] number of contributions; reused as the fill cursor of the segment
-    uint32_t *hit_mask;        // [nCells] bit s set = a contribution of insertion slot s (0 centre, 2d-1 "+d", 2d "-d")
-    uint32_t *seg_base;        // [nCells] start of the cell's segment in `contrib` (MLM_NIL for single-kind cells)
+    MlmCell *cs;               // [nCells] per-cell frame state (see MlmCell)
     MlmNode *nodes;            // [MLM_RAY_LISTS][node_cap]
     unsigned int node_cap;     // per region
     uint32_t *contrib;         // [contrib_cap] insertion times of the contributions of multi-kind cells, by cell

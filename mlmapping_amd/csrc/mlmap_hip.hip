@@ -208,6 +208,7 @@ struct Timed {
     KernelTime *kt = nullptr;
     Timed(mlm_handle *hh, hipStream_t st, const char *name) : h(hh), s(st) {
         if (!h->timing) return;
+        if (h->timing == 3 && strcmp(name, "k_bin_points") != 0) return; // dominant kernel only: 2 events per batch
         if (h->kpool_used == h->kpool.size()) {
             KernelTime k{name, nullptr, nullptr};
             hipEventCreate(&k.a);
@@ -745,10 +746,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     const size_t NC = (size_t)P.nCells;
     S.h_ctr = h->h_ctr_all + index;
     P.ctr = h->d_ctr_all + index;
-    if ((rc = dev_alloc(h, &P.hit_t, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hit_cnt, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hit_mask, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.seg_base, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.cs, NC))) return rc;
     if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
     if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
     if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
@@ -817,9 +815,10 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     }
     P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
     if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
-    HIPCHK(h, hipMemset(P.hit_t, 0xFF, NC * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.hit_cnt, 0, NC * sizeof(uint32_t)));
-    HIPCHK(h, hipMemset(P.hit_mask, 0, NC * sizeof(uint32_t)));
+    {
+        std::vector<MlmCell> init(NC, MlmCell{MLM_EMPTY_T, 0u, 0u, MLM_NIL});
+        HIPCHK(h, hipMemcpy(P.cs, init.data(), NC * sizeof(MlmCell), hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
     if ((rc = ensure_img(h, S, (size_t)h->lim.max_points))) return rc;
@@ -1618,7 +1617,7 @@ int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, 
         if (names) names[i] = h->ktimes[i].name;
         if (ms) ms[i] = t;
     }
-    if (h->timing == 2 && cap >= n) { // accumulate mode: reading the list consumes it
+    if (h->timing >= 2 && cap >= n) { // accumulate modes: reading the list consumes it
         h->ktimes.clear();
         h->kpool_used = 0;
     }
