@@ -12,6 +12,24 @@
 
 // x86-64 static_cast<int>(double) == cvttsd2si: NaN / out-of-range -> INT_MIN.  gfx950 v_cvt_i32_f64 saturates
 // and maps NaN to 0, so the x86 behaviour the reference silently relies on is spelled out.
+// Pointers loaded from MlmDev / MlmFrame are generic to the compiler, which then emits FLAT instructions (they count
+// on lgkmcnt as well as vmcnt, so every LDS / scalar-load wait also waits for them).  All of them point to device
+// memory: mlm_gp() re-types one as an address-space-1 pointer so that GLOBAL instructions are emitted; the g_atomic_*
+// wrappers are the device-scope relaxed atomics of HIP's atomicOr/atomicAdd/atomicMin on such pointers.
+#define MLM_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ MLM_GLOBAL T *mlm_gp(T *p) { return (MLM_GLOBAL T *)p; }
+template <class T> __device__ __forceinline__ T g_atomic_or(MLM_GLOBAL T *p, T v) {
+    return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ T g_atomic_add(MLM_GLOBAL T *p, T v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ T g_atomic_min(MLM_GLOBAL T *p, T v) {
+    return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+typedef unsigned int mlm_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mlm_u32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int mlm_cvt_int(double v) {
     if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
     return (int)v;

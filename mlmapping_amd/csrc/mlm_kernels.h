@@ -44,8 +44,18 @@ template <class F> __device__ __forceinline__ void mlm_wave_groups(int key, bool
     }
 }
 
-// One block = 4 waves; in dense mode a wave owns an 8x8 pixel tile (lanes row-major inside the tile, so a lower
-// lane always has the smaller pixel index = earlier insertion time) and the block a 32x8 strip.
+__device__ __forceinline__ uint32_t mlm_wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+// In dense mode a wave owns an 8x8 pixel tile (lanes row-major inside the tile, so a lower lane always has the smaller
+// pixel index = earlier insertion time) and the block (MlmDev::bin_block threads) a 32 x (bin_block/32) tile: the larger
+// the tile, the fewer (block, cell) pairs a frame produces, and each pair costs three device-scope atomics.
 struct MlmTile {
     int i;      // work item (pixel index / list position / point index), -1 = none
     bool valid;
@@ -53,12 +63,14 @@ struct MlmTile {
 template <int MODE> __device__ __forceinline__ MlmTile mlm_tile_item(const MlmFrame &F) {
     MlmTile t;
     if (MODE == 0) {
+        // block = 32 pixels wide, 8 rows per 4 waves (blockDim 256: 32x8 strip, 1024: 32x32 tile)
+        const int tile_h = (int)(blockDim.x >> 8) * 8;
         const int tiles_x = (F.width + 31) >> 5;
         const int by = blockIdx.x / tiles_x;
         const int bx = blockIdx.x - by * tiles_x;
         const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-        const int px = bx * 32 + w * 8 + (l & 7);
-        const int py = by * 8 + (l >> 3);
+        const int px = bx * 32 + (w & 3) * 8 + (l & 7);
+        const int py = by * tile_h + (w >> 2) * 8 + (l >> 3);
         t.valid = px < F.width && py < F.height;
         t.i = py * F.width + px;
     } else {
@@ -99,8 +111,21 @@ __device__ __forceinline__ void mlm_walk_ray_wave(const MlmDev &P, int rho, int 
             const int end = stop ? __ffsll((long long)stop) - 1 : 64; // exclusive
             const int len = end - lane;                               // <= 32: a run stays inside one word
             const uint32_t bits = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (r & 31);
-            atomicOr(&P.miss_bits[w], bits);
+            g_atomic_or(&mlm_gp(P.miss_bits)[w], bits);
         }
+    }
+}
+
+// the same walk by ONE lane (rare paths: LDS buffers of k_bin_points overflowed)
+__device__ __forceinline__ void mlm_walk_ray_lane(const MlmDev &P, int rho, int phi, int z) {
+    const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
+    if (rho >= P.nRho) {
+        z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
+        rho = P.nRho - 1;
+    }
+    for (int r = 1; r < rho; ++r) {
+        const int zr = mlm_cvt_int(round(z - ((rho - r) * slope)));
+        if (0 <= zr && zr < P.nZ) g_atomic_or(&mlm_gp(P.miss_bits)[(zr * P.nPhi + phi) * P.RW + (r >> 5)], 1u << (r & 31));
     }
 }
 
@@ -122,13 +147,14 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
 
 // MlmDev::node_lds contribution nodes are buffered per k_bin_points block; MlmDev::agg_lds (a power of two) entries of
 // a block-local table merge the block's groups per awareness cell
+#define MLM_AGG_RAY 0x80000000u // MlmCellAgg::kmask: this block walks the ray that starts in the cell
 struct MlmCellAgg {
     uint32_t cell;      // MLM_NIL = empty
     uint32_t tmin;      // earliest insertion time of the block's contributions to the cell
     uint32_t kmask;     // kinds
     uint32_t cnt;       // contributions
     uint32_t base;      // position of the block's first contribution inside the cell's segment
-    uint32_t start_min; // explore mode: first point whose hit centre is the cell
+    uint32_t start_min; // explore mode: first point whose hit centre is the cell; after phase C: ray queue index
 };
 
 // MODE 0: dense depth image, 1: indexed depth pixels, 2: explicit sensor-frame points
@@ -140,14 +166,49 @@ struct MlmCellAgg {
     const MlmFrame &F = frame_tab[slot_base + blockIdx.z];                                                            \
     (void)F;
 
-#define MLM_RAY_LDS 256 // rays buffered per k_bin_points block (every lane queues at most one)
+// a 24-byte node record as one 16-byte and one 8-byte global store
+__device__ __forceinline__ void mlm_store_node(MLM_GLOBAL MlmNode *dst, const MlmNode &nd) {
+    MLM_GLOBAL uint32_t *d = (MLM_GLOBAL uint32_t *)dst;
+    d[0] = nd.cell;
+    d[1] = nd.pos;
+    d[2] = nd.i00_sub;
+    d[3] = nd.pad;
+    *(MLM_GLOBAL unsigned long long *)(d + 4) = nd.mask;
+}
+
+#define MLM_RAY_LDS 128 // rays buffered per k_bin_points block (overflow: walked on the spot)
+#ifdef MLM_PHASE_PROF // diagnostic build only (tools/phase_prof.py): shader-clock cycles per phase of k_bin_points
+#define MLM_PHASE_BLOCKS 32768
+__device__ unsigned long long g_mlm_phase[MLM_PHASE_BLOCKS * 16]; // per block: no contended atomics in the measurement
+#define MLM_PHASE(n)                                                                                                   \
+    do {                                                                                                               \
+        const long long now_ = clock64();                                                                              \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_phase[n], (unsigned long long)(now_ - ph_t_));                       \
+        ph_t_ = now_;                                                                                                  \
+    } while (0)
+#define MLM_PHASE_BEGIN                                                                                                \
+    __shared__ unsigned long long s_phase[16];                                                                         \
+    if (threadIdx.x < 16) s_phase[threadIdx.x] = 0;                                                                    \
+    __syncthreads();                                                                                                   \
+    long long ph_t_ = clock64();
+#define MLM_PHASE_END                                                                                                  \
+    __syncthreads();                                                                                                   \
+    {                                                                                                                  \
+        const unsigned int b_ = blockIdx.x + gridDim.x * blockIdx.z;                                                   \
+        if (threadIdx.x < 16 && b_ < MLM_PHASE_BLOCKS) g_mlm_phase[b_ * 16 + threadIdx.x] = s_phase[threadIdx.x];      \
+    }
+#else
+#define MLM_PHASE(n)
+#define MLM_PHASE_BEGIN
+#define MLM_PHASE_END
+#endif
 template <int MODE>
-__global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
+__global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
-    __shared__ unsigned int s_cnt[4];
+    MLM_PHASE_BEGIN
+    __shared__ unsigned int s_cnt[16];
     __shared__ unsigned int s_nray;
-    __shared__ unsigned int s_nbase2;
-    __shared__ unsigned int s_nnode, s_nbase, s_ntouch, s_tbase;
+    __shared__ unsigned int s_nnode, s_nbase, s_nbase2, s_ntouch, s_nflag;
     // dynamic LDS, sized by the host from the configuration (how many kinds a point can spread into):
     // [node_lds nodes][agg_lds cell aggregates][agg_lds first-touched cells][MLM_RAY_LDS rays]
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -160,6 +221,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         s_nnode = 0;
         s_nray = 0;
         s_ntouch = 0;
+        s_nflag = 0;
     }
     for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
         s_agg[e].cell = MLM_NIL;
@@ -169,6 +231,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         s_agg[e].start_min = MLM_EMPTY_T;
     }
     __syncthreads();
+    MLM_PHASE(0);
     const MlmTile T = mlm_tile_item<MODE>(F);
     const int i = T.i;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -176,14 +239,14 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     double xs = 0, ys = 0, zs = 0;
     if (have) {
         if (MODE == 2) {
-            xs = F.pts[3 * (size_t)i + 0];
-            ys = F.pts[3 * (size_t)i + 1];
-            zs = F.pts[3 * (size_t)i + 2];
+            xs = mlm_gp(F.pts)[3 * (size_t)i + 0];
+            ys = mlm_gp(F.pts)[3 * (size_t)i + 1];
+            zs = mlm_gp(F.pts)[3 * (size_t)i + 2];
         } else {
-            const int pix = (MODE == 1) ? F.pix[i] : i;
+            const int pix = (MODE == 1) ? mlm_gp(F.pix)[i] : i;
             const int v = pix / F.width;
             const int u = pix - v * F.width;
-            const uint16_t raw = F.img[(size_t)v * F.row_stride + u];
+            const uint16_t raw = mlm_gp(F.img)[(size_t)v * F.row_stride + u];
             if (raw == 0) { // mlmap.cpp:338-341
                 have = false;
             } else {
@@ -207,21 +270,38 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
         inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
         if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
     }
+    MLM_PHASE(1);
     // work item of lane 0 of this wave (see MlmNode)
     const uint32_t i00 = (uint32_t)__shfl(i, 0, 64);
-    const uint32_t t0 = (uint32_t)i * MLM_TIME_SLOTS;
 
-    // One group = the lanes of this wave that contribute kind `sub` to `cell`.  Its lowest lane (= earliest
-    // insertion time) records the group as a node; all bookkeeping on the cell (first-touch time, kind mask, count,
-    // position) is done later by k_assign_nodes, 64 independent atomics at a time.
-    auto post = [&](int key, bool valid, int sub, bool centre) -> bool {
-        uint32_t old_start = ~0u;
+    // queue a ray for phase D; if the LDS queue is full (rare) walk it on the spot / hand it to k_ex_walk_rays directly
+    auto queue_ray = [&](int rh, int ph, int z, int pt) {
+        const unsigned int k = atomicAdd(&s_nray, 1u);
+        if (k < MLM_RAY_LDS) {
+            s_ray[k][0] = rh;
+            s_ray[k][1] = ph;
+            s_ray[k][2] = z;
+            s_ray[k][3] = pt;
+        } else if (!P.explore) {
+            mlm_walk_ray_lane(P, rh, ph, z);
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[blockIdx.x & 7][0], 1u);
+        } else {
+            MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, 1u);
+            q[0] = rh;
+            q[1] = ph;
+            q[2] = z;
+            q[3] = pt;
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[blockIdx.x & 7][0], 1u);
+        }
+    };
+    // ---- phase A: one group = the lanes of this wave that contribute kind `sub` to `cell`.  Its lowest lane (=
+    //      earliest insertion time) records the group as a node in LDS; no global memory is touched here.
+    auto post = [&](int key, bool valid, int sub) {
         unsigned long long my_mask = 0;
         int my_cell = -1;
         mlm_wave_groups(key, valid, [&](int cell, unsigned long long m) {
             my_cell = cell;
             my_mask = m;
-            if (centre && P.visibility) old_start = atomicOr(&P.start_bits[cell >> 5], 1u << (cell & 31));
         });
         if (my_cell >= 0) {
             const unsigned int k = atomicAdd(&s_nnode, 1u);
@@ -233,28 +313,29 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
             nd.mask = my_mask;
             if (k < MLM_NODE_LDS) {
                 s_node[k] = nd;
-            } else { // LDS buffer full: store the node directly; k_assign_nodes books it
+            } else { // LDS buffer full: store the node directly; k_assign_nodes books it (and walks its ray)
                 const unsigned int reg = blockIdx.x & 7;
-                const unsigned int g = atomicAdd(&P.ctr->node_cnt[reg][0], 1u);
+                const unsigned int g = g_atomic_add(&mlm_gp(P.ctr)->node_cnt[reg][0], 1u);
                 nd.pad = 1;
-                if (g < P.node_cap) P.nodes[(size_t)reg * P.node_cap + g] = nd;
-                atomicAdd(&P.ctr->n_unassigned, 1u);
+                if (g < P.node_cap) mlm_store_node(mlm_gp(P.nodes) + ((size_t)reg * P.node_cap + g), nd);
+                g_atomic_add(&mlm_gp(P.ctr)->n_unassigned, 1u);
             }
         }
-        // every point of one (rho,phi,z) cell casts the identical ray: only the first one queues it
-        return my_cell >= 0 && centre && P.visibility && (old_start & (1u << (my_cell & 31))) == 0;
     };
-    bool emit_ray = post(c0, inside, 0, true);
-    const float s3 = inside ? P.sigma3[rho] : 0.0f;
+    post(c0, inside, 0);
+    const float s3 = inside ? mlm_gp(P.sigma3)[rho] : 0.0f;
     for (int d = 1; __any(inside && mlm_spread_active(P, rho, d, s3)); ++d) {
         int cp = -1, cm = -1;
         if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, cp, cm);
-        post(cp, cp >= 0, 2 * d - 1, false);
-        post(cm, cm >= 0, 2 * d, false);
+        post(cp, cp >= 0, 2 * d - 1);
+        post(cm, cm >= 0, 2 * d);
     }
+    MLM_PHASE(2);
     // ---- points outside the map that can still cast (map_awareness.cpp:241,249-265): identical starts inside
-    //      the wave are merged, across waves they are simply walked again (idempotent bit sets)
+    //      the wave are merged, across waves they are simply walked again (idempotent bit sets).  Rays of in-range
+    //      points start at their hit cell; those are de-duplicated per FRAME in phase C.
     const bool outer = have && !inside && can_do_cast && P.visibility;
+    bool emit_ray = false;
     {
         unsigned long long todo = __ballot(outer);
         while (todo) {
@@ -268,52 +349,21 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
     // ---- statistics: per-block partial sums, no atomics
     const unsigned int n_pts = (unsigned int)__popcll(__ballot(have));
     const unsigned int n_oor = (unsigned int)__popcll(__ballot(have && !(can_do_cast && P.visibility)));
-    // ---- rays are walked by the block that queued them (LDS queue, one ray per wave at a time)
-    if (emit_ray) {
-        const unsigned int k = atomicAdd(&s_nray, 1u);
-        if (k < MLM_RAY_LDS) {
-            s_ray[k][0] = rho;
-            s_ray[k][1] = phi;
-            s_ray[k][2] = zi;
-            s_ray[k][3] = inside ? -1 : i; // explore mode: in-range starts take the cell's first point later
-        }
-    }
+    if (emit_ray) queue_ray(rho, phi, zi, i);
     if (lane == 0) s_cnt[wid] = n_pts | (n_oor << 10);
+    MLM_PHASE(3);
     __syncthreads();
+    MLM_PHASE(4);
+    // ---- phase B: merge the block's groups per cell in an LDS table, so that a cell costs three device-scope atomics
+    //      per BLOCK (first-touch time min, kind mask or, count add -> position) instead of three per group.
     const unsigned int reg = blockIdx.x & 7;
     const unsigned int nn = min(s_nnode, (unsigned int)MLM_NODE_LDS);
-    const unsigned int nr = min(s_nray, (unsigned int)MLM_RAY_LDS);
-    if (threadIdx.x == 0) {
-        unsigned int pts = 0, oor = 0;
-        for (int w = 0; w < 4; ++w) {
-            pts += s_cnt[w] & 1023u;
-            oor += s_cnt[w] >> 10;
-        }
-        P.blk_stats[2 * blockIdx.x] = pts;
-        P.blk_stats[2 * blockIdx.x + 1] = oor;
-        s_nbase = nn ? atomicAdd(&P.ctr->node_cnt[reg][0], nn) : 0u;
-        if (nr) atomicAdd(&P.ctr->ray_cnt[reg][0], nr); // statistic only
-    }
-    if (!P.explore) {
-        for (unsigned int r = wid; r < nr; r += MLM_BLOCK / 64) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
-    } else if (nr) {
-        // frontier mode needs each miss cell's insertion time, which depends on the FIRST point of a start cell; that
-        // is only known after k_assign_nodes, so the rays are queued and walked by k_ex_walk_rays
-        if (threadIdx.x == 0) s_nbase2 = atomicAdd(&P.ctr->n_ex_rays, nr);
-        __syncthreads();
-        for (unsigned int r = threadIdx.x; r < nr; r += blockDim.x) {
-            int32_t *q = P.ex_rays + 4 * (size_t)(s_nbase2 + r);
-            q[0] = s_ray[r][0];
-            q[1] = s_ray[r][1];
-            q[2] = s_ray[r][2];
-            q[3] = s_ray[r][3];
-        }
-    }
-    __syncthreads();
-    // ---- book the block's groups on their cells.  The groups are first merged per cell in an LDS table, so that a
-    //      cell costs three device-scope atomics per BLOCK (first-touch time min, kind mask or, count add -> position)
-    //      instead of three per (wave, kind) group.
     const int tile_w = (MODE == 0) ? F.width : 0;
+    auto late_ray = [&](uint32_t cell) { // a ray found outside phase C (rare path)
+        int z, ph, rh;
+        mlm_cell_rpz(P, cell, rh, ph, z);
+        queue_ray(rh, ph, z, -1);
+    };
     for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x) {
         const MlmNode nd = s_node[k];
         const int sub = (int)(nd.i00_sub >> 27);
@@ -338,50 +388,125 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_bin_points(MLM_SLOT_ARGS) {
             if (sub == 0) atomicMin(&s_agg[e].start_min, i_first);
             s_node[k].pad = e;
         } else { // table full (never seen): book the group on its own
-            atomicMin(&P.cs[nd.cell].t, t);
-            atomicOr(&P.cs[nd.cell].mask, 1u << sub);
-            const uint32_t pos = atomicAdd(&P.cs[nd.cell].cnt, cnt);
-            if (P.explore && sub == 0) atomicMin(&P.start_t[nd.cell], i_first);
+            g_atomic_min(&mlm_gp(P.cs)[nd.cell].t, t);
+            const uint32_t old = g_atomic_or(&mlm_gp(P.cs)[nd.cell].mask, 1u << sub);
+            const uint32_t pos = g_atomic_add(&mlm_gp(P.cs)[nd.cell].cnt, cnt);
+            if (P.explore && sub == 0) g_atomic_min(&mlm_gp(P.start_t)[nd.cell], i_first);
             s_node[k].pos = pos;
             s_node[k].pad = MLM_NIL;
             if (pos == 0) {
-                const unsigned int g = atomicAdd(&P.ctr->touch_cnt[reg][0], 1u);
-                if (g < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + g] = nd.cell;
+                const unsigned int g = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], 1u);
+                if (g < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + g] = nd.cell;
             }
+            if (sub == 0 && P.visibility && !(old & 1u)) late_ray(nd.cell);
         }
     }
+    MLM_PHASE(5);
     __syncthreads();
+    MLM_PHASE(6);
+    // ---- phase C: the block's only round trip to memory.  Per cell of the table: first-touch time, kind mask, count.
+    //      The returned count is the position of the block's contributions inside the cell's segment (0 = the cell's
+    //      first contributions of the frame: queue it for k_collect_hits); the returned mask tells whether this block
+    //      is the first of the frame to put a hit CENTRE into the cell — every point of one (rho,phi,z) cell casts the
+    //      identical ray (map_awareness.cpp:243-274), so exactly that block walks it.
+    //      (Waves that do not wait for each other here — per-wave reservations, or the bases published through an LDS
+    //      flag — were measured slower: 20.0 / 19.9 vs 19.3 us per frame.)
+    unsigned int node_base = 0;
+    if (threadIdx.x == 0) {
+        unsigned int pts = 0, oor = 0;
+        for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) {
+            pts += s_cnt[w] & 1023u;
+            oor += s_cnt[w] >> 10;
+        }
+        mlm_gp(P.blk_stats)[2 * blockIdx.x] = pts;
+        mlm_gp(P.blk_stats)[2 * blockIdx.x + 1] = oor;
+        if (nn) node_base = g_atomic_add(&mlm_gp(P.ctr)->node_cnt[reg][0], nn);
+    }
     for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
         const uint32_t cell = s_agg[e].cell;
         if (cell == MLM_NIL) continue;
-        atomicMin(&P.cs[cell].t, s_agg[e].tmin);
-        atomicOr(&P.cs[cell].mask, s_agg[e].kmask);
-        const uint32_t base = atomicAdd(&P.cs[cell].cnt, s_agg[e].cnt);
-        if (P.explore && s_agg[e].start_min != MLM_EMPTY_T) atomicMin(&P.start_t[cell], s_agg[e].start_min);
+        const uint32_t kmask = s_agg[e].kmask;
+        g_atomic_min(&mlm_gp(P.cs)[cell].t, s_agg[e].tmin);
+        const uint32_t old = g_atomic_or(&mlm_gp(P.cs)[cell].mask, kmask);
+        const uint32_t base = g_atomic_add(&mlm_gp(P.cs)[cell].cnt, s_agg[e].cnt);
+        if (P.explore && s_agg[e].start_min != MLM_EMPTY_T) g_atomic_min(&mlm_gp(P.start_t)[cell], s_agg[e].start_min);
         s_agg[e].base = base;
-        if (base == 0) s_touch[atomicAdd(&s_ntouch, 1u)] = cell; // first contributions of the cell this frame
+        if (base == 0) s_touch[atomicAdd(&s_ntouch, 1u)] = cell;
+        if (P.visibility && (kmask & 1u) && !(old & 1u)) { // walk the ray: flag the entry
+            s_agg[e].kmask = kmask | MLM_AGG_RAY;
+            s_agg[e].start_min = atomicAdd(&s_nflag, 1u); // explore mode: its place in the block's ray queue
+        }
     }
+    if (threadIdx.x == 0) s_nbase = node_base;
+    MLM_PHASE(7);
     __syncthreads();
+    MLM_PHASE(8);
+    // ---- phase D: flush.  Wave 0 reserves the block's part of the first-touch list (second round trip, hidden behind
+    //      the node flush and the ray walk) and writes it alone.
     const unsigned int nt = s_ntouch;
-    if (threadIdx.x == 0) s_tbase = nt ? atomicAdd(&P.ctr->touch_cnt[reg][0], nt) : 0u;
+    const unsigned int nr = min(s_nray, (unsigned int)MLM_RAY_LDS);
+    const unsigned int nf = s_nflag;
+    unsigned int touch_base = 0;
+    if (threadIdx.x == 0) {
+        if (nt) touch_base = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], nt);
+        if (nr + nf) {
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[reg][0], nr + nf); // statistic only
+            if (P.explore) s_nbase2 = g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, nr + nf);
+        }
+    }
     for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x) {
         MlmNode nd = s_node[k];
         if (nd.pad != MLM_NIL) nd.pos += s_agg[nd.pad].base;
         nd.pad = 0;
-        if (s_nbase + k < P.node_cap) P.nodes[(size_t)reg * P.node_cap + s_nbase + k] = nd;
+        if (s_nbase + k < P.node_cap) mlm_store_node(mlm_gp(P.nodes) + ((size_t)reg * P.node_cap + s_nbase + k), nd);
     }
-    __syncthreads();
-    for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
-        if (s_tbase + k < P.touch_cap) P.touched[(size_t)reg * P.touch_cap + s_tbase + k] = s_touch[k];
-}
-
-__device__ __forceinline__ uint32_t mlm_wave_incl_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
+    MLM_PHASE(9);
+    if (!P.explore) {
+        // one ray per wave at a time: the queued out-of-range starts, then the flagged cells of the table
+        for (unsigned int r = wid; r < nr; r += blockDim.x >> 6) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
+        if (nf)
+            for (unsigned int e0 = wid * 64; e0 < MLM_AGG_LDS; e0 += blockDim.x) {
+                const bool flagged = (s_agg[e0 + lane].kmask & MLM_AGG_RAY) != 0;
+                const uint32_t cell = s_agg[e0 + lane].cell;
+                unsigned long long todo = __ballot(flagged);
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    int z, ph, rh;
+                    mlm_cell_rpz(P, (uint32_t)__shfl((int)cell, src, 64), rh, ph, z);
+                    mlm_walk_ray_wave(P, rh, ph, z);
+                }
+            }
+    } else if (nr + nf) {
+        // frontier mode needs each miss cell's insertion time, which depends on the FIRST point of a start cell; that
+        // is only known after the whole frame was binned, so the rays are queued and walked by k_ex_walk_rays
+        __syncthreads(); // s_nbase2 (uniform branch)
+        for (unsigned int r = threadIdx.x; r < nr; r += blockDim.x) {
+            MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(s_nbase2 + r);
+            q[0] = s_ray[r][0];
+            q[1] = s_ray[r][1];
+            q[2] = s_ray[r][2];
+            q[3] = s_ray[r][3];
+        }
+        for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x)
+            if (s_agg[e].kmask & MLM_AGG_RAY) {
+                int z, ph, rh;
+                mlm_cell_rpz(P, s_agg[e].cell, rh, ph, z);
+                MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(s_nbase2 + nr + s_agg[e].start_min);
+                q[0] = rh;
+                q[1] = ph;
+                q[2] = z;
+                q[3] = -1; // in-range start: k_ex_walk_rays takes the cell's first point
+            }
     }
-    return v;
+    MLM_PHASE(10);
+    if (wid == 0 && nt) {
+        const unsigned int tb = (unsigned int)__shfl((int)touch_base, 0, 64);
+        for (unsigned int k = lane; k < nt; k += 64)
+            if (tb + k < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + tb + k] = s_touch[k];
+    }
+    MLM_PHASE(11);
+    MLM_PHASE_END
 }
 
 // odd of the contribution kind `sub` into a cell at rho_c (see the top of this section)
@@ -429,11 +554,25 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_assign_nodes(MLM_SLOT_ARGS, int t
             const uint32_t is = nd->i00_sub;
             const uint32_t t = ((is & 0x07FFFFFFu) + off) * MLM_TIME_SLOTS + (is >> 27);
             atomicMin(&P.cs[cell].t, t);
-            atomicOr(&P.cs[cell].mask, 1u << (is >> 27));
+            const uint32_t old = atomicOr(&P.cs[cell].mask, 1u << (is >> 27));
             if (P.explore && (is >> 27) == 0) atomicMin(&P.start_t[cell], (is & 0x07FFFFFFu) + off);
             const uint32_t pos = atomicAdd(&P.cs[cell].cnt, (unsigned int)__popcll(m));
             nd->pos = pos;
             first = pos == 0;
+            if ((is >> 27) == 0 && P.visibility && !(old & 1u)) { // first hit centre of the frame in this cell: its ray
+                int z, ph, rh;
+                mlm_cell_rpz(P, cell, rh, ph, z);
+                atomicAdd(&P.ctr->ray_cnt[reg][0], 1u);
+                if (!P.explore) {
+                    mlm_walk_ray_lane(P, rh, ph, z);
+                } else {
+                    int32_t *q = P.ex_rays + 4 * (size_t)atomicAdd(&P.ctr->n_ex_rays, 1u);
+                    q[0] = rh;
+                    q[1] = ph;
+                    q[2] = z;
+                    q[3] = -1;
+                }
+            }
         }
         const unsigned int at = mlm_block_append(P.ctr->touch_cnt, first, s_cnt, &s_base);
         if (first && at < P.touch_cap) P.touched[(size_t)(blockIdx.x & 7) * P.touch_cap + at] = cell;
@@ -508,10 +647,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
             P.cs[c].t = MLM_EMPTY_T;
             P.cs[c].mask = 0;
             P.cs[c].cnt = 0;
-            if (mask & 1u) {
-                atomicAnd(&P.start_bits[c >> 5], ~(1u << (c & 31))); // its ray was queued; reset for next frame
-                if (P.explore) P.start_t[c] = MLM_EMPTY_T; // (k_ex_walk_rays runs before this kernel)
-            }
+            if ((mask & 1u) && P.explore) P.start_t[c] = MLM_EMPTY_T; // (k_ex_walk_rays runs before this kernel)
             P.hl_cell[pos] = c;
             P.hl_t[pos] = t;
             P.hl_vt[pos] = t;

@@ -95,7 +95,6 @@ struct MlmDev {
     uint8_t *subs;             // [contrib_cap] per multi-kind cell: contribution kinds in insertion-time order
                                // (segments start 16-byte aligned; same offsets as `contrib`)
     unsigned int contrib_cap;
-    uint32_t *start_bits;      // [ceil(nCells/32)] hit-centre cells whose ray has been walked
     uint32_t *miss_bits;       // [nMissWords] free cells, row-major (z,phi) rows of RW words, bit = rho
     // ---- unique-hit list (capacity nCells)
     uint32_t *hl_cell;         // linear awareness cell idx
@@ -139,6 +138,7 @@ struct MlmDev {
     int explore;
     // LDS sizing of k_bin_points (host-chosen from the noise spread of the configuration)
     unsigned int node_lds, agg_lds, agg_shift, bin_lds_bytes;
+    unsigned int bin_block;    // threads per k_bin_points block: 256 (32x8 pixel strip) or 1024 (32x32 tile)
     uint8_t *frnt;             // [max_blocks*cells] 1 = the cell is in its block's frontier set
     uint8_t *blk_collapsed;    // [max_blocks] 1 = block was "released" (vectors resized to 1: frozen, element 0 answers)
     uint8_t *blk_observed;     // [max_blocks] observed_subboxes of the current frame

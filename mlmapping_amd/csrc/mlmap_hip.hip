@@ -168,7 +168,8 @@ struct mlm_handle {
     int set_pending[MLM_SETS] = {};
     bool async_mode = false;
     int cu_split = 0;
-    hipStream_t stream_a = nullptr;          // Stage A of whole batches (overlaps Stage B/C of the previous batch)
+    hipStream_t stream_as[MLM_SETS] = {};    // Stage A of whole batches, one stream per slot set (overlaps Stage B/C of the
+                                             // previous batch and the tails of the other set's Stage A kernels)
     hipEvent_t stage_a_done[MLM_SETS] = {};
     hipEvent_t set_free[MLM_SETS] = {}; // main stream finished reading the set's Stage A outputs
     MlmDev *d_slot_tab = nullptr;            // [2K] device copies of the slots' MlmDev
@@ -200,6 +201,12 @@ template <class T> int dev_alloc(mlm_handle *h, T **p, size_t n) {
     return MLM_OK;
 }
 inline unsigned int grid_for(size_t n) { return (unsigned int)((n + MLM_BLOCK - 1) / MLM_BLOCK); }
+// blocks of k_bin_points for one frame (tile geometry: mlm_tile_item)
+inline unsigned int bin_grid(const MlmDev &P, const MlmFrame &F, int mode) {
+    const int tile_h = (int)(P.bin_block / 256) * 8;
+    if (mode == 0) return (unsigned int)(((F.width + 31) / 32) * ((F.height + tile_h - 1) / tile_h));
+    return (unsigned int)(((size_t)F.n + P.bin_block - 1) / P.bin_block);
+}
 constexpr unsigned int kListGrid = 256; // blocks of the grid-stride kernels that walk a device-sized list
 
 struct Timed {
@@ -331,8 +338,8 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     const MlmDev &P = S0.P;
     const MlmFrame &F = S0.F;
     const int mode = S0.mode;
-    hipStream_t st = h->stream_a;
     const int set = base / ((int)h->slots.size() / MLM_SETS);
+    hipStream_t st = h->stream_as[set];
     // the previous user of this slot set must have been consumed by the main stream
     HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
     for (int j = 0; j < n; ++j) h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
@@ -341,18 +348,18 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));
     unsigned int nb = 0;
     if (F.n > 0) {
-        nb = (mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
+        nb = bin_grid(P, F, mode);
         if (nb > (unsigned int)h->lim.max_points / 64 + 1024) {
             h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
             return MLM_ERR_CAPACITY;
         }
         Timed t(h, st, "k_bin_points");
         if (mode == 0)
-            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, n), dim3(MLM_BLOCK), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
         else if (mode == 1)
-            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, n), dim3(MLM_BLOCK), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
         else
-            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(MLM_BLOCK), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     {
         Timed t(h, st, "k_assign_nodes");
@@ -495,17 +502,17 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     unsigned int nb = 0;
     const dim3 blk(MLM_BLOCK);
     if (F.n > 0) {
-        nb = (S.mode == 0) ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : grid_for((size_t)F.n);
+        nb = bin_grid(P, F, S.mode);
         if (nb > (unsigned int)h->lim.max_points / 64 + 1024) {
             h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
             return MLM_ERR_CAPACITY;
         }
         if (S.mode == 0)
-            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, 1), blk, P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
         else if (S.mode == 1)
-            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, 1), blk, P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
         else
-            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), blk, P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     }
     const int tile_w = S.mode == 0 ? F.width : 0;
     hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
@@ -747,7 +754,6 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     S.h_ctr = h->h_ctr_all + index;
     P.ctr = h->d_ctr_all + index;
     if ((rc = dev_alloc(h, &P.cs, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.start_bits, (NC + 31) / 32))) return rc;
     if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
     if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
     if ((rc = dev_alloc(h, &P.mt_big, NC))) return rc;
@@ -819,7 +825,6 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         std::vector<MlmCell> init(NC, MlmCell{MLM_EMPTY_T, 0u, 0u, MLM_NIL});
         HIPCHK(h, hipMemcpy(P.cs, init.data(), NC * sizeof(MlmCell), hipMemcpyHostToDevice));
     }
-    HIPCHK(h, hipMemset(P.start_bits, 0, (NC + 31) / 32 * sizeof(uint32_t)));
     HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
     if ((rc = ensure_img(h, S, (size_t)h->lim.max_points))) return rc;
     if ((rc = dev_alloc(h, &S.d_pix, (size_t)h->lim.max_points))) return rc;
@@ -959,11 +964,23 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             P.node_lds = 1024;
             P.agg_lds = 512;
         }
+        // block size of k_bin_points and its LDS buffers (the sizes above are per 256 threads); experiment knobs
+        P.bin_block = 256;
+        if (const char *e = getenv("MLM_BIN_BLOCK")) P.bin_block = (atoi(e) >= 1024) ? 1024u : (atoi(e) >= 512 ? 512u : 256u);
+        P.node_lds = P.node_lds * (P.bin_block / 256);
+        P.agg_lds = P.agg_lds * (P.bin_block / 256);
+        if (const char *e = getenv("MLM_NODE_LDS")) P.node_lds = (unsigned int)atoi(e);
+        if (const char *e = getenv("MLM_AGG_LDS")) P.agg_lds = (unsigned int)atoi(e); // power of two >= bin_block
         unsigned int lg = 0;
         while ((1u << lg) < P.agg_lds) ++lg;
         P.agg_shift = 32 - lg;
         P.bin_lds_bytes = P.node_lds * (unsigned int)sizeof(MlmNode) + P.agg_lds * (unsigned int)(sizeof(MlmCellAgg) + 4) +
                           MLM_RAY_LDS * 16;
+        if (P.bin_lds_bytes > 48 * 1024) { // above the default dynamic-LDS limit
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_bin_points<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bin_lds_bytes));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_bin_points<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bin_lds_bytes));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_bin_points<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bin_lds_bytes));
+        }
     }
     std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
     for (int p = 0; p < P.nPhi; ++p) {
@@ -1064,9 +1081,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         const int ncu = prop.multiProcessorCount;
         std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
         for (int c = h->cu_split; c < ncu; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
-        HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream_a, (uint32_t)mask.size(), mask.data()));
+        for (int k = 0; k < MLM_SETS; ++k)
+            HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream_as[k], (uint32_t)mask.size(), mask.data()));
     } else {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->stream_a, hipStreamNonBlocking));
+        for (int k = 0; k < MLM_SETS; ++k) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_as[k], hipStreamNonBlocking));
     }
     for (int k = 0; k < MLM_SETS; ++k) {
         HIPCHK(h, hipEventCreateWithFlags(&h->stage_a_done[k], hipEventDisableTiming));
@@ -1100,7 +1118,8 @@ int mlm_destroy(mlm_handle *h) {
         if (h->stage_a_done[k]) hipEventDestroy(h->stage_a_done[k]);
         if (h->set_free[k]) hipEventDestroy(h->set_free[k]);
     }
-    if (h->stream_a) hipStreamDestroy(h->stream_a);
+    for (int k = 0; k < MLM_SETS; ++k)
+        if (h->stream_as[k]) hipStreamDestroy(h->stream_as[k]);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     if (h->h_g) hipHostFree(h->h_g);
@@ -1173,7 +1192,7 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
             int rc = ensure_img(h, S, n_px);
             if (rc) return rc;
             HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t),
-                                     hipMemcpyHostToDevice, h->stream_a));
+                                     hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
             S.F = MlmFrame{};
             frame_setup(h, q_wb + 4 * (size_t)(k0 + j), t_wb + 3 * (size_t)(k0 + j), S.F);
             S.F.img = S.d_img;
@@ -1220,10 +1239,10 @@ int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int h
     const size_t n_px = (size_t)row_stride * height;
     int rc = ensure_img(h, S, n_px);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_a));
+    HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
     if (pixel_idx) {
         if (n_idx < 0 || n_idx > h->lim.max_points) return MLM_ERR_CAPACITY;
-        HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_a));
+        HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
     }
     return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, row_stride, pixel_idx ? S.d_pix : nullptr, n_idx, q_wb,
                                        t_wb);
@@ -1293,22 +1312,22 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
     if (is_f32) {
         float *d_f = nullptr;
         HIPCHK(h, hipMalloc((void **)&d_f, n_px * sizeof(float)));
-        hipError_t e = hipMemcpyAsync(d_f, depth, n_px * sizeof(float), hipMemcpyHostToDevice, h->stream_a);
+        hipError_t e = hipMemcpyAsync(d_f, depth, n_px * sizeof(float), hipMemcpyHostToDevice, h->stream_as[h->cur_set]);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_convert_f32_u16, dim3(grid_for(n_px)), dim3(MLM_BLOCK), 0, h->stream_a, d_f, S.d_img, n_px);
+            hipLaunchKernelGGL(k_convert_f32_u16, dim3(grid_for(n_px)), dim3(MLM_BLOCK), 0, h->stream_as[h->cur_set], d_f, S.d_img, n_px);
             if (sampled) {
                 host_u16.resize(n_px);
-                e = hipMemcpyAsync(host_u16.data(), S.d_img, n_px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream_a);
+                e = hipMemcpyAsync(host_u16.data(), S.d_img, n_px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream_as[h->cur_set]);
             }
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream_a);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream_as[h->cur_set]);
         hipFree(d_f);
         if (e != hipSuccess) {
             h->err = std::string("mlm_integrate_callback: ") + hipGetErrorString(e);
             return MLM_ERR_HIP;
         }
     } else {
-        HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_a));
+        HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
     }
     std::vector<int32_t> pix;
     if (sampled) {
@@ -1325,8 +1344,8 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
             pix.push_back((int32_t)(v * (size_t)width + u));
         }
         if (!pix.empty())
-            HIPCHK(h, hipMemcpyAsync(S.d_pix, pix.data(), pix.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_a));
-        HIPCHK(h, hipStreamSynchronize(h->stream_a)); // pix is a local
+            HIPCHK(h, hipMemcpyAsync(S.d_pix, pix.data(), pix.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
+        HIPCHK(h, hipStreamSynchronize(h->stream_as[h->cur_set])); // pix is a local
     }
     return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, width, sampled ? S.d_pix : nullptr, (int)pix.size(), qa, ta);
 }
@@ -1339,7 +1358,7 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
     }
     HIPCHK(h, hipSetDevice(h->device));
     MlmSlot &S = cur_slot(h, 0);
-    if (n > 0) HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream_a));
+    if (n > 0) HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
     S.F = MlmFrame{};
     frame_setup(h, q_wb, t_wb, S.F);
     S.F.pts = S.d_pts;
@@ -1625,3 +1644,16 @@ int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, 
 }
 
 } // extern "C"
+
+#ifdef MLM_PHASE_PROF
+// diagnostic build only: sum over blocks and clear the per-phase cycle counts of k_bin_points
+extern "C" int mlm_debug_phases(unsigned long long *out16) {
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> v((size_t)MLM_PHASE_BLOCKS * 16);
+    if (hipMemcpyFromSymbol(v.data(), HIP_SYMBOL(g_mlm_phase), v.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+    for (int k = 0; k < 16; ++k) out16[k] = 0;
+    for (size_t i = 0; i < v.size(); ++i) out16[i & 15] += v[i];
+    std::fill(v.begin(), v.end(), 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mlm_phase), v.data(), v.size() * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

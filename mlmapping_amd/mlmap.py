@@ -19,7 +19,7 @@ import numpy as np
 from .config import CConfig, MapConfig, to_c
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmlmap_hip.so")
+LIB_PATH = os.environ.get("MLMAP_HIP_LIB") or os.path.join(_HERE, "lib", "libmlmap_hip.so")  # env: development builds
 
 MLM_OK = 0
 STATUS = {0: "MLM_OK", -1: "MLM_ERR_INVALID", -2: "MLM_ERR_HIP", -3: "MLM_ERR_CAPACITY", -4: "MLM_ERR_UNSUPPORTED"}
