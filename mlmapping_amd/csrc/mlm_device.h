@@ -27,6 +27,10 @@ template <class T> __device__ __forceinline__ T g_atomic_add(MLM_GLOBAL T *p, T 
 template <class T> __device__ __forceinline__ T g_atomic_min(MLM_GLOBAL T *p, T v) {
     return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Broadcast of one lane's value when the source lane is wave-uniform: v_readlane_b32 (the general __shfl is a
+// ds_bpermute_b32, i.e. an LDS round trip per call).
+__device__ __forceinline__ int mlm_readlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ uint32_t mlm_readlane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 typedef unsigned int mlm_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int mlm_u32x2 __attribute__((ext_vector_type(2)));
 
@@ -217,7 +221,7 @@ __device__ __forceinline__ unsigned int mlm_wave_append(unsigned int *counter, b
     const int leader = __ffsll((long long)mask) - 1;
     unsigned int base = 0;
     if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
-    base = __shfl(base, leader, 64);
+    base = mlm_readlane(base, leader);
     return base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
 }
 

@@ -37,7 +37,7 @@ template <class F> __device__ __forceinline__ void mlm_wave_groups(int key, bool
     const int lane = threadIdx.x & 63;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(key, leader, 64);
+        const int k = mlm_readlane(key, leader);
         const unsigned long long m = __ballot(valid && key == k);
         if (lane == leader) f(k, m);
         todo &= ~m;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     }
     MLM_PHASE(1);
     // work item of lane 0 of this wave (see MlmNode)
-    const uint32_t i00 = (uint32_t)__shfl(i, 0, 64);
+    const uint32_t i00 = (uint32_t)mlm_readlane(i, 0);
 
     // queue a ray for phase D; if the LDS queue is full (rare) walk it on the spot / hand it to k_ex_walk_rays directly
     auto queue_ray = [&](int rh, int ph, int z, int pt) {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
         unsigned long long todo = __ballot(outer);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
-            const int kr = __shfl(rho, leader, 64), kp = __shfl(phi, leader, 64), kz = __shfl(zi, leader, 64);
+            const int kr = mlm_readlane(rho, leader), kp = mlm_readlane(phi, leader), kz = mlm_readlane(zi, leader);
             const unsigned long long m = __ballot(outer && rho == kr && phi == kp && zi == kz);
             if (lane == leader) emit_ray = true;
             todo &= ~m;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
                     const int src = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
                     int z, ph, rh;
-                    mlm_cell_rpz(P, (uint32_t)__shfl((int)cell, src, 64), rh, ph, z);
+                    mlm_cell_rpz(P, mlm_readlane(cell, src), rh, ph, z);
                     mlm_walk_ray_wave(P, rh, ph, z);
                 }
             }
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     }
     MLM_PHASE(10);
     if (wid == 0 && nt) {
-        const unsigned int tb = (unsigned int)__shfl((int)touch_base, 0, 64);
+        const unsigned int tb = mlm_readlane(touch_base, 0);
         for (unsigned int k = lane; k < nt; k += 64)
             if (tb + k < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + tb + k] = s_touch[k];
     }
@@ -697,9 +697,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int t
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const uint32_t b = __shfl(base, src, 64), pos = __shfl(nd.pos, src, 64), is = __shfl(nd.i00_sub, src, 64);
-            const unsigned long long m = ((unsigned long long)__shfl((uint32_t)(nd.mask >> 32), src, 64) << 32) |
-                                         (unsigned long long)__shfl((uint32_t)nd.mask, src, 64);
+            const uint32_t b = mlm_readlane(base, src), pos = mlm_readlane(nd.pos, src), is = mlm_readlane(nd.i00_sub, src);
+            const unsigned long long m = ((unsigned long long)mlm_readlane((uint32_t)(nd.mask >> 32), src) << 32) |
+                                         (unsigned long long)mlm_readlane((uint32_t)nd.mask, src);
             if ((m >> lane) & 1ull) {
                 const uint32_t key = ((is & 0x07FFFFFFu) + lane_off) * MLM_TIME_SLOTS + (is >> 27);
                 const uint32_t at = b + pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -914,13 +914,13 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_time_keys(const MlmDev P, unsigne
 // Stage C
 // ---------------------------------------------------------------------------------------------------------------
 // Last Stage A kernel (batched): everything about Stage C that does not depend on the map — the world voxel
-// (packed block key + cell id) of every unique hit cell and of every unique miss cell.  blockIdx.y == 0: one unique
-// hit per lane.  blockIdx.y == 1: one bit of the miss mask per lane -> compact miss-cell list; clears the mask.
+// (packed block key + cell id) of every unique hit cell and of every unique miss cell, and a speculative lookup of the
+// block's pool slot.  Hits: one per lane.  Misses: a wave takes 64 words of the miss mask (one per lane), reserves room
+// for all their set bits with one atomic, then expands the non-zero words two at a time (lane = bit); the mask is
+// cleared on the way.  No block barriers.
 __global__ __launch_bounds__(MLM_BLOCK) void k_prepare_voxels(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
-    __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
-    __shared__ unsigned int s_base;
-    if (blockIdx.y == 0) {
+    {
         const unsigned int n = P.ctr->u_hit;
         for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
             int rho, phi, z;
@@ -936,42 +936,63 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_prepare_voxels(MLM_SLOT_ARGS) {
             // exist yet (or is being inserted by an earlier frame's Stage C right now) is resolved by k_voxelize
             P.hl_slot[i] = mlm_block_find_k(P, bkey);
         }
-        return;
     }
-    const long long total = (long long)P.nMissWords * 32;
-    for (long long g0 = (long long)blockIdx.x * blockDim.x; g0 < total; g0 += (long long)gridDim.x * blockDim.x) {
-        const long long g = g0 + threadIdx.x;
-        const int w = (int)(g >> 5), b = (int)(g & 31);
+    if (P.explore) return; // frontier mode keeps insertion times instead of a bit mask (k_ex_collect_misses)
+    const int lane = threadIdx.x & 63;
+    const unsigned int sl = blockIdx.x & 7;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int half = lane >> 5, b = lane & 31;
+    for (unsigned int w0 = wave * 64; w0 < (unsigned int)P.nMissWords; w0 += n_waves * 64) {
+        const unsigned int w = w0 + lane;
         uint32_t bits = 0;
-        if (w < P.nMissWords) bits = P.miss_bits[w];
-        const bool set = (bits >> b) & 1u;
-        unsigned long long bkey = 0;
-        uint32_t cid = 0;
-        if (set) {
-            const int row = w / P.RW;
-            const int wi = w - row * P.RW;
-            const int z = row / P.nPhi;
-            const int phi = row - z * P.nPhi;
-            const int rho = wi * 32 + b;
-            double wx, wy, wz;
-            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-            int gx, gy, gz, c;
-            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, c);
-            bkey = mlm_pack_key(gx, gy, gz);
-            cid = (uint32_t)c;
-            if (P.record_awareness) {
-                const unsigned int pos = atomicAdd(&P.ctr->n_miss_list, 1u);
-                P.ml_cell[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+        if (w < (unsigned int)P.nMissWords) bits = P.miss_bits[w];
+        unsigned long long nz = __ballot(bits != 0);
+        if (!nz) continue;
+        if (bits) P.miss_bits[w] = 0;
+        const uint32_t cnt = (uint32_t)__popc(bits);
+        const uint32_t incl = mlm_wave_incl_scan(cnt);
+        const uint32_t total = mlm_readlane(incl, 63);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&P.ctr->mc_cnt[sl][0], total);
+        base = mlm_readlane(base, 0);
+        const uint32_t excl = incl - cnt;
+        while (nz) {
+            const int sa = __ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+            int sb = sa;
+            uint32_t bits_b = 0;
+            if (nz) {
+                sb = __ffsll((long long)nz) - 1;
+                nz &= nz - 1;
+                bits_b = mlm_readlane(bits, sb);
+            }
+            const uint32_t my_bits = half ? bits_b : mlm_readlane(bits, sa);
+            const uint32_t my_off = half ? mlm_readlane(excl, sb) : mlm_readlane(excl, sa);
+            const int wi_all = (int)w0 + (half ? sb : sa);
+            if ((my_bits >> b) & 1u) {
+                const int row = wi_all / P.RW;
+                const int wi = wi_all - row * P.RW;
+                const int z = row / P.nPhi;
+                const int phi = row - z * P.nPhi;
+                const int rho = wi * 32 + b;
+                double wx, wy, wz;
+                mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+                int gx, gy, gz, c;
+                mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, c);
+                const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+                if (P.record_awareness) {
+                    const unsigned int p2 = atomicAdd(&P.ctr->n_miss_list, 1u);
+                    P.ml_cell[p2] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+                }
+                const uint32_t pos = base + my_off + (uint32_t)__popc(my_bits & ((1u << b) - 1u));
+                if (pos < P.mc_cap) {
+                    P.mc_bkey[(size_t)sl * P.mc_cap + pos] = bkey;
+                    P.mc_cid[(size_t)sl * P.mc_cap + pos] = (uint32_t)c;
+                    P.mc_slot[(size_t)sl * P.mc_cap + pos] = mlm_block_find_k(P, bkey);
+                }
             }
         }
-        if (b == 0 && bits) P.miss_bits[w] = 0; // all 32 lanes of the word loaded it in the instruction above
-        const unsigned int pos = mlm_block_append(P.ctr->mc_cnt, set, s_cnt, &s_base);
-        if (set && pos < P.mc_cap) {
-            P.mc_bkey[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = bkey;
-            P.mc_cid[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = cid;
-            P.mc_slot[(size_t)(blockIdx.x & 7) * P.mc_cap + pos] = mlm_block_find_k(P, bkey);
-        }
-        __syncthreads();
     }
 }
 

@@ -391,8 +391,9 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     }
     {
         Timed t(h, st, "k_prepare_voxels");
-        const unsigned int pb = std::min<unsigned int>(grid_for((size_t)P.nMissWords * 32), n > 4 ? 1024u : 4096u);
-        hipLaunchKernelGGL(k_prepare_voxels, dim3(pb, 2, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        // one 256-word slice of the miss mask per block (the unique hits, far fewer, are strided over the same blocks)
+        const unsigned int pb = std::max(64u, grid_for((size_t)P.nMissWords));
+        hipLaunchKernelGGL(k_prepare_voxels, dim3(pb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
