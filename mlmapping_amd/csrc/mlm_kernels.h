@@ -147,14 +147,13 @@ __device__ __forceinline__ bool mlm_spread_active(const MlmDev &P, int rho, int 
 
 // MlmDev::node_lds contribution nodes are buffered per k_bin_points block; MlmDev::agg_lds (a power of two) entries of
 // a block-local table merge the block's groups per awareness cell
-#define MLM_AGG_RAY 0x80000000u // MlmCellAgg::kmask: this block walks the ray that starts in the cell
 struct MlmCellAgg {
     uint32_t cell;      // MLM_NIL = empty
     uint32_t tmin;      // earliest insertion time of the block's contributions to the cell
     uint32_t kmask;     // kinds
     uint32_t cnt;       // contributions
-    uint32_t base;      // position of the block's first contribution inside the cell's segment
-    uint32_t start_min; // explore mode: first point whose hit centre is the cell; after phase C: ray queue index
+    uint32_t idx;       // dense index of the entry inside the block = its slot in the block's slice of MlmDev::pairs
+    uint32_t start_min; // explore mode: first point whose hit centre is the cell
 };
 
 // MODE 0: dense depth image, 1: indexed depth pixels, 2: explicit sensor-frame points
@@ -208,20 +207,18 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_PHASE_BEGIN
     __shared__ unsigned int s_cnt[16];
     __shared__ unsigned int s_nray;
-    __shared__ unsigned int s_nnode, s_nbase, s_nbase2, s_ntouch, s_nflag;
+    __shared__ unsigned int s_nnode, s_na, s_nbase2;
     // dynamic LDS, sized by the host from the configuration (how many kinds a point can spread into):
-    // [node_lds nodes][agg_lds cell aggregates][agg_lds first-touched cells][MLM_RAY_LDS rays]
+    // [node_lds nodes][agg_lds cell aggregates][MLM_RAY_LDS rays]
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const unsigned int MLM_NODE_LDS = P.node_lds, MLM_AGG_LDS = P.agg_lds;
     MlmNode *s_node = (MlmNode *)s_dyn;
     MlmCellAgg *s_agg = (MlmCellAgg *)(s_node + MLM_NODE_LDS);
-    uint32_t *s_touch = (uint32_t *)(s_agg + MLM_AGG_LDS);
-    int(*s_ray)[4] = (int(*)[4])(s_touch + MLM_AGG_LDS);
+    int(*s_ray)[4] = (int(*)[4])(s_agg + MLM_AGG_LDS);
     if (threadIdx.x == 0) {
         s_nnode = 0;
         s_nray = 0;
-        s_ntouch = 0;
-        s_nflag = 0;
+        s_na = 0;
     }
     for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
         s_agg[e].cell = MLM_NIL;
@@ -316,7 +313,7 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
             } else { // LDS buffer full: store the node directly; k_assign_nodes books it (and walks its ray)
                 const unsigned int reg = blockIdx.x & 7;
                 const unsigned int g = g_atomic_add(&mlm_gp(P.ctr)->node_cnt[reg][0], 1u);
-                nd.pad = 1;
+                nd.pad = MLM_NIL;
                 if (g < P.node_cap) mlm_store_node(mlm_gp(P.nodes) + ((size_t)reg * P.node_cap + g), nd);
                 g_atomic_add(&mlm_gp(P.ctr)->n_unassigned, 1u);
             }
@@ -375,6 +372,7 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
         bool placed = false;
         for (unsigned int probe = 0; probe < MLM_AGG_LDS; ++probe) {
             const uint32_t prev = atomicCAS(&s_agg[e].cell, MLM_NIL, nd.cell);
+            if (prev == MLM_NIL) s_agg[e].idx = atomicAdd(&s_na, 1u); // claimed a new entry
             if (prev == MLM_NIL || prev == nd.cell) {
                 placed = true;
                 break;
@@ -404,107 +402,60 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_PHASE(5);
     __syncthreads();
     MLM_PHASE(6);
-    // ---- phase C: the block's only round trip to memory.  Per cell of the table: first-touch time, kind mask, count.
-    //      The returned count is the position of the block's contributions inside the cell's segment (0 = the cell's
-    //      first contributions of the frame: queue it for k_collect_hits); the returned mask tells whether this block
-    //      is the first of the frame to put a hit CENTRE into the cell — every point of one (rho,phi,z) cell casts the
-    //      identical ray (map_awareness.cpp:243-274), so exactly that block walks it.
-    //      (Waves that do not wait for each other here — per-wave reservations, or the bases published through an LDS
-    //      flag — were measured slower: 20.0 / 19.9 vs 19.3 us per frame.)
-    unsigned int node_base = 0;
+    // ---- phase C: write-out into the block's own slices of `bnodes` and `pairs`: plain stores, no atomics, no round
+    //      trip to memory.  The (block, cell) pairs are booked on their cells by k_book_cells, where the wait for the
+    //      returned counts does not hold this block's LDS and wave slots (measured: 18.8 -> see DESIGN.md).
+    const unsigned int na = s_na;
+    const unsigned int nr = min(s_nray, (unsigned int)MLM_RAY_LDS);
     if (threadIdx.x == 0) {
         unsigned int pts = 0, oor = 0;
         for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) {
             pts += s_cnt[w] & 1023u;
             oor += s_cnt[w] >> 10;
         }
-        mlm_gp(P.blk_stats)[2 * blockIdx.x] = pts;
-        mlm_gp(P.blk_stats)[2 * blockIdx.x + 1] = oor;
-        if (nn) node_base = g_atomic_add(&mlm_gp(P.ctr)->node_cnt[reg][0], nn);
-    }
-    for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
-        const uint32_t cell = s_agg[e].cell;
-        if (cell == MLM_NIL) continue;
-        const uint32_t kmask = s_agg[e].kmask;
-        g_atomic_min(&mlm_gp(P.cs)[cell].t, s_agg[e].tmin);
-        const uint32_t old = g_atomic_or(&mlm_gp(P.cs)[cell].mask, kmask);
-        const uint32_t base = g_atomic_add(&mlm_gp(P.cs)[cell].cnt, s_agg[e].cnt);
-        if (P.explore && s_agg[e].start_min != MLM_EMPTY_T) g_atomic_min(&mlm_gp(P.start_t)[cell], s_agg[e].start_min);
-        s_agg[e].base = base;
-        if (base == 0) s_touch[atomicAdd(&s_ntouch, 1u)] = cell;
-        if (P.visibility && (kmask & 1u) && !(old & 1u)) { // walk the ray: flag the entry
-            s_agg[e].kmask = kmask | MLM_AGG_RAY;
-            s_agg[e].start_min = atomicAdd(&s_nflag, 1u); // explore mode: its place in the block's ray queue
+        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)blockIdx.x) = mlm_u32x4{pts, oor, nn, na};
+        if (nr) {
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[reg][0], nr); // statistic only
+            if (P.explore) s_nbase2 = g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, nr);
         }
     }
-    if (threadIdx.x == 0) s_nbase = node_base;
-    MLM_PHASE(7);
-    __syncthreads();
-    MLM_PHASE(8);
-    // ---- phase D: flush.  Wave 0 reserves the block's part of the first-touch list (second round trip, hidden behind
-    //      the node flush and the ray walk) and writes it alone.
-    const unsigned int nt = s_ntouch;
-    const unsigned int nr = min(s_nray, (unsigned int)MLM_RAY_LDS);
-    const unsigned int nf = s_nflag;
-    unsigned int touch_base = 0;
-    if (threadIdx.x == 0) {
-        if (nt) touch_base = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], nt);
-        if (nr + nf) {
-            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[reg][0], nr + nf); // statistic only
-            if (P.explore) s_nbase2 = g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, nr + nf);
+    {
+        MLM_GLOBAL MlmNode *out = mlm_gp(P.bnodes) + (size_t)blockIdx.x * MLM_NODE_LDS;
+        const uint32_t pair0 = blockIdx.x * MLM_AGG_LDS;
+        for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x) {
+            MlmNode nd = s_node[k];
+            if (nd.pad != MLM_NIL) nd.pad = pair0 + s_agg[nd.pad].idx;
+            mlm_store_node(out + k, nd);
         }
-    }
-    for (unsigned int k = threadIdx.x; k < nn; k += blockDim.x) {
-        MlmNode nd = s_node[k];
-        if (nd.pad != MLM_NIL) nd.pos += s_agg[nd.pad].base;
-        nd.pad = 0;
-        if (s_nbase + k < P.node_cap) mlm_store_node(mlm_gp(P.nodes) + ((size_t)reg * P.node_cap + s_nbase + k), nd);
+        MLM_GLOBAL uint32_t *pr = (MLM_GLOBAL uint32_t *)(mlm_gp(P.pairs) + (size_t)pair0);
+        for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x) {
+            const uint32_t cell = s_agg[e].cell;
+            if (cell == MLM_NIL) continue;
+            MLM_GLOBAL uint32_t *d = pr + 6 * (size_t)s_agg[e].idx;
+            *(MLM_GLOBAL mlm_u32x2 *)(d + 0) = mlm_u32x2{cell, s_agg[e].tmin};
+            *(MLM_GLOBAL mlm_u32x2 *)(d + 2) = mlm_u32x2{s_agg[e].kmask, s_agg[e].cnt};
+            *(MLM_GLOBAL mlm_u32x2 *)(d + 4) = mlm_u32x2{s_agg[e].start_min, 0u};
+        }
     }
     MLM_PHASE(9);
-    if (!P.explore) {
-        // one ray per wave at a time: the queued out-of-range starts, then the flagged cells of the table
-        for (unsigned int r = wid; r < nr; r += blockDim.x >> 6) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
-        if (nf)
-            for (unsigned int e0 = wid * 64; e0 < MLM_AGG_LDS; e0 += blockDim.x) {
-                const bool flagged = (s_agg[e0 + lane].kmask & MLM_AGG_RAY) != 0;
-                const uint32_t cell = s_agg[e0 + lane].cell;
-                unsigned long long todo = __ballot(flagged);
-                while (todo) {
-                    const int src = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    int z, ph, rh;
-                    mlm_cell_rpz(P, mlm_readlane(cell, src), rh, ph, z);
-                    mlm_walk_ray_wave(P, rh, ph, z);
-                }
+    // ---- the queued rays (starts outside the map, rare late rays): one ray per wave at a time
+    if (nr) {
+        if (!P.explore) {
+            for (unsigned int r = wid; r < nr; r += blockDim.x >> 6) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
+        } else {
+            // frontier mode needs each miss cell's insertion time, which depends on the FIRST point of a start cell;
+            // that is only known after the whole frame was binned: k_ex_walk_rays walks the queued rays
+            __syncthreads(); // s_nbase2 (uniform branch)
+            for (unsigned int r = threadIdx.x; r < nr; r += blockDim.x) {
+                MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(s_nbase2 + r);
+                q[0] = s_ray[r][0];
+                q[1] = s_ray[r][1];
+                q[2] = s_ray[r][2];
+                q[3] = s_ray[r][3];
             }
-    } else if (nr + nf) {
-        // frontier mode needs each miss cell's insertion time, which depends on the FIRST point of a start cell; that
-        // is only known after the whole frame was binned, so the rays are queued and walked by k_ex_walk_rays
-        __syncthreads(); // s_nbase2 (uniform branch)
-        for (unsigned int r = threadIdx.x; r < nr; r += blockDim.x) {
-            MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(s_nbase2 + r);
-            q[0] = s_ray[r][0];
-            q[1] = s_ray[r][1];
-            q[2] = s_ray[r][2];
-            q[3] = s_ray[r][3];
         }
-        for (unsigned int e = threadIdx.x; e < MLM_AGG_LDS; e += blockDim.x)
-            if (s_agg[e].kmask & MLM_AGG_RAY) {
-                int z, ph, rh;
-                mlm_cell_rpz(P, s_agg[e].cell, rh, ph, z);
-                MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(s_nbase2 + nr + s_agg[e].start_min);
-                q[0] = rh;
-                q[1] = ph;
-                q[2] = z;
-                q[3] = -1; // in-range start: k_ex_walk_rays takes the cell's first point
-            }
     }
     MLM_PHASE(10);
-    if (wid == 0 && nt) {
-        const unsigned int tb = mlm_readlane(touch_base, 0);
-        for (unsigned int k = lane; k < nt; k += 64)
-            if (tb + k < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + tb + k] = s_touch[k];
-    }
     MLM_PHASE(11);
     MLM_PHASE_END
 }
@@ -530,6 +481,77 @@ __device__ __forceinline__ float mlm_logit(float p) {
     return (float)log10((double)ratio);
 }
 
+// One wave per k_bin_points block: book the block's (block, cell) pairs on their cells.  Per pair three device-scope
+// atomics: first-touch time (min), kind mask (or), contribution count (add).  The returned count is the position of the
+// block's contributions inside the cell's segment (0 = the cell's first contributions of the frame: queue the cell for
+// k_collect_hits); the returned mask tells whether this block is the first of the frame to put a hit CENTRE into the
+// cell — every point of one (rho,phi,z) cell casts the identical ray (map_awareness.cpp:243-274), so exactly that
+// wave walks it.  The wave holds no LDS and few registers while it waits for the round trip.
+__global__ __launch_bounds__(64) void k_book_cells(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
+    const unsigned int b = blockIdx.x, reg = blockIdx.x & 7;
+    const int lane = threadIdx.x;
+    const unsigned int na = min(mlm_gp(P.blk_stats)[4 * (size_t)b + 3], P.agg_lds);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (unsigned int e0 = 0; e0 < na; e0 += 64) {
+        const unsigned int e = e0 + lane;
+        const bool valid = e < na;
+        MLM_GLOBAL uint32_t *d = (MLM_GLOBAL uint32_t *)(mlm_gp(P.pairs) + ((size_t)b * P.agg_lds + e));
+        uint32_t cell = 0, kmask = 0, old = 0, base = 0;
+        if (valid) {
+            const mlm_u32x2 a = *(MLM_GLOBAL mlm_u32x2 *)(d + 0), m = *(MLM_GLOBAL mlm_u32x2 *)(d + 2);
+            const uint32_t start_min = d[4];
+            cell = a.x;
+            kmask = m.x;
+            g_atomic_min(&mlm_gp(P.cs)[cell].t, a.y);
+            old = g_atomic_or(&mlm_gp(P.cs)[cell].mask, kmask);
+            base = g_atomic_add(&mlm_gp(P.cs)[cell].cnt, m.y);
+            if (P.explore && start_min != MLM_EMPTY_T) g_atomic_min(&mlm_gp(P.start_t)[cell], start_min);
+            d[5] = base;
+        }
+        const bool first = valid && base == 0;
+        const bool cast = valid && P.visibility && (kmask & 1u) && !(old & 1u);
+        const unsigned long long bf = __ballot(first), bc = __ballot(cast);
+        unsigned int touch_base = 0, ray_base = 0;
+        if (lane == 0) { // second round trip, hidden behind the ray walk
+            if (bf) touch_base = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], (unsigned int)__popcll(bf));
+            if (bc) {
+                g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[reg][0], (unsigned int)__popcll(bc)); // statistic only
+                if (P.explore) ray_base = g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, (unsigned int)__popcll(bc));
+            }
+        }
+        if (bc) {
+            if (!P.explore) {
+                unsigned long long todo = bc;
+                while (todo) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    int z, ph, rh;
+                    mlm_cell_rpz(P, mlm_readlane(cell, src), rh, ph, z);
+                    mlm_walk_ray_wave(P, rh, ph, z);
+                }
+            } else {
+                // frontier mode: k_ex_walk_rays walks the queued rays once every cell's first point is known
+                ray_base = mlm_readlane(ray_base, 0);
+                if (cast) {
+                    int z, ph, rh;
+                    mlm_cell_rpz(P, cell, rh, ph, z);
+                    MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(ray_base + (unsigned int)__popcll(bc & below));
+                    q[0] = rh;
+                    q[1] = ph;
+                    q[2] = z;
+                    q[3] = -1; // in-range start: take the cell's first point
+                }
+            }
+        }
+        if (bf) {
+            touch_base = mlm_readlane(touch_base, 0);
+            const unsigned int at = touch_base + (unsigned int)__popcll(bf & below);
+            if (first && at < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + at] = cell;
+        }
+    }
+}
+
 // Groups that overflowed a k_bin_points block's LDS buffer (flag pad == 1; normally none): book each on its cell —
 // first-touch time (min), kind mask (or), count (add -> position); the one that finds the count at 0 queues the cell
 // for k_collect_hits.  gridDim.y = node region, blockIdx.z = slot.
@@ -544,9 +566,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_assign_nodes(MLM_SLOT_ARGS, int t
         const unsigned int k = k0 + threadIdx.x;
         bool first = false;
         uint32_t cell = 0;
-        if (k < n && P.nodes[(size_t)reg * P.node_cap + k].pad == 1) {
+        if (k < n) {
             MlmNode *nd = &P.nodes[(size_t)reg * P.node_cap + k];
-            nd->pad = 0;
+            nd->pad = MLM_NIL; // its position is absolute
             cell = nd->cell;
             const unsigned long long m = nd->mask;
             const int l0 = __ffsll((long long)m) - 1; // lowest lane = earliest insertion time of the group
@@ -591,18 +613,21 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
     __shared__ uint32_t s_base[3];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (blockIdx.x == 0 && blockIdx.y == 0 && wid == 0) { // fold the per-block statistics of k_bin_points
-        unsigned int a = 0, b = 0;
+        unsigned int a = 0, b = 0, g = 0;
         for (int j = lane; j < n_stat_blocks; j += 64) {
-            a += P.blk_stats[2 * j];
-            b += P.blk_stats[2 * j + 1];
+            a += P.blk_stats[4 * j];
+            b += P.blk_stats[4 * j + 1];
+            g += P.blk_stats[4 * j + 2];
         }
         for (int off = 32; off > 0; off >>= 1) {
             a += __shfl_xor(a, off, 64);
             b += __shfl_xor(b, off, 64);
+            g += __shfl_xor(g, off, 64);
         }
         if (lane == 0) {
             P.ctr->n_points = a;
             P.ctr->n_oor = b;
+            P.ctr->n_groups = g;
         }
     }
     const unsigned int k = blockIdx.y;
@@ -674,24 +699,37 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
     }
 }
 
-// One wave per contribution node: write the group's insertion times into its cell's segment of `contrib`
-// (multi-kind cells only).  tile_w > 0: dense 8x8 tiles of an image of that width; 0: linear work items.
-// gridDim.y = node region.
-__global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int tile_w) {
+// Write the insertion times of every group that feeds a multi-kind cell into the cell's segment of `contrib`.
+// A wave fetches 64 groups at once (one per lane, coalesced) and then expands them one after the other (lane = lane of
+// the group's mask).  tile_w > 0: dense 8x8 tiles of an image of that width; 0: linear work items.
+// blockIdx.x < n_bin_blocks: the groups k_bin_points block blockIdx.x left in its slice of `bnodes` (their positions are
+// relative to the pair's base); the blocks beyond take the overflow list (normally empty), region by region.
+__global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks) {
     MLM_SLOT_SETUP
-    const unsigned int reg = blockIdx.y;
-    const unsigned int n = min(P.ctr->node_cnt[reg][0], P.node_cap);
-    const int lane = threadIdx.x & 63;
-    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t lane_off = tile_w > 0 ? (uint32_t)((lane >> 3) * tile_w + (lane & 7)) : (uint32_t)lane;
-    // a wave fetches 64 nodes at once (one per lane, coalesced) and then expands them one after the other
-    for (unsigned int k0 = wave * 64; k0 < n; k0 += n_waves * 64) {
+    const MlmNode *list;
+    unsigned int n, k_first, k_step;
+    if ((int)blockIdx.x < n_bin_blocks) {
+        list = P.bnodes + (size_t)blockIdx.x * P.node_lds;
+        n = min(P.blk_stats[4 * (size_t)blockIdx.x + 2], P.node_lds);
+        k_first = wid * 64;
+        k_step = blockDim.x;
+    } else {
+        if (P.ctr->n_unassigned == 0) return;
+        const unsigned int ob = blockIdx.x - n_bin_blocks, reg = ob & 7, chunk = ob >> 3, n_chunks = (gridDim.x - n_bin_blocks) >> 3;
+        list = P.nodes + (size_t)reg * P.node_cap;
+        n = min(P.ctr->node_cnt[reg][0], P.node_cap);
+        k_first = (chunk * (blockDim.x >> 6) + wid) * 64;
+        k_step = n_chunks * blockDim.x;
+    }
+    for (unsigned int k0 = k_first; k0 < n; k0 += k_step) {
         MlmNode nd{};
         uint32_t base = MLM_NIL;
         if (k0 + lane < n) {
-            nd = P.nodes[(size_t)reg * P.node_cap + k0 + lane];
+            nd = list[k0 + lane];
             base = P.cs[nd.cell].seg;
+            if (base != MLM_NIL && nd.pad != MLM_NIL) nd.pos += P.pairs[nd.pad].base;
         }
         unsigned long long todo = __ballot(base != MLM_NIL);
         while (todo) {

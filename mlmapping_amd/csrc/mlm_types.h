@@ -21,7 +21,8 @@ struct MlmCounters {
     unsigned int n_ex_miss;   // explore mode: unique miss cells
     unsigned int n_ex_vox;    // explore mode: voxels touched by misses
     unsigned int n_big;       // multi-kind cells with more than 1024 contributions
-    unsigned int pad_b[3];
+    unsigned int n_groups;    // contribution groups kept in the blocks' own slices of `bnodes` (folded by k_collect_hits)
+    unsigned int pad_b[2];
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
@@ -52,6 +53,18 @@ struct MlmNode {
     unsigned long long mask;
 };
 #define MLM_NIL 0xFFFFFFFFu
+
+// What one k_bin_points block contributes to one awareness cell (its groups merged in LDS).  k_book_cells books the
+// pair on the cell with three atomics and records the returned count in `base`: the position of the block's
+// contributions inside the cell's segment (the groups' MlmNode::pos are relative to it).
+struct MlmPair {
+    uint32_t cell;
+    uint32_t tmin;      // earliest insertion time
+    uint32_t kmask;     // kinds
+    uint32_t cnt;       // contributions
+    uint32_t start_min; // explore mode: first point whose hit centre is the cell (MLM_EMPTY_T: none)
+    uint32_t base;
+};
 
 // Per-frame state of one awareness cell, 16 bytes so that the three atomics that book a group on a cell and the
 // reads of k_collect_hits touch ONE cache line.
@@ -84,10 +97,14 @@ struct MlmDev {
     const double *sin_phi;
     // ---- per-frame awareness scratch
     MlmCell *cs;               // [nCells] per-cell frame state (see MlmCell)
-    MlmNode *nodes;            // [MLM_RAY_LISTS][node_cap]
+    MlmNode *bnodes;           // [nb_cap][node_lds] groups of k_bin_points block b in slice b (count: blk_stats[4b+2]);
+                               // MlmNode::pad = index of the group's MlmPair in `pairs`
+    MlmPair *pairs;            // [nb_cap][agg_lds] (block, cell) pairs of block b in slice b (count: blk_stats[4b+3])
+    unsigned int nb_cap;       // most k_bin_points blocks per frame
+    MlmNode *nodes;            // [MLM_RAY_LISTS][node_cap] overflow: groups that did not fit a block's LDS buffer
     unsigned int node_cap;     // per region
     uint32_t *contrib;         // [contrib_cap] insertion times of the contributions of multi-kind cells, by cell
-    unsigned int *blk_stats;   // [2*max tiles] per-block partial sums: points fed, points out of range
+    unsigned int *blk_stats;   // [4*nb_cap] per k_bin_points block: points fed, points out of range, groups, pairs
     uint32_t *mt_list;         // [nCells] indices into the hit list of the multi-type cells
     uint32_t *mt_big;          // [nCells] those with more than 1024 contributions
     uint32_t *touched;         // [MLM_RAY_LISTS][touch_cap] hit cells in first-touch order of the GPU (arbitrary)

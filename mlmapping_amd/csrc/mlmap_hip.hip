@@ -361,6 +361,10 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         else
             hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     }
+    if (nb) {
+        Timed t(h, st, "k_book_cells");
+        hipLaunchKernelGGL(k_book_cells, dim3(nb, 1, n), dim3(64), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+    }
     {
         Timed t(h, st, "k_assign_nodes");
         hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
@@ -373,8 +377,8 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     }
     {
         Timed t(h, st, "k_expand_nodes");
-        hipLaunchKernelGGL(k_expand_nodes, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
-                           h->d_frame_tab, base, mode == 0 ? F.width : 0);
+        hipLaunchKernelGGL(k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+                           h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb);
     }
     {
         Timed t(h, st, "k_sort_contribs");
@@ -425,7 +429,7 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
     h->stats.n_multi_cells = c.n_multi;
     h->stats.n_contrib_slots = c.n_contrib;
-    int64_t ng = 0, nr = 0;
+    int64_t ng = c.n_groups, nr = 0;
     for (int k = 0; k < MLM_RAY_LISTS; ++k) {
         ng += c.node_cnt[k][0];
         nr += c.ray_cnt[k][0];
@@ -516,10 +520,12 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
             hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     }
     const int tile_w = S.mode == 0 ? F.width : 0;
+    if (nb) hipLaunchKernelGGL(k_book_cells, dim3(nb, 1, 1), dim3(64), 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
     hipLaunchKernelGGL(k_ex_walk_rays, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, (int)nb);
-    hipLaunchKernelGGL(k_expand_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
+    hipLaunchKernelGGL(k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w,
+                       (int)nb);
     hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 0u);
     hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(128, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 1024u);
     hipLaunchKernelGGL(k_chain, dim3(256, 1, 1), blk, (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
@@ -760,7 +766,10 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = dev_alloc(h, &P.mt_big, NC))) return rc;
     P.touch_cap = (unsigned int)NC;
     if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
-    if ((rc = dev_alloc(h, &P.blk_stats, 2 * ((size_t)h->lim.max_points / 64 + 1024)))) return rc;
+    P.nb_cap = (unsigned int)((size_t)h->lim.max_points / 64 + 1024);
+    if ((rc = dev_alloc(h, &P.blk_stats, 4 * (size_t)P.nb_cap))) return rc;
+    if ((rc = dev_alloc(h, &P.bnodes, (size_t)P.nb_cap * P.node_lds))) return rc;
+    if ((rc = dev_alloc(h, &P.pairs, (size_t)P.nb_cap * P.agg_lds))) return rc;
     {
         // most contributions one point can make: centre + (+d,-d) while d < 3*sigma(rho) (map_awareness.cpp:149)
         int dmax = 0;
