@@ -93,6 +93,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = S1 if args.workload == "cfg2" else S3
+    if os.environ.get("MLM_BENCH_NO_RAYCAST"):  # diagnostic only (not the BASELINE workload): hits without rays
+        import dataclasses
+        cfg = dataclasses.replace(cfg, use_raycasting=False)
     B, K, W = args.batch, args.steps, args.warmup
     n_total = (K + W) * B
     frames, q, t = make_inputs(cfg, args.distinct, n_total, seed=42 + rank)

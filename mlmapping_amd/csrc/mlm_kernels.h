@@ -82,42 +82,59 @@ template <int MODE> __device__ __forceinline__ MlmTile mlm_tile_item(const MlmFr
 
 // ray walk, map_awareness.cpp:243-274, from the binned start (rho,phi,z) of a point (in range or not):
 // slope = (z - zc)/rho, clamp to the outer border, then r = rho-1 .. 1, z' = round(z - (rho-r)*slope).
-// One WAVE walks one ray: lane l takes the steps r = l+1, l+65, ...; lanes whose cells fall into the same 32-bit
-// word of the miss mask (consecutive r with equal z') are merged so that one atomicOr per word run is issued.
-__device__ __forceinline__ void mlm_walk_ray_wave(const MlmDev &P, int rho, int phi, int z) {
+// Every lane may bring one ray start (has, rho, phi, z).  The per-ray setup (slope: an FP64 division; the clamp to the
+// outer border) is done by all lanes at once; then the WAVE walks the rays one after the other: lane l takes the steps
+// r = l+1, l+65, ...; lanes whose cells fall into the same 32-bit word of the miss mask (consecutive r with equal z')
+// are merged so that one atomicOr per word run is issued.  Must be called by all 64 lanes.
+__device__ __forceinline__ void mlm_walk_rays_wave(const MlmDev &P, bool has, int rho, int phi, int z) {
+    MLM_GLOBAL uint32_t *miss = mlm_gp(P.miss_bits) + (size_t)(blockIdx.x & (MLM_MISS_COPIES - 1)) * P.nMissWords;
     const int lane = threadIdx.x & 63;
-    const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
-    if (rho >= P.nRho) {
-        z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
-        rho = P.nRho - 1;
-    }
-    for (int r0 = 1; r0 < rho; r0 += 64) {
-        const int r = r0 + lane;
-        int w = -1;
-        if (r < rho) {
-            const int diff_r = rho - r;
-            const int zr = mlm_cvt_int(round(z - (diff_r * slope)));
-            if (0 <= zr && zr < P.nZ) w = (zr * P.nPhi + phi) * P.RW + (r >> 5);
+    double slope = 0.0;
+    int row_base = 0;
+    if (has) {
+        slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
+        if (rho >= P.nRho) {
+            z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
+            rho = P.nRho - 1;
         }
-        // run heads: lanes whose word differs from the previous lane's
-        const int w_prev = __shfl_up(w, 1, 64);
-        const bool head = w >= 0 && (lane == 0 || w_prev != w);
-        const unsigned long long valid = __ballot(w >= 0);
-        const unsigned long long heads = __ballot(head);
-        if (head) {
-            // the run ends before the next head or the next invalid lane
-            const unsigned long long above = ~((2ull << lane) - 1ull); // lanes > lane
-            const unsigned long long stop = (heads | ~valid) & above;
-            const int end = stop ? __ffsll((long long)stop) - 1 : 64; // exclusive
-            const int len = end - lane;                               // <= 32: a run stays inside one word
-            const uint32_t bits = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (r & 31);
-            g_atomic_or(&mlm_gp(P.miss_bits)[w], bits);
+        row_base = phi * P.RW;
+    }
+    const int row_pitch = P.nPhi * P.RW;
+    unsigned long long todo = __ballot(has && rho > 1);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int rho_s = mlm_readlane(rho, src), z_s = mlm_readlane(z, src), rb_s = mlm_readlane(row_base, src);
+        const double slope_s = __hiloint2double(mlm_readlane(__double2hiint(slope), src), mlm_readlane(__double2loint(slope), src));
+        for (int r0 = 1; r0 < rho_s; r0 += 64) {
+            const int r = r0 + lane;
+            int w = -1;
+            if (r < rho_s) {
+                const int diff_r = rho_s - r;
+                const int zr = mlm_cvt_int(round(z_s - (diff_r * slope_s)));
+                if (0 <= zr && zr < P.nZ) w = zr * row_pitch + rb_s + (r >> 5);
+            }
+            // run heads: lanes whose word differs from the previous lane's (wave_shr:1; lane 0 keeps -2)
+            const int w_prev = __builtin_amdgcn_update_dpp(-2, w, 0x138, 0xf, 0xf, false);
+            const bool head = w >= 0 && w_prev != w;
+            const unsigned long long valid = __ballot(w >= 0);
+            const unsigned long long heads = __ballot(head);
+            if (head) {
+                // the run ends before the next head or the next invalid lane
+                const unsigned long long above = ~((2ull << lane) - 1ull); // lanes > lane
+                const unsigned long long stop = (heads | ~valid) & above;
+                const int end = stop ? __ffsll((long long)stop) - 1 : 64; // exclusive
+                const int len = end - lane;                               // <= 32: a run stays inside one word
+                const uint32_t bits = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (r & 31);
+                g_atomic_or(&miss[w], bits);
+            }
         }
     }
 }
 
 // the same walk by ONE lane (rare paths: LDS buffers of k_bin_points overflowed)
 __device__ __forceinline__ void mlm_walk_ray_lane(const MlmDev &P, int rho, int phi, int z) {
+    MLM_GLOBAL uint32_t *miss = mlm_gp(P.miss_bits) + (size_t)(blockIdx.x & (MLM_MISS_COPIES - 1)) * P.nMissWords;
     const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
     if (rho >= P.nRho) {
         z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
@@ -125,7 +142,7 @@ __device__ __forceinline__ void mlm_walk_ray_lane(const MlmDev &P, int rho, int 
     }
     for (int r = 1; r < rho; ++r) {
         const int zr = mlm_cvt_int(round(z - ((rho - r) * slope)));
-        if (0 <= zr && zr < P.nZ) g_atomic_or(&mlm_gp(P.miss_bits)[(zr * P.nPhi + phi) * P.RW + (r >> 5)], 1u << (r & 31));
+        if (0 <= zr && zr < P.nZ) g_atomic_or(&miss[(zr * P.nPhi + phi) * P.RW + (r >> 5)], 1u << (r & 31));
     }
 }
 
@@ -441,7 +458,10 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     // ---- the queued rays (starts outside the map, rare late rays): one ray per wave at a time
     if (nr) {
         if (!P.explore) {
-            for (unsigned int r = wid; r < nr; r += blockDim.x >> 6) mlm_walk_ray_wave(P, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
+            for (unsigned int r0 = wid * 64; r0 < nr; r0 += blockDim.x) {
+                const unsigned int r = min(r0 + lane, nr - 1);
+                mlm_walk_rays_wave(P, r0 + lane < nr, s_ray[r][0], s_ray[r][1], s_ray[r][2]);
+            }
         } else {
             // frontier mode needs each miss cell's insertion time, which depends on the FIRST point of a start cell;
             // that is only known after the whole frame was binned: k_ex_walk_rays walks the queued rays
@@ -522,14 +542,9 @@ __global__ __launch_bounds__(64) void k_book_cells(MLM_SLOT_ARGS) {
         }
         if (bc) {
             if (!P.explore) {
-                unsigned long long todo = bc;
-                while (todo) {
-                    const int src = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    int z, ph, rh;
-                    mlm_cell_rpz(P, mlm_readlane(cell, src), rh, ph, z);
-                    mlm_walk_ray_wave(P, rh, ph, z);
-                }
+                int z = 0, ph = 0, rh = 0;
+                if (cast) mlm_cell_rpz(P, cell, rh, ph, z);
+                mlm_walk_rays_wave(P, cast, rh, ph, z);
             } else {
                 // frontier mode: k_ex_walk_rays walks the queued rays once every cell's first point is known
                 ray_base = mlm_readlane(ray_base, 0);
@@ -984,10 +999,16 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_prepare_voxels(MLM_SLOT_ARGS) {
     for (unsigned int w0 = wave * 64; w0 < (unsigned int)P.nMissWords; w0 += n_waves * 64) {
         const unsigned int w = w0 + lane;
         uint32_t bits = 0;
-        if (w < (unsigned int)P.nMissWords) bits = P.miss_bits[w];
+        if (w < (unsigned int)P.nMissWords) {
+#pragma unroll
+            for (int c = 0; c < MLM_MISS_COPIES; ++c) {
+                const uint32_t v = P.miss_bits[(size_t)c * P.nMissWords + w];
+                if (v) P.miss_bits[(size_t)c * P.nMissWords + w] = 0;
+                bits |= v;
+            }
+        }
         unsigned long long nz = __ballot(bits != 0);
         if (!nz) continue;
-        if (bits) P.miss_bits[w] = 0;
         const uint32_t cnt = (uint32_t)__popc(bits);
         const uint32_t incl = mlm_wave_incl_scan(cnt);
         const uint32_t total = mlm_readlane(incl, 63);

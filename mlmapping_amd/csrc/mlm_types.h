@@ -41,6 +41,8 @@ struct MlmGlobal {
 };
 #define MLM_CTR_FRAME_BYTES (64 + 6 * 8 * 32 * 4)
 #define MLM_RAY_LISTS 8
+#define MLM_MISS_COPIES 8 // private copies of the miss bit mask (chosen by blockIdx): rays of the whole image converge
+                          // on the words next to the sensor, and same-line atomics serialise (~11 ns each)
 
 // The hit contributions one wave makes to one awareness cell with one kind (`sub`): lanes in `mask`, work items
 // i = i00 + lane (linear modes) or i00 + (lane>>3)*W + (lane&7) (dense 8x8 pixel tile).  `pos` is where the group's
@@ -112,7 +114,8 @@ struct MlmDev {
     uint8_t *subs;             // [contrib_cap] per multi-kind cell: contribution kinds in insertion-time order
                                // (segments start 16-byte aligned; same offsets as `contrib`)
     unsigned int contrib_cap;
-    uint32_t *miss_bits;       // [nMissWords] free cells, row-major (z,phi) rows of RW words, bit = rho
+    uint32_t *miss_bits;       // [MLM_MISS_COPIES][nMissWords] free cells, row-major (z,phi) rows of RW words, bit = rho;
+                               // the mask of the frame is the OR of the copies (k_prepare_voxels)
     // ---- unique-hit list (capacity nCells)
     uint32_t *hl_cell;         // linear awareness cell idx
     uint32_t *hl_t;            // first-touch time

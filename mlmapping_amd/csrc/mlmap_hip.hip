@@ -761,7 +761,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     S.h_ctr = h->h_ctr_all + index;
     P.ctr = h->d_ctr_all + index;
     if ((rc = dev_alloc(h, &P.cs, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.miss_bits, (size_t)P.nMissWords))) return rc;
+    if ((rc = dev_alloc(h, &P.miss_bits, (size_t)MLM_MISS_COPIES * P.nMissWords))) return rc;
     if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
     if ((rc = dev_alloc(h, &P.mt_big, NC))) return rc;
     P.touch_cap = (unsigned int)NC;
@@ -835,7 +835,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         std::vector<MlmCell> init(NC, MlmCell{MLM_EMPTY_T, 0u, 0u, MLM_NIL});
         HIPCHK(h, hipMemcpy(P.cs, init.data(), NC * sizeof(MlmCell), hipMemcpyHostToDevice));
     }
-    HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)P.nMissWords * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)MLM_MISS_COPIES * P.nMissWords * sizeof(uint32_t)));
     if ((rc = ensure_img(h, S, (size_t)h->lim.max_points))) return rc;
     if ((rc = dev_alloc(h, &S.d_pix, (size_t)h->lim.max_points))) return rc;
     if ((rc = dev_alloc(h, &S.d_pts, (size_t)h->lim.max_points * 3))) return rc;
