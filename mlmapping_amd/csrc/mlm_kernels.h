@@ -86,7 +86,8 @@ template <int MODE> __device__ __forceinline__ MlmTile mlm_tile_item(const MlmFr
 // outer border) is done by all lanes at once; then the WAVE walks the rays one after the other: lane l takes the steps
 // r = l+1, l+65, ...; lanes whose cells fall into the same 32-bit word of the miss mask (consecutive r with equal z')
 // are merged so that one atomicOr per word run is issued.  Must be called by all 64 lanes.
-__device__ __forceinline__ void mlm_walk_rays_wave(const MlmDev &P, bool has, int rho, int phi, int z) {
+__device__ __forceinline__ void mlm_walk_rays_wave(const MlmDev &P, bool has, int rho, int phi, int z,
+                                                   uint32_t *s_wkey = nullptr, uint32_t *s_wbits = nullptr) {
     MLM_GLOBAL uint32_t *miss = mlm_gp(P.miss_bits) + (size_t)(blockIdx.x & (MLM_MISS_COPIES - 1)) * P.nMissWords;
     const int lane = threadIdx.x & 63;
     double slope = 0.0;
@@ -126,7 +127,19 @@ __device__ __forceinline__ void mlm_walk_rays_wave(const MlmDev &P, bool has, in
                 const int end = stop ? __ffsll((long long)stop) - 1 : 64; // exclusive
                 const int len = end - lane;                               // <= 32: a run stays inside one word
                 const uint32_t bits = (len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u)) << (r & 31);
-                g_atomic_or(&miss[w], bits);
+                bool staged = false;
+                if (s_wkey) { // OR into the workgroup's LDS table (s_wkey: word index or MLM_NIL); flushed by the caller
+                    uint32_t s = ((uint32_t)w * 2654435761u) >> 22; // 10 bits: MLM_BOOK_WORDS entries
+                    for (int probe = 0; probe < 16 && !staged; ++probe) {
+                        const uint32_t prev = atomicCAS(&s_wkey[s], MLM_NIL, (uint32_t)w);
+                        if (prev == MLM_NIL || prev == (uint32_t)w) {
+                            atomicOr(&s_wbits[s], bits);
+                            staged = true;
+                        }
+                        s = (s + 1) & 1023u;
+                    }
+                }
+                if (!staged) g_atomic_or(&miss[w], bits);
             }
         }
     }
@@ -501,69 +514,203 @@ __device__ __forceinline__ float mlm_logit(float p) {
     return (float)log10((double)ratio);
 }
 
-// One wave per k_bin_points block: book the block's (block, cell) pairs on their cells.  Per pair three device-scope
-// atomics: first-touch time (min), kind mask (or), contribution count (add).  The returned count is the position of the
-// block's contributions inside the cell's segment (0 = the cell's first contributions of the frame: queue the cell for
-// k_collect_hits); the returned mask tells whether this block is the first of the frame to put a hit CENTRE into the
-// cell — every point of one (rho,phi,z) cell casts the identical ray (map_awareness.cpp:243-274), so exactly that
-// wave walks it.  The wave holds no LDS and few registers while it waits for the round trip.
-__global__ __launch_bounds__(64) void k_book_cells(MLM_SLOT_ARGS) {
+// Book the (block, cell) pairs of k_bin_points on their cells — second level of the aggregation.  One workgroup takes
+// the pairs of MLM_BOOK_GROUP neighbouring k_bin_points blocks (dense mode: a 4x4 arrangement of 32-pixel-wide tiles),
+// merges them per cell in an LDS table and books each distinct cell with three device-scope atomics: first-touch time
+// (min), kind mask (or), contribution count (add).  Device-scope atomics are executed at the memory side (~35 G/s for
+// the whole chip, tools/probes/atomic_probe.hip) and are what bounds this path, so every level of merging pays.
+//  - The returned count is the position of the group's contributions inside the cell's segment (0 = the cell's first
+//    contributions of the frame: queue it for k_collect_hits); every pair gets its share through MlmPair::base.
+//  - The returned mask tells whether this workgroup is the first of the frame to put a hit CENTRE into the cell — every
+//    point of one (rho,phi,z) cell casts the identical ray (map_awareness.cpp:243-274), so exactly this workgroup walks
+//    it.  The rays of neighbouring cells run through the same words of the miss mask (all of them converge on the
+//    sensor), so they are OR-ed into an LDS table first and each distinct word costs one global atomic.
+#define MLM_BOOK_GROUP 16
+#define MLM_BOOK_THREADS 1024 // one wave per k_bin_points block of the group
+#define MLM_BOOK_CELLS 2048 // LDS cell table (power of two)
+#define MLM_BOOK_WORDS 1024 // LDS miss-word table (power of two)
+struct MlmBookCell {
+    uint32_t cell, tmin, kmask, cnt, start_min, base;
+};
+// bin block handled at position j (0..MLM_BOOK_GROUP-1) of workgroup g; tiles_x > 0: 4x4 tile arrangement
+__device__ __forceinline__ int mlm_book_block(int g, int j, int tiles_x, int tiles_y, int n_bin_blocks) {
+    if (tiles_x <= 0) {
+        const int b = g * MLM_BOOK_GROUP + j;
+        return b < n_bin_blocks ? b : -1;
+    }
+    const int groups_x = (tiles_x + 3) >> 2;
+    const int gy = g / groups_x, gx = g - gy * groups_x;
+    const int tx = gx * 4 + (j & 3), ty = gy * 4 + (j >> 2);
+    return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : -1;
+}
+__global__ __launch_bounds__(MLM_BOOK_THREADS) void k_book_cells(MLM_SLOT_ARGS, int tiles_x, int tiles_y, int n_bin_blocks) {
     MLM_SLOT_SETUP
-    const unsigned int b = blockIdx.x, reg = blockIdx.x & 7;
-    const int lane = threadIdx.x;
-    const unsigned int na = min(mlm_gp(P.blk_stats)[4 * (size_t)b + 3], P.agg_lds);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (unsigned int e0 = 0; e0 < na; e0 += 64) {
-        const unsigned int e = e0 + lane;
-        const bool valid = e < na;
-        MLM_GLOBAL uint32_t *d = (MLM_GLOBAL uint32_t *)(mlm_gp(P.pairs) + ((size_t)b * P.agg_lds + e));
-        uint32_t cell = 0, kmask = 0, old = 0, base = 0;
-        if (valid) {
+    __shared__ MlmBookCell s_cell[MLM_BOOK_CELLS];
+    __shared__ uint32_t s_wkey[MLM_BOOK_WORDS], s_wbits[MLM_BOOK_WORDS];
+    __shared__ uint32_t s_touch[MLM_BOOK_THREADS];
+    __shared__ unsigned int s_ntouch, s_tbase, s_nray;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned int reg = blockIdx.x & 7;
+    for (unsigned int e = threadIdx.x; e < MLM_BOOK_CELLS; e += blockDim.x) {
+        s_cell[e].cell = MLM_NIL;
+        s_cell[e].tmin = MLM_EMPTY_T;
+        s_cell[e].kmask = 0;
+        s_cell[e].cnt = 0;
+        s_cell[e].start_min = MLM_EMPTY_T;
+    }
+    for (unsigned int e = threadIdx.x; e < MLM_BOOK_WORDS; e += blockDim.x) {
+        s_wkey[e] = MLM_NIL;
+        s_wbits[e] = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_ntouch = 0;
+        s_nray = 0;
+    }
+    __syncthreads();
+    // ---- pass A: merge the pairs per cell.  A pair that finds the table full books itself (never seen).
+    for (int j = wid; j < MLM_BOOK_GROUP; j += MLM_BOOK_THREADS / 64) {
+        const int b = mlm_book_block((int)blockIdx.x, j, tiles_x, tiles_y, n_bin_blocks);
+        if (b < 0) continue;
+        const unsigned int na = min(mlm_gp(P.blk_stats)[4 * (size_t)b + 3], P.agg_lds);
+        for (unsigned int e = lane; e < na; e += 64) {
+            MLM_GLOBAL uint32_t *d = (MLM_GLOBAL uint32_t *)(mlm_gp(P.pairs) + ((size_t)b * P.agg_lds + e));
             const mlm_u32x2 a = *(MLM_GLOBAL mlm_u32x2 *)(d + 0), m = *(MLM_GLOBAL mlm_u32x2 *)(d + 2);
-            const uint32_t start_min = d[4];
-            cell = a.x;
-            kmask = m.x;
-            g_atomic_min(&mlm_gp(P.cs)[cell].t, a.y);
-            old = g_atomic_or(&mlm_gp(P.cs)[cell].mask, kmask);
-            base = g_atomic_add(&mlm_gp(P.cs)[cell].cnt, m.y);
-            if (P.explore && start_min != MLM_EMPTY_T) g_atomic_min(&mlm_gp(P.start_t)[cell], start_min);
-            d[5] = base;
-        }
-        const bool first = valid && base == 0;
-        const bool cast = valid && P.visibility && (kmask & 1u) && !(old & 1u);
-        const unsigned long long bf = __ballot(first), bc = __ballot(cast);
-        unsigned int touch_base = 0, ray_base = 0;
-        if (lane == 0) { // second round trip, hidden behind the ray walk
-            if (bf) touch_base = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], (unsigned int)__popcll(bf));
-            if (bc) {
-                g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[reg][0], (unsigned int)__popcll(bc)); // statistic only
-                if (P.explore) ray_base = g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, (unsigned int)__popcll(bc));
+            const uint32_t cell = a.x, start_min = d[4];
+            uint32_t s = (cell * 2654435761u) >> (32 - 11);
+            bool placed = false;
+            for (int probe = 0; probe < 64; ++probe) {
+                const uint32_t prev = atomicCAS(&s_cell[s].cell, MLM_NIL, cell);
+                if (prev == MLM_NIL || prev == cell) {
+                    placed = true;
+                    break;
+                }
+                s = (s + 1) & (MLM_BOOK_CELLS - 1);
             }
-        }
-        if (bc) {
-            if (!P.explore) {
-                int z = 0, ph = 0, rh = 0;
-                if (cast) mlm_cell_rpz(P, cell, rh, ph, z);
-                mlm_walk_rays_wave(P, cast, rh, ph, z);
+            if (placed) {
+                atomicMin(&s_cell[s].tmin, a.y);
+                atomicOr(&s_cell[s].kmask, m.x);
+                d[5] = atomicAdd(&s_cell[s].cnt, m.y); // offset inside the group's share; pass C adds the group's base
+                if (start_min != MLM_EMPTY_T) atomicMin(&s_cell[s].start_min, start_min);
             } else {
-                // frontier mode: k_ex_walk_rays walks the queued rays once every cell's first point is known
-                ray_base = mlm_readlane(ray_base, 0);
-                if (cast) {
+                g_atomic_min(&mlm_gp(P.cs)[cell].t, a.y);
+                const uint32_t old = g_atomic_or(&mlm_gp(P.cs)[cell].mask, m.x);
+                const uint32_t base = g_atomic_add(&mlm_gp(P.cs)[cell].cnt, m.y);
+                if (P.explore && start_min != MLM_EMPTY_T) g_atomic_min(&mlm_gp(P.start_t)[cell], start_min);
+                d[5] = base;
+                d[0] = MLM_NIL; // pass C: final
+                if (base == 0) {
+                    const unsigned int g = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], 1u);
+                    if (g < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + g] = cell;
+                }
+                if (P.visibility && (m.x & 1u) && !(old & 1u)) {
                     int z, ph, rh;
                     mlm_cell_rpz(P, cell, rh, ph, z);
-                    MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(ray_base + (unsigned int)__popcll(bc & below));
-                    q[0] = rh;
-                    q[1] = ph;
-                    q[2] = z;
-                    q[3] = -1; // in-range start: take the cell's first point
+                    g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[reg][0], 1u);
+                    if (!P.explore) {
+                        mlm_walk_ray_lane(P, rh, ph, z);
+                    } else {
+                        MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, 1u);
+                        q[0] = rh;
+                        q[1] = ph;
+                        q[2] = z;
+                        q[3] = -1;
+                    }
                 }
             }
         }
-        if (bf) {
-            touch_base = mlm_readlane(touch_base, 0);
-            const unsigned int at = touch_base + (unsigned int)__popcll(bf & below);
-            if (first && at < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + at] = cell;
+    }
+    __syncthreads();
+    // ---- pass B: the round trip to memory.  A lane owns MLM_BOOK_CELLS / MLM_BOOK_THREADS table entries; the atomics of all of
+    //      them are issued before the first returned value is used (one round trip, not one per entry).  Then the rays of
+    //      the cells this workgroup touched first with a hit centre are OR-ed into the LDS word table.
+    const unsigned long long below = (1ull << lane) - 1ull;
+    constexpr int PER = MLM_BOOK_CELLS / MLM_BOOK_THREADS;
+    uint32_t b_cell[PER], b_old[PER], b_base[PER], b_kmask[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const unsigned int e = i * MLM_BOOK_THREADS + threadIdx.x;
+        b_cell[i] = s_cell[e].cell;
+        b_kmask[i] = s_cell[e].kmask;
+        b_old[i] = 0;
+        b_base[i] = 1;
+        if (b_cell[i] != MLM_NIL) {
+            g_atomic_min(&mlm_gp(P.cs)[b_cell[i]].t, s_cell[e].tmin);
+            b_old[i] = g_atomic_or(&mlm_gp(P.cs)[b_cell[i]].mask, b_kmask[i]);
+            b_base[i] = g_atomic_add(&mlm_gp(P.cs)[b_cell[i]].cnt, s_cell[e].cnt);
+            if (P.explore && s_cell[e].start_min != MLM_EMPTY_T)
+                g_atomic_min(&mlm_gp(P.start_t)[b_cell[i]], s_cell[e].start_min);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const unsigned int e = i * MLM_BOOK_THREADS + threadIdx.x;
+        const uint32_t cell = b_cell[i];
+        const bool valid = cell != MLM_NIL;
+        if (valid) {
+            s_cell[e].base = b_base[i];
+            if (b_base[i] == 0) { // the cell's first contributions of the frame
+                const unsigned int k = atomicAdd(&s_ntouch, 1u);
+                if (k < MLM_BOOK_THREADS) {
+                    s_touch[k] = cell;
+                } else { // more than the staging buffer holds: append directly
+                    const unsigned int g = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], 1u);
+                    if (g < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + g] = cell;
+                }
+            }
+        }
+        const bool cast = valid && P.visibility && (b_kmask[i] & 1u) && !(b_old[i] & 1u);
+        const unsigned long long bc = __ballot(cast);
+        if (!bc) continue;
+        if (lane == 0) atomicAdd(&s_nray, (unsigned int)__popcll(bc));
+        int z = 0, ph = 0, rh = 0;
+        if (cast) mlm_cell_rpz(P, cell, rh, ph, z);
+        if (!P.explore) {
+            mlm_walk_rays_wave(P, cast, rh, ph, z, s_wkey, s_wbits);
+        } else {
+            // frontier mode: k_ex_walk_rays walks the queued rays once every cell's first point is known
+            unsigned int ray_base = 0;
+            if (lane == 0) ray_base = g_atomic_add(&mlm_gp(P.ctr)->n_ex_rays, (unsigned int)__popcll(bc));
+            ray_base = mlm_readlane(ray_base, 0);
+            if (cast) {
+                MLM_GLOBAL int32_t *q = mlm_gp(P.ex_rays) + 4 * (size_t)(ray_base + (unsigned int)__popcll(bc & below));
+                q[0] = rh;
+                q[1] = ph;
+                q[2] = z;
+                q[3] = -1; // in-range start: take the cell's first point
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pass C: reserve the first-touch slots (second round trip, hidden behind the fix-up of the pairs and the
+    //      flush of the miss words), hand every pair its final base
+    const unsigned int nt = min(s_ntouch, (unsigned int)MLM_BOOK_THREADS);
+    unsigned int touch_base = 0;
+    if (threadIdx.x == 0) {
+        if (nt) touch_base = g_atomic_add(&mlm_gp(P.ctr)->touch_cnt[reg][0], nt);
+        if (s_nray) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[reg][0], s_nray); // statistic only
+    }
+    for (int j = wid; j < MLM_BOOK_GROUP; j += MLM_BOOK_THREADS / 64) {
+        const int b = mlm_book_block((int)blockIdx.x, j, tiles_x, tiles_y, n_bin_blocks);
+        if (b < 0) continue;
+        const unsigned int na = min(mlm_gp(P.blk_stats)[4 * (size_t)b + 3], P.agg_lds);
+        for (unsigned int e = lane; e < na; e += 64) {
+            MLM_GLOBAL uint32_t *d = (MLM_GLOBAL uint32_t *)(mlm_gp(P.pairs) + ((size_t)b * P.agg_lds + e));
+            const uint32_t cell = d[0];
+            if (cell == MLM_NIL) continue; // booked itself in pass A
+            uint32_t s = (cell * 2654435761u) >> (32 - 11);
+            while (s_cell[s].cell != cell) s = (s + 1) & (MLM_BOOK_CELLS - 1);
+            d[5] += s_cell[s].base;
+        }
+    }
+    for (unsigned int e = threadIdx.x; e < MLM_BOOK_WORDS; e += blockDim.x) {
+        const uint32_t w = s_wkey[e];
+        if (w != MLM_NIL) g_atomic_or(&mlm_gp(P.miss_bits)[(size_t)(blockIdx.x & (MLM_MISS_COPIES - 1)) * P.nMissWords + w], s_wbits[e]);
+    }
+    if (nt) {
+        if (threadIdx.x == 0) s_tbase = touch_base;
+        __syncthreads();
+        for (unsigned int k = threadIdx.x; k < nt; k += blockDim.x)
+            if (s_tbase + k < P.touch_cap) mlm_gp(P.touched)[(size_t)reg * P.touch_cap + s_tbase + k] = s_touch[k];
     }
 }
 

@@ -331,6 +331,18 @@ int order_hits_exact(mlm_handle *h, MlmSlot &S, unsigned int U, int frame_idx) {
     return MLM_OK;
 }
 
+// workgroups of k_book_cells (MLM_BOOK_GROUP k_bin_points blocks each; dense mode: 4x4 tiles) and the tile geometry
+inline unsigned int book_grid(const MlmDev &P, const MlmFrame &F, int mode, int nb, int &tiles_x, int &tiles_y) {
+    if (mode != 0) {
+        tiles_x = tiles_y = 0;
+        return (unsigned int)((nb + MLM_BOOK_GROUP - 1) / MLM_BOOK_GROUP);
+    }
+    const int tile_h = (int)(P.bin_block / 256) * 8;
+    tiles_x = (F.width + 31) / 32;
+    tiles_y = (F.height + tile_h - 1) / tile_h;
+    return (unsigned int)(((tiles_x + 3) / 4) * ((tiles_y + 3) / 4));
+}
+
 // Stage A of a whole batch (slots base..base+n, same mode and image geometry) on stream_a: awareness raycast ->
 // unique hit lists (+odds) and miss masks.  One launch per kernel covers all n frames (blockIdx.z = slot).
 int launch_stage_a_batch(mlm_handle *h, int base, int n) {
@@ -363,7 +375,9 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     }
     if (nb) {
         Timed t(h, st, "k_book_cells");
-        hipLaunchKernelGGL(k_book_cells, dim3(nb, 1, n), dim3(64), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        int tx, ty;
+        const unsigned int ng = book_grid(P, F, mode, (int)nb, tx, ty);
+        hipLaunchKernelGGL(k_book_cells, dim3(ng, 1, n), dim3(MLM_BOOK_THREADS), 0, st, h->d_slot_tab, h->d_frame_tab, base, tx, ty, (int)nb);
     }
     {
         Timed t(h, st, "k_assign_nodes");
@@ -520,7 +534,11 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
             hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     }
     const int tile_w = S.mode == 0 ? F.width : 0;
-    if (nb) hipLaunchKernelGGL(k_book_cells, dim3(nb, 1, 1), dim3(64), 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+    if (nb) {
+        int tx, ty;
+        const unsigned int ng = book_grid(P, F, S.mode, (int)nb, tx, ty);
+        hipLaunchKernelGGL(k_book_cells, dim3(ng, 1, 1), dim3(MLM_BOOK_THREADS), 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tx, ty, (int)nb);
+    }
     hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
     hipLaunchKernelGGL(k_ex_walk_rays, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
     hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, (int)nb);

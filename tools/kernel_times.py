@@ -1,0 +1,35 @@
+"""Per-kernel HIP-event times with nothing else on the GPU: 16-frame batches of the bench workload submitted
+synchronously (each batch drains before the next is submitted, so Stage A and Stage B+C never overlap).
+Usage: python tools/kernel_times.py [cfg3] [batches]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_inputs  # noqa: E402
+from mlmapping_amd.config import S1, S3  # noqa: E402
+from mlmapping_amd.mlmap import MLMap  # noqa: E402
+
+cfg = S3 if "cfg3" in sys.argv else S1
+nb = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 8
+B = 16
+frames, q, t = make_inputs(cfg, B, B * (nb + 2), seed=42)
+m = MLMap(cfg, max_blocks=65536 if cfg is S3 else 32768, max_points=cfg.width * cfg.height, max_batch=B)
+m.set_async(False)
+for k in range(2):
+    m.update_map_batch(frames, q[B * k:B * k + B], t[B * k:B * k + B])
+m.sync()
+m.enable_kernel_timing(2)
+for k in range(2, nb + 2):
+    m.update_map_batch(frames, q[B * k:B * k + B], t[B * k:B * k + B])
+m.sync()
+acc = {}
+for name, ms in m.kernel_times():
+    a = acc.setdefault(name, [0.0, 0])
+    a[0] += ms
+    a[1] += 1
+tot = 0.0
+for name, (ms, n) in acc.items():
+    per = ms * 1e3 / (nb * B)
+    tot += per
+    print(f"{name:20s} {per:8.2f} us/frame   ({n} launches, {ms * 1e3 / n:8.1f} us each)")
+print(f"{'sum':20s} {tot:8.2f} us/frame")
