@@ -44,13 +44,17 @@ template <class F> __device__ __forceinline__ void mlm_wave_groups(int key, bool
     }
 }
 
+// wave64 inclusive prefix sum with DPP moves (no LDS): Hillis-Steele inside the rows of 16 lanes, then the row totals
+// are carried over with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).  Must be called by all 64 lanes.
 __device__ __forceinline__ uint32_t mlm_wave_incl_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
 }
 
 // In dense mode a wave owns an 8x8 pixel tile (lanes row-major inside the tile, so a lower lane always has the smaller
@@ -909,12 +913,22 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int t
     }
 }
 
-// One wave per multi-kind hit cell: order the cell's contributions by insertion time (bitonic sort of the keys in
-// LDS) and store their kinds (`sub`) in that order.
-// Launched twice per batch: CAP = 1024 (5 KB of LDS per wave, full occupancy) takes the cells with n <= 1024, CAP = 4096
-// the few larger ones (n_lo = 1024); cells beyond 4096 contributions are ranked from memory.
+// One wave per multi-kind hit cell: order the cell's contributions by insertion time and store their kinds (`sub`) in
+// that order.  A work item (pixel) contributes to one cell at most once (centre and +-d neighbours differ in rho), so
+// the order is the order of the pixels.
+//  - Bitmap path (the bulk): the pixels of one cell lie in a small image window.  The wave marks them in a
+//    128-column x 128-row bitmap in LDS anchored at the cell's first pixel (rows of the image = rows of the bitmap; for
+//    the list modes the work-item index is folded into rows of `row_w` = 64); the rank of a contribution is the number
+//    of marked pixels before its own — a prefix sum over the bitmap words plus one popcount.  O(n) per cell.
+//  - Fallbacks when a contribution falls outside the window: rank by counting (n <= 320), bitonic sort in LDS, or
+//    counting straight from memory beyond the LDS window.
+// Launched twice per batch: CAP = 1024 (4 KB of LDS per wave, full occupancy) takes the cells with n <= 1024, CAP = 4096
+// the few larger ones (n_lo = 1024).  div_m / div_s: exact division of a work-item index (< 2^27) by row_w as
+// (i * div_m) >> div_s.
+#define MLM_BMP_ROWS 128
 template <int MLM_SORT_CAP>
-__global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsigned int n_lo) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsigned int n_lo, int row_w,
+                                                             unsigned long long div_m, int div_s) {
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_BLOCK / 64][MLM_SORT_CAP];
     const bool big = MLM_SORT_CAP > 1024;
@@ -929,6 +943,81 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
         const uint32_t base = P.hl_base[pos];
         const uint32_t n = P.hl_cnt[pos];
         if (n <= n_lo || (n > MLM_SORT_CAP && !big)) continue; // the other launch's cells
+        if (n <= MLM_SORT_CAP) {
+            // ---- bitmap path.  LDS window of the wave: [0,2K) 256 x u64 bitmap words (row-major, 2 per row),
+            //      [2K,3K) exclusive prefix of their popcounts, [3K,..) the ordered kinds
+            unsigned long long *rows = (unsigned long long *)s_keys[wid];
+            volatile uint32_t *pre = (volatile uint32_t *)(s_keys[wid] + 512);
+            volatile uint8_t *S = (volatile uint8_t *)(s_keys[wid] + 768);
+            const uint32_t pix0 = P.hl_t[pos] / MLM_TIME_SLOTS; // the cell's first pixel: smallest row of the window
+            const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
+            const int xlo = (int)(pix0 - y0 * (uint32_t)row_w) - 64;
+            for (int j = lane; j < 2 * MLM_BMP_ROWS; j += 64) rows[j] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            bool bad = false;
+            // the keys of the first four rounds stay in registers for the second pass (covers n <= 256: the bulk)
+            uint32_t kreg[4] = {0, 0, 0, 0};
+            auto mark = [&](uint32_t key) {
+                const uint32_t pix = key / MLM_TIME_SLOTS;
+                const uint32_t y = (uint32_t)(((unsigned long long)pix * div_m) >> div_s);
+                const int dx = (int)(pix - y * (uint32_t)row_w) - xlo;
+                const uint32_t dy = y - y0;
+                if (dx < 0 || dx >= 128 || dy >= MLM_BMP_ROWS) {
+                    bad = true;
+                } else {
+                    atomicOr(&rows[2 * dy + ((uint32_t)dx >> 6)], 1ull << (dx & 63));
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t j = (uint32_t)lane + 64u * q;
+                if (j < n) {
+                    kreg[q] = P.contrib[base + j];
+                    mark(kreg[q]);
+                }
+            }
+            for (uint32_t j = lane + 256u; j < n; j += 64) mark(P.contrib[base + j]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t carry = 0;
+            if (!__any(bad)) {
+                for (int j0 = 0; j0 < 2 * MLM_BMP_ROWS; j0 += 64) {
+                    const uint32_t c = (uint32_t)__popcll(((volatile unsigned long long *)rows)[j0 + lane]);
+                    const uint32_t incl = mlm_wave_incl_scan(c);
+                    pre[j0 + lane] = carry + incl - c;
+                    carry += mlm_readlane(incl, 63);
+                }
+            }
+            if (carry == n) { // every contribution marked its own pixel
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                auto place = [&](uint32_t key) {
+                    const uint32_t pix = key / MLM_TIME_SLOTS;
+                    const uint32_t y = (uint32_t)(((unsigned long long)pix * div_m) >> div_s);
+                    const uint32_t dx = (uint32_t)((int)(pix - y * (uint32_t)row_w) - xlo);
+                    const uint32_t wi = 2 * (y - y0) + (dx >> 6);
+                    const uint32_t r = pre[wi] + (uint32_t)__popcll(((volatile unsigned long long *)rows)[wi] & ((1ull << (dx & 63)) - 1ull));
+                    const uint8_t sub = (uint8_t)(key - pix * MLM_TIME_SLOTS);
+                    if (MLM_SORT_CAP <= 1024) S[r] = sub;
+                    else P.subs[base + r] = sub; // large cells: straight to memory
+                };
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((uint32_t)lane + 64u * q < n) place(kreg[q]);
+                for (uint32_t j = lane + 256u; j < n; j += 64) place(P.contrib[base + j]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (MLM_SORT_CAP <= 1024) {
+                    const uint32_t n4 = (n + 3u) & ~3u;
+                    for (uint32_t j = lane; j < n4 / 4; j += 64)
+                        ((uint32_t *)(P.subs + base))[j] = ((volatile uint32_t *)(s_keys[wid] + 768))[j];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                continue;
+            }
+        }
         if (n <= 320) {
             // small cells (the bulk): rank by counting — every lane counts the keys below its own with 16-byte
             // broadcast reads; the ordered kinds are staged in the unused upper part of the wave's LDS window

@@ -200,6 +200,13 @@ template <class T> int dev_alloc(mlm_handle *h, T **p, size_t n) {
     *p = (T *)v;
     return MLM_OK;
 }
+// exact floor(i / d) for i < 2^27 as (i * m) >> s (Granlund-Montgomery: m = ceil(2^(27+L) / d), L = ceil(log2 d))
+inline void div_magic(unsigned int d, unsigned long long &m, int &s) {
+    int L = 0;
+    while ((1ull << L) < d) ++L;
+    s = 27 + L;
+    m = ((1ull << s) + d - 1) / d;
+}
 inline unsigned int grid_for(size_t n) { return (unsigned int)((n + MLM_BLOCK - 1) / MLM_BLOCK); }
 // blocks of k_bin_points for one frame (tile geometry: mlm_tile_item)
 inline unsigned int bin_grid(const MlmDev &P, const MlmFrame &F, int mode) {
@@ -396,10 +403,14 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     }
     {
         Timed t(h, st, "k_sort_contribs");
+        const int row_w = mode == 0 ? F.width : 64; // rows of the ranking bitmap (see k_sort_contribs)
+        unsigned long long dm;
+        int ds;
+        div_magic((unsigned int)row_w, dm, ds);
         hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
-                           h->d_frame_tab, base, 0u);
+                           h->d_frame_tab, base, 0u, row_w, dm, ds);
         hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
-                           h->d_frame_tab, base, 1024u);
+                           h->d_frame_tab, base, 1024u, row_w, dm, ds);
     }
     {
         Timed t(h, st, "k_chain");
@@ -544,8 +555,14 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, (int)nb);
     hipLaunchKernelGGL(k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w,
                        (int)nb);
-    hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 0u);
-    hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(128, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 1024u);
+    {
+        const int row_w = S.mode == 0 ? F.width : 64;
+        unsigned long long dm;
+        int ds;
+        div_magic((unsigned int)row_w, dm, ds);
+        hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 0u, row_w, dm, ds);
+        hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(128, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 1024u, row_w, dm, ds);
+    }
     hipLaunchKernelGGL(k_chain, dim3(256, 1, 1), blk, (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
                        slot_index, 0xFFFFFFFFu);
     hipLaunchKernelGGL(k_prepare_voxels, dim3(256, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index); // hits only
