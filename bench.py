@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step (one batched Stage A launch sequence)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--distinct", type=int, default=32, help="distinct depth frames kept in HBM (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -223,6 +223,7 @@ struct Timed {
     Timed(mlm_handle *hh, hipStream_t st, const char *name) : h(hh), s(st) {
         if (!h->timing) return;
         if (h->timing == 3 && strcmp(name, "k_bin_points") != 0) return; // dominant kernel only: 2 events per batch
+        if ((h->timing == 4) != (strncmp(name, "stage_", 6) == 0)) return; // mode 4: the two stage spans of a batch only
         if (h->kpool_used == h->kpool.size()) {
             KernelTime k{name, nullptr, nullptr};
             hipEventCreate(&k.a);
@@ -612,13 +613,20 @@ int submit_batch(mlm_handle *h, int base, int n) {
         S.seq = h->next_seq++;
         S.F.seq = S.seq;
     }
-    int rc = launch_stage_a_batch(h, base, n);
+    int rc;
+    {
+        Timed t(h, h->stream_as[set], "stage_a_batch");
+        rc = launch_stage_a_batch(h, base, n);
+    }
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
-    for (int j = 0; j < n; ++j) {
-        MlmSlot &S = h->slots[(size_t)(base + j)];
-        launch_stage_bc(h, S, h->hit_n_bkt);
-        h->pending.push_back(&S);
+    {
+        Timed t(h, h->stream, "stage_bc_batch");
+        for (int j = 0; j < n; ++j) {
+            MlmSlot &S = h->slots[(size_t)(base + j)];
+            launch_stage_bc(h, S, h->hit_n_bkt);
+            h->pending.push_back(&S);
+        }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters),
                              hipMemcpyDeviceToHost, h->stream));
