@@ -524,6 +524,9 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     MlmSlot &S = h->slots[(size_t)slot_index];
     const MlmDev &P = S.P;
     hipStream_t st = h->stream;
+    // the frame's inputs were uploaded on the slot set's Stage A stream: order this stream after them
+    HIPCHK(h, hipEventRecord(h->stage_a_done[h->cur_set], h->stream_as[h->cur_set]));
+    HIPCHK(h, hipStreamWaitEvent(st, h->stage_a_done[h->cur_set], 0));
     S.seq = 0;
     S.F.seq = 0;
     h->h_frame_tab[slot_index] = S.F;
