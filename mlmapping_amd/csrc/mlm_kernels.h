@@ -873,7 +873,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
 __global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks) {
     MLM_SLOT_SETUP
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint32_t lane_off = tile_w > 0 ? (uint32_t)((lane >> 3) * tile_w + (lane & 7)) : (uint32_t)lane;
     const MlmNode *list;
     unsigned int n, k_first, k_step;
     if ((int)blockIdx.x < n_bin_blocks) {
@@ -889,25 +888,38 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_expand_nodes(MLM_SLOT_ARGS, int t
         k_first = (chunk * (blockDim.x >> 6) + wid) * 64;
         k_step = n_chunks * blockDim.x;
     }
+    // eight lanes per group, one per row of its 8x8 lane mask: a lane writes the (at most eight) insertion times of its row
+    const int sub_lane = lane & 7, grp = lane >> 3;
+    const uint32_t row_off = tile_w > 0 ? (uint32_t)(sub_lane * tile_w) : (uint32_t)(sub_lane * 8);
     for (unsigned int k0 = k_first; k0 < n; k0 += k_step) {
         MlmNode nd{};
         uint32_t base = MLM_NIL;
         if (k0 + lane < n) {
             nd = list[k0 + lane];
             base = P.cs[nd.cell].seg;
-            if (base != MLM_NIL && nd.pad != MLM_NIL) nd.pos += P.pairs[nd.pad].base;
+            if (base != MLM_NIL) {
+                base += nd.pos;
+                if (nd.pad != MLM_NIL) base += P.pairs[nd.pad].base;
+            }
         }
-        unsigned long long todo = __ballot(base != MLM_NIL);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const uint32_t b = mlm_readlane(base, src), pos = mlm_readlane(nd.pos, src), is = mlm_readlane(nd.i00_sub, src);
-            const unsigned long long m = ((unsigned long long)mlm_readlane((uint32_t)(nd.mask >> 32), src) << 32) |
-                                         (unsigned long long)mlm_readlane((uint32_t)nd.mask, src);
-            if ((m >> lane) & 1ull) {
-                const uint32_t key = ((is & 0x07FFFFFFu) + lane_off) * MLM_TIME_SLOTS + (is >> 27);
-                const uint32_t at = b + pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (at < P.contrib_cap) P.contrib[at] = key;
+        if (!__any(base != MLM_NIL)) continue;
+#pragma unroll 1
+        for (int pass = 0; pass < 8; ++pass) {
+            const int src = pass * 8 + grp; // the group this lane helps with
+            const uint32_t b = __shfl(base, src, 64);
+            if (!__any(b != MLM_NIL)) continue;
+            const uint32_t is = __shfl(nd.i00_sub, src, 64);
+            const uint32_t mlo = __shfl((uint32_t)nd.mask, src, 64), mhi = __shfl((uint32_t)(nd.mask >> 32), src, 64);
+            if (b == MLM_NIL) continue;
+            const unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+            uint32_t bits = (uint32_t)(m >> (8 * sub_lane)) & 0xFFu;          // this lane's row
+            uint32_t at = b + (uint32_t)__popcll(m & ((1ull << (8 * sub_lane)) - 1ull)); // contributions of the rows before
+            const uint32_t key0 = ((is & 0x07FFFFFFu) + row_off) * MLM_TIME_SLOTS + (is >> 27);
+            while (bits) {
+                const int c = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                if (at < P.contrib_cap) P.contrib[at] = key0 + (uint32_t)c * MLM_TIME_SLOTS;
+                ++at;
             }
         }
     }
