@@ -73,16 +73,37 @@ __device__ __forceinline__ double mlm_fast_atan2(double y, double x) {
     return res - M_PI;
 }
 
+// Index of a coordinate: the reference computes (int)(v / d) or floor(v / d) with a correctly rounded FP64 division.
+// q = v * (1/d) differs from RN(v / d) by less than 4e-16 |q| (one rounding in 1/d, one in the product, one in the
+// division), so wherever q is farther than 4e-15 max(1, |q|) from every integer, trunc and floor of q and of the true
+// quotient agree, and the division (three quarter-rate instructions + a dozen FMAs) is skipped.  `exact` is cleared
+// when q is too close to an integer (or not finite / huge): the caller then takes the division.
+__device__ __forceinline__ double mlm_quot(double v, double inv_d, bool &exact) {
+    const double q = v * inv_d;
+    const double r = q - rint(q);
+    if (!(fabs(r) > 4e-15 * fmax(1.0, fabs(q)) && fabs(q) < 1e9)) exact = false; // NaN fails the comparison
+    return q;
+}
+
 // xyz2RhoPhiZwithBoderCheck, map_awareness.cpp:84-107
 __device__ __forceinline__ bool mlm_bin_point(const MlmDev &P, double x, double y, double z, int &rho_idx,
                                               int &phi_idx, int &z_idx, bool &can_do_cast) {
     const double rho = sqrt(x * x + y * y);
-    rho_idx = mlm_cvt_int(rho / P.dRho);
     double phi = mlm_fast_atan2(y, x);
     if (phi < 0) phi += 2 * M_PI;
-    phi_idx = mlm_cvt_int(phi / P.dPhi);
     const double zz = z - P.z_border_min;
-    z_idx = mlm_cvt_int(floor(zz / P.dZ));
+    bool exact = true;
+    const double qr = mlm_quot(rho, P.inv_dRho, exact), qp = mlm_quot(phi, P.inv_dPhi, exact), qz = mlm_quot(zz, P.inv_dZ, exact);
+    rho_idx = (int)qr;
+    phi_idx = (int)qp;
+    z_idx = (int)floor(qz);
+    if (!__all(exact)) { // rare: the whole wave skips the divisions otherwise
+        if (!exact) {
+            rho_idx = mlm_cvt_int(rho / P.dRho);
+            phi_idx = mlm_cvt_int(phi / P.dPhi);
+            z_idx = mlm_cvt_int(floor(zz / P.dZ));
+        }
+    }
     can_do_cast = (rho_idx >= 0 && phi_idx >= 0 && phi_idx < P.nPhi);
     return can_do_cast && z_idx >= 0 && rho_idx < P.nRho && z_idx < P.nZ;
 }
@@ -115,12 +136,25 @@ __device__ __forceinline__ void mlm_cell_center_w(const MlmDev &P, const double 
 // coordinate outside [0,n) maps to id 0 (operator[] default-inserts in the reference).
 __device__ __forceinline__ void mlm_voxel_of(const MlmDev &P, double x, double y, double z, int &gx, int &gy,
                                              int &gz, int &cid) {
-    gx = mlm_cvt_int(floor(x / P.d_glb));
-    gy = mlm_cvt_int(floor(y / P.d_glb));
-    gz = mlm_cvt_int(floor(z / P.d_glb));
-    const int cx = mlm_cvt_int(floor(x / P.d_sub) - gx * P.n);
-    const int cy = mlm_cvt_int(floor(y / P.d_sub) - gy * P.n);
-    const int cz = mlm_cvt_int(floor(z / P.d_sub) - gz * P.n);
+    bool exact = true;
+    const double qgx = mlm_quot(x, P.inv_d_glb, exact), qgy = mlm_quot(y, P.inv_d_glb, exact), qgz = mlm_quot(z, P.inv_d_glb, exact);
+    const double qsx = mlm_quot(x, P.inv_d_sub, exact), qsy = mlm_quot(y, P.inv_d_sub, exact), qsz = mlm_quot(z, P.inv_d_sub, exact);
+    gx = (int)floor(qgx);
+    gy = (int)floor(qgy);
+    gz = (int)floor(qgz);
+    int cx = (int)(floor(qsx) - gx * P.n);
+    int cy = (int)(floor(qsy) - gy * P.n);
+    int cz = (int)(floor(qsz) - gz * P.n);
+    if (!__all(exact)) { // rare: the whole wave skips the six divisions otherwise
+        if (!exact) {
+            gx = mlm_cvt_int(floor(x / P.d_glb));
+            gy = mlm_cvt_int(floor(y / P.d_glb));
+            gz = mlm_cvt_int(floor(z / P.d_glb));
+            cx = mlm_cvt_int(floor(x / P.d_sub) - gx * P.n);
+            cy = mlm_cvt_int(floor(y / P.d_sub) - gy * P.n);
+            cz = mlm_cvt_int(floor(z / P.d_sub) - gz * P.n);
+        }
+    }
     if (cx < 0 || cy < 0 || cz < 0 || cx >= P.n || cy >= P.n || cz >= P.n)
         cid = 0;
     else

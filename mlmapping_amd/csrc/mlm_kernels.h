@@ -164,11 +164,11 @@ __device__ __forceinline__ void mlm_walk_ray_lane(const MlmDev &P, int rho, int 
 }
 
 // neighbour cells of the noise spread (update_hits, map_awareness.cpp:149-168) for step d; -1 = none
-__device__ __forceinline__ void mlm_spread_cells(const MlmDev &P, int rho, int phi, int zi, int d, int &c_plus,
+// slope = raycasting_z_over_rho of the point's cell (map_awareness.cpp:64-71): (zi - zc) / rho, 0 for rho == 0
+__device__ __forceinline__ void mlm_spread_cells(const MlmDev &P, int rho, int phi, int zi, int d, double slope, int &c_plus,
                                                  int &c_minus) {
     c_plus = -1;
     c_minus = -1;
-    const double slope = (rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0; // raycasting_z_over_rho, map_awareness.cpp:64-71
     int rz = mlm_cvt_int(round(zi + (d * slope)));
     if (0 <= rz && rz < P.nZ) c_plus = rz * P.nRhoPhi + phi * P.nRho + rho + d;
     rz = mlm_cvt_int(round(zi - (d * slope)));
@@ -355,9 +355,10 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     };
     post(c0, inside, 0);
     const float s3 = inside ? mlm_gp(P.sigma3)[rho] : 0.0f;
+    const double slope = (inside && rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0; // once per point, not once per step
     for (int d = 1; __any(inside && mlm_spread_active(P, rho, d, s3)); ++d) {
         int cp = -1, cm = -1;
-        if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, cp, cm);
+        if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, slope, cp, cm);
         post(cp, cp >= 0, 2 * d - 1);
         post(cm, cm >= 0, 2 * d);
     }

@@ -87,6 +87,7 @@ struct MlmDev {
     int visibility;
     // ---- local map constants (map_local.cpp:46-139)
     double d_sub, d_glb, d_sub_half;
+    double inv_dRho, inv_dPhi, inv_dZ, inv_d_sub, inv_d_glb; // 1/d (rounded once): see mlm_quot in mlm_device.h
     int n, cells;
     float lo_min, lo_max, lo_miss, lo_sh;
     // ---- camera (mlmap.h:85-92)

@@ -978,6 +978,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     P.d_sub_half = P.d_sub * 0.5;
     P.n = cfg->subbox_n;
     P.d_glb = P.d_sub * P.n;
+    P.inv_dRho = 1.0 / P.dRho;
+    P.inv_dPhi = 1.0 / P.dPhi;
+    P.inv_dZ = 1.0 / P.dZ;
+    P.inv_d_sub = 1.0 / P.d_sub;
+    P.inv_d_glb = 1.0 / P.d_glb;
     P.cells = P.n * P.n * P.n;
     P.lo_min = static_cast<float>(cfg->log_odds_min);
     P.lo_max = static_cast<float>(cfg->log_odds_max);

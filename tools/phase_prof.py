@@ -12,8 +12,7 @@ from mlmapping_amd import synthetic as syn
 from mlmapping_amd.config import S1, S3
 
 NAMES = ["0 LDS init", "1 load+bin (FP64)", "2 A: wave grouping / node post", "3 A: outer rays+queue", "4 sync",
-         "5 B: LDS cell aggregation", "6 sync", "7 C: cell atomics (round trip)", "8 sync", "9 D: node flush",
-         "10 D: ray walk", "11 D: first-touch list"]
+         "5 B: LDS cell aggregation", "6 sync", "7 -", "8 -", "9 C: write-out (nodes, pairs)", "10 C: queued rays", "11 -"]
 L = mm.load_library(os.path.join(os.path.dirname(mm.LIB_PATH), "libmlmap_hip_prof.so"))
 L.mlm_debug_phases.argtypes = [ctypes.c_void_p]
 mm._lib = L  # MLMap() below binds to the diagnostic build
