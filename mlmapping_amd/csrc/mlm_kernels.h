@@ -325,23 +325,21 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
             g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[blockIdx.x & 7][0], 1u);
         }
     };
-    // ---- phase A: one group = the lanes of this wave that contribute kind `sub` to `cell`.  Its lowest lane (=
-    //      earliest insertion time) records the group as a node in LDS; no global memory is touched here.
-    auto post = [&](int key, bool valid, int sub) {
-        unsigned long long my_mask = 0;
-        int my_cell = -1;
-        mlm_wave_groups(key, valid, [&](int cell, unsigned long long m) {
-            my_cell = cell;
-            my_mask = m;
-        });
-        if (my_cell >= 0) {
+    // ---- phase A: one group = lanes of this wave that contribute kind `sub` to `cell`.  Its lowest lane (= earliest
+    //      insertion time) records the group as a node in LDS; no global memory is touched here.
+    //      The lanes are split ONCE, by centre cell (ballot/readlane peel): the +-d neighbour cells are functions of the
+    //      centre cell (map_awareness.cpp:149-168), so every centre group is also a group of each spread kind and only
+    //      its leader computes the neighbour cells.  (Two centre groups can land in the same neighbour cell: they stay
+    //      two groups, the LDS table merges them.)
+    auto post_node = [&](int cell, unsigned long long mask, int sub) { // lanes with cell >= 0 record a group
+        if (cell >= 0) {
             const unsigned int k = atomicAdd(&s_nnode, 1u);
             MlmNode nd;
-            nd.cell = (uint32_t)my_cell;
+            nd.cell = (uint32_t)cell;
             nd.pos = 0;
             nd.i00_sub = i00 | ((uint32_t)sub << 27);
             nd.pad = 0;
-            nd.mask = my_mask;
+            nd.mask = mask;
             if (k < MLM_NODE_LDS) {
                 s_node[k] = nd;
             } else { // LDS buffer full: store the node directly; k_assign_nodes books it (and walks its ray)
@@ -353,14 +351,20 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
             }
         }
     };
-    post(c0, inside, 0);
-    const float s3 = inside ? mlm_gp(P.sigma3)[rho] : 0.0f;
-    const double slope = (inside && rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0; // once per point, not once per step
-    for (int d = 1; __any(inside && mlm_spread_active(P, rho, d, s3)); ++d) {
+    unsigned long long my_mask = 0;
+    bool leader = false;
+    mlm_wave_groups(c0, inside, [&](int, unsigned long long m) {
+        leader = true;
+        my_mask = m;
+    });
+    post_node(leader ? c0 : -1, my_mask, 0);
+    const float s3 = leader ? mlm_gp(P.sigma3)[rho] : 0.0f;
+    const double slope = (leader && rho > 0) ? (zi - P.zc) / (rho * 1.0) : 0.0;
+    for (int d = 1; __any(leader && mlm_spread_active(P, rho, d, s3)); ++d) {
         int cp = -1, cm = -1;
-        if (inside && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, slope, cp, cm);
-        post(cp, cp >= 0, 2 * d - 1);
-        post(cm, cm >= 0, 2 * d);
+        if (leader && mlm_spread_active(P, rho, d, s3)) mlm_spread_cells(P, rho, phi, zi, d, slope, cp, cm);
+        post_node(cp, my_mask, 2 * d - 1);
+        post_node(cm, my_mask, 2 * d);
     }
     MLM_PHASE(2);
     // ---- points outside the map that can still cast (map_awareness.cpp:241,249-265): identical starts inside
