@@ -1322,28 +1322,52 @@ __device__ __forceinline__ unsigned long long mlm_bkt_entry(int seq, uint32_t t)
 // is already final), block lookup/creation (allocate_ram, map_local.h:215-231), push on the voxel's pending list.
 // blockIdx.y == 1 + k: miss-cell sub-list k — count the frame's misses per voxel (their order is irrelevant: every
 // miss adds the same constant, map_local.cpp:188-192).
+// Both Stage B+C kernels are short dependent chains of memory round trips (a frame is 17 k hits + 79 k miss cells), so
+// every lane issues the loads of its first item together with the loads that decide whether there is an item at all
+// (frame not failed, list length): two round trips per kernel instead of four.
 __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const MlmFrame F, unsigned long long n_bkt) {
     const int frame_idx = F.seq;
-    MLM_SKIP_IF_FAILED(P, frame_idx)
+    const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (blockIdx.y == 0) {
+        // speculative loads of item i0 (in bounds of the arrays, whatever u_hit turns out to be)
+        const bool inb = i0 < (unsigned int)P.nCells;
+        uint32_t p_cell = 0, p_vt = 0, p_cid = 0;
+        int p_slot = -1;
+        unsigned long long p_bkey = 0;
+        if (inb) {
+            p_cell = P.hl_cell[i0];
+            p_vt = P.hl_vt[i0];
+            p_slot = P.hl_slot[i0];
+            p_cid = P.hl_cid[i0];
+            p_bkey = P.hl_bkey[i0];
+        }
+        const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int n = P.ctr->u_hit;
-        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (ff <= frame_idx) return;
+        for (unsigned int i = i0; i < n; i += stride) {
+            if (i != i0) {
+                p_cell = P.hl_cell[i];
+                p_vt = P.hl_vt[i];
+                p_slot = P.hl_slot[i];
+                p_cid = P.hl_cid[i];
+                p_bkey = P.hl_bkey[i];
+            }
             if (n_bkt) {
                 int rho, phi, z;
-                mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+                mlm_cell_rpz(P, p_cell, rho, phi, z);
                 const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
-                atomicMin(&P.bkt64[b], mlm_bkt_entry(frame_idx, P.hl_vt[i]));
+                atomicMin(&P.bkt64[b], mlm_bkt_entry(frame_idx, p_vt));
                 P.hl_bkt[i] = (uint32_t)b;
             }
-            int slot = P.hl_slot[i];
-            if (slot < 0) slot = mlm_block_slot(P, P.hl_bkey[i]);
+            int slot = p_slot;
+            if (slot < 0) slot = mlm_block_slot(P, p_bkey);
             if (P.explore && slot >= 0 && P.blk_collapsed[slot]) slot = -3; // released block: allocate_ram() is false
             if (slot < 0) {
                 P.hl_vox[i] = -1;
                 P.hl_next[i] = -2;
                 continue;
             }
-            const int v = slot * P.cells + (int)P.hl_cid[i];
+            const int v = slot * P.cells + (int)p_cid;
             P.hl_vox[i] = v;
             P.hl_next[i] = atomicExch(&P.vox_head[v], (int)i);
             if (!P.explore) atomicOr(&P.vox_miss[v], MLM_HAS_HITS); // tells k_apply's miss side that a hit owner exists
@@ -1351,16 +1375,29 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
         return;
     }
     const unsigned int sl = blockIdx.y - 1;
+    const bool inb = i0 < P.mc_cap;
+    int p_slot = -1;
+    uint32_t p_cid = 0;
+    if (inb) {
+        p_slot = P.mc_slot[(size_t)sl * P.mc_cap + i0];
+        p_cid = P.mc_cid[(size_t)sl * P.mc_cap + i0];
+    }
+    const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int n = min(P.ctr->mc_cnt[sl][0], P.mc_cap);
+    if (ff <= frame_idx) return;
     unsigned int n_here = 0;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (unsigned int i = i0; i < n; i += stride) {
         ++n_here;
         const size_t at = (size_t)sl * P.mc_cap + i;
-        int slot = P.mc_slot[at];
+        if (i != i0) {
+            p_slot = P.mc_slot[at];
+            p_cid = P.mc_cid[at];
+        }
+        int slot = p_slot;
         if (slot < 0) slot = mlm_block_slot(P, P.mc_bkey[at]);
         int v = -1;
         if (slot >= 0) {
-            v = slot * P.cells + (int)P.mc_cid[at];
+            v = slot * P.cells + (int)p_cid;
             // the first miss of a voxel this frame owns it in k_apply; the others only count
             if ((atomicAdd(&P.vox_miss[v], 1u) & ~MLM_HAS_HITS) != 0) v = -1;
         }
@@ -1395,19 +1432,37 @@ __device__ __forceinline__ void mlm_apply_misses(const MlmDev &P, float &L, uint
 // blockIdx.y == 1 + k: miss cells of sub-list k that were their voxel's first miss — voxels that also have hits are left to the hit owner
 // (the MLM_HAS_HITS flag in the miss counter tells the two sides apart, so each voxel's misses are applied once).
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_idx, int explicit_keys) {
-    MLM_SKIP_IF_FAILED(P, frame_idx)
+    const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (blockIdx.y == 0) {
+        // speculative loads of item i0 (see k_voxelize)
+        int p_next = 0, p_vox = -1;
+        float p_inc = 0.0f;
+        if (i0 < (unsigned int)P.nCells) {
+            p_next = P.hl_next[i0];
+            p_vox = P.hl_vox[i0];
+            p_inc = P.hl_inc[i0];
+        }
+        const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int n = P.ctr->u_hit;
-        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-            if (P.hl_next[i] != -1) continue;
-            const int v = P.hl_vox[i];
+        if (ff <= frame_idx) return;
+        for (unsigned int i = i0; i < n; i += stride) {
+            if (i != i0) {
+                p_next = P.hl_next[i];
+                p_vox = P.hl_vox[i];
+                p_inc = P.hl_inc[i];
+            }
+            if (p_next != -1) continue;
+            const int v = p_vox;
+            // the voxel's miss count is fetched (and reset) in the same round trip as its state
+            uint32_t km = 0;
+            if (!P.explore) km = atomicExch(&P.vox_miss[v], 0u) & ~MLM_HAS_HITS;
             const int head = P.vox_head[v];
             float L = P.log_odds[v];
             uint8_t o = P.occ[v];
             const uint8_t o0 = o;
             if (head == (int)i) { // the common case: a single contribution
                 if (L < P.lo_max) {
-                    L = L + P.hl_inc[i];
+                    L = L + p_inc;
                     L = L > P.lo_max ? P.lo_max : L;
                 }
                 if (L > P.lo_sh && o != 'o') o = 'o';
@@ -1473,7 +1528,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
                 }
             }
             if (!P.explore) {
-                const uint32_t km = atomicExch(&P.vox_miss[v], 0u) & ~MLM_HAS_HITS;
                 mlm_apply_misses(P, L, o, km);
             } else if (o == 'o' && o0 != 'o') {
                 P.frnt[v] = 0; // frontier.erase(subbox_id), map_local.cpp:167-168
@@ -1485,17 +1539,21 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
         return;
     }
     const unsigned int sl = blockIdx.y - 1;
+    int p_v = -1;
+    if (i0 < P.mc_cap) p_v = P.mc_vox[(size_t)sl * P.mc_cap + i0];
+    const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int n = min(P.ctr->mc_cnt[sl][0], P.mc_cap);
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int v = P.mc_vox[(size_t)sl * P.mc_cap + i];
+    if (ff <= frame_idx) return;
+    for (unsigned int i = i0; i < n; i += stride) {
+        const int v = (i == i0) ? p_v : P.mc_vox[(size_t)sl * P.mc_cap + i];
         if (v < 0) continue; // not the voxel's first miss (or no block)
         // vox_miss[v]: 0 = a hit owner already applied the misses; MLM_HAS_HITS set = a hit owner will; else the
         // voxel has misses only and this lane is the only one that touches it
         const uint32_t k = __hip_atomic_load(&P.vox_miss[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float L = P.log_odds[v]; // same round trip as the counter; unused if a hit owner handles the voxel
+        uint8_t o = P.occ[v];
         if (k == 0 || (k & MLM_HAS_HITS)) continue;
         P.vox_miss[v] = 0;
-        float L = P.log_odds[v];
-        uint8_t o = P.occ[v];
         mlm_apply_misses(P, L, o, k);
         P.log_odds[v] = L;
         P.occ[v] = o;

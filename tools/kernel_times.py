@@ -1,4 +1,4 @@
-"""Per-kernel HIP-event times with nothing else on the GPU: 16-frame batches of the bench workload submitted
+"""Per-kernel HIP-event times with nothing else on the GPU: B-frame batches (B = 32, or MLM_KT_BATCH) of the bench workload submitted
 synchronously (each batch drains before the next is submitted, so Stage A and Stage B+C never overlap).
 Usage: python tools/kernel_times.py [cfg3] [batches]"""
 import os
@@ -11,7 +11,7 @@ from mlmapping_amd.mlmap import MLMap  # noqa: E402
 
 cfg = S3 if "cfg3" in sys.argv else S1
 nb = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 8
-B = 16
+B = int(os.environ.get("MLM_KT_BATCH", "32"))
 frames, q, t = make_inputs(cfg, B, B * (nb + 2), seed=42)
 m = MLMap(cfg, max_blocks=65536 if cfg is S3 else 32768, max_points=cfg.width * cfg.height, max_batch=B)
 m.set_async(False)
