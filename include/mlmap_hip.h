@@ -181,13 +181,14 @@ int mlm_get_odds_table(mlm_handle *h, float *out);
 
 /* Device time of the launches of the integrate calls, measured with HIP events on the streams the kernels run on
  * (milliseconds); names are static strings.  on = 1: the list describes the last call only; on = 2: it accumulates over
- * calls until read (mlm_get_kernel_times with cap >= n consumes it); on = 3: like 2 but only the batched
- * k_bin_points launches are bracketed (events around every kernel cost ~19 % throughput) — bench.py uses 3 over its
- * timed region and 2 on a few extra batches; on = 4: only the spans of a batch's Stage A and Stage B+C ("stage_a_batch",
+ * calls until read (mlm_get_kernel_times with cap >= n consumes it); on = 3: like 2 but only every `every`-th
+ * launch of ONE kernel is bracketed (mlm_set_timed_kernel, default "k_bin_points", 1; events around every kernel cost
+ * ~19 % throughput) — bench.py uses 2 on a few batches to find the dominant kernel and 3 on it over its timed region; on = 4: only the spans of a batch's Stage A and Stage B+C ("stage_a_batch",
  * "stage_bc_batch"; the latter starts when the main stream reaches it, i.e. after the previous batch's).
  * Stage A kernels are launched once per batch, so one entry of theirs covers all frames of that batch. */
 int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out);
 int mlm_enable_kernel_timing(mlm_handle *h, int on);
+int mlm_set_timed_kernel(mlm_handle *h, const char *name, int every);
 
 #ifdef __cplusplus
 }

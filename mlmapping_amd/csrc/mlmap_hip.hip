@@ -165,6 +165,8 @@ struct mlm_handle {
     std::vector<MlmSlot *> pending;
     int next_seq = 0;
     int cur_set = 0;
+    std::string timed_kernel = "k_bin_points"; // the kernel bracketed in timing mode 3 ...
+    unsigned int timed_every = 1, timed_count = 0; // ... on every timed_every-th launch
     int set_pending[MLM_SETS] = {};
     bool async_mode = false;
     int cu_split = 0;
@@ -222,7 +224,10 @@ struct Timed {
     KernelTime *kt = nullptr;
     Timed(mlm_handle *hh, hipStream_t st, const char *name) : h(hh), s(st) {
         if (!h->timing) return;
-        if (h->timing == 3 && strcmp(name, "k_bin_points") != 0) return; // dominant kernel only: 2 events per batch
+        if (h->timing == 3) { // one kernel only (bench: the dominant one), every `timed_every`-th launch of it
+            if (strcmp(name, h->timed_kernel.c_str()) != 0) return;
+            if (h->timed_count++ % h->timed_every != 0) return;
+        }
         if ((h->timing == 4) != (strncmp(name, "stage_", 6) == 0)) return; // mode 4: the two stage spans of a batch only
         if (h->kpool_used == h->kpool.size()) {
             KernelTime k{name, nullptr, nullptr};
@@ -1679,6 +1684,14 @@ int mlm_enable_kernel_timing(mlm_handle *h, int on) {
     h->ktimes.clear();
     h->kpool_used = 0;
     return rc;
+}
+
+int mlm_set_timed_kernel(mlm_handle *h, const char *name, int every) {
+    if (!h || !name || every < 1) return MLM_ERR_INVALID;
+    h->timed_kernel = name;
+    h->timed_every = (unsigned int)every;
+    h->timed_count = 0;
+    return MLM_OK;
 }
 
 int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out) {

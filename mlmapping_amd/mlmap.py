@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "mlm_export_blocks", "mlm_export_block_flags", "mlm_export_frontier", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
     "mlm_get_awareness_hits",
     "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
-    "mlm_enable_kernel_timing",
+    "mlm_enable_kernel_timing", "mlm_set_timed_kernel",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library(path: Optional[str] = None):
     L.mlm_get_odds_table.argtypes = [vp, vp]
     L.mlm_get_kernel_times.argtypes = [vp, i32, vp, vp, vp]
     L.mlm_enable_kernel_timing.argtypes = [vp, i32]
+    L.mlm_set_timed_kernel.argtypes = [vp, ctypes.c_char_p, i32]
     if path is None:
         _lib = L
     return L
@@ -341,6 +342,10 @@ class MLMap:
     def enable_kernel_timing(self, on=True):
         """True/1: per call; 2: accumulate over calls until kernel_times() is read; False/0: off."""
         self._chk(self._L.mlm_enable_kernel_timing(self._h, int(on)), "mlm_enable_kernel_timing")
+
+    def set_timed_kernel(self, name: str, every: int = 1):
+        """The one kernel whose launches (every `every`-th of them) timing mode 3 brackets."""
+        self._chk(self._L.mlm_set_timed_kernel(self._h, name.encode(), int(every)), "mlm_set_timed_kernel")
 
     def kernel_times(self, cap: int = 1 << 16) -> List[Tuple[str, float]]:
         names = (ctypes.c_char_p * cap)()
