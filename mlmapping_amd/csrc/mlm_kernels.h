@@ -1325,10 +1325,14 @@ __device__ __forceinline__ unsigned long long mlm_bkt_entry(int seq, uint32_t t)
 // Both Stage B+C kernels are short dependent chains of memory round trips (a frame is 17 k hits + 79 k miss cells), so
 // every lane issues the loads of its first item together with the loads that decide whether there is an item at all
 // (frame not failed, list length): two round trips per kernel instead of four.
-__global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const MlmFrame F, unsigned long long n_bkt) {
+__device__ __forceinline__ void mlm_voxelize_body(const MlmDev &P, const MlmFrame &F, unsigned long long n_bkt, unsigned int by) {
     const int frame_idx = F.seq;
+    // per-voxel scratch and bucket table of this frame's parity (see MlmDev::vox_head)
+    int *vox_head = P.vox_head + (size_t)(frame_idx & 1) * P.vox_stride;
+    uint32_t *vox_miss = P.vox_miss + (size_t)(frame_idx & 1) * P.vox_stride;
+    unsigned long long *bkt64 = P.bkt64 + (size_t)(frame_idx & 1) * P.bkt_stride;
     const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if (blockIdx.y == 0) {
+    if (by == 0) {
         // speculative loads of item i0 (in bounds of the arrays, whatever u_hit turns out to be)
         const bool inb = i0 < (unsigned int)P.nCells;
         uint32_t p_cell = 0, p_vt = 0, p_cid = 0;
@@ -1356,7 +1360,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
                 int rho, phi, z;
                 mlm_cell_rpz(P, p_cell, rho, phi, z);
                 const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
-                atomicMin(&P.bkt64[b], mlm_bkt_entry(frame_idx, p_vt));
+                atomicMin(&bkt64[b], mlm_bkt_entry(frame_idx, p_vt));
                 P.hl_bkt[i] = (uint32_t)b;
             }
             int slot = p_slot;
@@ -1369,12 +1373,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
             }
             const int v = slot * P.cells + (int)p_cid;
             P.hl_vox[i] = v;
-            P.hl_next[i] = atomicExch(&P.vox_head[v], (int)i);
-            if (!P.explore) atomicOr(&P.vox_miss[v], MLM_HAS_HITS); // tells k_apply's miss side that a hit owner exists
+            P.hl_next[i] = atomicExch(&vox_head[v], (int)i);
+            if (!P.explore) atomicOr(&vox_miss[v], MLM_HAS_HITS); // tells k_apply's miss side that a hit owner exists
         }
         return;
     }
-    const unsigned int sl = blockIdx.y - 1;
+    const unsigned int sl = by - 1;
     const bool inb = i0 < P.mc_cap;
     int p_slot = -1;
     uint32_t p_cid = 0;
@@ -1399,7 +1403,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
         if (slot >= 0) {
             v = slot * P.cells + (int)p_cid;
             // the first miss of a voxel this frame owns it in k_apply; the others only count
-            if ((atomicAdd(&P.vox_miss[v], 1u) & ~MLM_HAS_HITS) != 0) v = -1;
+            if ((atomicAdd(&vox_miss[v], 1u) & ~MLM_HAS_HITS) != 0) v = -1;
         }
         P.mc_vox[at] = v;
     }
@@ -1407,11 +1411,14 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const Ml
     for (int off = 32; off > 0; off >>= 1) n_here += __shfl_xor(n_here, off, 64);
     if ((threadIdx.x & 63) == 0 && n_here) atomicAdd(&P.ctr->umiss_part[blockIdx.x & 7][0], n_here);
 }
+__global__ __launch_bounds__(MLM_BLOCK) void k_voxelize(const MlmDev P, const MlmFrame F, unsigned long long n_bkt) {
+    mlm_voxelize_body(P, F, n_bkt, blockIdx.y);
+}
 
 // iteration-order key of unique hit j: larger = visited earlier by the reference's container walk
-__device__ __forceinline__ unsigned long long mlm_order_key(const MlmDev &P, int j, int explicit_keys) {
+__device__ __forceinline__ unsigned long long mlm_order_key(const MlmDev &P, const unsigned long long *bkt64, int j, int explicit_keys) {
     if (explicit_keys) return P.hl_key[j];
-    const unsigned long long first = P.bkt64[P.hl_bkt[j]] & 0xFFFFFFFFull;
+    const unsigned long long first = bkt64[P.hl_bkt[j]] & 0xFFFFFFFFull;
     return ((first + 1ull) << 32) | (unsigned long long)P.hl_vt[j];
 }
 
@@ -1431,9 +1438,12 @@ __device__ __forceinline__ void mlm_apply_misses(const MlmDev &P, float &L, uint
 // voxel's misses of this frame (the reference runs all hits before all misses, map_local.cpp:147,176).
 // blockIdx.y == 1 + k: miss cells of sub-list k that were their voxel's first miss — voxels that also have hits are left to the hit owner
 // (the MLM_HAS_HITS flag in the miss counter tells the two sides apart, so each voxel's misses are applied once).
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_idx, int explicit_keys) {
+__device__ __forceinline__ void mlm_apply_body(const MlmDev &P, int frame_idx, int explicit_keys, unsigned int by) {
+    int *vox_head = P.vox_head + (size_t)(frame_idx & 1) * P.vox_stride;
+    uint32_t *vox_miss = P.vox_miss + (size_t)(frame_idx & 1) * P.vox_stride;
+    const unsigned long long *bkt64 = P.bkt64 + (size_t)(frame_idx & 1) * P.bkt_stride;
     const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if (blockIdx.y == 0) {
+    if (by == 0) {
         // speculative loads of item i0 (see k_voxelize)
         int p_next = 0, p_vox = -1;
         float p_inc = 0.0f;
@@ -1455,8 +1465,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
             const int v = p_vox;
             // the voxel's miss count is fetched (and reset) in the same round trip as its state
             uint32_t km = 0;
-            if (!P.explore) km = atomicExch(&P.vox_miss[v], 0u) & ~MLM_HAS_HITS;
-            const int head = P.vox_head[v];
+            if (!P.explore) km = atomicExch(&vox_miss[v], 0u) & ~MLM_HAS_HITS;
+            const int head = vox_head[v];
             float L = P.log_odds[v];
             uint8_t o = P.occ[v];
             const uint8_t o0 = o;
@@ -1479,7 +1489,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
                 }
                 int cnt = 0;
                 for (int j = head; j >= 0; j = P.hl_next[j]) {
-                    unsigned long long k = mlm_order_key(P, j, explicit_keys);
+                    unsigned long long k = mlm_order_key(P, bkt64, j, explicit_keys);
                     float inc = P.hl_inc[j];
                     ++cnt;
 #pragma unroll
@@ -1511,7 +1521,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
                         int best = -1;
                         unsigned long long bestkey = 0;
                         for (int j = head; j >= 0; j = P.hl_next[j]) {
-                            const unsigned long long k = mlm_order_key(P, j, explicit_keys);
+                            const unsigned long long k = mlm_order_key(P, bkt64, j, explicit_keys);
                             if (k < last && (best < 0 || k > bestkey)) {
                                 best = j;
                                 bestkey = k;
@@ -1534,11 +1544,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
             }
             P.log_odds[v] = L;
             P.occ[v] = o;
-            P.vox_head[v] = -1;
+            vox_head[v] = -1;
         }
         return;
     }
-    const unsigned int sl = blockIdx.y - 1;
+    const unsigned int sl = by - 1;
     int p_v = -1;
     if (i0 < P.mc_cap) p_v = P.mc_vox[(size_t)sl * P.mc_cap + i0];
     const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1549,14 +1559,31 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
         if (v < 0) continue; // not the voxel's first miss (or no block)
         // vox_miss[v]: 0 = a hit owner already applied the misses; MLM_HAS_HITS set = a hit owner will; else the
         // voxel has misses only and this lane is the only one that touches it
-        const uint32_t k = __hip_atomic_load(&P.vox_miss[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t k = __hip_atomic_load(&vox_miss[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float L = P.log_odds[v]; // same round trip as the counter; unused if a hit owner handles the voxel
         uint8_t o = P.occ[v];
         if (k == 0 || (k & MLM_HAS_HITS)) continue;
-        P.vox_miss[v] = 0;
+        vox_miss[v] = 0;
         mlm_apply_misses(P, L, o, k);
         P.log_odds[v] = L;
         P.occ[v] = o;
+    }
+}
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_idx, int explicit_keys) {
+    mlm_apply_body(P, frame_idx, explicit_keys, blockIdx.y);
+}
+
+// k_apply of frame f and k_voxelize of frame f+1 in ONE launch (speculative path of a batch): the two touch different
+// copies of the per-voxel scratch (sequence parity) and different frame slots, and k_voxelize(f+1) needs nothing of
+// k_apply(f) — so the serial chain of a batch is n+1 launches instead of 2n.  blockIdx.y < 1 + MLM_RAY_LISTS: the apply
+// side; the rest: the voxelize side.  has_a / has_v: the first launch of a batch has no apply side, the last no
+// voxelize side.
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_voxelize(const MlmDev Pa, int frame_a, int has_a, const MlmDev Pv,
+                                                              const MlmFrame Fv, unsigned long long n_bkt, int has_v) {
+    if (blockIdx.y < 1 + MLM_RAY_LISTS) {
+        if (has_a) mlm_apply_body(Pa, frame_a, 0, blockIdx.y);
+    } else {
+        if (has_v) mlm_voxelize_body(Pv, Fv, n_bkt, blockIdx.y - (1 + MLM_RAY_LISTS));
     }
 }
 

@@ -151,8 +151,12 @@ struct MlmDev {
     float *log_odds;           // [max_blocks*cells]
     uint8_t *occ;              // [max_blocks*cells] 'u','f','o'
     uint8_t *infl;             // [max_blocks*cells]
-    int *vox_head;             // [max_blocks*cells] head of this frame's pending hit list, -1 = none
-    uint32_t *vox_miss;        // [max_blocks*cells] miss count of this frame
+    int *vox_head;             // [2][max_blocks*cells] head of this frame's pending hit list, -1 = none; the copy is chosen
+                               // by the frame's sequence number & 1, so that k_apply of frame f and k_voxelize of
+                               // frame f+1 can run in one launch
+    uint32_t *vox_miss;        // [2][max_blocks*cells] miss count of this frame
+    size_t vox_stride;         // max_blocks*cells
+    size_t bkt_stride;         // elements of one copy of bkt64 (also [2], same rule)
     int *miss_vox;             // [MLM_RAY_LISTS][mvox_cap] voxels touched by misses this frame
     unsigned int mvox_cap;
     // ---- exploration-frontier mode (use_exploration_frontiers: true) — map_local.cpp:7-33,208-232

@@ -629,11 +629,17 @@ int submit_batch(mlm_handle *h, int base, int n) {
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
     {
+        // launch j = k_apply of frame j-1 + k_voxelize of frame j (see k_apply_voxelize): n+1 launches for n frames
         Timed t(h, h->stream, "stage_bc_batch");
-        for (int j = 0; j < n; ++j) {
-            MlmSlot &S = h->slots[(size_t)(base + j)];
-            launch_stage_bc(h, S, h->hit_n_bkt);
-            h->pending.push_back(&S);
+        for (int j = 0; j <= n; ++j) {
+            MlmSlot &Sa = h->slots[(size_t)(base + (j > 0 ? j - 1 : 0))];
+            MlmSlot &Sv = h->slots[(size_t)(base + (j < n ? j : n - 1))];
+            {
+                Timed tk(h, h->stream, "k_apply_voxelize");
+                hipLaunchKernelGGL(k_apply_voxelize, dim3(160, 2 * (1 + MLM_RAY_LISTS)), dim3(MLM_BLOCK), 0, h->stream, Sa.P,
+                                   Sa.F.seq, j > 0 ? 1 : 0, Sv.P, Sv.F, h->hit_n_bkt, j < n ? 1 : 0);
+            }
+            if (j < n) h->pending.push_back(&Sv);
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters),
@@ -699,7 +705,7 @@ int drain(mlm_handle *h) {
     for (int k = 0; k < MLM_SETS; ++k) h->set_pending[k] = 0;
     if (h->next_seq > 0x3FFFFFFF) { // nothing in flight: sequence numbers restart, so the bucket table must forget them
         h->next_seq = 0;
-        HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, h->max_buckets * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long), h->stream));
     }
     return MLM_OK;
 }
@@ -1079,8 +1085,9 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         h->max_buckets = pol._M_next_bkt(2 * NC + 2);
     }
     if ((rc = dev_alloc(h, &P.bkt_first, h->max_buckets))) return rc;
-    if ((rc = dev_alloc(h, &P.bkt64, h->max_buckets))) return rc;
-    HIPCHK(h, hipMemset(P.bkt64, 0xFF, h->max_buckets * sizeof(unsigned long long)));
+    P.bkt_stride = h->max_buckets;
+    if ((rc = dev_alloc(h, &P.bkt64, 2 * h->max_buckets))) return rc;
+    HIPCHK(h, hipMemset(P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long)));
 
     // block table + pool (shared by all slots)
     size_t ht = 1;
@@ -1093,8 +1100,9 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &P.log_odds, NV))) return rc;
     if ((rc = dev_alloc(h, &P.occ, NV))) return rc;
     if ((rc = dev_alloc(h, &P.infl, NV))) return rc;
-    if ((rc = dev_alloc(h, &P.vox_head, NV))) return rc;
-    if ((rc = dev_alloc(h, &P.vox_miss, NV))) return rc;
+    P.vox_stride = NV;
+    if ((rc = dev_alloc(h, &P.vox_head, 2 * NV))) return rc;
+    if ((rc = dev_alloc(h, &P.vox_miss, 2 * NV))) return rc;
     if ((rc = dev_alloc(h, &P.g, 1))) return rc;
     if (P.explore) {
         if ((rc = dev_alloc(h, &P.frnt, NV))) return rc;
@@ -1112,8 +1120,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     HIPCHK(h, hipMemset(P.log_odds, 0, NV * sizeof(float)));            // allocate_ram: log_odds 0
     HIPCHK(h, hipMemset(P.occ, 'u', NV));                               //               occupancy 'u'
     HIPCHK(h, hipMemset(P.infl, 'u', NV));                              //               inflate_occupancy 'u'
-    HIPCHK(h, hipMemset(P.vox_head, 0xFF, NV * sizeof(int)));
-    HIPCHK(h, hipMemset(P.vox_miss, 0, NV * sizeof(uint32_t)));
+    HIPCHK(h, hipMemset(P.vox_head, 0xFF, 2 * NV * sizeof(int)));
+    HIPCHK(h, hipMemset(P.vox_miss, 0, 2 * NV * sizeof(uint32_t)));
     {
         MlmGlobal g0{};
         g0.fail_frame = 0x7FFFFFFF;
