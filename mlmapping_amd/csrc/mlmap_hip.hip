@@ -5,6 +5,7 @@
 // per-voxel work runs in the kernels of mlm_kernels.h.  There is no CPU fallback: every entry point fails with
 // MLM_ERR_HIP when the device is unavailable.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -223,12 +224,7 @@ struct Timed {
     hipStream_t s;
     KernelTime *kt = nullptr;
     Timed(mlm_handle *hh, hipStream_t st, const char *name) : h(hh), s(st) {
-        if (!h->timing) return;
-        if (h->timing == 3) { // one kernel only (bench: the dominant one), every `timed_every`-th launch of it
-            if (strcmp(name, h->timed_kernel.c_str()) != 0) return;
-            if (h->timed_count++ % h->timed_every != 0) return;
-        }
-        if ((h->timing == 4) != (strncmp(name, "stage_", 6) == 0)) return; // mode 4: the two stage spans of a batch only
+        if (h->timing != 4) return; // mode 4: the two stage spans of a batch (plain event pairs on the stream)
         if (h->kpool_used == h->kpool.size()) {
             KernelTime k{name, nullptr, nullptr};
             hipEventCreate(&k.a);
@@ -246,6 +242,35 @@ struct Timed {
         }
     }
 };
+
+// Launch a kernel; when its launches are being timed, through hipExtLaunchKernelGGL with a start/stop event pair: the
+// pair reports the kernel's own begin/end on the device (what rocprofv3 reports as its duration), not the time the
+// stream waited for compute units behind the other streams' waves.
+inline KernelTime *timing_slot(mlm_handle *h, const char *name) {
+    if (!h->timing || h->timing == 4) return nullptr;
+    if (h->timing == 3) { // one kernel only (bench: the dominant one), every `timed_every`-th launch of it
+        if (strcmp(name, h->timed_kernel.c_str()) != 0) return nullptr;
+        if (h->timed_count++ % h->timed_every != 0) return nullptr;
+    }
+    if (h->kpool_used == h->kpool.size()) {
+        KernelTime k{name, nullptr, nullptr};
+        hipEventCreate(&k.a);
+        hipEventCreate(&k.b);
+        h->kpool.push_back(k);
+    }
+    KernelTime *kt = &h->kpool[h->kpool_used++];
+    kt->name = name;
+    return kt;
+}
+template <class K, class... A>
+inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, A... args) {
+    if (KernelTime *kt = timing_slot(h, name)) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, st, kt->a, kt->b, 0, args...);
+        h->ktimes.push_back(*kt);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
+    }
+}
 
 // T_ls and t_wa of one frame (map_awareness.cpp:184-186) — SURVEY.md App. C1, evaluated in that order
 void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb_in[3], MlmFrame &F) {
@@ -378,57 +403,49 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
             h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
             return MLM_ERR_CAPACITY;
         }
-        Timed t(h, st, "k_bin_points");
         if (mode == 0)
-            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_points", k_bin_points<0>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
         else if (mode == 1)
-            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_points", k_bin_points<1>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
         else
-            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_points", k_bin_points<2>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     if (nb) {
-        Timed t(h, st, "k_book_cells");
         int tx, ty;
         const unsigned int ng = book_grid(P, F, mode, (int)nb, tx, ty);
-        hipLaunchKernelGGL(k_book_cells, dim3(ng, 1, n), dim3(MLM_BOOK_THREADS), 0, st, h->d_slot_tab, h->d_frame_tab, base, tx, ty, (int)nb);
+        tlaunch(h, "k_book_cells", k_book_cells, dim3(ng, 1, n), dim3(MLM_BOOK_THREADS), 0, st, h->d_slot_tab, h->d_frame_tab, base, tx, ty, (int)nb);
     }
     {
-        Timed t(h, st, "k_assign_nodes");
-        hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_assign_nodes", k_assign_nodes, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, mode == 0 ? F.width : 0);
     }
     {
-        Timed t(h, st, "k_collect_hits");
-        hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_collect_hits", k_collect_hits, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, (int)nb);
     }
     {
-        Timed t(h, st, "k_expand_nodes");
-        hipLaunchKernelGGL(k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_expand_nodes", k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb);
     }
     {
-        Timed t(h, st, "k_sort_contribs");
         const int row_w = mode == 0 ? F.width : 64; // rows of the ranking bitmap (see k_sort_contribs)
         unsigned long long dm;
         int ds;
         div_magic((unsigned int)row_w, dm, ds);
-        hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_sort_contribs", k_sort_contribs<1024>, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 0u, row_w, dm, ds);
-        hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_sort_contribs", k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 1024u, row_w, dm, ds);
     }
     {
-        Timed t(h, st, "k_chain");
-        hipLaunchKernelGGL(k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st,
+        tlaunch(h, "k_chain", k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st,
                            h->d_slot_tab, h->d_frame_tab, base,
                            (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
     }
     {
-        Timed t(h, st, "k_prepare_voxels");
         // one 256-word slice of the miss mask per block (the unique hits, far fewer, are strided over the same blocks)
         const unsigned int pb = std::max(64u, grid_for((size_t)P.nMissWords));
-        hipLaunchKernelGGL(k_prepare_voxels, dim3(pb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        tlaunch(h, "k_prepare_voxels", k_prepare_voxels, dim3(pb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
@@ -439,12 +456,10 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
 void launch_stage_bc(mlm_handle *h, MlmSlot &S, unsigned long long n_bkt) {
     const MlmDev &P = S.P;
     {
-        Timed t(h, h->stream, "k_voxelize");
-        hipLaunchKernelGGL(k_voxelize, dim3(160, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F, n_bkt);
+        tlaunch(h, "k_voxelize", k_voxelize, dim3(160, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F, n_bkt);
     }
     {
-        Timed t(h, h->stream, "k_apply");
-        hipLaunchKernelGGL(k_apply, dim3(160, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq, n_bkt ? 0 : 1);
+        tlaunch(h, "k_apply", k_apply, dim3(160, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F.seq, n_bkt ? 0 : 1);
     }
 }
 
@@ -634,11 +649,8 @@ int submit_batch(mlm_handle *h, int base, int n) {
         for (int j = 0; j <= n; ++j) {
             MlmSlot &Sa = h->slots[(size_t)(base + (j > 0 ? j - 1 : 0))];
             MlmSlot &Sv = h->slots[(size_t)(base + (j < n ? j : n - 1))];
-            {
-                Timed tk(h, h->stream, "k_apply_voxelize");
-                hipLaunchKernelGGL(k_apply_voxelize, dim3(160, 2 * (1 + MLM_RAY_LISTS)), dim3(MLM_BLOCK), 0, h->stream, Sa.P,
-                                   Sa.F.seq, j > 0 ? 1 : 0, Sv.P, Sv.F, h->hit_n_bkt, j < n ? 1 : 0);
-            }
+            tlaunch(h, "k_apply_voxelize", k_apply_voxelize, dim3(160, 2 * (1 + MLM_RAY_LISTS)), dim3(MLM_BLOCK), 0, h->stream, Sa.P,
+                    Sa.F.seq, j > 0 ? 1 : 0, Sv.P, Sv.F, h->hit_n_bkt, j < n ? 1 : 0);
             if (j < n) h->pending.push_back(&Sv);
         }
     }
