@@ -853,6 +853,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
                 P.hl_base[pos] = base;
                 P.hl_cnt[pos] = cnt;
                 P.mt_list[off_m + (uint32_t)__popcll(bm & below)] = pos;
+                P.mt_rec[off_m + (uint32_t)__popcll(bm & below)] = make_uint4(pos, base, cnt, t);
                 if (cnt > 1024u) P.mt_big[atomicAdd(&P.ctr->n_big, 1u)] = pos; // few: second k_sort_contribs launch
             } else {
                 // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
@@ -950,31 +951,43 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[MLM_BLOCK / 64][MLM_SORT_CAP];
     const bool big = MLM_SORT_CAP > 1024;
     const unsigned int n_cells = big ? P.ctr->n_big : P.ctr->n_multi;
-    const uint32_t *list = big ? P.mt_big : P.mt_list;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     volatile uint32_t *K = s_keys[wid];
-    for (unsigned int w = wave; w < n_cells; w += n_waves) {
-        const uint32_t pos = list[w];
-        const uint32_t base = P.hl_base[pos];
-        const uint32_t n = P.hl_cnt[pos];
-        if (n <= n_lo || (n > MLM_SORT_CAP && !big)) continue; // the other launch's cells
+    // One cell ahead: the cell's record {hit-list position, segment base, contribution count, first-touch time} (written
+    // by k_collect_hits) and its first 256 keys are loaded while the previous cell is processed — a cell is otherwise a
+    // chain of four dependent memory round trips.
+    auto load_rec = [&](unsigned int w) -> uint4 {
+        if (!big) return P.mt_rec[w];
+        const uint32_t pos = P.mt_big[w];
+        return make_uint4(pos, P.hl_base[pos], P.hl_cnt[pos], P.hl_t[pos]);
+    };
+    auto load_keys = [&](const uint4 &r, uint32_t (&k)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = (uint32_t)lane + 64u * q;
+            k[q] = (j < r.z) ? P.contrib[r.y + j] : 0u;
+        }
+    };
+    auto process = [&](const uint4 &rec, const uint32_t (&kreg)[4]) {
+        const uint32_t pos = rec.x, base = rec.y, n = rec.z;
+        (void)pos;
+        if (n <= n_lo || (n > MLM_SORT_CAP && !big)) return; // the other launch's cells
         if (n <= MLM_SORT_CAP) {
             // ---- bitmap path.  LDS window of the wave: [0,2K) 256 x u64 bitmap words (row-major, 2 per row),
             //      [2K,3K) exclusive prefix of their popcounts, [3K,..) the ordered kinds
             unsigned long long *rows = (unsigned long long *)s_keys[wid];
             volatile uint32_t *pre = (volatile uint32_t *)(s_keys[wid] + 512);
             volatile uint8_t *S = (volatile uint8_t *)(s_keys[wid] + 768);
-            const uint32_t pix0 = P.hl_t[pos] / MLM_TIME_SLOTS; // the cell's first pixel: smallest row of the window
+            const uint32_t pix0 = rec.w / MLM_TIME_SLOTS; // the cell's first pixel: smallest row of the window
             const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
             const int xlo = (int)(pix0 - y0 * (uint32_t)row_w) - 64;
             for (int j = lane; j < 2 * MLM_BMP_ROWS; j += 64) rows[j] = 0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bool bad = false;
-            // the keys of the first four rounds stay in registers for the second pass (covers n <= 256: the bulk)
-            uint32_t kreg[4] = {0, 0, 0, 0};
+            // the keys of the first four rounds are in registers (loaded one cell ahead; covers n <= 256: the bulk)
             auto mark = [&](uint32_t key) {
                 const uint32_t pix = key / MLM_TIME_SLOTS;
                 const uint32_t y = (uint32_t)(((unsigned long long)pix * div_m) >> div_s);
@@ -989,10 +1002,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t j = (uint32_t)lane + 64u * q;
-                if (j < n) {
-                    kreg[q] = P.contrib[base + j];
-                    mark(kreg[q]);
-                }
+                if (j < n) mark(kreg[q]);
             }
             for (uint32_t j = lane + 256u; j < n; j += 64) mark(P.contrib[base + j]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1032,7 +1042,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
-                continue;
+                return;
             }
         }
         if (n <= 320) {
@@ -1104,6 +1114,23 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
                 P.subs[base + r] = (uint8_t)(my % MLM_TIME_SLOTS);
             }
         }
+    };
+    uint4 rec_cur = make_uint4(0, 0, 0, 0), rec_nxt = make_uint4(0, 0, 0, 0);
+    uint32_t k_cur[4] = {0, 0, 0, 0}, k_nxt[4] = {0, 0, 0, 0};
+    if (wave < n_cells) {
+        rec_cur = load_rec(wave);
+        load_keys(rec_cur, k_cur);
+    }
+    if (wave + n_waves < n_cells) rec_nxt = load_rec(wave + n_waves);
+    for (unsigned int w = wave; w < n_cells; w += n_waves) {
+        uint4 rec_nn = make_uint4(0, 0, 0, 0);
+        if (w + n_waves < n_cells) load_keys(rec_nxt, k_nxt);
+        if (w + 2 * n_waves < n_cells) rec_nn = load_rec(w + 2 * n_waves);
+        process(rec_cur, k_cur);
+        rec_cur = rec_nxt;
+        rec_nxt = rec_nn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k_cur[q] = k_nxt[q];
     }
 }
 

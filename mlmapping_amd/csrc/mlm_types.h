@@ -109,6 +109,7 @@ struct MlmDev {
     uint32_t *contrib;         // [contrib_cap] insertion times of the contributions of multi-kind cells, by cell
     unsigned int *blk_stats;   // [4*nb_cap] per k_bin_points block: points fed, points out of range, groups, pairs
     uint32_t *mt_list;         // [nCells] indices into the hit list of the multi-type cells
+    uint4 *mt_rec;             // [nCells] per multi-type cell: {hit-list index, segment base, contribution count, first-touch time}
     uint32_t *mt_big;          // [nCells] those with more than 1024 contributions
     uint32_t *touched;         // [MLM_RAY_LISTS][touch_cap] hit cells in first-touch order of the GPU (arbitrary)
     unsigned int touch_cap;    // per sub-list

@@ -832,6 +832,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = dev_alloc(h, &P.cs, NC))) return rc;
     if ((rc = dev_alloc(h, &P.miss_bits, (size_t)MLM_MISS_COPIES * P.nMissWords))) return rc;
     if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.mt_rec, NC))) return rc;
     if ((rc = dev_alloc(h, &P.mt_big, NC))) return rc;
     P.touch_cap = (unsigned int)NC;
     if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
