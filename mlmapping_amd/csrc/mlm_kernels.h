@@ -958,6 +958,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
     // One cell ahead: the cell's record {hit-list position, segment base, contribution count, first-touch time} (written
     // by k_collect_hits) and its first 256 keys are loaded while the previous cell is processed — a cell is otherwise a
     // chain of four dependent memory round trips.
+    for (int j = lane; j < 2 * MLM_BMP_ROWS; j += 64) ((unsigned long long *)s_keys[wid])[j] = 0ull; // ranking bitmap
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     auto load_rec = [&](unsigned int w) -> uint4 {
         if (!big) return P.mt_rec[w];
         const uint32_t pos = P.mt_big[w];
@@ -983,9 +986,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
             const uint32_t pix0 = rec.w / MLM_TIME_SLOTS; // the cell's first pixel: smallest row of the window
             const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
             const int xlo = (int)(pix0 - y0 * (uint32_t)row_w) - 64;
-            for (int j = lane; j < 2 * MLM_BMP_ROWS; j += 64) rows[j] = 0ull;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            // (the bitmap is all zero here: cleared at kernel start and after every use)
             bool bad = false;
             // the keys of the first four rounds are in registers (loaded one cell ahead; covers n <= 256: the bulk)
             auto mark = [&](uint32_t key) {
@@ -1008,13 +1009,18 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             uint32_t carry = 0;
+            int used = 2 * MLM_BMP_ROWS; // bitmap words to clear afterwards
             if (!__any(bad)) {
-                for (int j0 = 0; j0 < 2 * MLM_BMP_ROWS; j0 += 64) {
+                // the window is anchored at the cell's first row, so the marked words come first: stop once all n
+                // contributions are accounted for (typically after the first 64 words)
+                int j0 = 0;
+                for (; j0 < 2 * MLM_BMP_ROWS && carry < n; j0 += 64) {
                     const uint32_t c = (uint32_t)__popcll(((volatile unsigned long long *)rows)[j0 + lane]);
                     const uint32_t incl = mlm_wave_incl_scan(c);
                     pre[j0 + lane] = carry + incl - c;
                     carry += mlm_readlane(incl, 63);
                 }
+                if (carry == n) used = j0;
             }
             if (carry == n) { // every contribution marked its own pixel
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1035,6 +1041,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
                 for (uint32_t j = lane + 256u; j < n; j += 64) place(P.contrib[base + j]);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                for (int j = lane; j < used; j += 64) rows[j] = 0ull; // clean for the next cell
                 if (MLM_SORT_CAP <= 1024) {
                     const uint32_t n4 = (n + 3u) & ~3u;
                     for (uint32_t j = lane; j < n4 / 4; j += 64)
@@ -1114,6 +1121,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_sort_contribs(MLM_SLOT_ARGS, unsi
                 P.subs[base + r] = (uint8_t)(my % MLM_TIME_SLOTS);
             }
         }
+        // only the fallbacks get here, and they used the wave's LDS window for keys: clear the ranking bitmap again
+        for (int j = lane; j < 2 * MLM_BMP_ROWS; j += 64) ((unsigned long long *)s_keys[wid])[j] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
     uint4 rec_cur = make_uint4(0, 0, 0, 0), rec_nxt = make_uint4(0, 0, 0, 0);
     uint32_t k_cur[4] = {0, 0, 0, 0}, k_nxt[4] = {0, 0, 0, 0};
