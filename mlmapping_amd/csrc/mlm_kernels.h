@@ -541,7 +541,7 @@ __device__ __forceinline__ float mlm_logit(float p) {
 struct MlmBookCell {
     uint32_t cell, tmin, kmask, cnt, start_min, base;
 };
-// bin block handled at position j (0..MLM_BOOK_GROUP-1) of workgroup g; tiles_x > 0: 4x4 tile arrangement
+// bin block handled at position j (0..MLM_BOOK_GROUP-1) of workgroup g; tiles_x > 0: 4 x (MLM_BOOK_GROUP/4) tile arrangement
 __device__ __forceinline__ int mlm_book_block(int g, int j, int tiles_x, int tiles_y, int n_bin_blocks) {
     if (tiles_x <= 0) {
         const int b = g * MLM_BOOK_GROUP + j;
@@ -549,7 +549,7 @@ __device__ __forceinline__ int mlm_book_block(int g, int j, int tiles_x, int til
     }
     const int groups_x = (tiles_x + 3) >> 2;
     const int gy = g / groups_x, gx = g - gy * groups_x;
-    const int tx = gx * 4 + (j & 3), ty = gy * 4 + (j >> 2);
+    const int tx = gx * 4 + (j & 3), ty = gy * (MLM_BOOK_GROUP / 4) + (j >> 2);
     return (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : -1;
 }
 __global__ __launch_bounds__(MLM_BOOK_THREADS) void k_book_cells(MLM_SLOT_ARGS, int tiles_x, int tiles_y, int n_bin_blocks) {

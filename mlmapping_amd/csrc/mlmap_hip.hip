@@ -379,7 +379,7 @@ inline unsigned int book_grid(const MlmDev &P, const MlmFrame &F, int mode, int 
     const int tile_h = (int)(P.bin_block / 256) * 8;
     tiles_x = (F.width + 31) / 32;
     tiles_y = (F.height + tile_h - 1) / tile_h;
-    return (unsigned int)(((tiles_x + 3) / 4) * ((tiles_y + 3) / 4));
+    return (unsigned int)(((tiles_x + 3) / 4) * ((tiles_y + MLM_BOOK_GROUP / 4 - 1) / (MLM_BOOK_GROUP / 4)));
 }
 
 // Stage A of a whole batch (slots base..base+n, same mode and image geometry) on stream_a: awareness raycast ->
@@ -1052,7 +1052,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             P.agg_lds = 512;
         }
         // block size of k_bin_points and its LDS buffers (the sizes above are per 256 threads); experiment knobs
-        P.bin_block = 512; // measured on config 2: 26.9k frames/s vs 26.2k with 256 (fewer (block, cell) pairs to book)
+        P.bin_block = 256; // measured on config 2: 34.4k frames/s vs 33.6k with 512 and 31.9k with 1024
         if (const char *e = getenv("MLM_BIN_BLOCK")) P.bin_block = (atoi(e) >= 1024) ? 1024u : (atoi(e) >= 512 ? 512u : 256u);
         P.node_lds = P.node_lds * (P.bin_block / 256);
         P.agg_lds = P.agg_lds * (P.bin_block / 256);
