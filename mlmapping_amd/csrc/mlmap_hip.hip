@@ -166,6 +166,7 @@ struct mlm_handle {
     std::vector<MlmSlot *> pending;
     int next_seq = 0;
     int cur_set = 0;
+    bool sc_grid_fixed = false;              // MLM_SC_GRID given: do not adapt
     unsigned int sc_grid = 80;               // blocks per list of k_apply_voxelize (grid-stride loops; 40..120 measured equal, 160 3 % slower)
     std::string timed_kernel = "k_bin_points"; // the kernel bracketed in timing mode 3 ...
     unsigned int timed_every = 1, timed_count = 0; // ... on every timed_every-th launch
@@ -647,10 +648,16 @@ int submit_batch(mlm_handle *h, int base, int n) {
     {
         // launch j = k_apply of frame j-1 + k_voxelize of frame j (see k_apply_voxelize): n+1 launches for n frames
         Timed t(h, h->stream, "stage_bc_batch");
+        // blocks per list: one item per thread for a frame like the last confirmed one (grid-stride loops take the rest)
+        unsigned int scg = h->sc_grid;
+        if (!h->sc_grid_fixed) {
+            const long long items = std::max<long long>(h->stats.n_hit_cells, h->stats.n_miss_cells / MLM_RAY_LISTS);
+            scg = (unsigned int)std::min<long long>(1024, std::max<long long>(h->sc_grid, (items * 5 / 4 + MLM_BLOCK - 1) / MLM_BLOCK));
+        }
         for (int j = 0; j <= n; ++j) {
             MlmSlot &Sa = h->slots[(size_t)(base + (j > 0 ? j - 1 : 0))];
             MlmSlot &Sv = h->slots[(size_t)(base + (j < n ? j : n - 1))];
-            tlaunch(h, "k_apply_voxelize", k_apply_voxelize, dim3(h->sc_grid, 2 * (1 + MLM_RAY_LISTS)), dim3(MLM_BLOCK), 0, h->stream, Sa.P,
+            tlaunch(h, "k_apply_voxelize", k_apply_voxelize, dim3(scg, 2 * (1 + MLM_RAY_LISTS)), dim3(MLM_BLOCK), 0, h->stream, Sa.P,
                     Sa.F.seq, j > 0 ? 1 : 0, Sv.P, Sv.F, h->hit_n_bkt, j < n ? 1 : 0);
             if (j < n) h->pending.push_back(&Sv);
         }
@@ -954,7 +961,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // leaves the rest to Stage A, so that the chain is not stretched by queueing behind Stage A's waves.
         int lo = 0, hi = 0; // numerically lower = higher priority
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        if (const char *e = getenv("MLM_SC_GRID")) h->sc_grid = (unsigned int)std::max(1, atoi(e));
+        if (const char *e = getenv("MLM_SC_GRID")) {
+            h->sc_grid = (unsigned int)std::max(1, atoi(e));
+            h->sc_grid_fixed = true;
+        }
         const char *env = getenv("MLM_CU_SPLIT");
         h->cu_split = env ? atoi(env) : 0;
         hipDeviceProp_t prop;
