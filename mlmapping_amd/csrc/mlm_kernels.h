@@ -1618,6 +1618,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_i
 // voxelize side.
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_voxelize(const MlmDev Pa, int frame_a, int has_a, const MlmDev Pv,
                                                               const MlmFrame Fv, unsigned long long n_bkt, int has_v) {
+    __builtin_amdgcn_s_setprio(3); // the serial chain of the pipeline: its few waves issue ahead of Stage A's
     if (blockIdx.y < 1 + MLM_RAY_LISTS) {
         if (has_a) mlm_apply_body(Pa, frame_a, 0, blockIdx.y);
     } else {
