@@ -166,6 +166,8 @@ struct mlm_handle {
     std::vector<MlmSlot *> pending;
     int next_seq = 0;
     int cur_set = 0;
+    unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
+    unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
     bool sc_grid_fixed = false;              // MLM_SC_GRID given: do not adapt
     unsigned int sc_grid = 80;               // blocks per list of k_apply_voxelize (grid-stride loops; 40..120 measured equal, 160 3 % slower)
     std::string timed_kernel = "k_bin_points"; // the kernel bracketed in timing mode 3 ...
@@ -418,15 +420,15 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         tlaunch(h, "k_book_cells", k_book_cells, dim3(ng, 1, n), dim3(MLM_BOOK_THREADS), 0, st, h->d_slot_tab, h->d_frame_tab, base, tx, ty, (int)nb);
     }
     {
-        tlaunch(h, "k_assign_nodes", k_assign_nodes, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_assign_nodes", k_assign_nodes, dim3(8, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, mode == 0 ? F.width : 0);
     }
     {
-        tlaunch(h, "k_collect_hits", k_collect_hits, dim3(64, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_collect_hits", k_collect_hits, dim3(h->collect_grid, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, (int)nb);
     }
     {
-        tlaunch(h, "k_expand_nodes", k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_expand_nodes", k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, n), dim3(h->expand_block), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb);
     }
     {
@@ -961,6 +963,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // leaves the rest to Stage A, so that the chain is not stretched by queueing behind Stage A's waves.
         int lo = 0, hi = 0; // numerically lower = higher priority
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (const char *e = getenv("MLM_EXPAND_BLOCK")) h->expand_block = (unsigned int)std::max(64, atoi(e));
+        if (const char *e = getenv("MLM_COLLECT_GRID")) h->collect_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_SC_GRID")) {
             h->sc_grid = (unsigned int)std::max(1, atoi(e));
             h->sc_grid_fixed = true;

@@ -26,7 +26,9 @@ for k in range(2, nb + 2):
     m.update_map_batch(frames, q[B * k:B * k + B], t[B * k:B * k + B])
 m.sync()
 acc = {}
-for name, ms in m.kernel_times():
+all_times = m.kernel_times()
+sc = [ms for name, ms in all_times if name == "k_apply_voxelize"]
+for name, ms in all_times:
     a = acc.setdefault(name, [0.0, 0])
     a[0] += ms
     a[1] += 1
@@ -36,3 +38,9 @@ for name, (ms, n) in acc.items():
     tot += per
     print(f"{name:20s} {per:8.2f} us/frame   ({n} launches, {ms * 1e3 / n:8.1f} us each)")
 print(f"{'sum':20s} {tot:8.2f} us/frame")
+if sc and len(sc) == nb * (B + 1):
+    first = [sc[i * (B + 1)] for i in range(nb)]
+    last = [sc[i * (B + 1) + B] for i in range(nb)]
+    mid = [sc[i * (B + 1) + j] for i in range(nb) for j in range(1, B)]
+    print(f"k_apply_voxelize: voxelize side only {sum(first)/len(first)*1e3:.1f} us, apply side only {sum(last)/len(last)*1e3:.1f} us, "
+          f"both {sum(mid)/len(mid)*1e3:.1f} us")
