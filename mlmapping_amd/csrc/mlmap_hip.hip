@@ -167,6 +167,7 @@ struct mlm_handle {
     int next_seq = 0;
     int cur_set = 0;
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
+    unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
     bool sc_grid_fixed = false;              // MLM_SC_GRID given: do not adapt
     unsigned int sc_grid = 80;               // blocks per list of k_apply_voxelize (grid-stride loops; 40..120 measured equal, 160 3 % slower)
@@ -175,6 +176,7 @@ struct mlm_handle {
     int set_pending[MLM_SETS] = {};
     bool async_mode = false;
     int cu_split = 0;
+    int cu_reserve = 0;
     hipStream_t stream_as[MLM_SETS] = {};    // Stage A of whole batches, one stream per slot set (overlaps Stage B/C of the
                                              // previous batch and the tails of the other set's Stage A kernels)
     hipEvent_t stage_a_done[MLM_SETS] = {};
@@ -436,7 +438,7 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         unsigned long long dm;
         int ds;
         div_magic((unsigned int)row_w, dm, ds);
-        tlaunch(h, "k_sort_contribs", k_sort_contribs<1024>, dim3(n > 4 ? 256 : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_sort_contribs", k_sort_contribs<1024>, dim3(n > 4 ? h->sort_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 0u, row_w, dm, ds);
         tlaunch(h, "k_sort_contribs", k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 1024u, row_w, dm, ds);
@@ -964,6 +966,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         int lo = 0, hi = 0; // numerically lower = higher priority
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
         if (const char *e = getenv("MLM_EXPAND_BLOCK")) h->expand_block = (unsigned int)std::max(64, atoi(e));
+        if (const char *e = getenv("MLM_SORT_GRID")) h->sort_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_COLLECT_GRID")) h->collect_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_SC_GRID")) {
             h->sc_grid = (unsigned int)std::max(1, atoi(e));
@@ -971,6 +974,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         }
         const char *env = getenv("MLM_CU_SPLIT");
         h->cu_split = env ? atoi(env) : 0;
+        // MLM_CU_RESERVE=k: Stage A stays off the first k CUs, the main stream may use all of them
+        if (const char *e = getenv("MLM_CU_RESERVE")) h->cu_reserve = std::max(0, atoi(e));
         hipDeviceProp_t prop;
         HIPCHK(h, hipGetDeviceProperties(&prop, device));
         const int ncu = prop.multiProcessorCount;
@@ -1178,12 +1183,12 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     HIPCHK(h, hipHostMalloc((void **)&h->h_frame_tab, NS * sizeof(MlmFrame), hipHostMallocDefault));
     std::memset(h->h_ctr_all, 0, NS * sizeof(MlmCounters));
     std::memset(h->h_frame_tab, 0, NS * sizeof(MlmFrame));
-    if (h->cu_split > 0) {
+    if (h->cu_split > 0 || h->cu_reserve > 0) {
         hipDeviceProp_t prop;
         HIPCHK(h, hipGetDeviceProperties(&prop, device));
         const int ncu = prop.multiProcessorCount;
         std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-        for (int c = h->cu_split; c < ncu; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+        for (int c = std::max(h->cu_split, h->cu_reserve); c < ncu; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
         for (int k = 0; k < MLM_SETS; ++k)
             HIPCHK(h, hipExtStreamCreateWithCUMask(&h->stream_as[k], (uint32_t)mask.size(), mask.data()));
     } else {

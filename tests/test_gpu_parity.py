@@ -417,8 +417,11 @@ def test_random_configurations(mods):
     """Fuzz: random map geometries, noise levels, thresholds and camera models — the HIP path must track the oracle on
     all of them (sets and classes exact, odds within 1e-4)."""
     MLMap, OracleMap = mods
-    rng = np.random.default_rng(2024)
-    for trial in range(30):
+    import os
+
+    # MLM_FUZZ_SEED / MLM_FUZZ_TRIALS: longer or different runs of the same fuzz (default: 30 trials, seed 2024)
+    rng = np.random.default_rng(int(os.environ.get("MLM_FUZZ_SEED", "2024")))
+    for trial in range(int(os.environ.get("MLM_FUZZ_TRIALS", "30"))):
         d = float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.25]))
         cfg = S1.with_(
             am_d_Rho=d, am_d_Phi_deg=float(rng.choice([0.5, 1.0, 2.0, 3.0, 5.0])), am_d_Z=float(rng.choice([d, 2 * d, 0.5 * d])),
