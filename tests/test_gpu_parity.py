@@ -88,6 +88,31 @@ def test_stream_parity(mods, scene, poses, cfg, frames):
     print(scene, poses, worst)
 
 
+@pytest.mark.parametrize("node_lds,agg_lds", [(32, 256), (448, 16), (48, 16)])
+def test_forced_buffer_overflows(mods, monkeypatch, node_lds, agg_lds):
+    """The rare paths of k_bin_points / k_book_cells (a block's LDS group buffer or cell table overflows: groups booked one
+    by one by k_assign_nodes, rays walked lane by lane) forced by shrinking the buffers; results must not change."""
+    MLMap, OracleMap = mods
+    monkeypatch.setenv("MLM_NODE_LDS", str(node_lds))
+    monkeypatch.setenv("MLM_AGG_LDS", str(agg_lds))
+    for scene, poses, cfg, frames in (("room_jitter", "random", S1, 3), ("scatter", "static", S1, 2)):
+        gpu, cpu = MLMap(cfg, max_blocks=8192, record_awareness=True), OracleMap(cfg)
+        for k, (img, (q, t)) in enumerate(syn.stream(cfg, scene, poses, frames)):
+            gpu.update_map(img, q, t)
+            cpu.update_depth(img, q, t)
+            _awareness_equal(gpu, cpu)
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"overflow {node_lds}/{agg_lds} {scene} frame {k}")
+        gpu.close()
+    cfg = S1.with_(use_exploration_frontiers=True)
+    gpu, cpu = MLMap(cfg, max_blocks=8192, record_awareness=True), OracleMap(cfg)
+    for k, (img, (q, t)) in enumerate(syn.stream(cfg, "room_jitter", "smooth", 3)):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"overflow {node_lds}/{agg_lds} frontier frame {k}")
+        assert np.array_equal(gpu.export_frontier(), cpu.export_frontier())
+    gpu.close()
+
+
 def test_config3_720p(mods):
     """BASELINE config 3: 1280x720, 0.05 m voxels."""
     MLMap, OracleMap = mods
