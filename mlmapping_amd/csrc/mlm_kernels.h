@@ -1879,6 +1879,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_convert_f32_u16(const float *src,
     }
 }
 
+// the sampled pixels of a frame (already converted on the host) into the device image at their positions
+__global__ __launch_bounds__(MLM_BLOCK) void k_scatter_u16(uint16_t *img, const int32_t *pix, const int32_t *raw, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) img[pix[i]] = (uint16_t)raw[i];
+}
+
 __global__ __launch_bounds__(MLM_BLOCK) void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }

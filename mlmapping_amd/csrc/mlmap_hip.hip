@@ -177,6 +177,8 @@ struct mlm_handle {
     bool async_mode = false;
     int cu_split = 0;
     int cu_reserve = 0;
+    float *d_f32 = nullptr;                  // staging of a 32FC1 frame (mlm_integrate_callback)
+    size_t f32_cap = 0;
     hipStream_t stream_as[MLM_SETS] = {};    // Stage A of whole batches, one stream per slot set (overlaps Stage B/C of the
                                              // previous batch and the tails of the other set's Stage A kernels)
     hipEvent_t stage_a_done[MLM_SETS] = {};
@@ -797,6 +799,7 @@ int ensure_img(mlm_handle *h, MlmSlot &S, size_t n_px) {
 
 int ensure_query(mlm_handle *h, size_t n) {
     if (n <= h->q_cap) return MLM_OK;
+    if (h->d_f32) hipFree(h->d_f32);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     h->d_qpos = nullptr;
@@ -1228,6 +1231,7 @@ int mlm_destroy(mlm_handle *h) {
     }
     for (int k = 0; k < MLM_SETS; ++k)
         if (h->stream_as[k]) hipStreamDestroy(h->stream_as[k]);
+    if (h->d_f32) hipFree(h->d_f32);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     if (h->h_g) hipHostFree(h->h_g);
@@ -1416,10 +1420,53 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
     MlmSlot &S = cur_slot(h, 0);
     rc = ensure_img(h, S, n_px);
     if (rc) return rc;
+    std::vector<int32_t> pix;
+    if (sampled && 2 * (size_t)h->cfg.sample_cnt <= (size_t)h->lim.max_points) {
+        // project_depth, mlmap.cpp:311-349 (glibc rand(), v first, zeros skipped).  Only the sampled pixels are ever read
+        // by the kernels, so only they travel: the host converts them (same float arithmetic as k_convert_f32_u16), a tiny
+        // kernel drops them into the device image at their pixel positions.
+        std::vector<int32_t> raw;
+        const size_t want = (size_t)h->cfg.sample_cnt;
+        int cnt = 0;
+        const int max_iter = 2 * h->cfg.sample_cnt;
+        while (pix.size() < want && cnt < max_iter) {
+            cnt++;
+            const size_t v = static_cast<size_t>(rand() % height);
+            const size_t u = static_cast<size_t>(rand() % width);
+            const size_t at = v * (size_t)width + u;
+            int r;
+            if (is_f32) {
+                const float sv = ((const float *)depth)[at] * 1000.0f;
+                r = 0;
+                if (sv == sv) r = (int)fminf(fmaxf(rintf(sv), 0.0f), 65535.0f);
+            } else {
+                r = ((const uint16_t *)depth)[at];
+            }
+            if (r == 0) continue;
+            pix.push_back((int32_t)at);
+            raw.push_back(r);
+        }
+        if (!pix.empty()) {
+            hipStream_t st = h->stream_as[h->cur_set];
+            int32_t *d_raw = S.d_pix + h->lim.max_points / 2;
+            HIPCHK(h, hipMemcpyAsync(S.d_pix, pix.data(), pix.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(d_raw, raw.data(), raw.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_scatter_u16, dim3(grid_for(pix.size())), dim3(MLM_BLOCK), 0, st, S.d_img, S.d_pix, d_raw, (int)pix.size());
+            HIPCHK(h, hipStreamSynchronize(st)); // pix and raw are locals
+        }
+        return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, width, S.d_pix, (int)pix.size(), qa, ta);
+    }
     std::vector<uint16_t> host_u16; // needed only by the sampler when the input is float
     if (is_f32) {
-        float *d_f = nullptr;
-        HIPCHK(h, hipMalloc((void **)&d_f, n_px * sizeof(float)));
+        // the converted frame stays in a buffer owned by the handle (no allocation per call)
+        if (h->f32_cap < n_px) {
+            if (h->d_f32) hipFree(h->d_f32);
+            h->d_f32 = nullptr;
+            h->f32_cap = 0;
+            HIPCHK(h, hipMalloc((void **)&h->d_f32, n_px * sizeof(float)));
+            h->f32_cap = n_px;
+        }
+        float *d_f = h->d_f32;
         hipError_t e = hipMemcpyAsync(d_f, depth, n_px * sizeof(float), hipMemcpyHostToDevice, h->stream_as[h->cur_set]);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_convert_f32_u16, dim3(grid_for(n_px)), dim3(MLM_BLOCK), 0, h->stream_as[h->cur_set], d_f, S.d_img, n_px);
@@ -1428,8 +1475,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
                 e = hipMemcpyAsync(host_u16.data(), S.d_img, n_px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream_as[h->cur_set]);
             }
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream_as[h->cur_set]);
-        hipFree(d_f);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream_as[h->cur_set]); // `depth` is the caller's
         if (e != hipSuccess) {
             h->err = std::string("mlm_integrate_callback: ") + hipGetErrorString(e);
             return MLM_ERR_HIP;
@@ -1437,9 +1483,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
     } else {
         HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
     }
-    std::vector<int32_t> pix;
-    if (sampled) {
-        // project_depth, mlmap.cpp:311-349: the sampler needs the raw values to skip zeros
+    if (sampled) { // (sample count larger than half the point capacity: the general path)
         const uint16_t *img = is_f32 ? host_u16.data() : (const uint16_t *)depth;
         const size_t want = (size_t)h->cfg.sample_cnt;
         int cnt = 0;
