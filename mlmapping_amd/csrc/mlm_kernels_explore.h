@@ -210,8 +210,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) {
 
 // release scan (map_local.cpp:208-232): one workgroup per allocated block; blocks observed this frame whose frontier is
 // empty and whose occupancy is uniform are collapsed (they stop accepting updates; element 0 answers queries)
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P, unsigned int n_blocks) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) {
     __shared__ int s_bad;
+    const unsigned int n_blocks = min(P.g->n_blocks, (unsigned int)P.max_blocks); // read on the device: no host sync
     for (unsigned int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         if (!P.blk_observed[b]) continue; // uniform per workgroup
         __syncthreads();

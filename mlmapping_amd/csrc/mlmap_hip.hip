@@ -612,10 +612,8 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     hipLaunchKernelGGL(k_ex_miss_tau, dim3(kListGrid), blk, 0, st, P, S.F);
     hipLaunchKernelGGL(k_ex_observe, dim3(kListGrid), blk, 0, st, P, S.F);
     hipLaunchKernelGGL(k_ex_apply_misses, dim3(kListGrid), blk, 0, st, P);
+    hipLaunchKernelGGL(k_ex_release, dim3(1024), blk, 0, st, P);
     HIPCHK(h, hipMemcpyAsync(h->h_g, P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    const unsigned int n_blocks = std::min<unsigned int>(h->h_g->n_blocks, (unsigned int)P.max_blocks);
-    if (n_blocks) hipLaunchKernelGGL(k_ex_release, dim3(std::min(n_blocks, 1024u)), blk, 0, st, P, n_blocks);
     HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
