@@ -113,6 +113,25 @@ def test_forced_buffer_overflows(mods, monkeypatch, node_lds, agg_lds):
     gpu.close()
 
 
+@pytest.mark.parametrize("w,h", [(333, 77), (5, 3), (33, 9), (640, 1), (1, 240)])
+def test_odd_image_sizes(mods, w, h):
+    """Frame sizes that are not multiples of the 32x8 pixel tiles / the 4x4 tile groups (partial tiles, single rows and
+    columns) must give the same map as the oracle."""
+    MLMap, OracleMap = mods
+    cfg = S1.with_(width=w, height=h, cam_cx=w / 2.0, cam_cy=h / 2.0)
+    gpu, cpu = MLMap(cfg, max_blocks=8192, max_points=max(w * h, 4096), record_awareness=True), OracleMap(cfg)
+    rng = np.random.default_rng(w * 1000 + h)
+    for k in range(3):
+        depth = rng.integers(400, 6000, size=(h, w)).astype(np.uint16)
+        depth[rng.random((h, w)) < 0.05] = 0
+        q, t = syn.random_poses(3, seed=h)[k]
+        gpu.update_map(depth, q, t)
+        cpu.update_depth(depth, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{w}x{h} frame {k}")
+    gpu.close()
+
+
 def test_config3_720p(mods):
     """BASELINE config 3: 1280x720, 0.05 m voxels."""
     MLMap, OracleMap = mods
