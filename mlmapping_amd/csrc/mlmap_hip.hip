@@ -120,6 +120,7 @@ struct MlmSlot {
     int mode = 0;
     int seq = 0;              // sequence number of the frame it currently holds
     unsigned int nb = 0;      // k_bin_points blocks
+    unsigned int ex_um = 0;   // frontier mode: unique miss cells of the frame it holds
     uint16_t *d_img = nullptr; // staging for host images
     size_t img_cap = 0;
     int32_t *d_pix = nullptr;
@@ -347,22 +348,22 @@ int order_hits_exact(mlm_handle *h, MlmSlot &S, unsigned int U, int frame_idx) {
     const bool multi = ep.size() > 1;
     if (multi) {
         // arrival index = rank of the first-touch time
-        hipLaunchKernelGGL(k_time_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
+        tlaunch(h, "k_time_keys", k_time_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
         if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U,
                                    h->stream) != 0) {
             h->err = "radix sort failed";
             return MLM_ERR_HIP;
         }
-        hipLaunchKernelGGL(k_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
+        tlaunch(h, "k_assign_rank", k_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
     }
     for (size_t e = 0; e < ep.size(); ++e) {
         const unsigned int m = (unsigned int)ep[e].first;
         const unsigned long long nb = ep[e].second;
         const bool final_pass = (e + 1 == ep.size());
         HIPCHK(h, hipMemsetAsync(P.bkt_first, 0xFF, nb * sizeof(uint32_t), h->stream));
-        hipLaunchKernelGGL(k_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, m,
+        tlaunch(h, "k_bucket_min", k_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, m,
                            multi ? 1 : 0);
-        hipLaunchKernelGGL(k_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, m,
+        tlaunch(h, "k_make_keys", k_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, frame_idx, nb, m,
                            multi ? 1 : 0, final_pass ? 1 : 0, h->sk_in, h->sv_in);
         if (!final_pass) {
             // list order of the epoch = descending key; the rehash re-inserts the nodes in that order
@@ -371,7 +372,7 @@ int order_hits_exact(mlm_handle *h, MlmSlot &S, unsigned int U, int frame_idx) {
                 h->err = "radix sort failed";
                 return MLM_ERR_HIP;
             }
-            hipLaunchKernelGGL(k_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
+            tlaunch(h, "k_assign_rank", k_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
         }
     }
     return MLM_OK;
@@ -427,6 +428,8 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         tlaunch(h, "k_assign_nodes", k_assign_nodes, dim3(8, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, mode == 0 ? F.width : 0);
     }
+    if (P.explore) // frontier mode: the queued rays are walked once every start cell's first point is known
+        tlaunch(h, "k_ex_walk_rays", k_ex_walk_rays, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
     {
         tlaunch(h, "k_collect_hits", k_collect_hits, dim3(h->collect_grid, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, (int)nb);
@@ -448,13 +451,15 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     {
         tlaunch(h, "k_chain", k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st,
                            h->d_slot_tab, h->d_frame_tab, base,
-                           (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
+                           P.explore ? 0xFFFFFFFFu : (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
     }
     {
         // one 256-word slice of the miss mask per block (the unique hits, far fewer, are strided over the same blocks)
         const unsigned int pb = std::max(64u, grid_for((size_t)P.nMissWords));
         tlaunch(h, "k_prepare_voxels", k_prepare_voxels, dim3(pb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
     }
+    if (P.explore)
+        tlaunch(h, "k_ex_collect_misses", k_ex_collect_misses, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
 }
@@ -522,29 +527,65 @@ int order_misses_exact(mlm_handle *h, MlmSlot &S, unsigned int U) {
     if (U == 0) return MLM_OK;
     const bool multi = ep.size() > 1;
     if (multi) {
-        hipLaunchKernelGGL(k_ex_time_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
+        tlaunch(h, "k_ex_time_keys", k_ex_time_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sk_in, h->sv_in);
         if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U, h->stream) != 0) {
             h->err = "radix sort failed";
             return MLM_ERR_HIP;
         }
-        hipLaunchKernelGGL(k_ex_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
+        tlaunch(h, "k_ex_assign_rank", k_ex_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, U, 1);
     }
     for (size_t e = 0; e < ep.size(); ++e) {
         const unsigned int m = (unsigned int)ep[e].first;
         const unsigned long long nb = ep[e].second;
         const bool final_pass = (e + 1 == ep.size());
         HIPCHK(h, hipMemsetAsync(P.bktm_first, 0xFF, nb * sizeof(uint32_t), h->stream));
-        hipLaunchKernelGGL(k_ex_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0);
-        hipLaunchKernelGGL(k_ex_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0,
+        tlaunch(h, "k_ex_bucket_min", k_ex_bucket_min, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0);
+        tlaunch(h, "k_ex_make_keys", k_ex_make_keys, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, nb, m, multi ? 1 : 0,
                            final_pass ? 1 : 0, h->sk_in, h->sv_in);
         if (!final_pass) {
             if (mlm_sort_pairs_u64_u32(h->sort_tmp, h->sort_tmp_bytes, h->sk_in, h->sk_out, h->sv_in, h->sv_out, U, h->stream) != 0) {
                 h->err = "radix sort failed";
                 return MLM_ERR_HIP;
             }
-            hipLaunchKernelGGL(k_ex_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
+            tlaunch(h, "k_ex_assign_rank", k_ex_assign_rank, dim3(kListGrid), dim3(MLM_BLOCK), 0, h->stream, P, U, h->sv_out, m, 0);
         }
     }
+    return MLM_OK;
+}
+
+// Frontier mode, the part of a frame that needs the map (main stream, no host synchronisation): exact iteration order
+// of both containers (the host replays the two rehash policies from the frame's counts in S.h_ctr), hits, then the
+// miss-side frontier bookkeeping and the release scan.  Ends with the asynchronous read-back of the counters.
+int explore_stage_bc(mlm_handle *h, int slot_index) {
+    MlmSlot &S = h->slots[(size_t)slot_index];
+    const MlmDev &P = S.P;
+    hipStream_t st = h->stream;
+    const dim3 blk(MLM_BLOCK);
+    const unsigned int U = S.h_ctr->u_hit, UM = S.h_ctr->n_ex_miss;
+    S.ex_um = UM;
+    int rc = order_hits_exact(h, S, U, 0);
+    if (rc) return rc;
+    rc = order_misses_exact(h, S, UM);
+    if (rc) return rc;
+    tlaunch(h, "k_voxelize", k_voxelize, dim3(64, 1), blk, 0, st, P, S.F, 0ull);   // hits: push on voxel lists (explicit keys)
+    tlaunch(h, "k_apply", k_apply, dim3(64, 1), blk, 0, st, P, 0, 1);           // hits: ordered replay, frontier erase on 'o'
+    tlaunch(h, "k_ex_miss_tau", k_ex_miss_tau, dim3(kListGrid), blk, 0, st, P, S.F);
+    tlaunch(h, "k_ex_observe", k_ex_observe, dim3(kListGrid), blk, 0, st, P, S.F);
+    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, st, P);
+    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, st, P);
+    HIPCHK(h, hipMemcpyAsync(h->h_g, P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
+    return MLM_OK;
+}
+// after the stream has been synchronised
+int explore_finish(mlm_handle *h, int slot_index) {
+    MlmSlot &S = h->slots[(size_t)slot_index];
+    const int rc = check_queues(h, S);
+    if (rc) return rc;
+    h->last_slot = slot_index;
+    fill_stats(h, S);
+    h->stats.n_miss_cells = S.ex_um;
+    h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
     return MLM_OK;
 }
 
@@ -602,28 +643,11 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
-    const unsigned int U = S.h_ctr->u_hit, UM = S.h_ctr->n_ex_miss;
-    int rc = order_hits_exact(h, S, U, 0);
+    int rc = explore_stage_bc(h, slot_index);
     if (rc) return rc;
-    rc = order_misses_exact(h, S, UM);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_voxelize, dim3(64, 1), blk, 0, st, P, S.F, 0ull);   // hits: push on voxel lists (explicit keys)
-    hipLaunchKernelGGL(k_apply, dim3(64, 1), blk, 0, st, P, 0, 1);           // hits: ordered replay, frontier erase on 'o'
-    hipLaunchKernelGGL(k_ex_miss_tau, dim3(kListGrid), blk, 0, st, P, S.F);
-    hipLaunchKernelGGL(k_ex_observe, dim3(kListGrid), blk, 0, st, P, S.F);
-    hipLaunchKernelGGL(k_ex_apply_misses, dim3(kListGrid), blk, 0, st, P);
-    hipLaunchKernelGGL(k_ex_release, dim3(1024), blk, 0, st, P);
-    HIPCHK(h, hipMemcpyAsync(h->h_g, P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
-    rc = check_queues(h, S);
-    if (rc) return rc;
-    h->last_slot = slot_index;
-    fill_stats(h, S);
-    h->stats.n_miss_cells = UM;
-    h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
-    return MLM_OK;
+    return explore_finish(h, slot_index);
 }
 
 // ---- submission / confirmation ---------------------------------------------------------------------------------
@@ -756,10 +780,30 @@ int run_slots(mlm_handle *h, int n) {
         h->ktimes.clear();
         h->kpool_used = 0;
     }
-    if (h->P.explore) { // frontier mode: frame by frame, exact
+    if (h->P.explore) { // frontier mode: exact ordering of both containers, no speculation
         const int K = (int)h->slots.size() / MLM_SETS;
+        const int base = h->cur_set * K;
+        if (n == 1) return run_frame_explore(h, base);
+        // a batch: Stage A of all frames in one launch sequence (it does not depend on the map), one synchronisation to
+        // learn the frames' hit/miss counts, then the map-dependent part frame by frame without further synchronisation
         for (int j = 0; j < n; ++j) {
-            const int rc = run_frame_explore(h, h->cur_set * K + j);
+            h->slots[(size_t)(base + j)].seq = 0;
+            h->slots[(size_t)(base + j)].F.seq = 0;
+        }
+        int rc = launch_stage_a_batch(h, base, n);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[h->cur_set], 0));
+        HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int j = 0; j < n; ++j) {
+            rc = explore_stage_bc(h, base + j);
+            if (rc) return rc;
+        }
+        HIPCHK(h, hipEventRecord(h->set_free[h->cur_set], h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        for (int j = 0; j < n; ++j) {
+            rc = explore_finish(h, base + j);
             if (rc) return rc;
         }
         return MLM_OK;
@@ -948,7 +992,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if (h->lim.max_points <= 0) h->lim.max_points = 1280 * 720;
     if (h->lim.max_batch <= 0) h->lim.max_batch = 8;
     if (h->lim.max_batch > 64) h->lim.max_batch = 64;
-    if (cfg->use_exploration_frontiers) h->lim.max_batch = 1; // frontier mode integrates frame by frame
+    // (frontier mode: Stage A is batched too; the map-dependent part runs frame by frame, see run_slots)
     if ((long long)h->lim.max_points * 256 > 0xFFFFFFF0ll && cfg->use_exploration_frontiers) {
         h->err = "max_points too large for 32-bit miss insertion times";
         return MLM_ERR_UNSUPPORTED;

@@ -132,6 +132,31 @@ def test_odd_image_sizes(mods, w, h):
     gpu.close()
 
 
+def test_frontier_mode_batch(mods):
+    """Frontier mode through the batch entry point (Stage A of all frames in one launch sequence, the map-dependent part
+    frame by frame): same map, frontier and released blocks as frame-by-frame submission and as the oracle."""
+    MLMap, OracleMap = mods
+    cfg = S1.with_(use_exploration_frontiers=True)
+    n = 10
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "smooth", n)])
+    poses = [p for _, p in syn.stream(cfg, "room_jitter", "smooth", n)]
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    a, b, cpu = MLMap(cfg, max_blocks=8192, max_batch=4), MLMap(cfg, max_blocks=8192), OracleMap(cfg)
+    a.update_map_batch(frames, q, t)  # 4 + 4 + 2
+    for k in range(n):
+        b.update_map(frames[k], q[k], t[k])
+        cpu.update_depth(frames[k], q[k], t[k])
+    ea, eb = a.export_blocks(), b.export_blocks()
+    for key in ("keys", "occ", "infl", "collapsed"):
+        assert np.array_equal(ea[key], eb[key]), key
+    assert np.array_equal(ea["log_odds"], eb["log_odds"])
+    assert np.array_equal(a.export_frontier(), b.export_frontier())
+    compare_maps(ea, cpu.export_blocks(), "frontier batch vs oracle")
+    assert np.array_equal(a.export_frontier(), cpu.export_frontier())
+    assert a.frame_stats()["n_miss_cells"] == b.frame_stats()["n_miss_cells"]
+
+
 def test_config3_720p(mods):
     """BASELINE config 3: 1280x720, 0.05 m voxels."""
     MLMap, OracleMap = mods

@@ -43,6 +43,18 @@ for img, (q, t) in frames[:6]:
 c = 6 / (time.perf_counter() - t0)
 out["frontier_mode_frames_per_s"] = {"gpu": g, "cpu_oracle_1_thread": c, "workload": "640x480 room+jitter, S1, frame by frame"}
 gpu.close()
+# the same through the batch entry point: Stage A of 16 frames in one launch sequence
+gpu = MLMap(cfg, max_blocks=32768, max_batch=16)
+fb = np.stack([f[0] for f in frames[:16]])
+qb = np.stack([f[1][0] for f in frames[:16]])
+tb = np.stack([f[1][1] for f in frames[:16]])
+gpu.update_map_batch(fb, qb, tb)
+t0 = time.perf_counter()
+for _ in range(6):
+    gpu.update_map_batch(fb, qb, tb)
+gpu.sync()
+out["frontier_mode_batch16_frames_per_s"] = {"gpu": 6 * 16 / (time.perf_counter() - t0), "cpu_oracle_1_thread": c}
+gpu.close()
 
 # ---- map for the query rows: 40 frames of the bench stream
 cfg = S1
