@@ -168,21 +168,67 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_observe(const MlmDev P, const 
         const int slot = v / P.cells, cid = v - slot * P.cells;
         P.blk_observed[slot] = 1; // observed_subboxes.emplace(glb_idx)
         const int gx0 = P.block_keys[3 * slot], gy0 = P.block_keys[3 * slot + 1], gz0 = P.block_keys[3 * slot + 2];
+        // nbr_disp_real (map_local.cpp:84-89): +z,-z,+y,-y,+x,-x.  The reference stops at the first neighbour that is
+        // still unknown; here the state of all six is fetched at once (one round trip instead of up to six) and the first
+        // qualifying one is taken.
+        int nvs[6], ncids[6];
+        unsigned long long nbk[6];
+#pragma unroll
         for (int d = 0; d < 6; ++d) {
-            // nbr_disp_real (map_local.cpp:84-89): +z,-z,+y,-y,+x,-x
+            nvs[d] = -1;
+            nbk[d] = 0;
+            ncids[d] = 0;
             const double nx = wx + (d == 4 ? P.d_sub : (d == 5 ? -P.d_sub : 0.0));
             const double ny = wy + (d == 2 ? P.d_sub : (d == 3 ? -P.d_sub : 0.0));
             const double nz = wz + (d == 0 ? P.d_sub : (d == 1 ? -P.d_sub : 0.0));
             if (!mlm_inside_exp_bd(nx, ny, nz)) continue;
             int gx = gx0, gy = gy0, gz = gz0, ncid = cid;
             mlm_neighbor(P, d, gx, gy, gz, ncid);
-            const int ns = mlm_ex_block_slot(P, mlm_pack_key(gx, gy, gz)); // allocate_ram(glb_idx_nb)
-            if (ns < 0) continue;
-            const int nv = ns * P.cells + ncid;
+            // a neighbour inside the voxel's own block needs no table probe; for the others a read-only probe: the
+            // reference allocates a neighbour's block (allocate_ram) only if it gets that far, so blocks that do not
+            // exist yet are created in the ordered pass below
+            nbk[d] = mlm_pack_key(gx, gy, gz);
+            ncids[d] = ncid;
+            int ns = slot;
+            if (!(gx == gx0 && gy == gy0 && gz == gz0)) {
+                ns = mlm_block_find_k(P, nbk[d]);
+                if (ns >= 0 && P.blk_collapsed[ns]) ns = -3; // released block: allocate_ram() is false
+                if (ns == -1) ns = -4;                       // not there (yet): allocate in order
+            }
+            nvs[d] = ns >= 0 ? ns * P.cells + ncid : ns;
+        }
+        uint8_t n_occ[6];
+        uint32_t n_miss[6];
+        unsigned long long n_tau[6];
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            n_occ[d] = 0;
+            n_miss[d] = 0;
+            n_tau[d] = 0;
+            if (nvs[d] >= 0) {
+                n_occ[d] = P.occ[nvs[d]];
+                n_miss[d] = __hip_atomic_load(&P.vox_miss[nvs[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n_tau[d] = P.vox_tau[nvs[d]];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            int nv = nvs[d];
+            uint8_t o = n_occ[d];
+            uint32_t km = n_miss[d];
+            unsigned long long nt = n_tau[d];
+            if (nv == -4) { // the block did not exist when probed: allocate_ram now (rare; its state is read afresh)
+                const int ns = mlm_ex_block_slot(P, nbk[d]);
+                if (ns < 0) continue;
+                nv = ns * P.cells + ncids[d];
+                o = P.occ[nv];
+                km = __hip_atomic_load(&P.vox_miss[nv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                nt = P.vox_tau[nv];
+            }
+            if (nv < 0) continue;
             // unknown at this moment: unknown after the hit phase, and not already turned free by an earlier miss
-            const bool turns_earlier =
-                (__hip_atomic_load(&P.vox_miss[nv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) && P.vox_tau[nv] > tau;
-            if (P.occ[nv] == 'u' && !turns_earlier) {
+            const bool turns_earlier = (km != 0) && nt > tau;
+            if (o == 'u' && !turns_earlier) {
                 P.frnt[nv] = 1;
                 break;
             }

@@ -569,8 +569,8 @@ int explore_stage_bc(mlm_handle *h, int slot_index) {
     if (rc) return rc;
     tlaunch(h, "k_voxelize", k_voxelize, dim3(64, 1), blk, 0, st, P, S.F, 0ull);   // hits: push on voxel lists (explicit keys)
     tlaunch(h, "k_apply", k_apply, dim3(64, 1), blk, 0, st, P, 0, 1);           // hits: ordered replay, frontier erase on 'o'
-    tlaunch(h, "k_ex_miss_tau", k_ex_miss_tau, dim3(kListGrid), blk, 0, st, P, S.F);
-    tlaunch(h, "k_ex_observe", k_ex_observe, dim3(kListGrid), blk, 0, st, P, S.F);
+    tlaunch(h, "k_ex_miss_tau", k_ex_miss_tau, dim3(4 * kListGrid), blk, 0, st, P, S.F);
+    tlaunch(h, "k_ex_observe", k_ex_observe, dim3(4 * kListGrid), blk, 0, st, P, S.F);
     tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, st, P);
     tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, st, P);
     HIPCHK(h, hipMemcpyAsync(h->h_g, P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
