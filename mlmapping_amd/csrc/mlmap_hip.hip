@@ -170,6 +170,7 @@ struct mlm_handle {
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
+    unsigned int sc_block = 128;             // threads per k_apply_voxelize block (its duration in the pipeline: 18 us vs 27 us with 256)
     bool sc_grid_fixed = false;              // MLM_SC_GRID given: do not adapt
     unsigned int sc_grid = 80;               // blocks per list of k_apply_voxelize (grid-stride loops; 40..120 measured equal, 160 3 % slower)
     std::string timed_kernel = "k_bin_points"; // the kernel bracketed in timing mode 3 ...
@@ -685,7 +686,7 @@ int submit_batch(mlm_handle *h, int base, int n) {
         for (int j = 0; j <= n; ++j) {
             MlmSlot &Sa = h->slots[(size_t)(base + (j > 0 ? j - 1 : 0))];
             MlmSlot &Sv = h->slots[(size_t)(base + (j < n ? j : n - 1))];
-            tlaunch(h, "k_apply_voxelize", k_apply_voxelize, dim3(scg, 2 * (1 + MLM_RAY_LISTS)), dim3(MLM_BLOCK), 0, h->stream, Sa.P,
+            tlaunch(h, "k_apply_voxelize", k_apply_voxelize, dim3(scg * (MLM_BLOCK / h->sc_block), 2 * (1 + MLM_RAY_LISTS)), dim3(h->sc_block), 0, h->stream, Sa.P,
                     Sa.F.seq, j > 0 ? 1 : 0, Sv.P, Sv.F, h->hit_n_bkt, j < n ? 1 : 0);
             if (j < n) h->pending.push_back(&Sv);
         }
@@ -1013,6 +1014,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (const char *e = getenv("MLM_EXPAND_BLOCK")) h->expand_block = (unsigned int)std::max(64, atoi(e));
         if (const char *e = getenv("MLM_SORT_GRID")) h->sort_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_COLLECT_GRID")) h->collect_grid = (unsigned int)std::max(1, atoi(e));
+        if (const char *e = getenv("MLM_SC_BLOCK")) h->sc_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
         if (const char *e = getenv("MLM_SC_GRID")) {
             h->sc_grid = (unsigned int)std::max(1, atoi(e));
             h->sc_grid_fixed = true;
