@@ -168,6 +168,7 @@ struct mlm_handle {
     int next_seq = 0;
     int cur_set = 0;
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
+    unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
     unsigned int sc_block = 128;             // threads per k_apply_voxelize block (its duration in the pipeline: 18 us vs 27 us with 256)
@@ -444,7 +445,7 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         unsigned long long dm;
         int ds;
         div_magic((unsigned int)row_w, dm, ds);
-        tlaunch(h, "k_sort_contribs", k_sort_contribs<1024>, dim3(n > 4 ? h->sort_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_sort_contribs", k_sort_contribs<1024>, dim3((n > 4 ? h->sort_grid : 1024) * (MLM_BLOCK / h->sort_block), 1, n), dim3(h->sort_block), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 0u, row_w, dm, ds);
         tlaunch(h, "k_sort_contribs", k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
                            h->d_frame_tab, base, 1024u, row_w, dm, ds);
@@ -1012,6 +1013,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         int lo = 0, hi = 0; // numerically lower = higher priority
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
         if (const char *e = getenv("MLM_EXPAND_BLOCK")) h->expand_block = (unsigned int)std::max(64, atoi(e));
+        if (const char *e = getenv("MLM_SORT_BLOCK")) h->sort_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
         if (const char *e = getenv("MLM_SORT_GRID")) h->sort_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_COLLECT_GRID")) h->collect_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_SC_BLOCK")) h->sc_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
