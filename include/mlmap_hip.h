@@ -93,7 +93,7 @@ typedef struct mlm_frame_stats {
     /* device-side work counters (no reference counterpart) */
     int64_t n_multi_cells;   /* hit cells that received more than one kind of contribution (need the ordered replay) */
     int64_t n_contrib_slots; /* 16-padded contribution slots reserved for those cells */
-    int64_t n_groups;        /* (wave, cell, kind) contribution groups = global atomics issued for hits */
+    int64_t n_groups;        /* (wave, cell, kind) contribution groups (merged per cell in LDS before any global atomic) */
     int64_t n_rays;          /* rays walked after de-duplication */
     int64_t n_spec_replays;  /* frames so far whose Stage B had to be replayed with a rehash plan */
 } mlm_frame_stats;
@@ -126,7 +126,8 @@ int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_
 int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_frames, size_t frame_stride, int width,
                               int height, int row_stride, const double *q_wb, const double *t_wb);
 /* replaces the body of mlmap::depth_odom_input_callback (src/mlmap.cpp:463-532) for a ROS-free host: depth is the
- * sensor_msgs/Image payload (encoding 32FC1 metres -> converted x1000 to 16UC1 on the device, mlmap.cpp:480-483; or
+ * sensor_msgs/Image payload (encoding 32FC1 metres -> converted x1000 to 16UC1 like cv::Mat::convertTo, mlmap.cpp:480-483:
+ * the dense path on the device, the sampler's few pixels on the host with the same float arithmetic; or
  * 16UC1 millimetres), odom_* / imu_w the nav_msgs/Odometry pose+twist and sensor_msgs/Imu angular velocity, stamps in
  * seconds; the pose is forwarded to the image stamp by the reference's linear model (mlmap.cpp:485-498).
  * sampled != 0: project_depth's rand() sampler (<= sample_cnt pixels, glibc rand(), v first, mlmap.cpp:322-327);
