@@ -112,6 +112,14 @@ class mlmap {
         check(mlm_query_odds(h_, p, 1, &r), "mlm_query_odds");
         return r;
     }
+    // include/mlmap.h:227-235: float getOdd(const Vec3I &glb_id, size_t subbox_id)
+    template <class V3I> float getOdd(const V3I &glb_id, size_t subbox_id) {
+        const int32_t g[3] = {(int32_t)glb_id[0], (int32_t)glb_id[1], (int32_t)glb_id[2]};
+        const int32_t c = (int32_t)subbox_id;
+        float r = 0.5f;
+        check(mlm_query_odds_at(h_, g, &c, 1, &r), "mlm_query_odds_at");
+        return r;
+    }
     // include/mlmap.h:237-295
     template <class V3> Vec3d getOddGrad(const V3 &pos_w, size_t max_iter = 5) {
         const double p[3] = {pos_w[0], pos_w[1], pos_w[2]};

@@ -14,8 +14,14 @@
  *  - every function returns 0 on success, a negative mlm_status otherwise; no exceptions cross the ABI
  *    (the reference has no error channel at all: yaml-cpp / vector::at exceptions kill the nodelet);
  *  - plain pointers and sizes only; host buffers are borrowed for the duration of the call;
- *  - one handle = one device + one HIP stream.  integrate_* calls on a handle are serialised by the
- *    caller; query_* calls observe the map as of the last integrate call issued before them;
+ *  - one handle = one device + one HIP stream.  Every entry point takes the handle's lock, so a handle may be used
+ *    from several threads (the reference serves planner queries and the depth callback from an MT nodelet,
+ *    src/nodelet_map.cpp:21): calls are serialised, query_* calls observe the map as of the last integrate call
+ *    that returned (in async mode they first wait for everything submitted).  mlm_last_error is per handle: read it
+ *    on the thread that got the failure before that thread issues another call.  mlm_destroy must not race with
+ *    other calls;
+ *  - after MLM_ERR_CAPACITY the handle stays usable: the map keeps what the failing call applied before it ran out
+ *    of room, blocks that did not fit stay absent, later frames integrate normally;
  *  - poses are q_wb = (w,x,y,z) and t_wb of T_wb (body in world), exactly what mlmap.cpp:494 builds;
  *  - positions are world-frame doubles (Vec3 of include/common.h:22), n x 3 row-major.
  */
@@ -29,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MLM_ABI_VERSION 1
+#define MLM_ABI_VERSION 2
 
 typedef enum mlm_status {
     MLM_OK = 0,
@@ -104,7 +110,10 @@ int mlm_destroy(mlm_handle *h);
 const char *mlm_last_error(mlm_handle *h);
 int mlm_abi_version(void);
 
-/* Use an externally owned HIP stream (e.g. the framework's current stream) instead of the handle's own. */
+/* Use an externally owned HIP stream (e.g. the framework's current stream) instead of the handle's own for the
+ * map-dependent stage, queries and exports.  Device inputs of the *_dev entry points may then be produced by work
+ * enqueued on that stream before the call: the per-frame stage that reads them (which runs on streams of the handle)
+ * is ordered behind it.  With the handle's own stream (the default) device inputs must be complete before the call. */
 int mlm_set_stream(mlm_handle *h, void *hip_stream);
 
 /* replaces mlmap::project_depth + update_map (src/mlmap.cpp:311-349,382-386).
@@ -147,6 +156,9 @@ int mlm_query_occupancy_inflate(mlm_handle *h, const double *pos, int n, float i
 int mlm_query_inflate_occupancy(mlm_handle *h, const double *pos, int n, int8_t *out);
 int mlm_query_odds(mlm_handle *h, const double *pos, int n, float *out);
 int mlm_query_odd_grad(mlm_handle *h, const double *pos, int n, int max_iter, double *out3);
+/* float mlmap::getOdd(const Vec3I &glb_id, size_t subbox_id), include/mlmap.h:227-235: glb_id n x 3 block indices,
+ * subbox_id n cell ids in [0, subbox_n^3) (out of range is undefined behaviour in the reference: MLM_ERR_INVALID here) */
+int mlm_query_odds_at(mlm_handle *h, const int32_t *glb_id, const int32_t *subbox_id, int n, float *out);
 /* src/mlmap.cpp:388-407 */
 int mlm_set_free_in_bound(mlm_handle *h, const double box_min[3], const double box_max[3]);
 /* mlmap::inflate_map (src/mlmap.cpp:286-309) around vehicle position ct_pos */
@@ -163,8 +175,27 @@ int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, ui
 int mlm_export_block_flags(mlm_handle *h, int cap, uint8_t *collapsed, int *n_out);
 /* frontier cells as (gx,gy,gz,cell id) quadruples = the /frontier cloud before centre conversion (rviz_vis.cpp:267-293) */
 int mlm_export_frontier(mlm_handle *h, int cap, int32_t *keys_cell, int *n_out);
-/* float xyz of inflated-'o' cell centres = PointCloud2 payload of /global_map (rviz_vis.cpp:296-327) */
+/* float xyz of inflated-'o' cell centres = PointCloud2 payload of /global_map (rviz_vis.cpp:296-327), unordered */
 int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out);
+/* float xyz of the frontier cells' centres = PointCloud2 payload of /frontier (rviz_vis.cpp:267-293,
+ * subbox_id2xyz_glb include/map_local.h:201-206), unordered; empty unless use_exploration_frontiers */
+int mlm_export_frontier_points(mlm_handle *h, int cap_points, float *xyz, int *n_out);
+/* Load blocks into the map (no reference counterpart: the reference never persists or merges maps; this is how a
+ * merged global map, mlmapping_amd/merge.py, is put back behind the query interface).  keys [n*3]; log_odds / occ /
+ * infl [n*cells] and collapsed [n] as mlm_export_blocks / mlm_export_block_flags write them, any of them may be NULL
+ * (that plane keeps its current content; new blocks start as allocate_ram leaves them: 0 / 'u' / 'u'); sources may
+ * be host or device memory.  Blocks already present are overwritten cell by cell, others are created. */
+int mlm_import_blocks(mlm_handle *h, int n, const int32_t *keys, const float *log_odds, const uint8_t *occ,
+                      const uint8_t *infl, const uint8_t *collapsed);
+
+/* The two device-side steps of the optional global-map merge across GPUs (mlmapping_amd/merge.py; no reference
+ * counterpart: SURVEY.md §8e).  All pointers are device memory; both calls return when the buffers are written.
+ * pack:   row b of log_odds_dev / seen_dev [n*cells] = this map's cells of block keys_dev[3b..3b+2] (0 / 0 where the
+ *         map does not hold the block; seen = occupancy != 'u').  These rows are what the ranks exchange and sum.
+ * finish: summed log-odds clamped to [log_odds_min, log_odds_max]; occ = 'o' above occupied_sh, else 'f' where any
+ *         rank had seen the voxel, else 'u'. */
+int mlm_merge_pack(mlm_handle *h, const int32_t *keys_dev, int n, float *log_odds_dev, uint8_t *seen_dev);
+int mlm_merge_finish(mlm_handle *h, float *log_odds_dev, const uint8_t *seen_dev, size_t n_cells, uint8_t *occ_dev);
 
 int mlm_sync(mlm_handle *h);
 /* async = 1: integrate calls return once the work is SUBMITTED (two batches may be in flight); errors of a batch and

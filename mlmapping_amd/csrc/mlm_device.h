@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mlm_types.h"
+#include "mlm_host.h" // mlm_cv_f32_to_u16 (host + device)
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846

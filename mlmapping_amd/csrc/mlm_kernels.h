@@ -1756,6 +1756,66 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_query(const MlmDev P, int mode, c
     }
 }
 
+// getOdd(const Vec3I &glb_id, size_t subbox_id), mlmap.h:227-235
+__global__ __launch_bounds__(MLM_BLOCK) void k_query_odds_at(const MlmDev P, const int32_t *glb, const int32_t *sub, int n, float *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = mlm_get_odd_at(P, glb[3 * (size_t)i], glb[3 * (size_t)i + 1], glb[3 * (size_t)i + 2], sub[i]);
+}
+
+// mlm_import_blocks: find or create the block of every imported key (allocate_ram, map_local.h:215-231) ...
+__global__ __launch_bounds__(MLM_BLOCK) void k_import_slots(const MlmDev P, const int32_t *keys, int n, int *slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    slots[i] = mlm_block_slot(P, mlm_pack_key(keys[3 * (size_t)i], keys[3 * (size_t)i + 1], keys[3 * (size_t)i + 2]));
+}
+// ... and overwrite its cells (any source may be null: that plane is left as it is)
+__global__ __launch_bounds__(MLM_BLOCK) void k_import_cells(const MlmDev P, const int *slots, int n, const float *lo, const uint8_t *occ,
+                                                            const uint8_t *infl, const uint8_t *collapsed) {
+    const long long total = (long long)n * P.cells;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / P.cells), c = (int)(i - (long long)b * P.cells);
+        const int slot = slots[b];
+        if (slot < 0) continue;
+        const size_t v = (size_t)slot * P.cells + c;
+        if (lo) P.log_odds[v] = lo[i];
+        if (occ) P.occ[v] = occ[i];
+        if (infl) P.infl[v] = infl[i];
+        if (c == 0 && collapsed && P.explore) P.blk_collapsed[slot] = collapsed[b];
+    }
+}
+
+// Global-map merge (no reference counterpart), packing side: row b of the dense exchange buffers = the
+// cells of block keys[b] (zeros / "not observed" where this map does not hold the block).  A released block answers with
+// its element 0 (map_local.cpp:221-226).
+__global__ __launch_bounds__(MLM_BLOCK) void k_merge_pack(const MlmDev P, const int32_t *keys, int n, float *lo, uint8_t *seen) {
+    const long long total = (long long)n * P.cells;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / P.cells);
+        int c = (int)(i - (long long)b * P.cells);
+        const int slot = mlm_block_find(P, keys[3 * (size_t)b], keys[3 * (size_t)b + 1], keys[3 * (size_t)b + 2]);
+        float L = 0.0f;
+        uint8_t s = 0;
+        if (slot >= 0) {
+            if (P.explore && P.blk_collapsed[slot]) c = 0;
+            L = P.log_odds[(size_t)slot * P.cells + c];
+            s = P.occ[(size_t)slot * P.cells + c] != 'u';
+        }
+        lo[i] = L;
+        seen[i] = s;
+    }
+}
+// ... and the finishing side: summed log-odds clamped to [min, max]; class 'o' above occupied_sh, else 'f' where any map
+// had observed the voxel, else 'u'
+__global__ __launch_bounds__(MLM_BLOCK) void k_merge_finish(const MlmDev P, float *lo, const uint8_t *seen, size_t n, uint8_t *occ) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float L = lo[i];
+        L = L < P.lo_min ? P.lo_min : (L > P.lo_max ? P.lo_max : L);
+        lo[i] = L;
+        occ[i] = L > P.lo_sh ? 'o' : (seen[i] ? 'f' : 'u');
+    }
+}
+
 // setFree_map_in_bound, mlmap.cpp:388-407: the lattice coordinates are produced on the host by the same
 // accumulating additions (x += d) and handed over as three axis arrays.
 __global__ __launch_bounds__(MLM_BLOCK) void k_set_free(const MlmDev P, const double *xs, int nx, const double *ys, int ny,
@@ -1834,14 +1894,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_inflate_spread(const MlmDev P, in
             }
 }
 // /global_map payload (rviz_vis.cpp:296-327): float centres (PointXYZ) of the cells whose inflate_occupancy is 'o'
+// which = 1: the /frontier payload instead (rviz_vis.cpp:267-293): centres of the cells in the blocks' frontier sets
 __global__ __launch_bounds__(MLM_BLOCK) void k_export_global(const MlmDev P, unsigned int n_blocks, float *xyz,
-                                                             unsigned int cap, unsigned int *counter) {
+                                                             unsigned int cap, unsigned int *counter, int which) {
     __shared__ unsigned int s_cnt[MLM_BLOCK / 64];
     __shared__ unsigned int s_base;
     const long long total = (long long)n_blocks * P.cells;
     for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < total; i0 += (long long)gridDim.x * blockDim.x) {
         const long long i = i0 + threadIdx.x;
-        const bool on = i < total && P.infl[i] == 'o';
+        const bool on = i < total && (which ? P.frnt[i] != 0 : P.infl[i] == 'o');
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         const unsigned long long m = __ballot(on);
         if (lane == 0) s_cnt[wid] = (unsigned int)__popcll(m);
@@ -1868,14 +1929,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_export_global(const MlmDev P, uns
     }
 }
 
-// cv::Mat::convertTo(CV_16UC1, 1000) of the 32FC1 depth image (mlmap.cpp:482): float product, round half to even,
-// saturate
+// cv::Mat::convertTo(CV_16UC1, 1000) of the 32FC1 depth image (mlmap.cpp:482), see mlm_cv_f32_to_u16
 __global__ __launch_bounds__(MLM_BLOCK) void k_convert_f32_u16(const float *src, uint16_t *dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float s = src[i] * 1000.0f;
-        int r = 0;
-        if (s == s) r = (int)fminf(fmaxf(rintf(s), 0.0f), 65535.0f);
-        dst[i] = (uint16_t)r;
+        dst[i] = (uint16_t)mlm_cv_f32_to_u16(src[i]);
     }
 }
 

@@ -11,12 +11,16 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/mlmap_hip.h"
 #include "mlm_kernels_explore.h"
+#include "mlm_host.h"
+
+using namespace mlm_host;
 
 extern "C" size_t mlm_sort_temp_bytes(size_t n);
 extern "C" int mlm_sort_pairs_u64_u32(void *temp, size_t temp_bytes, const unsigned long long *kin,
@@ -24,84 +28,6 @@ extern "C" int mlm_sort_pairs_u64_u32(void *temp, size_t temp_bytes, const unsig
                                       hipStream_t stream);
 
 namespace {
-
-// ---- Eigen::Quaterniond / Sophus::SE3 pieces of the frame setup (so3.cpp:36-96, se3.cpp:29-95) -----------------
-struct Q4 {
-    double w, x, y, z;
-};
-struct D3 {
-    double x, y, z;
-};
-inline Q4 q_mul(const Q4 &a, const Q4 &b) { // Eigen generic quat_product
-    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
-}
-inline Q4 q_norm(const Q4 &q) { // normalize(): coeffs / sqrt(x²+y²+z²+w²)
-    const double n = std::sqrt(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
-    return {q.w / n, q.x / n, q.y / n, q.z / n};
-}
-inline D3 q_rot(const Q4 &q, const D3 &v) { // _transformVector
-    D3 uv{q.y * v.z - q.z * v.y, q.z * v.x - q.x * v.z, q.x * v.y - q.y * v.x};
-    uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
-    const D3 c{q.y * uv.z - q.z * uv.y, q.z * uv.x - q.x * uv.z, q.x * uv.y - q.y * uv.x};
-    return {(v.x + q.w * uv.x) + c.x, (v.y + q.w * uv.y) + c.y, (v.z + q.w * uv.z) + c.z};
-}
-Q4 q_from_R(const double m[9]) { // Eigen Quaternion(Matrix3): Shepperd, no normalisation (so3.cpp:39-40)
-    auto M = [&](int r, int c) { return m[r * 3 + c]; };
-    Q4 q;
-    double t = M(0, 0) + M(1, 1) + M(2, 2);
-    if (t > 0.0) {
-        t = std::sqrt(t + 1.0);
-        q.w = 0.5 * t;
-        t = 0.5 / t;
-        q.x = (M(2, 1) - M(1, 2)) * t;
-        q.y = (M(0, 2) - M(2, 0)) * t;
-        q.z = (M(1, 0) - M(0, 1)) * t;
-    } else {
-        int i = 0;
-        if (M(1, 1) > M(0, 0)) i = 1;
-        if (M(2, 2) > M(i, i)) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = std::sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
-        double v[3];
-        v[i] = 0.5 * t;
-        t = 0.5 / t;
-        q.w = (M(k, j) - M(j, k)) * t;
-        v[j] = (M(j, i) + M(i, j)) * t;
-        v[k] = (M(k, i) + M(i, k)) * t;
-        q.x = v[0];
-        q.y = v[1];
-        q.z = v[2];
-    }
-    return q;
-}
-
-// ---- odds table (map_awareness.cpp:36-46,119-132; map_awareness.h:120-146) -------------------------------------
-struct OddsModel {
-    double dRho, noise;
-    float sigma_in_dr(size_t x) const {
-        float dis = (x * dRho);
-        return noise * dis * dis / dRho;
-    }
-    static float standard_ND(float x) { // A&S 7.1.26; fabs/exp resolve to the float overloads
-        const double a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
-        const double p = 0.3275911;
-        int sign = 1;
-        if (x < 0) sign = -1;
-        x = std::fabs(x) / std::sqrt(2.0);
-        const double t = 1.0 / (1.0 + p * x);
-        const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
-        return 0.5 * (1.0 + sign * y);
-    }
-    float get_odds(int diff, size_t r) const {
-        if (r == 0) r = 1;
-        const float up = standard_ND(static_cast<float>(diff + 0.5) / sigma_in_dr(r));
-        const float down = standard_ND(static_cast<float>(diff - 0.5) / sigma_in_dr(r));
-        float res = up - down < 0.001 ? 0.001 : up - down;
-        res = res >= 0.999 ? 0.999 : res;
-        return res;
-    }
-};
 
 #define MLM_SETS 2 // slot sets: one being filled while the other drains (3 measured slower: 34.1k vs 35.7k frames/s)
 
@@ -192,7 +118,9 @@ struct mlm_handle {
     MlmCounters *d_ctr_all = nullptr;        // [2K] contiguous per-slot counters
     MlmCounters *h_ctr_all = nullptr;        // pinned mirror
     hipEvent_t batch_done[MLM_SETS] = {};
+    hipEvent_t inputs_ready = nullptr;       // caller-supplied stream only: orders Stage A after the caller's work on it
     MlmGlobal *h_gb[MLM_SETS] = {}; // pinned snapshots of P.g taken at the end of each batch
+    std::recursive_mutex mu;   // serialises the entry points of this handle (see MLM_LOCK)
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
 };
 
@@ -207,19 +135,17 @@ namespace {
         }                                                                                                             \
     } while (0)
 
+// Every entry point takes the handle's lock: integrate calls, queries and exports may come from different threads (the
+// reference runs planner queries and the depth callback on an MT nodelet, nodelet_map.cpp:21); a query then observes the
+// map of the last integrate call that returned.  Recursive because entry points call each other.
+#define MLM_LOCK(h) std::lock_guard<std::recursive_mutex> lock__((h)->mu)
+
 template <class T> int dev_alloc(mlm_handle *h, T **p, size_t n) {
     void *v = nullptr;
     HIPCHK(h, hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(T)));
     h->allocs.push_back(v);
     *p = (T *)v;
     return MLM_OK;
-}
-// exact floor(i / d) for i < 2^27 as (i * m) >> s (Granlund-Montgomery: m = ceil(2^(27+L) / d), L = ceil(log2 d))
-inline void div_magic(unsigned int d, unsigned long long &m, int &s) {
-    int L = 0;
-    while ((1ull << L) < d) ++L;
-    s = 27 + L;
-    m = ((1ull << s) + d - 1) / d;
 }
 inline unsigned int grid_for(size_t n) { return (unsigned int)((n + MLM_BLOCK - 1) / MLM_BLOCK); }
 // blocks of k_bin_points for one frame (tile geometry: mlm_tile_item)
@@ -283,56 +209,11 @@ inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 b
     }
 }
 
-// T_ls and t_wa of one frame (map_awareness.cpp:184-186) — SURVEY.md App. C1, evaluated in that order
+// T_ls and t_wa of one frame (map_awareness.cpp:184-186)
 void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb_in[3], MlmFrame &F) {
-    const Q4 q_wb = q_norm(Q4{q_wb_in[0], q_wb_in[1], q_wb_in[2], q_wb_in[3]}); // SO3(Quaterniond), so3.cpp:43-47
-    const D3 t_wb{t_wb_in[0], t_wb_in[1], t_wb_in[2]};
-    // T_wa = (I, t_wb)
-    const Q4 q_wa = q_norm(Q4{1, 0, 0, 0});
-    // T_ws = T_wb * T_bs
-    const D3 r1 = q_rot(q_wb, h->t_bs);
-    const D3 t_ws{t_wb.x + r1.x, t_wb.y + r1.y, t_wb.z + r1.z};
-    const Q4 q_ws = q_norm(q_mul(q_wb, h->q_bs));
-    // T_wa^-1
-    const Q4 q_ai = q_norm(Q4{q_wa.w, -q_wa.x, -q_wa.y, -q_wa.z});
-    const D3 t_ai = q_rot(q_ai, D3{t_wb.x * -1., t_wb.y * -1., t_wb.z * -1.});
-    // T_ls = T_wa^-1 * T_ws
-    const D3 r2 = q_rot(q_ai, t_ws);
-    const Q4 q_ls = q_norm(q_mul(q_ai, q_ws));
-    F.q_ls[0] = q_ls.w;
-    F.q_ls[1] = q_ls.x;
-    F.q_ls[2] = q_ls.y;
-    F.q_ls[3] = q_ls.z;
-    F.t_ls[0] = t_ai.x + r2.x;
-    F.t_ls[1] = t_ai.y + r2.y;
-    F.t_ls[2] = t_ai.z + r2.z;
-    F.t_wa[0] = t_wb.x;
-    F.t_wa[1] = t_wb.y;
-    F.t_wa[2] = t_wb.z;
+    frame_pose(h->q_bs, h->t_bs, q_wb_in, t_wb_in, F.q_ls, F.t_ls, F.t_wa);
 }
 
-// Replay the rehash policy of libstdc++'s _Hashtable for `U` unique insertions into a cleared container.
-// Returns the epochs: (number of elements present when the epoch ends, bucket count during the epoch).
-// Uses the very policy object std::unordered_map uses, so it follows whatever libstdc++ this library is linked to.
-std::vector<std::pair<size_t, size_t>> plan_epochs_for(std::__detail::_Prime_rehash_policy &pol, size_t &n_bkt, size_t U) {
-    std::vector<std::pair<size_t, size_t>> ep;
-    size_t n = n_bkt;
-    size_t i = 0;
-    while (i < U) {
-        // _M_insert_unique_node: _M_need_rehash(bucket_count, element_count, 1) before linking the node
-        const auto r = pol._M_need_rehash(n, i, 1);
-        if (r.first) {
-            if (i > 0) ep.emplace_back(i, n);
-            n = r.second;
-        }
-        // the policy is inert while element_count + 1 <= _M_next_resize
-        const size_t next = std::max<size_t>(i + 1, pol._M_next_resize);
-        i = std::min(U, next);
-    }
-    ep.emplace_back(U, n);
-    n_bkt = n;
-    return ep;
-}
 std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
     return plan_epochs_for(h->hit_pol, h->hit_n_bkt, U);
 }
@@ -403,6 +284,14 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     hipStream_t st = h->stream_as[set];
     // the previous user of this slot set must have been consumed by the main stream
     HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
+    if (!h->own_stream) {
+        // mlm_set_stream: device inputs (the *_dev entry points) may still be being produced by work the caller enqueued
+        // on that stream; Stage A reads them on its own stream, so order it behind everything enqueued there so far.
+        // (Costs the overlap of this batch's Stage A with the previous batch's Stage B+C; the handle's own stream,
+        // which nobody else can enqueue on, needs no such edge.)
+        HIPCHK(h, hipEventRecord(h->inputs_ready, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(st, h->inputs_ready, 0));
+    }
     for (int j = 0; j < n; ++j) h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
     HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
                              hipMemcpyHostToDevice, st));
@@ -596,6 +485,7 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     const MlmDev &P = S.P;
     hipStream_t st = h->stream;
     // the frame's inputs were uploaded on the slot set's Stage A stream: order this stream after them
+    // (device inputs produced on a caller-supplied stream are ordered by that stream itself: everything below runs on it)
     HIPCHK(h, hipEventRecord(h->stage_a_done[h->cur_set], h->stream_as[h->cur_set]));
     HIPCHK(h, hipStreamWaitEvent(st, h->stage_a_done[h->cur_set], 0));
     S.seq = 0;
@@ -775,6 +665,20 @@ int finish_set(mlm_handle *h, int set) {
     return drain(h);
 }
 
+// After a failed call: re-arm the device flags so that the handle stays usable.  MLM_ERR_CAPACITY leaves the map as
+// far as the failing frame got (blocks that did not fit the pool are published as "pool full" and stay unusable; frames
+// that touch only existing blocks integrate normally afterwards).
+void clear_device_error(mlm_handle *h) {
+    MlmGlobal g{};
+    if (hipMemcpy(&g, h->P.g, sizeof(g), hipMemcpyDeviceToHost) != hipSuccess) return;
+    g.n_blocks = std::min<unsigned int>(g.n_blocks, (unsigned int)h->P.max_blocks);
+    g.err = 0;
+    g.fail_frame = 0x7FFFFFFF;
+    hipMemcpy(h->P.g, &g, sizeof(g), hipMemcpyHostToDevice);
+    *h->h_g = g;
+    for (int k = 0; k < MLM_SETS; ++k) *h->h_gb[k] = g;
+}
+
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
 int run_slots(mlm_handle *h, int n) {
     (void)hipGetLastError(); // a stale error of unrelated HIP calls in this thread is not ours
@@ -827,6 +731,7 @@ int run_slots(mlm_handle *h, int n) {
         hipDeviceSynchronize();
         h->pending.clear();
         for (int k = 0; k < MLM_SETS; ++k) h->set_pending[k] = 0;
+        clear_device_error(h);
     }
     return rc;
 }
@@ -843,11 +748,11 @@ int ensure_img(mlm_handle *h, MlmSlot &S, size_t n_px) {
 
 int ensure_query(mlm_handle *h, size_t n) {
     if (n <= h->q_cap) return MLM_OK;
-    if (h->d_f32) hipFree(h->d_f32);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     h->d_qpos = nullptr;
     h->d_qout = nullptr;
+    h->q_cap = 0;
     const size_t cap = std::max<size_t>(n, 4096);
     HIPCHK(h, hipMalloc((void **)&h->d_qpos, cap * 3 * sizeof(double)));
     HIPCHK(h, hipMalloc(&h->d_qout, cap * 3 * sizeof(double)));
@@ -859,6 +764,7 @@ int run_query(mlm_handle *h, int mode, const double *pos, int n, float inflate, 
               size_t out_elem) {
     if (!h || !pos || !out || n < 0) return MLM_ERR_INVALID;
     if (n == 0) return MLM_OK;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);
     if (rc) return rc;
@@ -1260,6 +1166,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
 
 int mlm_destroy(mlm_handle *h) {
     if (!h) return MLM_ERR_INVALID;
+    h->mu.lock(); // waits for a call in flight on another thread; the caller guarantees that none starts after this
+    h->mu.unlock();
     if (!h->stream) { // creation failed before the device was touched
         delete h;
         return MLM_OK;
@@ -1277,6 +1185,7 @@ int mlm_destroy(mlm_handle *h) {
     }
     for (int k = 0; k < MLM_SETS; ++k)
         if (h->stream_as[k]) hipStreamDestroy(h->stream_as[k]);
+    if (h->inputs_ready) hipEventDestroy(h->inputs_ready);
     if (h->d_f32) hipFree(h->d_f32);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
@@ -1296,10 +1205,15 @@ int mlm_destroy(mlm_handle *h) {
 
 int mlm_set_stream(mlm_handle *h, void *s) {
     if (!h) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = drain(h);
+    if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)s;
     h->own_stream = false;
+    if (!h->inputs_ready) HIPCHK(h, hipEventCreateWithFlags(&h->inputs_ready, hipEventDisableTiming));
     return MLM_OK;
 }
 
@@ -1307,6 +1221,7 @@ int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_
                                   int height, int row_stride, const double *q_wb, const double *t_wb) {
     if (!h || !img_dev || n_frames < 0 || !q_wb || !t_wb || width <= 0 || height <= 0 || row_stride < width)
         return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     if ((long long)width * height > h->lim.max_points) {
         h->err = "frame has more points than mlm_limits.max_points";
         return MLM_ERR_CAPACITY;
@@ -1336,6 +1251,7 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
                               int height, int row_stride, const double *q_wb, const double *t_wb) {
     if (!h || !img_host || n_frames < 0 || !q_wb || !t_wb || width <= 0 || height <= 0 || row_stride < width)
         return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     if ((long long)width * height > h->lim.max_points) {
         h->err = "frame has more points than mlm_limits.max_points";
         return MLM_ERR_CAPACITY;
@@ -1369,6 +1285,7 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
 int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int width, int height, int row_stride,
                                 const int32_t *pixel_idx_dev, int n_idx, const double q_wb[4], const double t_wb[3]) {
     if (!h || !img_dev || width <= 0 || height <= 0 || row_stride < width || !q_wb || !t_wb) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     if (pixel_idx_dev && n_idx < 0) return MLM_ERR_INVALID;
     const long long n = pixel_idx_dev ? n_idx : (long long)width * height;
     if (n > h->lim.max_points) {
@@ -1392,6 +1309,7 @@ int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int widt
 int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int height, int row_stride,
                             const int32_t *pixel_idx, int n_idx, const double q_wb[4], const double t_wb[3]) {
     if (!h || !img || width <= 0 || height <= 0 || row_stride < width) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     MlmSlot &S = cur_slot(h, 0);
     const size_t n_px = (size_t)row_stride * height;
@@ -1410,52 +1328,16 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
                            const double odom_p[3], const double odom_q[4], const double odom_v[3], double t_odom,
                            const double imu_w[3], double t_imu, double latency, int sampled, double T_wb_out[7]) {
     if (!h || !depth || width <= 0 || height <= 0 || !odom_p || !odom_q || !odom_v || !imu_w) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     const size_t n_px = (size_t)width * height;
     if ((long long)n_px > h->lim.max_points) {
         h->err = "frame has more points than mlm_limits.max_points";
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    // ---- pose latency compensation, mlmap.cpp:470-498 (Sophus so3.cpp:127-197, Eigen toRotationMatrix)
-    const double gap_odom = t_img - t_odom, gap_imu = t_img - t_imu;
-    const double time_gap = gap_imu - latency;
-    const Q4 q = q_norm(Q4{odom_q[0], odom_q[1], odom_q[2], odom_q[3]});
-    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
-    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
-    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
-    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx,
-                         txz - twy, tyz + twx, 1 - (txx + tyy)};
-    const D3 rot_dot{(R[0] * imu_w[0] + R[1] * imu_w[1]) + R[2] * imu_w[2], (R[3] * imu_w[0] + R[4] * imu_w[1]) + R[5] * imu_w[2],
-                     (R[6] * imu_w[0] + R[7] * imu_w[1]) + R[8] * imu_w[2]};
-    D3 lg;
-    {
-        const double EPS = 1e-10; // SMALL_EPS, so3.h:35
-        const double n = std::sqrt((q.x * q.x + q.y * q.y) + q.z * q.z), w = q.w;
-        double f;
-        if (n < EPS)
-            f = 2. / w - 2. * (n * n) / (w * (w * w));
-        else
-            f = 2 * std::atan(n / w) / n;
-        lg = D3{f * q.x, f * q.y, f * q.z};
-    }
-    const D3 rot_cp{lg.x + time_gap * rot_dot.x, lg.y + time_gap * rot_dot.y, lg.z + time_gap * rot_dot.z};
-    Q4 q_wb;
-    {
-        const double EPS = 1e-10;
-        const double theta = std::sqrt((rot_cp.x * rot_cp.x + rot_cp.y * rot_cp.y) + rot_cp.z * rot_cp.z);
-        const double half = 0.5 * theta, re = std::cos(half);
-        double im;
-        if (theta < EPS) {
-            const double t2 = theta * theta, t4 = t2 * t2;
-            im = 0.5 - 0.0208333 * t2 + 0.000260417 * t4;
-        } else {
-            im = std::sin(half) / theta;
-        }
-        q_wb = q_norm(Q4{re, im * rot_cp.x, im * rot_cp.y, im * rot_cp.z});
-    }
-    const double dtv = gap_odom - latency;
-    const double qa[4] = {q_wb.w, q_wb.x, q_wb.y, q_wb.z};
-    const double ta[3] = {odom_p[0] + dtv * odom_v[0], odom_p[1] + dtv * odom_v[1], odom_p[2] + dtv * odom_v[2]};
+    // ---- pose latency compensation, mlmap.cpp:470-498 (mlm_host.h)
+    double qa[4], ta[3];
+    compensate_pose(odom_p, odom_q, odom_v, imu_w, t_img, t_odom, t_imu, latency, qa, ta);
     if (T_wb_out) {
         for (int i = 0; i < 4; ++i) T_wb_out[i] = qa[i];
         for (int i = 0; i < 3; ++i) T_wb_out[4 + i] = ta[i];
@@ -1482,9 +1364,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
             const size_t at = v * (size_t)width + u;
             int r;
             if (is_f32) {
-                const float sv = ((const float *)depth)[at] * 1000.0f;
-                r = 0;
-                if (sv == sv) r = (int)fminf(fmaxf(rintf(sv), 0.0f), 65535.0f);
+                r = mlm_cv_f32_to_u16(((const float *)depth)[at]);
             } else {
                 r = ((const uint16_t *)depth)[at];
             }
@@ -1550,6 +1430,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
 
 int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q_wb[4], const double t_wb[3]) {
     if (!h || (!xyz && n > 0) || n < 0 || !q_wb || !t_wb) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     if (n > h->lim.max_points) {
         h->err = "frame has more points than mlm_limits.max_points";
         return MLM_ERR_CAPACITY;
@@ -1585,6 +1466,7 @@ int mlm_query_odd_grad(mlm_handle *h, const double *pos, int n, int max_iter, do
 
 int mlm_set_free_in_bound(mlm_handle *h, const double bmin[3], const double bmax[3]) {
     if (!h || !bmin || !bmax) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     // mlmap.cpp:392-396: `for (double x = min; x <= max; x += d)` — the accumulated coordinates, not i*d
     std::vector<double> ax[3];
@@ -1615,6 +1497,7 @@ int mlm_set_free_in_bound(mlm_handle *h, const double bmin[3], const double bmax
 
 int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
     if (!h || !ct_pos) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     const int R = h->cfg.inflate_n, G = h->cfg.inflate_global_n;
     if (R < 0 || G < 0 || R >= h->P.n || G > 16) {
@@ -1635,6 +1518,7 @@ int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
     if (rc) return rc;
     if (h->h_g->err) {
         h->err = "block pool or block hash table full (raise mlm_limits.max_blocks)";
+        clear_device_error(h);
         return MLM_ERR_CAPACITY;
     }
     return MLM_OK;
@@ -1642,6 +1526,7 @@ int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
 
 int mlm_block_count(mlm_handle *h, int *n_out) {
     if (!h || !n_out) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     int rc = read_global(h);
     if (rc) return rc;
@@ -1651,6 +1536,7 @@ int mlm_block_count(mlm_handle *h, int *n_out) {
 
 int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, uint8_t *occ, uint8_t *infl, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     int n = 0;
     int rc = mlm_block_count(h, &n);
     if (rc) return rc;
@@ -1668,6 +1554,7 @@ int mlm_export_blocks(mlm_handle *h, int cap, int32_t *keys, float *log_odds, ui
 
 int mlm_export_block_flags(mlm_handle *h, int cap, uint8_t *collapsed, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     int n = 0;
     int rc = mlm_block_count(h, &n);
     if (rc) return rc;
@@ -1683,6 +1570,7 @@ int mlm_export_block_flags(mlm_handle *h, int cap, uint8_t *collapsed, int *n_ou
 
 int mlm_export_frontier(mlm_handle *h, int cap, int32_t *keys_cell, int *n_out) {
     if (!h || cap < 0 || (cap > 0 && !keys_cell)) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     if (n_out) *n_out = 0;
     if (!h->P.explore) return MLM_OK;
     int nb = 0;
@@ -1711,44 +1599,148 @@ int mlm_export_frontier(mlm_handle *h, int cap, int32_t *keys_cell, int *n_out) 
     return MLM_OK;
 }
 
-int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out) {
-    if (!h || cap_points < 0 || (cap_points > 0 && !xyz)) return MLM_ERR_INVALID;
+static int export_points(mlm_handle *h, int cap_points, float *xyz, int *n_out, int which, const char *what) {
     HIPCHK(h, hipSetDevice(h->device));
+    if (n_out) *n_out = 0;
+    if (which == 1 && !h->P.explore) return MLM_OK; // frontier sets only exist with use_exploration_frontiers
     int nb = 0;
     int rc = mlm_block_count(h, &nb);
     if (rc) return rc;
     float *d_xyz = nullptr;
     unsigned int *d_cnt = nullptr;
     HIPCHK(h, hipMalloc((void **)&d_xyz, std::max<size_t>((size_t)cap_points * 3 * sizeof(float), 16)));
-    HIPCHK(h, hipMalloc((void **)&d_cnt, sizeof(unsigned int)));
-    HIPCHK(h, hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), h->stream));
-    if (nb > 0)
+    hipError_t e = hipMalloc((void **)&d_cnt, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned int), h->stream);
+    if (e == hipSuccess && nb > 0)
         hipLaunchKernelGGL(k_export_global, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, h->P, (unsigned int)nb, d_xyz,
-                           (unsigned int)cap_points, d_cnt);
+                           (unsigned int)cap_points, d_cnt, which);
     unsigned int cnt = 0;
-    hipError_t e = hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && cnt && cap_points)
         e = hipMemcpy(xyz, d_xyz, (size_t)std::min<unsigned int>(cnt, (unsigned int)cap_points) * 3 * sizeof(float),
                       hipMemcpyDefault);
     hipFree(d_xyz);
-    hipFree(d_cnt);
+    if (d_cnt) hipFree(d_cnt);
     if (e != hipSuccess) {
-        h->err = std::string("mlm_export_global_map: ") + hipGetErrorString(e);
+        h->err = std::string(what) + ": " + hipGetErrorString(e);
         return MLM_ERR_HIP;
     }
     if (n_out) *n_out = (int)cnt;
     return MLM_OK;
 }
 
+int mlm_export_global_map(mlm_handle *h, int cap_points, float *xyz, int *n_out) {
+    if (!h || cap_points < 0 || (cap_points > 0 && !xyz)) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    return export_points(h, cap_points, xyz, n_out, 0, "mlm_export_global_map");
+}
+
+int mlm_export_frontier_points(mlm_handle *h, int cap_points, float *xyz, int *n_out) {
+    if (!h || cap_points < 0 || (cap_points > 0 && !xyz)) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    return export_points(h, cap_points, xyz, n_out, 1, "mlm_export_frontier_points");
+}
+
+int mlm_import_blocks(mlm_handle *h, int n, const int32_t *keys, const float *log_odds, const uint8_t *occ, const uint8_t *infl,
+                      const uint8_t *collapsed) {
+    if (!h || n < 0 || (n > 0 && !keys)) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = drain(h);
+    if (rc || n == 0) return rc;
+    const size_t C = (size_t)h->P.cells, N = (size_t)n;
+    // one staging buffer: keys | slots | log_odds | occ | infl | collapsed (sources may be host or device memory)
+    const size_t o_keys = 0, o_slots = o_keys + N * 12, o_lo = (o_slots + N * 4 + 15) & ~(size_t)15, o_occ = o_lo + N * C * 4,
+                 o_infl = o_occ + N * C, o_col = o_infl + N * C, total = o_col + N;
+    char *d = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d, total));
+    hipError_t e = hipMemcpyAsync(d + o_keys, keys, N * 12, hipMemcpyDefault, h->stream);
+    if (e == hipSuccess && log_odds) e = hipMemcpyAsync(d + o_lo, log_odds, N * C * 4, hipMemcpyDefault, h->stream);
+    if (e == hipSuccess && occ) e = hipMemcpyAsync(d + o_occ, occ, N * C, hipMemcpyDefault, h->stream);
+    if (e == hipSuccess && infl) e = hipMemcpyAsync(d + o_infl, infl, N * C, hipMemcpyDefault, h->stream);
+    if (e == hipSuccess && collapsed) e = hipMemcpyAsync(d + o_col, collapsed, N, hipMemcpyDefault, h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_import_slots, dim3(grid_for(N)), dim3(MLM_BLOCK), 0, h->stream, h->P, (const int32_t *)(d + o_keys), n,
+                           (int *)(d + o_slots));
+        hipLaunchKernelGGL(k_import_cells, dim3(std::min<unsigned int>(4096u, grid_for(N * C))), dim3(MLM_BLOCK), 0, h->stream, h->P,
+                           (const int *)(d + o_slots), n, log_odds ? (const float *)(d + o_lo) : nullptr,
+                           occ ? (const uint8_t *)(d + o_occ) : nullptr, infl ? (const uint8_t *)(d + o_infl) : nullptr,
+                           collapsed ? (const uint8_t *)(d + o_col) : nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) {
+        h->err = std::string("mlm_import_blocks: ") + hipGetErrorString(e);
+        return MLM_ERR_HIP;
+    }
+    rc = read_global(h);
+    if (rc) return rc;
+    if (h->h_g->err) {
+        h->err = "block pool or block hash table full (raise mlm_limits.max_blocks)";
+        clear_device_error(h);
+        return MLM_ERR_CAPACITY;
+    }
+    return MLM_OK;
+}
+
+int mlm_merge_pack(mlm_handle *h, const int32_t *keys_dev, int n, float *log_odds_dev, uint8_t *seen_dev) {
+    if (!h || n < 0 || (n > 0 && (!keys_dev || !log_odds_dev || !seen_dev))) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = drain(h);
+    if (rc || n == 0) return rc;
+    hipLaunchKernelGGL(k_merge_pack, dim3(std::min<unsigned int>(8192u, grid_for((size_t)n * h->P.cells))), dim3(MLM_BLOCK), 0, h->stream,
+                       h->P, keys_dev, n, log_odds_dev, seen_dev);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+int mlm_merge_finish(mlm_handle *h, float *log_odds_dev, const uint8_t *seen_dev, size_t n_cells, uint8_t *occ_dev) {
+    if (!h || (n_cells > 0 && (!log_odds_dev || !seen_dev || !occ_dev))) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n_cells == 0) return MLM_OK;
+    hipLaunchKernelGGL(k_merge_finish, dim3(std::min<unsigned int>(8192u, grid_for(n_cells))), dim3(MLM_BLOCK), 0, h->stream, h->P,
+                       log_odds_dev, seen_dev, n_cells, occ_dev);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
+int mlm_query_odds_at(mlm_handle *h, const int32_t *glb_id, const int32_t *subbox_id, int n, float *out) {
+    if (!h || !glb_id || !subbox_id || !out || n < 0) return MLM_ERR_INVALID;
+    for (int i = 0; i < n; ++i) // std::vector::operator[] out of range is undefined behaviour in the reference
+        if (subbox_id[i] < 0 || subbox_id[i] >= h->P.cells) return MLM_ERR_INVALID;
+    if (n == 0) return MLM_OK;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = drain(h);
+    if (rc) return rc;
+    rc = ensure_query(h, (size_t)n);
+    if (rc) return rc;
+    int32_t *d_g = (int32_t *)h->d_qpos, *d_s = d_g + 3 * (size_t)n;
+    HIPCHK(h, hipMemcpyAsync(d_g, glb_id, (size_t)n * 12, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_s, subbox_id, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_query_odds_at, dim3(grid_for((size_t)n)), dim3(MLM_BLOCK), 0, h->stream, h->P, d_g, d_s, n, (float *)h->d_qout);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->d_qout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
 int mlm_sync(mlm_handle *h) {
     if (!h) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     return drain(h);
 }
 
 int mlm_set_async(mlm_handle *h, int on) {
     if (!h) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     const int rc = drain(h);
     h->async_mode = on != 0;
@@ -1757,12 +1749,14 @@ int mlm_set_async(mlm_handle *h, int on) {
 
 int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {
     if (!h || !out) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     *out = h->stats;
     return MLM_OK;
 }
 
 int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *odds, uint32_t *t_first, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     {
         const int rc = drain(h);
@@ -1781,6 +1775,7 @@ int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *od
 
 int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     if (!h->P.record_awareness && !h->P.explore) {
         h->err = "mlm_limits.record_awareness was not set";
         return MLM_ERR_INVALID;
@@ -1796,6 +1791,7 @@ int mlm_get_awareness_misses(mlm_handle *h, int cap, uint32_t *cell_idx, int *n_
 
 int mlm_get_T_ls(mlm_handle *h, double q[4], double t[3]) {
     if (!h || !q || !t) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     const MlmFrame &F = h->slots[(size_t)h->last_slot].F;
     for (int i = 0; i < 4; ++i) q[i] = F.q_ls[i];
     for (int i = 0; i < 3; ++i) t[i] = F.t_ls[i];
@@ -1804,12 +1800,14 @@ int mlm_get_T_ls(mlm_handle *h, double q[4], double t[3]) {
 
 int mlm_get_odds_table(mlm_handle *h, float *out) {
     if (!h || !out) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     std::memcpy(out, h->odds_table.data(), h->odds_table.size() * sizeof(float));
     return MLM_OK;
 }
 
 int mlm_enable_kernel_timing(mlm_handle *h, int on) {
     if (!h) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     const int rc = drain(h);
     h->timing = on;
@@ -1820,6 +1818,7 @@ int mlm_enable_kernel_timing(mlm_handle *h, int on) {
 
 int mlm_set_timed_kernel(mlm_handle *h, const char *name, int every) {
     if (!h || !name || every < 1) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     h->timed_kernel = name;
     h->timed_every = (unsigned int)every;
     h->timed_count = 0;
@@ -1828,6 +1827,7 @@ int mlm_set_timed_kernel(mlm_handle *h, const char *name, int every) {
 
 int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out) {
     if (!h || cap < 0) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
     HIPCHK(h, hipSetDevice(h->device));
     {
         const int rc = drain(h);

@@ -2,19 +2,29 @@
 gloo in the CPU tests.
 
 This step has NO counterpart in the reference (single process) — it is the one place the path has a real
-exchange, so it is the one place a collective is used; the per-frame path never communicates.
+exchange, so it is the one place collectives are used; the per-frame path never communicates.
 
 Protocol (all ranks end with the same merged map):
-  1. all-gather the block keys (12 B each) -> identical sorted union on every rank;
-  2. every rank packs its log-odds of the union's blocks into a dense [n_union, n^3] float tensor (0 where absent) and
-     an "observed" flag tensor (occupancy != 'u');
-  3. all-reduce(sum) both (xGMI: 7 point-to-point links per GPU; one large message lets RCCL use all of them);
-  4. clamp the summed log-odds to [log_odds_min, log_odds_max]; class = 'o' if L > occupied_sh, else 'f' if any rank
-     observed the voxel, else 'u'.
+  1. all-gather the block keys (12 B each) -> identical sorted union on every rank, padded to a multiple of the world
+     size so that it splits into equal shards of whole blocks;
+  2. every rank packs its map into the union's layout: log-odds [n_u, n^3] float32 (0 where it does not hold the block)
+     and a "seen" plane [n_u, n^3] uint8 (occupancy != 'u') — 5 bytes per voxel;
+  3. DIRECT reduce-scatter: one all-to-all hands shard r of every rank's buffers to rank r, which sums the log-odds and
+     ORs the seen flags locally.  xGMI is a point-to-point fabric (7 links per GPU, a fully connected 8-GPU node): the
+     all-to-all puts 1/world of the buffer on every link at once, where a ring would be bound by one link;
+  4. rank r finishes ITS shard only: clamp to [log_odds_min, log_odds_max]; class 'o' above occupied_sh, else 'f' where
+     any rank had seen the voxel, else 'u';
+  5. all-gather the finished shards (log-odds + class, 5 bytes per voxel).
+Per rank and voxel 2 x 5 x (w-1)/w bytes cross the fabric (two dense fp32 all-reduces would move 16).
+
+Two front ends share the protocol: `merge_global_map` takes block dumps (numpy / torch, any device — what the gloo test
+and a host-side caller use) and `merge_device_maps` works on a live `MLMap` handle: keys, packing and finishing run as
+HIP kernels of libmlmap_hip.so straight from / into the device-resident map (mlm_merge_pack / mlm_merge_finish /
+mlm_import_blocks), torch only owns the exchange buffers and issues the collectives.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Callable, Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -23,6 +33,7 @@ import torch.distributed as dist
 from .config import MapConfig
 
 _BIAS = 1 << 20
+_PAD = torch.iinfo(torch.int64).max
 
 
 def _pack(keys: torch.Tensor) -> torch.Tensor:
@@ -35,10 +46,69 @@ def _unpack(p: torch.Tensor) -> torch.Tensor:
     return torch.stack([((p >> 42) & m) - _BIAS, ((p >> 21) & m) - _BIAS, (p & m) - _BIAS], dim=1).to(torch.int32)
 
 
+def _key_union(keys: torch.Tensor, world: int, group) -> Tuple[torch.Tensor, int]:
+    """Step 1.  Returns (sorted packed union padded with _PAD to a multiple of `world`, number of real blocks)."""
+    dev = keys.device
+    n = keys.shape[0]
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    cnts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    n_max = max(int(cnts.max().item()), 1)
+    packed = torch.full((n_max,), _PAD, dtype=torch.int64, device=dev)
+    if n:
+        packed[:n] = _pack(keys)
+    gathered = torch.empty(world * n_max, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, packed, group=group)
+    union = torch.unique(gathered)  # sorted ascending = lexicographic (x,y,z); _PAD sorts last
+    union = union[union != _PAD]
+    n_u = int(union.shape[0])
+    n_pad = (n_u + world - 1) // world * world
+    if n_pad > n_u:
+        union = torch.cat([union, torch.full((n_pad - n_u,), _PAD, dtype=torch.int64, device=dev)])
+    return union, n_u
+
+
+def _exchange(dense: torch.Tensor, seen: torch.Tensor, finish: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], world: int,
+              group) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Steps 3-5 on the packed planes [n_pad, C] (n_pad a multiple of world)."""
+    n_pad, C = dense.shape
+    shard = n_pad // world
+    if world > 1:
+        r_lo = torch.empty_like(dense)
+        r_seen = torch.empty_like(seen)
+        dist.all_to_all_single(r_lo, dense, group=group)    # chunk j of the input goes to rank j
+        dist.all_to_all_single(r_seen, seen, group=group)
+        my_lo = r_lo.view(world, shard, C).sum(dim=0).contiguous()
+        my_seen = r_seen.view(world, shard, C).amax(dim=0).contiguous()
+    else:
+        my_lo, my_seen = dense.clone(), seen
+    my_occ = finish(my_lo, my_seen)  # clamps my_lo in place
+    out_lo = torch.empty_like(dense)
+    out_occ = torch.empty_like(seen)
+    dist.all_gather_into_tensor(out_lo, my_lo.contiguous(), group=group)
+    dist.all_gather_into_tensor(out_occ, my_occ.contiguous(), group=group)
+    return out_lo, out_occ
+
+
+def _finish_torch(cfg: MapConfig) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
+    lo_min = float(np.float32(cfg.lm_log_odds_min))
+    lo_max = float(np.float32(cfg.lm_log_odds_max))
+    sh = float(np.float32(cfg.lm_occupied_sh))
+
+    def finish(lo: torch.Tensor, seen: torch.Tensor) -> torch.Tensor:
+        lo.clamp_(lo_min, lo_max)
+        occ = torch.where(seen > 0, ord("f"), ord("u")).to(torch.uint8)
+        occ[lo > sh] = ord("o")
+        return occ
+
+    return finish
+
+
 def merge_global_map(blocks: Dict[str, "torch.Tensor | np.ndarray"], cfg: MapConfig, group=None,
                      device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
-    """blocks: {'keys': [n,3] int32, 'log_odds': [n,C] float32, 'occ': [n,C] uint8} of THIS rank (any order).
-    Returns the merged map (same dict layout, keys sorted) as tensors on `device`."""
+    """blocks: {'keys': [n,3] int32, 'log_odds': [n,C] float32, 'occ': [n,C] uint8} of THIS rank (any order; the layout
+    MLMap.export_blocks and the oracle binding both produce).  Returns the merged map (same layout, keys sorted) as
+    tensors on `device`."""
     world = dist.get_world_size(group)
     dev = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl"
                      else torch.device("cpu"))
@@ -47,37 +117,50 @@ def merge_global_map(blocks: Dict[str, "torch.Tensor | np.ndarray"], cfg: MapCon
     lo = as_t(blocks["log_odds"], torch.float32)
     occ = as_t(blocks["occ"], torch.uint8)
     C = cfg.cells_per_block
-    n = keys.shape[0]
-    # 1. union of block keys
-    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    n_max = int(max(int(c.item()) for c in cnts))
-    packed = torch.full((max(n_max, 1),), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
-    if n:
-        packed[:n] = _pack(keys)
-    gathered = [torch.empty_like(packed) for _ in range(world)]
-    dist.all_gather(gathered, packed, group=group)
-    union = torch.unique(torch.cat(gathered))
-    union = union[union != torch.iinfo(torch.int64).max]  # sorted ascending = lexicographic (x,y,z)
-    n_u = union.shape[0]
-    # 2. dense pack
-    dense = torch.zeros((n_u, C), dtype=torch.float32, device=dev)
-    seen = torch.zeros((n_u, C), dtype=torch.float32, device=dev)
-    if n:
+    union, n_u = _key_union(keys, world, group)
+    dense = torch.zeros((union.shape[0], C), dtype=torch.float32, device=dev)
+    seen = torch.zeros((union.shape[0], C), dtype=torch.uint8, device=dev)
+    if keys.shape[0]:
         pos = torch.searchsorted(union, _pack(keys))
         dense[pos] = lo
-        seen[pos] = (occ != ord("u")).to(torch.float32)
-    # 3. exchange
+        seen[pos] = (occ != ord("u")).to(torch.uint8)
+    out_lo, out_occ = _exchange(dense, seen, _finish_torch(cfg), world, group)
+    return {"keys": _unpack(union[:n_u]), "log_odds": out_lo[:n_u], "occ": out_occ[:n_u]}
+
+
+def merge_device_maps(m, group=None, load_back: bool = True) -> Dict[str, torch.Tensor]:
+    """Merge the device-resident maps of all ranks (`m`: this rank's MLMap) over RCCL.  Packing and finishing are HIP
+    kernels of the map library working on the handle's own HBM; with `load_back` the merged map replaces the handle's
+    content (mlm_import_blocks), so that the usual queries answer from the global map.  Returns the merged map as device
+    tensors (keys sorted)."""
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    C = m.cells
+    n = m.block_count()
+    keys = torch.empty((max(n, 1), 3), dtype=torch.int32, device=dev)
+    if n:
+        m.export_block_keys_dev(keys.data_ptr(), n)
+    union, n_u = _key_union(keys[:n], world, group)
+    n_pad = int(union.shape[0])
+    ukeys = _unpack(union[:n_u]).contiguous()
+    dense = torch.empty((n_pad, C), dtype=torch.float32, device=dev)
+    seen = torch.empty((n_pad, C), dtype=torch.uint8, device=dev)
+    dense[n_u:] = 0  # padding rows (the union is padded to equal shards)
+    seen[n_u:] = 0
+    torch.cuda.synchronize()
     if n_u:
-        dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(seen, op=dist.ReduceOp.SUM, group=group)
-    # 4. clamp + class
-    lo_min = float(np.float32(cfg.lm_log_odds_min))
-    lo_max = float(np.float32(cfg.lm_log_odds_max))
-    sh = float(np.float32(cfg.lm_occupied_sh))
-    dense.clamp_(lo_min, lo_max)
-    cls = torch.full((n_u, C), ord("u"), dtype=torch.uint8, device=dev)
-    cls[seen > 0] = ord("f")
-    cls[dense > sh] = ord("o")
-    return {"keys": _unpack(union), "log_odds": dense, "occ": cls}
+        m.merge_pack(ukeys.data_ptr(), n_u, dense.data_ptr(), seen.data_ptr())
+
+    def finish(lo: torch.Tensor, sn: torch.Tensor) -> torch.Tensor:
+        assert lo.is_contiguous() and sn.is_contiguous()
+        occ = torch.empty_like(sn)
+        torch.cuda.synchronize()
+        m.merge_finish(lo.data_ptr(), sn.data_ptr(), lo.numel(), occ.data_ptr())
+        return occ
+
+    out_lo, out_occ = _exchange(dense, seen, finish, world, group) if n_pad else (dense, seen)
+    torch.cuda.synchronize()
+    merged = {"keys": ukeys, "log_odds": out_lo[:n_u], "occ": out_occ[:n_u]}
+    if load_back and n_u:
+        m.import_blocks((merged["keys"].data_ptr(), n_u), log_odds=merged["log_odds"].data_ptr(), occ=merged["occ"].data_ptr())
+    return merged

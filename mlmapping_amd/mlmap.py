@@ -30,7 +30,9 @@ ABI_SYMBOLS = [
     "mlm_integrate_depth_u16", "mlm_integrate_depth_u16_dev", "mlm_integrate_depth_batch_dev",
     "mlm_integrate_depth_batch", "mlm_integrate_callback",
     "mlm_integrate_points", "mlm_query_occupancy", "mlm_query_occupancy_inflate", "mlm_query_inflate_occupancy",
-    "mlm_query_odds", "mlm_query_odd_grad", "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
+    "mlm_query_odds", "mlm_query_odd_grad", "mlm_query_odds_at", "mlm_export_frontier_points", "mlm_import_blocks",
+    "mlm_merge_pack", "mlm_merge_finish",
+    "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
     "mlm_export_blocks", "mlm_export_block_flags", "mlm_export_frontier", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
     "mlm_get_awareness_hits",
     "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
@@ -89,6 +91,11 @@ def load_library(path: Optional[str] = None):
     L.mlm_query_inflate_occupancy.argtypes = [vp, vp, i32, vp]
     L.mlm_query_odds.argtypes = [vp, vp, i32, vp]
     L.mlm_query_odd_grad.argtypes = [vp, vp, i32, i32, vp]
+    L.mlm_query_odds_at.argtypes = [vp, vp, vp, i32, vp]
+    L.mlm_export_frontier_points.argtypes = [vp, i32, vp, vp]
+    L.mlm_import_blocks.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.mlm_merge_pack.argtypes = [vp, vp, i32, vp, vp]
+    L.mlm_merge_finish.argtypes = [vp, vp, vp, ctypes.c_size_t, vp]
     L.mlm_set_free_in_bound.argtypes = [vp, vp, vp]
     L.mlm_inflate_map.argtypes = [vp, vp]
     L.mlm_block_count.argtypes = [vp, vp]
@@ -248,6 +255,14 @@ class MLMap:
         self._chk(self._L.mlm_query_odds(self._h, _p(pos), pos.shape[0], _p(out)), "mlm_query_odds")
         return out
 
+    def getOddAt(self, glb_id, subbox_id) -> np.ndarray:
+        """float getOdd(const Vec3I &glb_id, size_t subbox_id), mlmap.h:227-235."""
+        g = np.ascontiguousarray(glb_id, dtype=np.int32).reshape(-1, 3)
+        c = np.ascontiguousarray(subbox_id, dtype=np.int32).reshape(-1)
+        out = np.empty(g.shape[0], dtype=np.float32)
+        self._chk(self._L.mlm_query_odds_at(self._h, _p(g), _p(c), g.shape[0], _p(out)), "mlm_query_odds_at")
+        return out
+
     def getOddGrad(self, pos_w, max_iter: int = 5) -> np.ndarray:
         pos = _f64(pos_w).reshape(-1, 3)
         out = np.empty((pos.shape[0], 3), dtype=np.float64)
@@ -295,6 +310,49 @@ class MLMap:
         if n.value:
             self._chk(self._L.mlm_export_frontier(self._h, n.value, _p(out), ctypes.byref(n)), "mlm_export_frontier")
         return out[np.lexsort((out[:, 3], out[:, 2], out[:, 1], out[:, 0]))]
+
+    def frontier_points(self) -> np.ndarray:
+        """float32 [n,3] centres of the frontier cells: the PointCloud2 payload of /frontier (rviz_vis.cpp:267-293)."""
+        n = ctypes.c_int32()
+        self._chk(self._L.mlm_export_frontier_points(self._h, 0, None, ctypes.byref(n)), "mlm_export_frontier_points")
+        out = np.empty((n.value, 3), dtype=np.float32)
+        if n.value:
+            self._chk(self._L.mlm_export_frontier_points(self._h, n.value, _p(out), ctypes.byref(n)),
+                      "mlm_export_frontier_points")
+        return out
+
+    def import_blocks(self, keys, log_odds=None, occ=None, infl=None, collapsed=None):
+        """Load blocks (layout of export_blocks) into the map; host numpy arrays or device pointers (ints)."""
+        def ptr(a, dt):
+            if a is None:
+                return None, None
+            if isinstance(a, int):
+                return ctypes.c_void_p(a), None
+            arr = np.ascontiguousarray(a, dtype=dt)
+            return _p(arr), arr
+        if isinstance(keys, tuple):  # (device pointer, n)
+            kp, n, keep = ctypes.c_void_p(keys[0]), int(keys[1]), None
+        else:
+            keep = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 3)
+            kp, n = _p(keep), keep.shape[0]
+        holds = [ptr(log_odds, np.float32), ptr(occ, np.uint8), ptr(infl, np.uint8), ptr(collapsed, np.uint8)]
+        self._chk(self._L.mlm_import_blocks(self._h, n, kp, holds[0][0], holds[1][0], holds[2][0], holds[3][0]),
+                  "mlm_import_blocks")
+
+    def export_block_keys_dev(self, keys_dev_ptr: int, cap: int) -> int:
+        """Block keys straight into device memory ([cap,3] int32); returns the block count."""
+        m = ctypes.c_int32()
+        self._chk(self._L.mlm_export_blocks(self._h, cap, ctypes.c_void_p(keys_dev_ptr), None, None, None, ctypes.byref(m)),
+                  "mlm_export_blocks")
+        return m.value
+
+    def merge_pack(self, keys_dev_ptr: int, n: int, log_odds_dev_ptr: int, seen_dev_ptr: int):
+        self._chk(self._L.mlm_merge_pack(self._h, ctypes.c_void_p(keys_dev_ptr), n, ctypes.c_void_p(log_odds_dev_ptr),
+                                         ctypes.c_void_p(seen_dev_ptr)), "mlm_merge_pack")
+
+    def merge_finish(self, log_odds_dev_ptr: int, seen_dev_ptr: int, n_cells: int, occ_dev_ptr: int):
+        self._chk(self._L.mlm_merge_finish(self._h, ctypes.c_void_p(log_odds_dev_ptr), ctypes.c_void_p(seen_dev_ptr), n_cells,
+                                           ctypes.c_void_p(occ_dev_ptr)), "mlm_merge_finish")
 
     def class_counts(self) -> Dict[str, int]:
         b = self.export_blocks()

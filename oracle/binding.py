@@ -74,6 +74,14 @@ def lib():
         L.mlo_inflate_map.argtypes = [vp, vp]
         L.mlo_global_map_points.restype = sz
         L.mlo_global_map_points.argtypes = [vp, vp]
+        L.mlo_frontier_points.restype = sz
+        L.mlo_frontier_points.argtypes = [vp, vp]
+        L.mlo_get_odd_at.argtypes = [vp, vp, vp, i32, vp]
+        L.mlo_cv_f32_to_u16.argtypes = [vp, i32, vp]
+        for name in ("mlo_so3_from_quat", "mlo_so3_exp", "mlo_so3_log", "mlo_so3_matrix", "mlo_se3_inverse"):
+            getattr(L, name).argtypes = [vp, vp]
+        for name in ("mlo_so3_mul", "mlo_se3_mul", "mlo_se3_apply"):
+            getattr(L, name).argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 
@@ -252,6 +260,19 @@ class OracleMap:
         lib().mlo_get_odd_grad(self._h, _p(pos), pos.shape[0], max_iter, _p(out))
         return out
 
+    def getOddAt(self, glb_id, subbox_id) -> np.ndarray:
+        g = np.ascontiguousarray(glb_id, dtype=np.int32).reshape(-1, 3)
+        c = np.ascontiguousarray(subbox_id, dtype=np.int32).reshape(-1)
+        out = np.empty(g.shape[0], dtype=np.float32)
+        lib().mlo_get_odd_at(self._h, _p(g), _p(c), g.shape[0], _p(out))
+        return out
+
+    def frontier_points(self) -> np.ndarray:
+        n = lib().mlo_frontier_points(self._h, None)
+        out = np.empty((n, 3), dtype=np.float32)
+        lib().mlo_frontier_points(self._h, _p(out))
+        return out
+
     def setFree_map_in_bound(self, box_min, box_max):
         lib().mlo_set_free_in_bound(self._h, _p(_f64(box_min)), _p(_f64(box_max)))
 
@@ -263,3 +284,50 @@ class OracleMap:
         out = np.empty((n, 3), dtype=np.float32)
         lib().mlo_global_map_points(self._h, _p(out))
         return out
+
+
+# ---- SO3 / SE3 restatements on their own (for the Sophus property tests) -------------------------------------------
+def _call(name, out_n, *args):
+    a = [_f64(x) for x in args]
+    out = np.empty(out_n)
+    getattr(lib(), name)(*[_p(x) for x in a], _p(out))
+    return out
+
+
+def so3_from_quat(q):
+    return _call("mlo_so3_from_quat", 4, q)
+
+
+def so3_exp(omega):
+    return _call("mlo_so3_exp", 4, omega)
+
+
+def so3_log(q):
+    return _call("mlo_so3_log", 3, q)
+
+
+def so3_mul(a, b):
+    return _call("mlo_so3_mul", 4, a, b)
+
+
+def so3_matrix(q):
+    return _call("mlo_so3_matrix", 9, q).reshape(3, 3)
+
+
+def se3_mul(a, b):
+    return _call("mlo_se3_mul", 7, a, b)
+
+
+def se3_inverse(a):
+    return _call("mlo_se3_inverse", 7, a)
+
+
+def se3_apply(a, p):
+    return _call("mlo_se3_apply", 3, a, p)
+
+
+def cv_f32_to_u16(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+    out = np.empty(a.size, dtype=np.uint16)
+    lib().mlo_cv_f32_to_u16(_p(a), a.size, _p(out))
+    return out

@@ -889,12 +889,18 @@ int mlo_update_depth_sampled(mlo_handle *h, const uint16_t *img, int rows, int c
     return (int)h->pc_eigen.size();
 }
 
-/* cv::Mat::convertTo(CV_16UC1, 1000) on a 32FC1 image (mlmap.cpp:482).  OpenCV is not in the reference tree; its
- * documented rule is dst = saturate_cast<ushort>(src*alpha) with the product in float and round-half-to-even. */
+/* cv::Mat::convertTo(CV_16UC1, 1000) on a 32FC1 image (mlmap.cpp:482).  OpenCV is not in the reference tree (a
+ * system dependency, version unpinned: CMakeLists.txt find_package(OpenCV)); its rule for float -> ushort with a scale
+ * is dst = saturate_cast<ushort>(cvRound(src*alpha)) with the product in float.  cvRound on x86-64 is cvtss2si: round
+ * half to even, and INT_MIN for NaN / Inf / anything outside int32; saturate_cast<ushort>(int) clamps to [0, 65535].
+ * So non-finite pixels (REP-117 "no return") become 0 and are skipped by project_depth (mlmap.cpp:338-341). */
 static inline uint16_t cv_f32_to_u16(float v) {
     const float s = v * 1000.0f;
-    if (!(s == s)) return 0;
-    const long r = std::lrintf(s);
+    int r;
+    if (!(s == s) || !(s < 2147483648.0f) || s < -2147483648.0f)
+        r = INT32_MIN;
+    else
+        r = (int)std::lrintf(s);
     return (uint16_t)(r < 0 ? 0 : (r > 65535 ? 65535 : r));
 }
 
@@ -1078,6 +1084,72 @@ size_t mlo_global_map_points(mlo_handle *h, float *xyz) {
         }
     }
     return n;
+}
+
+/* rviz_vis.cpp:267-293 + map_local.h:201-206: PointP(float) of every frontier cell, block then set iteration order */
+size_t mlo_frontier_points(mlo_handle *h, float *xyz) {
+    size_t n = 0;
+    for (auto &kv : h->lm.observed_group_map)
+        for (int c : kv.second.frontier) {
+            if (xyz) {
+                V3 p = h->lm.subbox_id2xyz_glb_vec(kv.first, c);
+                xyz[3 * n] = (float)p.x;
+                xyz[3 * n + 1] = (float)p.y;
+                xyz[3 * n + 2] = (float)p.z;
+            }
+            n++;
+        }
+    return n;
+}
+/* float mlmap::getOdd(const Vec3I &glb_id, size_t subbox_id), mlmap.h:227-235 */
+void mlo_get_odd_at(mlo_handle *h, const int32_t *glb_id, const int32_t *subbox_id, int n, float *out) {
+    for (int i = 0; i < n; i++)
+        out[i] = h->getOdd(V3i{glb_id[3 * i], glb_id[3 * i + 1], glb_id[3 * i + 2]}, (size_t)subbox_id[i]);
+}
+
+/* cv::Mat::convertTo(CV_16UC1, 1000) per pixel (mlmap.cpp:482), see cv_f32_to_u16 */
+void mlo_cv_f32_to_u16(const float *in, int n, uint16_t *out) {
+    for (int i = 0; i < n; i++) out[i] = cv_f32_to_u16(in[i]);
+}
+
+/* ---- the SO3 / SE3 restatements on their own, for the property tests the reference holds for Sophus
+ *      (3rdPartLib/Sophus/sophus/test_so3.cpp:14-110, test_se3.cpp:10-86).  q = (w,x,y,z). ---- */
+void mlo_so3_from_quat(const double q[4], double out[4]) { /* SO3(Quaterniond): normalises, so3.cpp:43-47 */
+    Quat r = quat_normalized(Quat{q[0], q[1], q[2], q[3]});
+    out[0] = r.w, out[1] = r.x, out[2] = r.y, out[3] = r.z;
+}
+void mlo_so3_exp(const double omega[3], double out[4]) {
+    Quat r = so3_exp(V3{omega[0], omega[1], omega[2]});
+    out[0] = r.w, out[1] = r.x, out[2] = r.y, out[3] = r.z;
+}
+void mlo_so3_log(const double q[4], double out[3]) {
+    V3 r = so3_log(Quat{q[0], q[1], q[2], q[3]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+void mlo_so3_mul(const double a[4], const double b[4], double out[4]) { /* so3.cpp:73-78 */
+    Quat r = quat_normalized(quat_mul(Quat{a[0], a[1], a[2], a[3]}, Quat{b[0], b[1], b[2], b[3]}));
+    out[0] = r.w, out[1] = r.x, out[2] = r.y, out[3] = r.z;
+}
+void mlo_so3_matrix(const double q[4], double R[9]) { quat_to_R(Quat{q[0], q[1], q[2], q[3]}, R); }
+/* T = (q, t) as 7 doubles */
+void mlo_se3_mul(const double a[7], const double b[7], double out[7]) {
+    SE3 A, B;
+    A.q = Quat{a[0], a[1], a[2], a[3]}, A.t = V3{a[4], a[5], a[6]};
+    B.q = Quat{b[0], b[1], b[2], b[3]}, B.t = V3{b[4], b[5], b[6]};
+    SE3 r = se3_mul(A, B);
+    out[0] = r.q.w, out[1] = r.q.x, out[2] = r.q.y, out[3] = r.q.z, out[4] = r.t.x, out[5] = r.t.y, out[6] = r.t.z;
+}
+void mlo_se3_inverse(const double a[7], double out[7]) {
+    SE3 A;
+    A.q = Quat{a[0], a[1], a[2], a[3]}, A.t = V3{a[4], a[5], a[6]};
+    SE3 r = se3_inv(A);
+    out[0] = r.q.w, out[1] = r.q.x, out[2] = r.q.y, out[3] = r.q.z, out[4] = r.t.x, out[5] = r.t.y, out[6] = r.t.z;
+}
+void mlo_se3_apply(const double a[7], const double p[3], double out[3]) {
+    SE3 A;
+    A.q = Quat{a[0], a[1], a[2], a[3]}, A.t = V3{a[4], a[5], a[6]};
+    V3 r = se3_apply(A, V3{p[0], p[1], p[2]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
 }
 
 } /* extern "C" */

@@ -123,6 +123,25 @@ void mlo_inflate_map(mlo_handle *h, const double ct_pos[3]);
 /* PointCloud2 payload of pub_global_local_map (rviz_vis.cpp:296-327): float xyz of inflated 'o' cells */
 size_t mlo_global_map_points(mlo_handle *h, float *xyz /* may be NULL to count */);
 
+/* PointCloud2 payload of pub_frontier (rviz_vis.cpp:267-293): float xyz of the frontier cells' centres */
+size_t mlo_frontier_points(mlo_handle *h, float *xyz /* may be NULL to count */);
+/* float mlmap::getOdd(const Vec3I &glb_id, size_t subbox_id), mlmap.h:227-235 */
+void mlo_get_odd_at(mlo_handle *h, const int32_t *glb_id, const int32_t *subbox_id, int n, float *out);
+
+/* cv::Mat::convertTo(CV_16UC1, 1000) of 32FC1 pixels (mlmap.cpp:482) */
+void mlo_cv_f32_to_u16(const float *in, int n, uint16_t *out);
+
+/* The SO3 / SE3 restatements on their own (q = w,x,y,z; T = q then t), for the property tests the reference holds for
+ * Sophus: 3rdPartLib/Sophus/sophus/test_so3.cpp:14-110, test_se3.cpp:10-86. */
+void mlo_so3_from_quat(const double q[4], double out[4]);
+void mlo_so3_exp(const double omega[3], double out[4]);
+void mlo_so3_log(const double q[4], double out[3]);
+void mlo_so3_mul(const double a[4], const double b[4], double out[4]);
+void mlo_so3_matrix(const double q[4], double R[9]);
+void mlo_se3_mul(const double a[7], const double b[7], double out[7]);
+void mlo_se3_inverse(const double a[7], double out[7]);
+void mlo_se3_apply(const double a[7], const double p[3], double out[3]);
+
 #ifdef __cplusplus
 }
 #endif

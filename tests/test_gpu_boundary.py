@@ -1,0 +1,254 @@
+"""GPU tests of the drop-in boundary itself: the C++ facade used from a real C++ program, thread safety of the entry
+points, caller-supplied streams, recovery after a capacity error, and the multi-GPU merge path over RCCL with the maps
+taken from and loaded back into live device handles."""
+import ctypes
+import os
+import struct
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from mlmapping_amd import synthetic as syn
+from mlmapping_amd.config import S1, SDEF, to_c
+from tests.util import ODDS_TOL, compare_maps, voxel_centres
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mlmapping_amd.mlmap import MLMap
+    from oracle.binding import OracleMap
+
+    return MLMap, OracleMap
+
+
+def test_cpp_facade_client_process(mods, tmp_path):
+    """include/mlmap_facade.hpp instantiated and used by a C++ program (g++, linked against libmlmap_hip.so only), run
+    as a fresh child process: every template method is compiled and called, its answers must equal the oracle's."""
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    exe = tmp_path / "facade_client"
+    lib_dir = os.path.join(ROOT, "mlmapping_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_client.cpp"), "-o", str(exe), "-L", lib_dir, "-lmlmap_hip",
+                           f"-Wl,-rpath,{lib_dir}"])
+    n_frames, n_pos = 4, 3000
+    cpu = OracleMap(cfg)
+    rng = np.random.default_rng(4)
+    blob = bytearray(bytes(to_c(cfg)))
+    blob += struct.pack("4i", n_frames, cfg.width, cfg.height, n_pos)
+    for img, (q, t) in syn.stream(cfg, "room_jitter", "smooth", n_frames):
+        blob += np.concatenate([q, t]).astype(np.float64).tobytes() + np.ascontiguousarray(img, dtype=np.uint16).tobytes()
+        cpu.update_depth(img, q, t)
+    cpu.inflate_map([0.0, 0.0, 1.5])
+    pos = np.concatenate([rng.uniform([-2, -5, 0], [6, 5, 3], size=(n_pos - 1000, 3)), voxel_centres(cpu.export_blocks(), cfg, 1000)])
+    blob += pos.astype(np.float64).tobytes()
+    path = tmp_path / "in.bin"
+    path.write_bytes(bytes(blob))
+    out = subprocess.run([str(exe), str(path)], check=True, capture_output=True, text=True).stdout.splitlines()
+    rows = [ln.split() for ln in out[:n_pos]]
+    occ = np.array([int(r[0]) for r in rows])
+    occ_i = np.array([int(r[1]) for r in rows])
+    infl = np.array([int(r[2]) for r in rows])
+    odd = np.array([float.fromhex(r[3]) for r in rows], dtype=np.float32)
+    grad = np.array([[float.fromhex(x) for x in r[4:7]] for r in rows])
+    grad2 = np.array([[float.fromhex(x) for x in r[7:10]] for r in rows])
+    assert np.array_equal(occ, cpu.getOccupancy(pos))
+    assert np.array_equal(occ_i, cpu.getOccupancy(pos, inflate=0.15))
+    assert np.array_equal(infl, cpu.getInflateOccupancy(pos))
+    assert np.abs(odd - cpu.getOdd(pos)).max() <= ODDS_TOL
+    for g, it in ((grad, 5), (grad2, 2)):
+        cg = cpu.getOddGrad(pos, it)
+        assert np.abs(g - cg).max() <= 1e-4 * max(1.0, np.abs(cg).max())
+    at = [float.fromhex(x) for x in out[n_pos].split()[1:]]
+    want = cpu.getOddAt(np.array([[0, 0, 1], [40, 40, 40]], dtype=np.int32), np.array([7, 0], dtype=np.int32))
+    assert np.abs(np.array(at, dtype=np.float32) - want).max() <= ODDS_TOL and at[1] == 0.5
+    cpu.setFree_map_in_bound([0.5, -0.5, 1.0], [1.0, 0.5, 1.5])
+    o_free = int(cpu.getOccupancy(np.array([[0.75, 0.0, 1.25]]))[0])
+    assert out[n_pos + 1].split()[1:] == [str(o_free), str(int(o_free == 1))]
+    # and the same answers through the ctypes path
+    gpu = MLMap(cfg, max_blocks=8192)
+    for img, (q, t) in syn.stream(cfg, "room_jitter", "smooth", n_frames):
+        gpu.update_map(img, q, t)
+    gpu.inflate_map([0.0, 0.0, 1.5])
+    assert np.array_equal(occ, gpu.getOccupancy(pos)) and np.array_equal(infl, gpu.getInflateOccupancy(pos))
+    assert np.array_equal(odd.view(np.uint32), gpu.getOdd(pos).view(np.uint32))
+
+
+def test_queries_from_a_second_thread(mods):
+    """Planner thread vs depth callback (the reference runs both on an MT nodelet without locking): queries issued from a
+    second thread while the first one integrates must neither crash nor corrupt anything; every answer must be one the
+    map could give at some frame boundary, and the final map must equal the oracle's."""
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    n = 12
+    frames = list(syn.stream(cfg, "room_jitter", "smooth", n))
+    cpu = OracleMap(cfg)
+    rng = np.random.default_rng(8)
+    pos = rng.uniform([-2, -5, 0], [6, 5, 3], size=(4000, 3))
+    states = [cpu.getOccupancy(pos).copy()]  # answers at every frame boundary
+    for img, (q, t) in frames:
+        cpu.update_depth(img, q, t)
+        states.append(cpu.getOccupancy(pos).copy())
+    states = np.stack(states)
+    gpu = MLMap(cfg, max_blocks=8192, max_batch=4)
+    errors, answers = [], []
+    stop = threading.Event()
+
+    def planner():
+        try:
+            while not stop.is_set():
+                a = gpu.getOccupancy(pos)
+                o = gpu.getOdd(pos[:500])
+                assert np.isfinite(o).all()
+                answers.append(a)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=planner)
+    th.start()
+    for mode in (False, True):
+        gpu.set_async(mode)
+        for img, (q, t) in frames[: n // 2] if not mode else frames[n // 2:]:
+            gpu.update_map(img, q, t)
+    gpu.sync()
+    stop.set()
+    th.join()
+    assert not errors, errors
+    assert len(answers) >= 2
+    for a in answers:  # a query observes a completed integrate call: the map at SOME frame boundary
+        assert (states == a[None, :]).all(axis=1).any(), "a concurrent query saw a map no frame boundary produces"
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "after concurrent queries")
+
+
+def test_caller_stream_orders_device_inputs(mods):
+    """mlm_set_stream: a depth image produced by work enqueued on the caller's stream (here: a long chain of torch kernels
+    ending in the copy that fills the image) is read only after that work — no host synchronisation by the caller."""
+    import torch
+
+    MLMap, OracleMap = mods
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=8192, max_batch=4), OracleMap(cfg)
+    s = torch.cuda.Stream()
+    gpu.set_stream(s.cuda_stream)
+    frames = [img for img, _ in syn.stream(cfg, "room_jitter", "smooth", 6)]
+    poses = syn.smooth_trajectory(6, 42)
+    src = [torch.from_numpy(f.view(np.int16)).cuda() for f in frames]
+    buf = torch.zeros((4, cfg.height, cfg.width), dtype=torch.int16, device="cuda")
+    junk = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for k0 in (0, 3):
+        with torch.cuda.stream(s):
+            for _ in range(20):  # keep the stream busy so that the copies below complete late
+                junk = junk @ junk * 1e-3
+            for j in range(3):
+                buf[j].copy_(src[k0 + j])
+        q = np.stack([poses[k0 + j][0] for j in range(3)])
+        t = np.stack([poses[k0 + j][1] for j in range(3)])
+        gpu.update_map_batch_dev(buf.data_ptr(), 3, cfg.width, cfg.height, q, t)  # no synchronize() in between
+        for j in range(3):
+            cpu.update_depth(frames[k0 + j], q[j], t[j])
+        gpu.sync()  # (buf is overwritten by the next round)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "caller stream")
+    gpu.close()
+
+
+def test_handle_survives_capacity_error(mods):
+    """After MLM_ERR_CAPACITY (block pool full) the handle stays usable: frames that fit integrate and match an oracle
+    that never saw the oversized frame's lost blocks... here: a fresh small frame into a pool that still has room."""
+    from mlmapping_amd.mlmap import MlmError
+
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    gpu = MLMap(cfg, max_blocks=40)
+    img = syn.room_depth(cfg)
+    near = np.full_like(img, 600)  # a wall 0.6 m ahead: a handful of blocks
+    q, t = syn.static_pose()
+    gpu.update_map(near, q, t)
+    before = gpu.export_blocks()
+    with pytest.raises(MlmError, match="CAPACITY"):
+        gpu.update_map(img, q, t)  # the whole room: far more than 40 blocks
+    # the pool is full now, but every block that exists keeps working: the near wall again, same blocks only
+    gpu.update_map(near, q, t)
+    after = gpu.export_blocks()
+    assert after["keys"].shape[0] == 40
+    idx = {tuple(k): i for i, k in enumerate(after["keys"])}
+    rows = [idx[tuple(k)] for k in before["keys"]]
+    assert (after["log_odds"][rows] != before["log_odds"]).any(), "existing blocks no longer accept updates"
+    assert gpu.getOccupancy(np.array([[0.7, 0.0, 1.5]])).shape == (1,)
+
+
+def test_merge_over_rccl_world_size_1(mods):
+    """BASELINE config 4's exchange step on the hardware at hand: a world-size-1 `nccl` group (RCCL really initialised),
+    the map taken from a live device handle, packed / finished by the library's HIP kernels, loaded back with
+    mlm_import_blocks and queried.  With one rank the merged map is the clamp/class rule applied to the map itself."""
+    import torch
+    import torch.distributed as dist
+
+    from mlmapping_amd.merge import merge_device_maps, merge_global_map
+
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    gpu, cpu = MLMap(cfg, max_blocks=4096), OracleMap(cfg)
+    for img, (q, t) in syn.stream(cfg, "room_jitter", "random", 5):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 2000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        x = torch.ones(8, device="cuda")
+        dist.all_reduce(x)  # the communicator exists and works
+        assert float(x.sum()) == 8.0
+        b = cpu.export_blocks()
+        merged = merge_device_maps(gpu, load_back=False)
+        # expectation: clamp + class rule on the oracle's map
+        lo = np.clip(b["log_odds"], np.float32(cfg.lm_log_odds_min), np.float32(cfg.lm_log_odds_max))
+        cls = np.where(b["occ"] != ord("u"), ord("f"), ord("u")).astype(np.uint8)
+        cls[lo > np.float32(cfg.lm_occupied_sh)] = ord("o")
+        assert np.array_equal(merged["keys"].cpu().numpy(), b["keys"])
+        assert np.array_equal(merged["occ"].cpu().numpy(), cls)
+        g = gpu.export_blocks()
+        lo_g = np.clip(g["log_odds"], np.float32(cfg.lm_log_odds_min), np.float32(cfg.lm_log_odds_max))
+        assert np.array_equal(merged["log_odds"].cpu().numpy().view(np.uint32), lo_g.view(np.uint32))
+        # the generic front end (block dumps -> tensors) over the same communicator gives the same map
+        m2 = merge_global_map(g, cfg)
+        assert np.array_equal(m2["occ"].cpu().numpy(), cls) and np.array_equal(m2["keys"].cpu().numpy(), b["keys"])
+        # load the merged map into a SECOND, empty handle and query it
+        other = MLMap(cfg, max_blocks=4096)
+        other.import_blocks((merged["keys"].data_ptr(), merged["keys"].shape[0]), log_odds=merged["log_odds"].data_ptr(),
+                            occ=merged["occ"].data_ptr())
+        e = other.export_blocks()
+        assert np.array_equal(e["keys"], b["keys"]) and np.array_equal(e["occ"], cls)
+        assert np.array_equal(e["log_odds"].view(np.uint32), lo_g.view(np.uint32))
+        pos = np.concatenate([np.random.default_rng(2).uniform(-4, 6, size=(20000, 3)), voxel_centres(b, cfg, 20000)])
+        want = np.full(pos.shape[0], -1)
+        # occupancy of the merged map, evaluated with numpy from (keys, cls)
+        d = cfg.subbox_d_xyz
+        gk = np.floor(pos / (d * cfg.subbox_n)).astype(np.int64)
+        ck = np.floor(pos / d).astype(np.int64) - gk * cfg.subbox_n
+        idx = {tuple(k): i for i, k in enumerate(b["keys"])}
+        for i in range(pos.shape[0]):
+            j = idx.get(tuple(gk[i]))
+            if j is not None:
+                c = cls[j, ck[i, 2] * cfg.subbox_n ** 2 + ck[i, 1] * cfg.subbox_n + ck[i, 0]]
+                want[i] = 0 if c == ord("o") else (1 if c == ord("f") else -1)
+        assert np.array_equal(other.getOccupancy(pos), want)
+        # load_back on the original handle: idempotent for a single rank
+        merge_device_maps(gpu, load_back=True)
+        assert np.array_equal(gpu.export_blocks()["occ"], cls)
+        # import from host arrays as well, into a handle that already holds part of the map
+        third = MLMap(cfg, max_blocks=4096)
+        third.update_map(syn.room_depth(cfg), *syn.static_pose())
+        third.import_blocks(b["keys"], log_odds=lo_g, occ=cls)
+        e3 = third.export_blocks()
+        rows = {tuple(k): i for i, k in enumerate(e3["keys"])}
+        sel = [rows[tuple(k)] for k in b["keys"]]
+        assert np.array_equal(e3["occ"][sel], cls) and np.array_equal(e3["log_odds"][sel].view(np.uint32), lo_g.view(np.uint32))
+    finally:
+        dist.destroy_process_group()
