@@ -11,7 +11,9 @@ library is missing or no MI355X is visible, construction raises.
 from __future__ import annotations
 
 import ctypes
+import importlib.util
 import os
+import sys
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -63,6 +65,26 @@ class FrameStats(ctypes.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """A process can drive the GPU through ONE HIP/HSA runtime only.  libmlmap_hip.so asks for `libamdhip64.so.7`
+    (the system ROCm); PyTorch-ROCm wheels bundle their own copy and ask for it by another name, so importing torch
+    AFTER this library would bring a second runtime that finds "no ROCm-capable device".  When a torch installation is
+    present (it owns streams / RCCL in bench.py and in the merge), load ITS runtime first: the library then binds to it
+    through the shared soname, whichever of the two is imported first.  MLMAP_HIP_RUNTIME=system keeps the system one
+    (hosts without torch, e.g. the C++ facade, are not affected either way)."""
+    if "torch" in sys.modules or os.environ.get("MLMAP_HIP_RUNTIME") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load_library(path: Optional[str] = None):
     """dlopen libmlmap_hip.so and declare the prototypes.  Raises if the library is not built."""
     global _lib
@@ -72,6 +94,7 @@ def load_library(path: Optional[str] = None):
     if not os.path.exists(p):
         raise MlmError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = ctypes.CDLL(p)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     L.mlm_create.argtypes = [vp, vp, i32, ctypes.POINTER(vp)]
