@@ -1386,6 +1386,10 @@ __device__ __forceinline__ void mlm_voxelize_body(const MlmDev &P, const MlmFram
         const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int n = P.ctr->u_hit;
         if (ff <= frame_idx) return;
+        if (n > F.rehash_thr) { // the frame does not fit the emulated container without a rehash: speculation miss
+            if (i0 == 0) atomicMin(&P.g->fail_frame, frame_idx);
+            return;
+        }
         for (unsigned int i = i0; i < n; i += stride) {
             if (i != i0) {
                 p_cell = P.hl_cell[i];
@@ -1426,7 +1430,8 @@ __device__ __forceinline__ void mlm_voxelize_body(const MlmDev &P, const MlmFram
     }
     const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int n = min(P.ctr->mc_cnt[sl][0], P.mc_cap);
-    if (ff <= frame_idx) return;
+    const unsigned int n_hits = P.ctr->u_hit;
+    if (ff <= frame_idx || n_hits > F.rehash_thr) return; // (the hit side flags the speculation miss)
     unsigned int n_here = 0;
     for (unsigned int i = i0; i < n; i += stride) {
         ++n_here;

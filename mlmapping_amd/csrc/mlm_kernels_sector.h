@@ -1,0 +1,799 @@
+// mlm_kernels_sector.h — Stage A by azimuth sector (the default path; mlm_kernels.h keeps the cell-table path that
+// frontier mode uses and that a frame falls back to when a sector's LDS tables overflow).
+//
+// Everything awareness_map_cylindrical::input_pc_pose does to one azimuth column phi stays inside that column: the noise
+// spread of a hit moves along rho (and z) at the point's phi (map_awareness.cpp:149-168) and its ray runs radially inwards
+// at that phi (map_awareness.cpp:243-274).  So the frame is cut into nPhi independent sectors:
+//
+//   k_bin_sectors   point -> (rho,phi,z); the lanes of a wave that share a centre cell become ONE record (cell, lane mask);
+//                   a block buckets its <= 256 records by column in LDS and hands each (block, column) run to the column
+//                   with one returning atomic (a chunk descriptor).  Nothing else leaves the block.
+//   k_sector        one workgroup per column: per-cell hit bookkeeping (first-touch time, kinds, counts) in an LDS hash
+//                   table, the column's miss bit mask in LDS, the point-order replay of the float noisy-OR chain for
+//                   cells that received several kinds, the unique-hit list with odds / log-odds increments / world
+//                   voxels, and the unique miss cells with their world voxels.  No global atomics except one list
+//                   reservation per workgroup and list.
+//
+// Compared with the cell-table path this removes every per-cell and per-miss-word device-scope atomic (they are executed
+// at the memory side, ~34 G/s for the whole chip), the 8 global copies of the miss mask and their scan, and the
+// scattered insertion-time stores (0.9 M per VGA frame).
+#pragma once
+#include "mlm_kernels.h"
+
+#define MLM_SEC_THREADS 512
+#define MLM_SEC_WAVES (MLM_SEC_THREADS / 64)
+#define MLM_SEC_COLS 64     // distinct columns one k_bin_sectors block can feed (more: the frame falls back)
+#define MLM_SEC_CHUNKS 512  // chunk descriptors staged per pass of k_sector (= MLM_SEC_THREADS: one per thread)
+#define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
+#define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
+
+// one hit cell of the column while k_sector works on it (28 bytes)
+struct MlmSecCell {
+    uint32_t key;   // z * nRho + rho, MLM_NIL = empty
+    uint32_t tmin;  // first-touch time (min over contributions)
+    uint32_t kmask; // kinds
+    uint32_t cnt;   // contributions
+    uint32_t gcnt;  // (record, kind) references; single-kind cells: float bits of the cell's odd once it is known
+    uint32_t gpos;  // start of its references in s_refs, then the fill cursor (ends at start + gcnt)
+    uint32_t aux;   // single-kind cells: index in the frame's unique-hit list; multi-kind cells: start of the ordered kinds
+                    // in MlmDev::subs (the 16 bytes in front of them hold {hit-list index, odd bits})
+};
+
+__device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
+    mlm_gp(P.ctr)->sector_overflow = 1u;
+    g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
+    __shared__ MlmNode s_node[256];
+    __shared__ uint32_t s_col_phi[MLM_SEC_COLS], s_col_cnt[MLM_SEC_COLS], s_col_off[MLM_SEC_COLS];
+    __shared__ uint16_t s_rec_col[256], s_rec_pos[256];
+    __shared__ unsigned int s_cnt[4];
+    __shared__ unsigned int s_nnode, s_over;
+    if (threadIdx.x < MLM_SEC_COLS) {
+        s_col_phi[threadIdx.x] = MLM_NIL;
+        s_col_cnt[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_nnode = 0;
+        s_over = 0;
+    }
+    __syncthreads();
+    const MlmTile T = mlm_tile_item<MODE>(F);
+    const int i = T.i;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bool have = T.valid;
+    double xs = 0, ys = 0, zs = 0;
+    if (have) {
+        if (MODE == 2) {
+            xs = mlm_gp(F.pts)[3 * (size_t)i + 0];
+            ys = mlm_gp(F.pts)[3 * (size_t)i + 1];
+            zs = mlm_gp(F.pts)[3 * (size_t)i + 2];
+        } else {
+            const int pix = (MODE == 1) ? mlm_gp(F.pix)[i] : i;
+            const int v = pix / F.width;
+            const int u = pix - v * F.width;
+            const uint16_t raw = mlm_gp(F.img)[(size_t)v * F.row_stride + u];
+            if (raw == 0) { // mlmap.cpp:338-341
+                have = false;
+            } else {
+                // mlmap.cpp:329,344-346: (size_t u - float cx_) is a float subtraction, the rest is double
+                const double depth = raw * P.inv_factor;
+                xs = ((float)u - P.cx) * depth / P.fx;
+                ys = ((float)v - P.cy) * depth / P.fy;
+                zs = depth;
+            }
+        }
+    }
+    int rho = 0, phi = 0, zi = 0, c0 = -1;
+    bool can_do_cast = false, inside = false;
+    if (have) {
+        // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
+        double x, y, z;
+        mlm_quat_rot(F.q_ls, xs, ys, zs, x, y, z);
+        x = x + F.t_ls[0];
+        y = y + F.t_ls[1];
+        z = z + F.t_ls[2];
+        inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
+        if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
+    }
+    const uint32_t i00 = (uint32_t)mlm_readlane(i, 0); // work item of lane 0 of this wave (see MlmNode)
+    // lanes of one centre cell -> one record, held by their lowest lane (= earliest insertion time)
+    unsigned long long my_mask = 0;
+    bool leader = false;
+    mlm_wave_groups(c0, inside, [&](int, unsigned long long m) {
+        leader = true;
+        my_mask = m;
+    });
+    // points outside the map that can still cast (map_awareness.cpp:241,249-265): identical starts merged per wave
+    const bool outer = have && !inside && can_do_cast && P.visibility;
+    bool ray_leader = false;
+    {
+        unsigned long long todo = __ballot(outer);
+        while (todo) {
+            const int ld = __ffsll((long long)todo) - 1;
+            const int kr = mlm_readlane(rho, ld), kp = mlm_readlane(phi, ld), kz = mlm_readlane(zi, ld);
+            const unsigned long long m = __ballot(outer && rho == kr && phi == kp && zi == kz);
+            if (lane == ld) {
+                ray_leader = true;
+                my_mask = m;
+            }
+            todo &= ~m;
+        }
+    }
+    if (leader || ray_leader) {
+        const unsigned int k = atomicAdd(&s_nnode, 1u); // <= 256: a lane belongs to exactly one record
+        MlmNode nd;
+        nd.cell = leader ? (uint32_t)c0 : (uint32_t)rho;
+        nd.pos = leader ? 0u : (uint32_t)zi;
+        nd.i00_sub = i00 | (leader ? 0u : (MLM_SEC_OUTER << 27));
+        nd.pad = (uint32_t)phi;
+        nd.mask = my_mask;
+        s_node[k] = nd;
+    }
+    const unsigned int n_pts = (unsigned int)__popcll(__ballot(have));
+    const unsigned int n_oor = (unsigned int)__popcll(__ballot(have && !(can_do_cast && P.visibility)));
+    if (lane == 0) s_cnt[wid] = n_pts | (n_oor << 10);
+    __syncthreads();
+    // ---- bucket the block's records by column
+    const unsigned int nn = s_nnode;
+    if (threadIdx.x < nn) {
+        const uint32_t ph = s_node[threadIdx.x].pad;
+        uint32_t e = (ph * 2654435761u) >> 26;
+        bool placed = false;
+        for (int probe = 0; probe < MLM_SEC_COLS; ++probe) {
+            const uint32_t prev = atomicCAS(&s_col_phi[e], MLM_NIL, ph);
+            if (prev == MLM_NIL || prev == ph) {
+                placed = true;
+                break;
+            }
+            e = (e + 1) & (MLM_SEC_COLS - 1);
+        }
+        if (placed) {
+            s_rec_col[threadIdx.x] = (uint16_t)e;
+            s_rec_pos[threadIdx.x] = (uint16_t)atomicAdd(&s_col_cnt[e], 1u);
+        } else {
+            s_rec_col[threadIdx.x] = 0xFFFFu;
+            s_over = 1;
+        }
+    }
+    __syncthreads();
+    if (wid == 0) { // one wave: offsets of the columns' runs inside the block's slice, one chunk descriptor per run
+        const uint32_t cnt = s_col_cnt[lane];
+        const uint32_t incl = mlm_wave_incl_scan(cnt);
+        s_col_off[lane] = incl - cnt;
+        if (cnt) {
+            const uint32_t ph = s_col_phi[lane];
+            const unsigned int k = g_atomic_add(&mlm_gp(P.col_cnt)[ph], 1u);
+            if (k < P.chunk_cap)
+                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)ph * P.chunk_cap + k)) =
+                    mlm_u32x2{blockIdx.x * 256u + (incl - cnt), cnt};
+            else
+                s_over = 1;
+        }
+        if (lane == 0) {
+            unsigned int pts = 0, oor = 0;
+            for (unsigned int w = 0; w < 4; ++w) {
+                pts += s_cnt[w] & 1023u;
+                oor += s_cnt[w] >> 10;
+            }
+            *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)blockIdx.x) = mlm_u32x4{pts, oor, nn, 0u};
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nn && s_rec_col[threadIdx.x] != 0xFFFFu) {
+        const unsigned int e = s_rec_col[threadIdx.x];
+        mlm_store_node(mlm_gp(P.bnodes) + ((size_t)blockIdx.x * 256u + s_col_off[e] + s_rec_pos[threadIdx.x]), s_node[threadIdx.x]);
+    }
+    if (threadIdx.x == 0 && s_over) mlm_sector_fail(P, F);
+}
+
+// find (or with INSERT create) the table entry of a column-local cell key; -1: table full
+template <bool INSERT>
+__device__ __forceinline__ int mlm_sec_entry(MlmSecCell *tab, uint32_t tab_mask, uint32_t key) {
+    uint32_t e = ((key * 2654435761u) >> 12) & tab_mask;
+    for (uint32_t probe = 0; probe <= tab_mask; ++probe) {
+        if (INSERT) {
+            const uint32_t prev = atomicCAS(&tab[e].key, MLM_NIL, key);
+            if (prev == MLM_NIL || prev == key) return (int)e;
+        } else {
+            const uint32_t k = tab[e].key;
+            if (k == key) return (int)e;
+            if (k == MLM_NIL) return -1;
+        }
+        e = (e + 1) & tab_mask;
+    }
+    return -1;
+}
+
+// exclusive prefix sums over the workgroup of four values per thread at once (one pair of barriers); v[] is replaced by
+// this thread's offsets, total[] gets the sums.  s_w needs 4 * MLM_SEC_WAVES words.
+__device__ __forceinline__ void mlm_block_excl_scan4(uint32_t (&v)[4], uint32_t *s_w, uint32_t (&total)[4]) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t incl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) incl[k] = mlm_wave_incl_scan(v[k]);
+    __syncthreads(); // s_w may still be read from a previous use
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_w[4 * wid + k] = incl[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < MLM_SEC_WAVES; ++w) {
+            const uint32_t t = s_w[4 * w + k];
+            if (w < wid) off += t;
+            tot += t;
+        }
+        total[k] = tot;
+        v[k] = off + incl[k] - v[k];
+    }
+}
+__device__ __forceinline__ uint32_t mlm_block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t *total) {
+    uint32_t a[4] = {v, 0u, 0u, 0u}, t[4];
+    mlm_block_excl_scan4(a, s_w, t);
+    *total = t[0];
+    return a[0];
+}
+
+// The targets of a hit-centre record: its own cell (kind 0) and the +-d neighbours (kinds 2d-1, 2d), update_hits
+// map_awareness.cpp:135-171.  f(column-local key, kind).  s3 = 3 * sigma_in_dr(rho).
+template <class F>
+__device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int phi, int zi, float s3, F &&f) {
+    f((uint32_t)(zi * P.nRho + rho), 0);
+    const double slope = rho > 0 ? (zi - P.zc) / (rho * 1.0) : 0.0;
+    for (int d = 1; mlm_spread_active(P, rho, d, s3); ++d) {
+        // neighbour cells of step d (mlm_spread_cells), as column-local keys
+        int rz = mlm_cvt_int(round(zi + (d * slope)));
+        if (0 <= rz && rz < P.nZ) f((uint32_t)(rz * P.nRho + rho + d), 2 * d - 1);
+        rz = mlm_cvt_int(round(zi - (d * slope)));
+        if (0 <= rz && rz < P.nZ && rho - d >= 0) f((uint32_t)(rz * P.nRho + rho - d), 2 * d);
+    }
+}
+
+// LDS plan of k_sector (dynamic): the host computes the same offsets (mlm_sec_lds_bytes)
+struct MlmSecLds {
+    uint32_t tab, refs, miss, rec_mask, rec_i00, odds, sigma, multi, rays, rank, total;
+};
+__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t REFS, uint32_t RCAP, uint32_t n_miss, uint32_t n_rho) {
+    MlmSecLds L;
+    uint32_t o = 0;
+    L.rec_mask = o; o += RCAP * 8u;                      // u64 lane masks of the column's records
+    L.rank = o;     o += MLM_SEC_WAVES * MLM_SEC_RANK_WORDS * (8u + 2u); // per wave: bitmap + 16-bit prefix strip; the chunk
+                                                         // staging of the record passes aliases it (2 * MLM_SEC_CHUNKS words)
+    L.tab = o;      o += TAB * (uint32_t)sizeof(MlmSecCell);
+    L.rec_i00 = o;  o += RCAP * 4u;
+    L.odds = o;     o += (2u * MLM_DIFF_RANGE + 1u) * n_rho * 4u;
+    L.sigma = o;    o += ((n_rho + 3u) & ~3u) * 4u;
+    L.miss = o;     o += ((n_miss + 3u) & ~3u) * 4u;
+    L.refs = o;     o += ((REFS + 1u) & ~1u) * 2u;
+    L.multi = o;    o += TAB * 2u;
+    L.rays = L.rank + 2u * MLM_SEC_CHUNKS * 4u;          // (list of ray starts: behind the chunk staging, also in the idle ranking scratch)
+    L.total = (o + 15u) & ~15u;
+    return L;
+}
+
+// tile_w > 0: dense 8x8 pixel tiles of an image of that width; 0: linear work items (see MlmNode).  row_w, div_m, div_s:
+// rows of the ranking bitmap and the exact division by row_w (see k_sort_contribs).
+__global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s,
+                                                            int n_bin_blocks) {
+    MLM_SLOT_SETUP
+    const int phi = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && wid == 0) { // fold the per-block statistics of k_bin_sectors
+        unsigned int a = 0, b = 0, g = 0;
+        for (int j = lane; j < n_bin_blocks; j += 64) {
+            const mlm_u32x4 st = *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)j);
+            a += st.x;
+            b += st.y;
+            g += st.z;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, 64);
+            b += __shfl_xor(b, off, 64);
+            g += __shfl_xor(g, off, 64);
+        }
+        if (lane == 0) {
+            mlm_gp(P.ctr)->n_points = a;
+            mlm_gp(P.ctr)->n_oor = b;
+            mlm_gp(P.ctr)->n_groups = g;
+        }
+    }
+    const unsigned int nch_all = mlm_gp(P.col_cnt)[phi];
+    if (nch_all == 0) return; // nothing fell into this column (uniform)
+    const unsigned int nch = min(nch_all, P.chunk_cap);
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const uint32_t TAB = P.sec_tab, REFS = P.sec_refs, RCAP = P.sec_rcap, NMISS = (uint32_t)(P.nZ * P.RW);
+    const MlmSecLds L = mlm_sec_lds(TAB, REFS, RCAP, NMISS, (uint32_t)P.nRho);
+    MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
+    uint16_t *s_refs = (uint16_t *)(s_dyn + L.refs);
+    uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
+    unsigned long long *s_rec_mask = (unsigned long long *)(s_dyn + L.rec_mask);
+    uint32_t *s_rec_i00 = (uint32_t *)(s_dyn + L.rec_i00);
+    float *s_odds = (float *)(s_dyn + L.odds);
+    float *s_sigma = (float *)(s_dyn + L.sigma);
+    uint16_t *s_multi = (uint16_t *)(s_dyn + L.multi);
+    uint16_t *s_rays = (uint16_t *)(s_dyn + L.rays);
+    unsigned long long *s_rank = (unsigned long long *)(s_dyn + L.rank);
+    uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.rank);         // (record passes only: the ranking scratch is idle then)
+    uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
+    __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
+    __shared__ uint32_t s_base[4];
+    __shared__ unsigned int s_fail, s_nouter;
+    for (uint32_t e = threadIdx.x; e < TAB; e += MLM_SEC_THREADS) {
+        s_tab[e].key = MLM_NIL;
+        s_tab[e].tmin = MLM_EMPTY_T;
+        s_tab[e].kmask = 0;
+        s_tab[e].cnt = 0;
+        s_tab[e].gcnt = 0;
+    }
+    for (uint32_t e = threadIdx.x; e < NMISS; e += MLM_SEC_THREADS) s_miss[e] = 0;
+    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_odds[e] = mlm_gp(P.odds_table)[e];
+    for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_sigma[e] = mlm_gp(P.sigma3)[e];
+    if (threadIdx.x == 0) {
+        s_fail = nch_all > P.chunk_cap ? 1u : 0u;
+        s_nouter = 0;
+    }
+    MLM_PHASE_BEGIN
+    const uint32_t tab_mask = TAB - 1;
+    const MLM_GLOBAL uint32_t *chunks = mlm_gp(P.col_chunks) + 2 * (size_t)phi * P.chunk_cap;
+    const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
+    // flat record r of the staged chunks -> index into `bnodes`
+    auto rec_index = [&](uint32_t r, uint32_t n_staged) -> uint32_t {
+        uint32_t lo = 0, hi = n_staged; // largest c with start[c] <= r
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_chunk_start[mid] <= r) lo = mid;
+            else hi = mid;
+        }
+        return s_chunk_first[lo] + (r - s_chunk_start[lo]);
+    };
+    // pass = 0: book every record's contributions on the cells of the column, keep its lane mask in LDS (and walk the
+    // rays of points outside the map); pass = 1: hand every (record, kind) of a multi-kind cell a slot in s_refs
+    auto for_records = [&](int pass) {
+        uint32_t flat0 = 0; // records of the chunk batches before this one
+        for (uint32_t c0 = 0; c0 < nch; c0 += MLM_SEC_CHUNKS) {
+            const uint32_t n_staged = min(nch - c0, (uint32_t)MLM_SEC_CHUNKS);
+            __syncthreads();
+            uint32_t total = 0;
+            {
+                const uint32_t j = threadIdx.x;
+                mlm_u32x2 d = mlm_u32x2{0u, 0u};
+                if (j < n_staged) d = *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
+                const uint32_t off = mlm_block_excl_scan(d.y, s_w, &total);
+                if (j < n_staged) {
+                    s_chunk_first[j] = d.x;
+                    s_chunk_start[j] = off;
+                }
+            }
+            __syncthreads();
+            for (uint32_t r = threadIdx.x; r < total; r += MLM_SEC_THREADS) {
+                const uint32_t gi = rec_index(r, n_staged);
+                const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + gi);
+                const mlm_u32x4 a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
+                const uint32_t kind = a.z >> 27;
+                const uint32_t flat = flat0 + r;
+                if (kind == MLM_SEC_OUTER) {
+                    if (pass == 0) { // ray of a point outside the map: one lane walks it into the LDS mask
+                        int rho = (int)a.x, z = (int)a.y;
+                        const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
+                        if (rho >= P.nRho) {
+                            z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
+                            rho = P.nRho - 1;
+                        }
+                        for (int rr = 1; rr < rho; ++rr) {
+                            const int zr = mlm_cvt_int(round(z - ((rho - rr) * slope)));
+                            if (0 <= zr && zr < P.nZ) atomicOr(&s_miss[zr * P.RW + (rr >> 5)], 1u << (rr & 31));
+                        }
+                        atomicAdd(&s_nouter, 1u);
+                    }
+                    continue;
+                }
+                const uint32_t cell = a.x;
+                const int z = (int)(cell / (uint32_t)P.nRhoPhi);
+                const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
+                if (pass == 0) {
+                    const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
+                    if (flat < RCAP) {
+                        s_rec_mask[flat] = mask;
+                        s_rec_i00[flat] = a.z & 0x07FFFFFFu;
+                    } else {
+                        s_fail = 1;
+                    }
+                    const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
+                    const uint32_t i_first = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
+                    const uint32_t cnt = (uint32_t)__popcll(mask);
+                    mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub) {
+                        const int e = mlm_sec_entry<true>(s_tab, tab_mask, key);
+                        if (e < 0) {
+                            s_fail = 1;
+                            return;
+                        }
+                        atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
+                        atomicOr(&s_tab[e].kmask, 1u << sub);
+                        atomicAdd(&s_tab[e].cnt, cnt);
+                        atomicAdd(&s_tab[e].gcnt, 1u);
+                    });
+                } else {
+                    mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub) {
+                        const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
+                        if (e >= 0 && __popc(s_tab[e].kmask) > 1) {
+                            const uint32_t at = atomicAdd(&s_tab[e].gpos, 1u);
+                            if (at < REFS) s_refs[at] = (uint16_t)((flat << 5) | (uint32_t)sub);
+                        }
+                    });
+                }
+            }
+            flat0 += total;
+        }
+    };
+    __syncthreads();
+    MLM_PHASE(0);
+    for_records(0);
+    __syncthreads();
+    MLM_PHASE(1);
+    // ---- per cell: hit-list slot, reference segment and ordered-kinds segment (multi-kind), odd (single-kind), ray start
+    uint32_t n_multi = 0, n_rays = 0;
+    {
+        const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread
+        uint32_t v[4] = {0u, 0u, 0u, 0u}, v_rays = 0; // occupied, multi, references, ordered-kinds slots (+ header)
+        for (uint32_t q = 0; q < per; ++q) {
+            const MlmSecCell &c = s_tab[threadIdx.x * per + q];
+            if (c.key == MLM_NIL) continue;
+            ++v[0];
+            v_rays += c.kmask & 1u;
+            if (__popc(c.kmask) > 1) {
+                ++v[1];
+                v[2] += c.gcnt;
+                v[3] += 16u + ((c.cnt + 15u) & ~15u);
+            }
+        }
+        uint32_t tot[4];
+        mlm_block_excl_scan4(v, s_w, tot);
+        uint32_t tot_rays;
+        uint32_t o_rays = mlm_block_excl_scan(v_rays, s_w, &tot_rays);
+        n_multi = tot[1];
+        n_rays = P.visibility ? tot_rays : 0u;
+        if (threadIdx.x == 0) {
+            s_base[0] = tot[0] ? g_atomic_add(&mlm_gp(P.ctr)->u_hit, tot[0]) : 0u;
+            s_base[1] = tot[3] ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot[3]) : 0u;
+            if (tot[1]) g_atomic_add(&mlm_gp(P.ctr)->n_multi, tot[1]);
+            if (tot[2] > REFS) s_fail = 1;
+        }
+        __syncthreads();
+        const uint32_t hbase = s_base[0], sbase = s_base[1];
+        if (sbase + tot[3] > P.contrib_cap) s_fail = 1; // (uniform)
+        uint32_t o_occ = v[0], o_multi = v[1], o_refs = v[2], o_subs = v[3];
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t e = threadIdx.x * per + q;
+            MlmSecCell &c = s_tab[e];
+            if (c.key == MLM_NIL) continue;
+            const uint32_t hidx = hbase + o_occ++;
+            if (c.kmask & 1u) s_rays[o_rays++] = (uint16_t)e;
+            if (__popc(c.kmask) > 1) {
+                s_multi[o_multi++] = (uint16_t)e;
+                c.gpos = o_refs;
+                o_refs += c.gcnt;
+                c.aux = sbase + o_subs + 16u;
+                if (c.aux + c.cnt <= P.contrib_cap) *(MLM_GLOBAL uint32_t *)(mlm_gp(P.subs) + (c.aux - 16u)) = hidx;
+                o_subs += 16u + ((c.cnt + 15u) & ~15u);
+            } else {
+                // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
+                const int rho_c = (int)(c.key % (uint32_t)P.nRho);
+                const float a = mlm_contribution_odd(P, s_odds, rho_c, __ffs((int)c.kmask) - 1);
+                float p = a;
+                for (uint32_t j = 1; j < c.cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
+                c.gcnt = __float_as_uint(p);
+                c.aux = hidx;
+            }
+        }
+    }
+    __syncthreads();
+    MLM_PHASE(2);
+    if (s_fail) { // a table of this column overflowed: the frame is redone by the cell-table path (uniform branch)
+        if (threadIdx.x == 0) {
+            mlm_sector_fail(P, F);
+            mlm_gp(P.col_cnt)[phi] = 0;
+        }
+        return;
+    }
+    // ---- references of the multi-kind cells
+    if (n_multi) for_records(1);
+    MLM_PHASE(3);
+    // ---- rays of the cells that hold a hit centre (every point of one (rho,phi,z) cell casts the identical ray,
+    //      map_awareness.cpp:243-274: once per cell): one ray per LANE, walked from the sensor outwards; consecutive steps
+    //      that fall into the same word of the column's mask are merged in a register
+    for (uint32_t k0 = wid * 64; k0 < n_rays; k0 += MLM_SEC_THREADS) {
+        const uint32_t k = k0 + lane;
+        int rho = 0, z = 0;
+        if (k < n_rays) {
+            const uint32_t key = s_tab[s_rays[k]].key;
+            z = (int)(key / (uint32_t)P.nRho);
+            rho = (int)(key - (uint32_t)z * (uint32_t)P.nRho);
+        }
+        const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0; // (rho < nRho: no clamp for in-range starts)
+        int cur_w = -1;
+        uint32_t cur_bits = 0;
+        for (int r = 1; r < rho; ++r) {
+            const int zr = mlm_cvt_int(round(z - ((rho - r) * slope)));
+            const int w = (0 <= zr && zr < P.nZ) ? zr * P.RW + (r >> 5) : -1;
+            if (w != cur_w) {
+                if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
+                cur_w = w;
+                cur_bits = 0;
+            }
+            cur_bits |= 1u << (r & 31);
+        }
+        if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < MLM_SEC_WAVES * MLM_SEC_RANK_WORDS; e += MLM_SEC_THREADS) s_rank[e] = 0ull; // (held the chunk staging)
+    __syncthreads();
+    MLM_PHASE(4);
+    // ---- order the contributions of every multi-kind cell by insertion time (= pixel order: a pixel contributes to a
+    //      cell at most once) and store their kinds in that order; one wave per cell, bitmap ranking as k_sort_contribs
+    //      but fed with the records' 8x8 lane masks (eight row bytes per record) instead of one key per contribution
+    {
+        unsigned long long *rows = s_rank + (size_t)wid * MLM_SEC_RANK_WORDS;
+        // exclusive prefix of the bitmap words' popcounts: the wave's own strip behind the bitmaps (16-bit: n <= 65535)
+        volatile uint16_t *pref = (volatile uint16_t *)(s_rank + (size_t)MLM_SEC_WAVES * MLM_SEC_RANK_WORDS) + (size_t)wid * MLM_SEC_RANK_WORDS;
+        for (uint32_t m = wid; m < n_multi; m += MLM_SEC_WAVES) {
+            const MlmSecCell &c = s_tab[s_multi[m]];
+            const uint32_t n = c.cnt, n_refs = c.gcnt, ref0 = c.gpos - c.gcnt, soff = c.aux;
+            const uint32_t pix0 = c.tmin / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
+            const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
+            const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64; // multiple of 8: a record's row byte never straddles a word
+            MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + soff;
+            bool bad = n > 0xFFFFu;
+            // (record, row) pairs over the lanes; up to 4 rounds are kept in registers for the placing pass
+            auto load_pair = [&](uint32_t p, uint32_t &bits, uint32_t &pix, uint32_t &sub) {
+                bits = 0;
+                pix = 0;
+                sub = 0;
+                if (p < n_refs * 8u) {
+                    const uint32_t ref = s_refs[ref0 + (p >> 3)], row = p & 7u, idx = ref >> 5;
+                    bits = (uint32_t)(s_rec_mask[idx] >> (8 * row)) & 0xFFu;
+                    pix = s_rec_i00[idx] + (tile_w > 0 ? row * (uint32_t)tile_w : row * 8u);
+                    sub = ref & 31u;
+                }
+            };
+            auto locate = [&](uint32_t pix, uint32_t &wi, uint32_t &sh) -> bool {
+                const uint32_t y = (uint32_t)(((unsigned long long)pix * div_m) >> div_s);
+                const int dx = (int)(pix - y * (uint32_t)row_w) - xlo;
+                const uint32_t dy = y - y0;
+                wi = 2 * dy + ((uint32_t)dx >> 6);
+                sh = (uint32_t)dx & 63u;
+                return dx >= 0 && dx <= 120 && dy < MLM_BMP_ROWS;
+            };
+            uint32_t r_bits[4], r_pix[4], r_sub[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_pair((uint32_t)lane + 64u * q, r_bits[q], r_pix[q], r_sub[q]);
+            if (!bad) {
+                auto mark = [&](uint32_t bits, uint32_t pix) {
+                    if (!bits) return;
+                    uint32_t wi, sh;
+                    if (locate(pix, wi, sh)) atomicOr(&rows[wi], (unsigned long long)bits << sh);
+                    else bad = true;
+                };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mark(r_bits[q], r_pix[q]);
+                for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
+                    uint32_t b, px, sb;
+                    load_pair(p, b, px, sb);
+                    mark(b, px);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            bad = __any(bad);
+            uint32_t carry = 0;
+            int used = MLM_SEC_RANK_WORDS;
+            if (!bad) {
+                int j0 = 0;
+                for (; j0 < MLM_SEC_RANK_WORDS && carry < n; j0 += 64) {
+                    const uint32_t cw = (uint32_t)__popcll(((volatile unsigned long long *)rows)[j0 + lane]);
+                    const uint32_t incl = mlm_wave_incl_scan(cw);
+                    pref[j0 + lane] = (uint16_t)(carry + incl - cw);
+                    carry += mlm_readlane(incl, 63);
+                }
+                if (carry == n) used = j0;
+                else bad = true; // (two contributions on one pixel cannot happen; a count mismatch means a window miss)
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!bad) {
+                auto place = [&](uint32_t bits, uint32_t pix, uint32_t sub) {
+                    if (!bits) return;
+                    uint32_t wi, sh;
+                    locate(pix, wi, sh);
+                    const unsigned long long word = ((volatile unsigned long long *)rows)[wi];
+                    const uint32_t before = pref[wi];
+                    while (bits) { // the row's own set bits, in pixel order; other records' bits may lie between them
+                        const int b = __ffs((int)bits) - 1;
+                        bits &= bits - 1;
+                        S[before + (uint32_t)__popcll(word & ((1ull << (sh + b)) - 1ull))] = (uint8_t)sub;
+                    }
+                };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) place(r_bits[q], r_pix[q], r_sub[q]);
+                for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
+                    uint32_t b, px, sb;
+                    load_pair(p, b, px, sb);
+                    place(b, px, sb);
+                }
+            } else {
+                // slow exact path (a contribution outside the bitmap window, or a huge cell): write every contribution's
+                // work item into the cell's segment of `contrib`, then rank by counting straight from memory
+                MLM_GLOBAL uint32_t *K = mlm_gp(P.contrib) + soff;
+                uint32_t base = 0;
+                for (uint32_t p0 = 0; p0 < n_refs * 8u; p0 += 64) {
+                    uint32_t b, px, sb;
+                    load_pair(p0 + lane, b, px, sb);
+                    const uint32_t cb = (uint32_t)__popc(b);
+                    const uint32_t incl = mlm_wave_incl_scan(cb);
+                    uint32_t at = base + incl - cb;
+                    while (b) {
+                        const int bit = __ffs((int)b) - 1;
+                        b &= b - 1;
+                        K[at++] = ((px + (uint32_t)bit) << 5) | sb;
+                    }
+                    base += mlm_readlane(incl, 63);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t j = lane; j < n; j += 64) {
+                    const uint32_t my = __hip_atomic_load(&K[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t r = 0;
+                    for (uint32_t q = 0; q < n; ++q) r += __hip_atomic_load(&K[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my;
+                    S[r] = (uint8_t)(my & 31u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j < used; j += 64) rows[j] = 0ull; // clean for the next cell
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    MLM_PHASE(5);
+    // ---- replay update_odds_hashmap (map_awareness.h:147-154) over the ordered kinds: one lane per multi-kind cell; the
+    //      result goes into the segment's header next to the cell's hit-list index
+    for (uint32_t m = threadIdx.x; m < n_multi; m += MLM_SEC_THREADS) {
+        const MlmSecCell &c = s_tab[s_multi[m]];
+        const int rho_c = (int)(c.key % (uint32_t)P.nRho);
+        const uint32_t n = c.cnt;
+        MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + c.aux; // 16-byte aligned segments
+        float p = 0.0f;
+        bool first = true;
+        mlm_u32x4 nxt = *(const MLM_GLOBAL mlm_u32x4 *)S;
+        for (uint32_t j0 = 0; j0 < n && p != 1.0f; j0 += 16) {
+            const mlm_u32x4 v = nxt;
+            if (j0 + 16 < n) nxt = *(const MLM_GLOBAL mlm_u32x4 *)(S + j0 + 16); // one segment ahead
+            const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+            float a[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int sub = (int)((word[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
+                if (j0 + q >= n) sub = 0; // padding bytes are not kinds
+                a[q] = mlm_contribution_odd(P, s_odds, rho_c, sub);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (j0 + q < n) {
+                    if (first) {
+                        p = a[q];
+                        first = false;
+                    } else {
+                        p = 1 - (1 - p) * (1 - a[q]);
+                    }
+                }
+            }
+        }
+        *(MLM_GLOBAL uint32_t *)(S - 12) = __float_as_uint(p);
+    }
+    __syncthreads();
+    MLM_PHASE(6);
+    // ---- the column's unique hits: cell, first-touch time, odd, increment, world voxel + speculative block slot
+    //      (what k_collect_hits / k_chain / k_prepare_voxels leave behind on the cell-table path)
+    for (uint32_t e = threadIdx.x; e < TAB; e += MLM_SEC_THREADS) {
+        const MlmSecCell c = s_tab[e];
+        if (c.key == MLM_NIL) continue;
+        const int z = (int)(c.key / (uint32_t)P.nRho);
+        const int rho = (int)(c.key - (uint32_t)z * (uint32_t)P.nRho);
+        uint32_t pos = c.aux, pbits = c.gcnt;
+        if (__popc(c.kmask) > 1) {
+            const mlm_u32x2 hd = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.subs) + (c.aux - 16u));
+            pos = hd.x;
+            pbits = hd.y;
+        }
+        const float p = __uint_as_float(pbits);
+        mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+        mlm_gp(P.hl_t)[pos] = c.tmin;
+        mlm_gp(P.hl_vt)[pos] = c.tmin;
+        mlm_gp(P.hl_odd)[pos] = p;
+        mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
+        double wx, wy, wz;
+        mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+        int gx, gy, gz, cid;
+        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
+        const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+        mlm_gp(P.hl_bkey)[pos] = bkey;
+        mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
+        mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
+    }
+    MLM_PHASE(7);
+    // ---- the column's unique miss cells (its bit mask) with their world voxels, appended to sub-list (column & 7)
+    {
+        const unsigned int sl = blockIdx.x & 7;
+        uint32_t v = 0;
+        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) v += (uint32_t)__popc(s_miss[w]);
+        uint32_t total;
+        mlm_block_excl_scan(v, s_w, &total); // (only the total is needed: positions are re-derived per 64-word group)
+        if (threadIdx.x == 0) {
+            s_base[2] = total ? g_atomic_add(&mlm_gp(P.ctr)->mc_cnt[sl][0], total) : 0u;
+            s_base[3] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
+            if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
+            mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
+        }
+        __syncthreads();
+        if (total) {
+            // groups of 64 words, one per wave at a time; the offset of a group = bits in the groups before it
+            uint32_t group_base = s_base[2];
+            const uint32_t rec_base = s_base[3];
+            const int half = lane >> 5, b = lane & 31;
+            for (uint32_t w0 = 0; w0 < NMISS; w0 += 64) {
+                const uint32_t w = w0 + lane;
+                const uint32_t bits = w < NMISS ? s_miss[w] : 0u;
+                const uint32_t cnt = (uint32_t)__popc(bits);
+                const uint32_t incl = mlm_wave_incl_scan(cnt);
+                const uint32_t gtot = mlm_readlane(incl, 63);
+                if ((w0 >> 6) % MLM_SEC_WAVES == (uint32_t)wid && gtot) {
+                    const uint32_t excl = incl - cnt;
+                    unsigned long long nz = __ballot(bits != 0);
+                    while (nz) {
+                        const int sa = __ffsll((long long)nz) - 1;
+                        nz &= nz - 1;
+                        int sb = sa;
+                        uint32_t bits_b = 0;
+                        if (nz) {
+                            sb = __ffsll((long long)nz) - 1;
+                            nz &= nz - 1;
+                            bits_b = mlm_readlane(bits, sb);
+                        }
+                        const uint32_t my_bits = half ? bits_b : mlm_readlane(bits, sa);
+                        const uint32_t my_off = half ? mlm_readlane(excl, sb) : mlm_readlane(excl, sa);
+                        const int wi_all = (int)w0 + (half ? sb : sa);
+                        if ((my_bits >> b) & 1u) {
+                            const int z = wi_all / P.RW;
+                            const int rho = (wi_all - z * P.RW) * 32 + b;
+                            double wx, wy, wz;
+                            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+                            int gx, gy, gz, cid;
+                            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
+                            const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+                            const uint32_t within = my_off + (uint32_t)__popc(my_bits & ((1u << b) - 1u));
+                            const uint32_t pos = group_base + within;
+                            if (P.record_awareness)
+                                mlm_gp(P.ml_cell)[rec_base + (pos - s_base[2])] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+                            if (pos < P.mc_cap) {
+                                const size_t at = (size_t)sl * P.mc_cap + pos;
+                                mlm_gp(P.mc_bkey)[at] = bkey;
+                                mlm_gp(P.mc_cid)[at] = (uint32_t)cid;
+                                mlm_gp(P.mc_slot)[at] = mlm_block_find_k(P, bkey);
+                            }
+                        }
+                    }
+                }
+                group_base += gtot;
+            }
+        }
+    }
+    MLM_PHASE(8);
+    MLM_PHASE_END
+}

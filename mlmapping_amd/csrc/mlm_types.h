@@ -22,7 +22,8 @@ struct MlmCounters {
     unsigned int n_ex_vox;    // explore mode: voxels touched by misses
     unsigned int n_big;       // multi-kind cells with more than 1024 contributions
     unsigned int n_groups;    // contribution groups kept in the blocks' own slices of `bnodes` (folded by k_collect_hits)
-    unsigned int pad_b[2];
+    unsigned int sector_overflow; // sector path: an LDS table of some column overflowed -> the frame is redone by the cell-table path
+    unsigned int pad_b[1];
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
@@ -179,6 +180,12 @@ struct MlmDev {
     unsigned long long *ex_key;// ... iteration-order key (larger = earlier)
     int *ex_vox;               // ... voxel address or -1
     uint32_t *bktm_first;      // [max buckets of the miss container] min vt per bucket
+    // ---- sector path (mlm_kernels_sector.h)
+    unsigned int *col_cnt;     // [nPhi] chunk descriptors handed to each column this frame (reset by k_sector)
+    uint32_t *col_chunks;      // [nPhi][chunk_cap][2] {first record in `bnodes`, record count} per (bin block, column) run
+    unsigned int chunk_cap;
+    unsigned int sec_tab, sec_refs, sec_rcap, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two),
+                               // reference slots, records of one column kept in LDS
     MlmCounters *ctr;          // this slot's per-frame counters
     MlmGlobal *g;
 };
@@ -194,5 +201,5 @@ struct MlmFrame {
     int width, height, row_stride;
     int n;                 // work items: pixels (dense), list length (indexed) or points
     int seq;               // sequence number of the frame (speculation bookkeeping)
-    int pad;
+    unsigned int rehash_thr; // the emulated hit container takes this many elements without a rehash (speculative Stage B)
 };

@@ -18,6 +18,7 @@
 
 #include "../../include/mlmap_hip.h"
 #include "mlm_kernels_explore.h"
+#include "mlm_kernels_sector.h"
 #include "mlm_host.h"
 
 using namespace mlm_host;
@@ -120,6 +121,8 @@ struct mlm_handle {
     hipEvent_t batch_done[MLM_SETS] = {};
     hipEvent_t inputs_ready = nullptr;       // caller-supplied stream only: orders Stage A after the caller's work on it
     MlmGlobal *h_gb[MLM_SETS] = {}; // pinned snapshots of P.g taken at the end of each batch
+    bool use_sectors = true;   // Stage A by azimuth sector (mlm_kernels_sector.h); MLM_SECTORS=0: the cell-table path
+    long long n_sector_fallbacks = 0; // frames redone by the cell-table path because a sector's LDS tables overflowed
     std::recursive_mutex mu;   // serialises the entry points of this handle (see MLM_LOCK)
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
 };
@@ -212,6 +215,7 @@ inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 b
 // T_ls and t_wa of one frame (map_awareness.cpp:184-186)
 void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb_in[3], MlmFrame &F) {
     frame_pose(h->q_bs, h->t_bs, q_wb_in, t_wb_in, F.q_ls, F.t_ls, F.t_wa);
+    F.rehash_thr = 0xFFFFFFFFu; // only the speculative Stage B arms the check (submit_batch)
 }
 
 std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
@@ -355,10 +359,55 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     return MLM_OK;
 }
 
+// Stage A by azimuth sector (mlm_kernels_sector.h): two launches per batch.
+int launch_stage_a_sector(mlm_handle *h, int base, int n) {
+    const MlmSlot &S0 = h->slots[(size_t)base];
+    const MlmDev &P = S0.P;
+    const MlmFrame &F = S0.F;
+    const int mode = S0.mode;
+    const int set = base / ((int)h->slots.size() / MLM_SETS);
+    hipStream_t st = h->stream_as[set];
+    HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
+    if (!h->own_stream) { // see launch_stage_a_batch
+        HIPCHK(h, hipEventRecord(h->inputs_ready, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(st, h->inputs_ready, 0));
+    }
+    for (int j = 0; j < n; ++j) h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
+    HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));
+    unsigned int nb = 0;
+    if (F.n > 0) {
+        nb = mode == 0 ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : (unsigned int)(((size_t)F.n + 255) / 256);
+        if (nb > P.nb_cap) {
+            h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
+            return MLM_ERR_CAPACITY;
+        }
+        if (mode == 0)
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<0>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        else if (mode == 1)
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<1>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        else
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<2>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+    }
+    {
+        const int row_w = mode == 0 ? F.width : 64; // rows of the ranking bitmap
+        unsigned long long dm;
+        int ds;
+        div_magic((unsigned int)row_w, dm, ds);
+        tlaunch(h, "k_sector", k_sector, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
+                h->d_frame_tab, base, mode == 0 ? F.width : 0, row_w, dm, ds, (int)nb);
+    }
+    HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
+    return MLM_OK;
+}
+
 // Stage B+C of one frame on the main stream.  n_bkt != 0: speculative single-epoch ordering inside k_voxelize;
 // n_bkt == 0: hl_key was produced by order_hits_exact.
 void launch_stage_bc(mlm_handle *h, MlmSlot &S, unsigned long long n_bkt) {
     const MlmDev &P = S.P;
+    // exact keys: nothing to check; speculative relaunch: against the policy state the host holds NOW
+    S.F.rehash_thr = n_bkt ? (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu) : 0xFFFFFFFFu;
     {
         tlaunch(h, "k_voxelize", k_voxelize, dim3(160, 1 + MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, P, S.F, n_bkt);
     }
@@ -387,6 +436,7 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_groups = ng;
     h->stats.n_rays = nr;
     h->stats.n_spec_replays = h->n_spec_miss;
+    h->stats.n_sector_fallbacks = h->n_sector_fallbacks;
 }
 
 int check_queues(mlm_handle *h, const MlmSlot &S) {
@@ -557,11 +607,12 @@ int submit_batch(mlm_handle *h, int base, int n) {
         MlmSlot &S = h->slots[(size_t)(base + j)];
         S.seq = h->next_seq++;
         S.F.seq = S.seq;
+        S.F.rehash_thr = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
     }
     int rc;
     {
         Timed t(h, h->stream_as[set], "stage_a_batch");
-        rc = launch_stage_a_batch(h, base, n);
+        rc = h->use_sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
     }
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
@@ -617,13 +668,27 @@ int drain(mlm_handle *h) {
         int rc = confirm_front(h, (int)ok);
         if (rc) return rc;
         if (h->pending.empty()) break;
-        // pending.front() does not fit the emulated container without a rehash: replay its Stage B exactly
-        h->n_spec_miss++;
+        // pending.front() does not fit the emulated container without a rehash (replay its Stage B exactly), or one of
+        // its azimuth sectors overflowed its LDS tables (redo its Stage A on the cell-table path first)
         MlmSlot &S = *h->pending.front();
-        rc = check_queues(h, S);
-        if (rc) return rc;
         h->h_g->fail_frame = 0x7FFFFFFF;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (S.h_ctr->sector_overflow) {
+            h->n_sector_fallbacks++;
+            const int si = (int)(&S - h->slots.data());
+            const int set = si / ((int)h->slots.size() / MLM_SETS);
+            HIPCHK(h, hipStreamSynchronize(h->stream)); // fail_frame is re-armed before the cell-table kernels may flag it again
+            rc = launch_stage_a_batch(h, si, 1);
+            if (rc) return rc;
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
+            HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+        } else {
+            h->n_spec_miss++;
+        }
+        rc = check_queues(h, S);
+        if (rc) return rc;
         rc = order_hits_exact(h, S, S.h_ctr->u_hit, S.seq);
         if (rc) return rc;
         launch_stage_bc(h, S, 0);
@@ -632,7 +697,7 @@ int drain(mlm_handle *h) {
         // the new policy state (their unique-hit counts are known), then resubmit their Stage B/C
         int ff = 0x7FFFFFFF;
         for (size_t j = h->pending.size(); j-- > 1;)
-            if (h->pending[j]->h_ctr->u_hit > h->hit_pol._M_next_resize) ff = h->pending[j]->seq;
+            if (h->pending[j]->h_ctr->sector_overflow || h->pending[j]->h_ctr->u_hit > h->hit_pol._M_next_resize) ff = h->pending[j]->seq;
         HIPCHK(h, hipStreamSynchronize(h->stream)); // h_g is about to be rewritten
         h->h_g->fail_frame = ff;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -830,6 +895,10 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         P.node_cap = (unsigned int)(cap / MLM_RAY_LISTS + 4096);
         if ((rc = dev_alloc(h, &P.nodes, (size_t)MLM_RAY_LISTS * P.node_cap))) return rc;
     }
+    P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
+    if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
+    if ((rc = dev_alloc(h, &P.col_chunks, h->use_sectors ? 2 * (size_t)P.nPhi * P.chunk_cap : 2))) return rc;
+    HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
     if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_t, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_odd, NC))) return rc;
@@ -1042,6 +1111,24 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             HIPCHK(h, hipFuncSetAttribute((const void *)k_bin_points<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bin_lds_bytes));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_bin_points<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bin_lds_bytes));
         }
+    }
+    {
+        // sector path: LDS tables of one azimuth column (k_sector).  Cell table: a column rarely holds more hit cells than a
+        // few per range step; references: (record, kind) pairs of its multi-kind cells.  A column that needs more makes
+        // its frame fall back to the cell-table path.
+        unsigned int tab = 1024;
+        while (tab < 12u * (unsigned int)P.nRho && tab < 2048u) tab <<= 1;
+        if (const char *e = getenv("MLM_SEC_TAB")) tab = (unsigned int)std::max(MLM_SEC_THREADS, atoi(e)); // power of two
+        P.sec_tab = tab;
+        P.sec_refs = tab == 1024 ? 4096u : 16384u;
+        P.sec_rcap = tab == 1024 ? 1280u : 2048u; // (references carry an 11-bit record index)
+        if (const char *e = getenv("MLM_SEC_REFS")) P.sec_refs = (unsigned int)std::max(64, atoi(e));
+        if (const char *e = getenv("MLM_SEC_RCAP")) P.sec_rcap = (unsigned int)std::min(2048, std::max(64, atoi(e)));
+        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, P.sec_refs, P.sec_rcap, (unsigned int)(P.nZ * P.RW), (unsigned int)P.nRho).total;
+        h->use_sectors = !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u;
+        if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
+        if (h->use_sectors)
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_sector, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
     }
     std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
     for (int p = 0; p < P.nPhi; ++p) {

@@ -705,3 +705,34 @@ def test_callback_query_interleaving(mods):
         assert np.array_equal(gpu.getOccupancy(sel), cpu.getOccupancy(sel)), f"queries after callback {k}"
         assert np.abs(gpu.getOdd(sel[:200000]) - cpu.getOdd(sel[:200000])).max() <= ODDS_TOL
     gpu.close()
+
+
+@pytest.mark.parametrize("env", [{"MLM_SEC_REFS": "64"}, {"MLM_SEC_TAB": "512", "MLM_SEC_REFS": "2048"}, {"MLM_SECTORS": "0"}])
+def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
+    """Stage A by azimuth sector falls back to the cell-table path frame by frame when a column overflows its LDS tables
+    (forced here by shrinking them); MLM_SECTORS=0 runs the cell-table path alone.  Results must not change."""
+    MLMap, OracleMap = mods
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = S1
+    n = 10
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
+    poses = syn.random_poses(n, 42)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=4, record_awareness=True), OracleMap(cfg)
+    gpu.update_map_batch(frames[:7], q[:7], t[:7])  # 4 + 3
+    for k in range(7):
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{env} batch")
+    for k in range(7, n):
+        gpu.update_map(frames[k], q[k], t[k])
+        cpu.update_depth(frames[k], q[k], t[k])
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{env} frame {k}")
+    st = gpu.frame_stats()
+    if "MLM_SEC_REFS" in env and env["MLM_SEC_REFS"] == "64":
+        assert st["n_sector_fallbacks"] >= n - 1, st
+    if "MLM_SECTORS" in env:
+        assert st["n_sector_fallbacks"] == 0
+    gpu.close()

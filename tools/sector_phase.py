@@ -1,0 +1,37 @@
+"""Where k_sector spends its cycles: the bench workload through the diagnostic build (`make -C mlmapping_amd/csrc prof`,
+per-phase shader-clock sums over the workgroups' waves) — each phase's share of the summed wave time."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mlmapping_amd import mlmap as mm
+from mlmapping_amd import synthetic as syn
+from mlmapping_amd.config import S1, S3
+
+NAMES = ["0 LDS init", "1 pass 0: book records on cells", "2 per-cell scans, single-kind odds", "3 pass 1: references",
+         "4 rays into the LDS mask", "5 ranking of multi-kind cells", "6 noisy-OR chains", "7 hit write-out + voxels",
+         "8 miss expansion + voxels"]
+L = mm.load_library(os.path.join(os.path.dirname(mm.LIB_PATH), "libmlmap_hip_prof.so"))
+L.mlm_debug_phases.argtypes = [ctypes.c_void_p]
+mm._lib = L
+cfg = S3 if "cfg3" in sys.argv else S1
+n = 16
+m = mm.MLMap(cfg, max_blocks=32768, max_batch=n)
+frames = list(syn.stream(cfg, "room_jitter", "random", n))
+imgs = np.stack([f[0] for f in frames])
+q = np.stack([f[1][0] for f in frames])
+t = np.stack([f[1][1] for f in frames])
+buf = (ctypes.c_ulonglong * 16)()
+m.update_map_batch(imgs, q, t)
+L.mlm_debug_phases(buf)
+for rep in range(2):
+    m.update_map_batch(imgs, q, t)
+    L.mlm_debug_phases(buf)
+    tot = sum(buf[:9])
+    print(f"rep {rep}: total wave-cycles {tot/1e6:.1f} M  ({tot / n / 8 / 1e3:.1f} k cycles per frame per wave slot)")
+    for nm, v in zip(NAMES, buf[:9]):
+        print(f"  {nm:40s} {100.0 * v / tot:5.1f} %   {v / n / 1e6:.3f} M wave-cycles per frame")
+print(m.frame_stats())
