@@ -9,10 +9,13 @@
 //                   a block buckets its <= 256 records by column in LDS and hands each (block, column) run to the column
 //                   with one returning atomic (a chunk descriptor).  Nothing else leaves the block.
 //   k_sector        one workgroup per column: per-cell hit bookkeeping (first-touch time, kinds, counts) in an LDS hash
-//                   table, the column's miss bit mask in LDS, the point-order replay of the float noisy-OR chain for
-//                   cells that received several kinds, the unique-hit list with odds / log-odds increments / world
-//                   voxels, and the unique miss cells with their world voxels.  No global atomics except one list
-//                   reservation per workgroup and list.
+//                   table, the column's miss bit mask in LDS (rays walked by an integer DDA), the unique-hit list
+//                   (cells that received ONE kind of contribution get their odd right away) with world voxels, the unique
+//                   miss cells with their world voxels, and for every cell that received several kinds the list of
+//                   (record, kind) references.  No global atomics except one list reservation per workgroup and list.
+//   k_rank          one wave per multi-kind cell: order its contributions by pixel (bitmap ranking fed with the records'
+//                   8x8 lane masks) and store the kinds in that order; k_chain (mlm_kernels.h) then replays the float
+//                   noisy-OR chain.
 //
 // Compared with the cell-table path this removes every per-cell and per-miss-word device-scope atomic (they are executed
 // at the memory side, ~34 G/s for the whole chip), the 8 global copies of the miss mask and their scan, and the
@@ -27,16 +30,14 @@
 #define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
 #define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
 
-// one hit cell of the column while k_sector works on it (28 bytes)
+// one hit cell of the column while k_sector works on it (24 bytes)
 struct MlmSecCell {
     uint32_t key;   // z * nRho + rho, MLM_NIL = empty
     uint32_t tmin;  // first-touch time (min over contributions)
     uint32_t kmask; // kinds
     uint32_t cnt;   // contributions
-    uint32_t gcnt;  // (record, kind) references; single-kind cells: float bits of the cell's odd once it is known
-    uint32_t gpos;  // start of its references in s_refs, then the fill cursor (ends at start + gcnt)
-    uint32_t aux;   // single-kind cells: index in the frame's unique-hit list; multi-kind cells: start of the ordered kinds
-                    // in MlmDev::subs (the 16 bytes in front of them hold {hit-list index, odd bits})
+    uint32_t gcnt;  // (record, kind) references of the cell
+    uint32_t gpos;  // multi-kind cells: fill cursor into MlmDev::refs (starts at the cell's segment)
 };
 
 __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
@@ -256,32 +257,25 @@ __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int ph
     }
 }
 
-// LDS plan of k_sector (dynamic): the host computes the same offsets (mlm_sec_lds_bytes)
+// LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
-    uint32_t tab, refs, miss, rec_mask, rec_i00, odds, sigma, multi, rays, rank, total;
+    uint32_t tab, miss, odds, sigma, rays, chunk, total;
 };
-__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t REFS, uint32_t RCAP, uint32_t n_miss, uint32_t n_rho) {
+__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho) {
     MlmSecLds L;
     uint32_t o = 0;
-    L.rec_mask = o; o += RCAP * 8u;                      // u64 lane masks of the column's records
-    L.rank = o;     o += MLM_SEC_WAVES * MLM_SEC_RANK_WORDS * (8u + 2u); // per wave: bitmap + 16-bit prefix strip; the chunk
-                                                         // staging of the record passes aliases it (2 * MLM_SEC_CHUNKS words)
     L.tab = o;      o += TAB * (uint32_t)sizeof(MlmSecCell);
-    L.rec_i00 = o;  o += RCAP * 4u;
+    L.chunk = o;    o += 2u * MLM_SEC_CHUNKS * 4u;       // staged chunk descriptors of the record passes
     L.odds = o;     o += (2u * MLM_DIFF_RANGE + 1u) * n_rho * 4u;
     L.sigma = o;    o += ((n_rho + 3u) & ~3u) * 4u;
     L.miss = o;     o += ((n_miss + 3u) & ~3u) * 4u;
-    L.refs = o;     o += ((REFS + 1u) & ~1u) * 2u;
-    L.multi = o;    o += TAB * 2u;
-    L.rays = L.rank + 2u * MLM_SEC_CHUNKS * 4u;          // (list of ray starts: behind the chunk staging, also in the idle ranking scratch)
+    L.rays = o;     o += TAB * 2u;                       // table entries that start a ray
     L.total = (o + 15u) & ~15u;
     return L;
 }
 
-// tile_w > 0: dense 8x8 pixel tiles of an image of that width; 0: linear work items (see MlmNode).  row_w, div_m, div_s:
-// rows of the ranking bitmap and the exact division by row_w (see k_sort_contribs).
-__global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s,
-                                                            int n_bin_blocks) {
+__global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
+                                                            int rho_s) {
     MLM_SLOT_SETUP
     const int phi = (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -308,22 +302,17 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     if (nch_all == 0) return; // nothing fell into this column (uniform)
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    const uint32_t TAB = P.sec_tab, REFS = P.sec_refs, RCAP = P.sec_rcap, NMISS = (uint32_t)(P.nZ * P.RW);
-    const MlmSecLds L = mlm_sec_lds(TAB, REFS, RCAP, NMISS, (uint32_t)P.nRho);
+    const uint32_t TAB = P.sec_tab, NMISS = (uint32_t)(P.nZ * P.RW);
+    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
-    uint16_t *s_refs = (uint16_t *)(s_dyn + L.refs);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
-    unsigned long long *s_rec_mask = (unsigned long long *)(s_dyn + L.rec_mask);
-    uint32_t *s_rec_i00 = (uint32_t *)(s_dyn + L.rec_i00);
     float *s_odds = (float *)(s_dyn + L.odds);
     float *s_sigma = (float *)(s_dyn + L.sigma);
-    uint16_t *s_multi = (uint16_t *)(s_dyn + L.multi);
     uint16_t *s_rays = (uint16_t *)(s_dyn + L.rays);
-    unsigned long long *s_rank = (unsigned long long *)(s_dyn + L.rank);
-    uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.rank);         // (record passes only: the ranking scratch is idle then)
+    uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.chunk);
     uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
-    __shared__ uint32_t s_base[4];
+    __shared__ uint32_t s_base[6];
     __shared__ unsigned int s_fail, s_nouter;
     for (uint32_t e = threadIdx.x; e < TAB; e += MLM_SEC_THREADS) {
         s_tab[e].key = MLM_NIL;
@@ -336,13 +325,17 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_odds[e] = mlm_gp(P.odds_table)[e];
     for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_sigma[e] = mlm_gp(P.sigma3)[e];
     if (threadIdx.x == 0) {
-        s_fail = nch_all > P.chunk_cap ? 1u : 0u;
+        s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)F.seq % P.sec_fail_every == 0)) ? 1u : 0u;
         s_nouter = 0;
     }
     MLM_PHASE_BEGIN
     const uint32_t tab_mask = TAB - 1;
     const MLM_GLOBAL uint32_t *chunks = mlm_gp(P.col_chunks) + 2 * (size_t)phi * P.chunk_cap;
     const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
+    auto key_rz = [&](uint32_t key, int &rho, int &z) { // key = z * nRho + rho (exact division by multiplication, key < 2^27)
+        z = (int)(((unsigned long long)key * rho_m) >> rho_s);
+        rho = (int)key - z * P.nRho;
+    };
     // flat record r of the staged chunks -> index into `bnodes`
     auto rec_index = [&](uint32_t r, uint32_t n_staged) -> uint32_t {
         uint32_t lo = 0, hi = n_staged; // largest c with start[c] <= r
@@ -353,10 +346,9 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         }
         return s_chunk_first[lo] + (r - s_chunk_start[lo]);
     };
-    // pass = 0: book every record's contributions on the cells of the column, keep its lane mask in LDS (and walk the
-    // rays of points outside the map); pass = 1: hand every (record, kind) of a multi-kind cell a slot in s_refs
+    // pass = 0: book every record's contributions on the cells of the column (and walk the rays of points outside the
+    // map); pass = 1: write a (record, kind) reference for every contribution group of a multi-kind cell
     auto for_records = [&](int pass) {
-        uint32_t flat0 = 0; // records of the chunk batches before this one
         for (uint32_t c0 = 0; c0 < nch; c0 += MLM_SEC_CHUNKS) {
             const uint32_t n_staged = min(nch - c0, (uint32_t)MLM_SEC_CHUNKS);
             __syncthreads();
@@ -377,7 +369,6 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                 const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + gi);
                 const mlm_u32x4 a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
                 const uint32_t kind = a.z >> 27;
-                const uint32_t flat = flat0 + r;
                 if (kind == MLM_SEC_OUTER) {
                     if (pass == 0) { // ray of a point outside the map: one lane walks it into the LDS mask
                         int rho = (int)a.x, z = (int)a.y;
@@ -399,12 +390,6 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                 const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
                 if (pass == 0) {
                     const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
-                    if (flat < RCAP) {
-                        s_rec_mask[flat] = mask;
-                        s_rec_i00[flat] = a.z & 0x07FFFFFFu;
-                    } else {
-                        s_fail = 1;
-                    }
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
                     const uint32_t i_first = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
                     const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -424,12 +409,11 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                         const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
                         if (e >= 0 && __popc(s_tab[e].kmask) > 1) {
                             const uint32_t at = atomicAdd(&s_tab[e].gpos, 1u);
-                            if (at < REFS) s_refs[at] = (uint16_t)((flat << 5) | (uint32_t)sub);
+                            if (at < P.contrib_cap) mlm_gp(P.refs)[at] = (gi << 5) | (uint32_t)sub;
                         }
                     });
                 }
             }
-            flat0 += total;
         }
     };
     __syncthreads();
@@ -437,90 +421,68 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for_records(0);
     __syncthreads();
     MLM_PHASE(1);
-    // ---- per cell: hit-list slot, reference segment and ordered-kinds segment (multi-kind), odd (single-kind), ray start
-    uint32_t n_multi = 0, n_rays = 0;
-    {
-        const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread
-        uint32_t v[4] = {0u, 0u, 0u, 0u}, v_rays = 0; // occupied, multi, references, ordered-kinds slots (+ header)
-        for (uint32_t q = 0; q < per; ++q) {
-            const MlmSecCell &c = s_tab[threadIdx.x * per + q];
-            if (c.key == MLM_NIL) continue;
-            ++v[0];
-            v_rays += c.kmask & 1u;
-            if (__popc(c.kmask) > 1) {
-                ++v[1];
-                v[2] += c.gcnt;
-                v[3] += 16u + ((c.cnt + 15u) & ~15u);
-            }
+    // ---- per cell: slots in the hit list / multi-kind list / reference array / ordered-kinds array
+    const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread
+    uint32_t v[4] = {0u, 0u, 0u, 0u}, v_rays = 0; // occupied, multi, references, ordered-kinds slots
+    for (uint32_t q = 0; q < per; ++q) {
+        const MlmSecCell &c = s_tab[threadIdx.x * per + q];
+        if (c.key == MLM_NIL) continue;
+        ++v[0];
+        v_rays += c.kmask & 1u;
+        if (__popc(c.kmask) > 1) {
+            ++v[1];
+            v[2] += c.gcnt;
+            v[3] += (c.cnt + 15u) & ~15u;
         }
-        uint32_t tot[4];
-        mlm_block_excl_scan4(v, s_w, tot);
-        uint32_t tot_rays;
-        uint32_t o_rays = mlm_block_excl_scan(v_rays, s_w, &tot_rays);
-        n_multi = tot[1];
-        n_rays = P.visibility ? tot_rays : 0u;
-        if (threadIdx.x == 0) {
-            s_base[0] = tot[0] ? g_atomic_add(&mlm_gp(P.ctr)->u_hit, tot[0]) : 0u;
-            s_base[1] = tot[3] ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot[3]) : 0u;
-            if (tot[1]) g_atomic_add(&mlm_gp(P.ctr)->n_multi, tot[1]);
-            if (tot[2] > REFS) s_fail = 1;
-        }
-        __syncthreads();
-        const uint32_t hbase = s_base[0], sbase = s_base[1];
-        if (sbase + tot[3] > P.contrib_cap) s_fail = 1; // (uniform)
-        uint32_t o_occ = v[0], o_multi = v[1], o_refs = v[2], o_subs = v[3];
-        for (uint32_t q = 0; q < per; ++q) {
-            const uint32_t e = threadIdx.x * per + q;
-            MlmSecCell &c = s_tab[e];
-            if (c.key == MLM_NIL) continue;
-            const uint32_t hidx = hbase + o_occ++;
-            if (c.kmask & 1u) s_rays[o_rays++] = (uint16_t)e;
-            if (__popc(c.kmask) > 1) {
-                s_multi[o_multi++] = (uint16_t)e;
-                c.gpos = o_refs;
-                o_refs += c.gcnt;
-                c.aux = sbase + o_subs + 16u;
-                if (c.aux + c.cnt <= P.contrib_cap) *(MLM_GLOBAL uint32_t *)(mlm_gp(P.subs) + (c.aux - 16u)) = hidx;
-                o_subs += 16u + ((c.cnt + 15u) & ~15u);
-            } else {
-                // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
-                const int rho_c = (int)(c.key % (uint32_t)P.nRho);
-                const float a = mlm_contribution_odd(P, s_odds, rho_c, __ffs((int)c.kmask) - 1);
-                float p = a;
-                for (uint32_t j = 1; j < c.cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
-                c.gcnt = __float_as_uint(p);
-                c.aux = hidx;
-            }
-        }
+    }
+    uint32_t tot[4];
+    mlm_block_excl_scan4(v, s_w, tot);
+    uint32_t tot_rays;
+    uint32_t o_rays = mlm_block_excl_scan(v_rays, s_w, &tot_rays);
+    const uint32_t n_multi = tot[1], n_rays = P.visibility ? tot_rays : 0u;
+    // the four list reservations of this column: one round trip, issued now, awaited after the rays (which do not need them)
+    uint32_t r_hit = 0, r_multi = 0, r_refs = 0, r_subs = 0;
+    if (threadIdx.x == 0) {
+        if (tot[0]) r_hit = g_atomic_add(&mlm_gp(P.ctr)->u_hit, tot[0]);
+        if (tot[1]) r_multi = g_atomic_add(&mlm_gp(P.ctr)->n_multi, tot[1]);
+        if (tot[2]) r_refs = g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot[2]);
+        if (tot[3]) r_subs = g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot[3]);
+    }
+    for (uint32_t q = 0; q < per; ++q) { // list of the cells that hold a hit centre
+        const uint32_t e = threadIdx.x * per + q;
+        if (s_tab[e].key != MLM_NIL && (s_tab[e].kmask & 1u)) s_rays[o_rays++] = (uint16_t)e;
     }
     __syncthreads();
     MLM_PHASE(2);
-    if (s_fail) { // a table of this column overflowed: the frame is redone by the cell-table path (uniform branch)
-        if (threadIdx.x == 0) {
-            mlm_sector_fail(P, F);
-            mlm_gp(P.col_cnt)[phi] = 0;
-        }
-        return;
-    }
-    // ---- references of the multi-kind cells
-    if (n_multi) for_records(1);
-    MLM_PHASE(3);
     // ---- rays of the cells that hold a hit centre (every point of one (rho,phi,z) cell casts the identical ray,
-    //      map_awareness.cpp:243-274: once per cell): one ray per LANE, walked from the sensor outwards; consecutive steps
-    //      that fall into the same word of the column's mask are merged in a register
+    //      map_awareness.cpp:243-274: once per cell), one ray per LANE.  z' = round(z - k (z - zc) / rho) for k = 1 ..
+    //      rho-1 is followed by an integer DDA on N_k = 2 (z rho - k (z - zc)) + rho: z' = floor(N_k / 2 rho) unless
+    //      N_k is a multiple of 2 rho — the exact value is then a half-integer and only the reference's own FP64
+    //      sequence (slope = dz / rho rounded, k * slope rounded, z - .. rounded, round half away) says which way it
+    //      goes; everywhere else that sequence is at most ~1e-12 away from the exact value, which is at least 1 / (2 rho)
+    //      away from the next half-integer.  Consecutive steps that fall into one word of the mask are merged in a register.
     for (uint32_t k0 = wid * 64; k0 < n_rays; k0 += MLM_SEC_THREADS) {
-        const uint32_t k = k0 + lane;
+        const uint32_t kk = k0 + lane;
         int rho = 0, z = 0;
-        if (k < n_rays) {
-            const uint32_t key = s_tab[s_rays[k]].key;
-            z = (int)(key / (uint32_t)P.nRho);
-            rho = (int)(key - (uint32_t)z * (uint32_t)P.nRho);
-        }
-        const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0; // (rho < nRho: no clamp for in-range starts)
+        if (kk < n_rays) key_rz(s_tab[s_rays[kk]].key, rho, z);
+        const int dz = z - P.zc, two_rho = 2 * rho;
+        const double slope = (rho > 0) ? dz / (rho * 1.0) : 0.0; // (rho < nRho: no clamp for in-range starts)
+        int q = z, rem = rho; // N_0 = 2 z rho + rho
         int cur_w = -1;
         uint32_t cur_bits = 0;
-        for (int r = 1; r < rho; ++r) {
-            const int zr = mlm_cvt_int(round(z - ((rho - r) * slope)));
+        for (int k = 1; k < rho; ++k) {
+            const int r = rho - k;
+            rem -= 2 * dz;
+            while (rem < 0) {
+                rem += two_rho;
+                --q;
+            }
+            while (rem >= two_rho) {
+                rem -= two_rho;
+                ++q;
+            }
+            int zr = q;
+            if (rem == 0) zr = mlm_cvt_int(round(z - (k * slope))); // exact tie: the reference's FP64 sequence decides
             const int w = (0 <= zr && zr < P.nZ) ? zr * P.RW + (r >> 5) : -1;
             if (w != cur_w) {
                 if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
@@ -531,221 +493,86 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         }
         if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
     }
+    if (threadIdx.x == 0) {
+        s_base[0] = r_hit;
+        s_base[1] = r_multi;
+        s_base[2] = r_refs;
+        s_base[3] = r_subs;
+        if (r_refs + tot[2] > P.contrib_cap || r_subs + tot[3] > P.contrib_cap) s_fail = 1;
+    }
     __syncthreads();
-    for (uint32_t e = threadIdx.x; e < MLM_SEC_WAVES * MLM_SEC_RANK_WORDS; e += MLM_SEC_THREADS) s_rank[e] = 0ull; // (held the chunk staging)
-    __syncthreads();
-    MLM_PHASE(4);
-    // ---- order the contributions of every multi-kind cell by insertion time (= pixel order: a pixel contributes to a
-    //      cell at most once) and store their kinds in that order; one wave per cell, bitmap ranking as k_sort_contribs
-    //      but fed with the records' 8x8 lane masks (eight row bytes per record) instead of one key per contribution
+    MLM_PHASE(3);
+    if (s_fail) { // a table of this column overflowed: the frame is redone by the cell-table path (uniform branch)
+        if (threadIdx.x == 0) {
+            mlm_sector_fail(P, F);
+            mlm_gp(P.col_cnt)[phi] = 0;
+        }
+        return;
+    }
+    // ---- the column's unique hits: cell, first-touch time, world voxel + speculative block slot; single-kind cells get
+    //      their odd and increment here, multi-kind cells a descriptor for k_rank / k_chain
     {
-        unsigned long long *rows = s_rank + (size_t)wid * MLM_SEC_RANK_WORDS;
-        // exclusive prefix of the bitmap words' popcounts: the wave's own strip behind the bitmaps (16-bit: n <= 65535)
-        volatile uint16_t *pref = (volatile uint16_t *)(s_rank + (size_t)MLM_SEC_WAVES * MLM_SEC_RANK_WORDS) + (size_t)wid * MLM_SEC_RANK_WORDS;
-        for (uint32_t m = wid; m < n_multi; m += MLM_SEC_WAVES) {
-            const MlmSecCell &c = s_tab[s_multi[m]];
-            const uint32_t n = c.cnt, n_refs = c.gcnt, ref0 = c.gpos - c.gcnt, soff = c.aux;
-            const uint32_t pix0 = c.tmin / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
-            const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
-            const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64; // multiple of 8: a record's row byte never straddles a word
-            MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + soff;
-            bool bad = n > 0xFFFFu;
-            // (record, row) pairs over the lanes; up to 4 rounds are kept in registers for the placing pass
-            auto load_pair = [&](uint32_t p, uint32_t &bits, uint32_t &pix, uint32_t &sub) {
-                bits = 0;
-                pix = 0;
-                sub = 0;
-                if (p < n_refs * 8u) {
-                    const uint32_t ref = s_refs[ref0 + (p >> 3)], row = p & 7u, idx = ref >> 5;
-                    bits = (uint32_t)(s_rec_mask[idx] >> (8 * row)) & 0xFFu;
-                    pix = s_rec_i00[idx] + (tile_w > 0 ? row * (uint32_t)tile_w : row * 8u);
-                    sub = ref & 31u;
-                }
-            };
-            auto locate = [&](uint32_t pix, uint32_t &wi, uint32_t &sh) -> bool {
-                const uint32_t y = (uint32_t)(((unsigned long long)pix * div_m) >> div_s);
-                const int dx = (int)(pix - y * (uint32_t)row_w) - xlo;
-                const uint32_t dy = y - y0;
-                wi = 2 * dy + ((uint32_t)dx >> 6);
-                sh = (uint32_t)dx & 63u;
-                return dx >= 0 && dx <= 120 && dy < MLM_BMP_ROWS;
-            };
-            uint32_t r_bits[4], r_pix[4], r_sub[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) load_pair((uint32_t)lane + 64u * q, r_bits[q], r_pix[q], r_sub[q]);
-            if (!bad) {
-                auto mark = [&](uint32_t bits, uint32_t pix) {
-                    if (!bits) return;
-                    uint32_t wi, sh;
-                    if (locate(pix, wi, sh)) atomicOr(&rows[wi], (unsigned long long)bits << sh);
-                    else bad = true;
-                };
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mark(r_bits[q], r_pix[q]);
-                for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
-                    uint32_t b, px, sb;
-                    load_pair(p, b, px, sb);
-                    mark(b, px);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            bad = __any(bad);
-            uint32_t carry = 0;
-            int used = MLM_SEC_RANK_WORDS;
-            if (!bad) {
-                int j0 = 0;
-                for (; j0 < MLM_SEC_RANK_WORDS && carry < n; j0 += 64) {
-                    const uint32_t cw = (uint32_t)__popcll(((volatile unsigned long long *)rows)[j0 + lane]);
-                    const uint32_t incl = mlm_wave_incl_scan(cw);
-                    pref[j0 + lane] = (uint16_t)(carry + incl - cw);
-                    carry += mlm_readlane(incl, 63);
-                }
-                if (carry == n) used = j0;
-                else bad = true; // (two contributions on one pixel cannot happen; a count mismatch means a window miss)
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (!bad) {
-                auto place = [&](uint32_t bits, uint32_t pix, uint32_t sub) {
-                    if (!bits) return;
-                    uint32_t wi, sh;
-                    locate(pix, wi, sh);
-                    const unsigned long long word = ((volatile unsigned long long *)rows)[wi];
-                    const uint32_t before = pref[wi];
-                    while (bits) { // the row's own set bits, in pixel order; other records' bits may lie between them
-                        const int b = __ffs((int)bits) - 1;
-                        bits &= bits - 1;
-                        S[before + (uint32_t)__popcll(word & ((1ull << (sh + b)) - 1ull))] = (uint8_t)sub;
-                    }
-                };
-#pragma unroll
-                for (int q = 0; q < 4; ++q) place(r_bits[q], r_pix[q], r_sub[q]);
-                for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
-                    uint32_t b, px, sb;
-                    load_pair(p, b, px, sb);
-                    place(b, px, sb);
-                }
+        uint32_t o_occ = s_base[0] + v[0], o_multi = s_base[1] + v[1], o_refs = s_base[2] + v[2], o_subs = s_base[3] + v[3];
+        for (uint32_t q = 0; q < per; ++q) {
+            MlmSecCell &c = s_tab[threadIdx.x * per + q];
+            if (c.key == MLM_NIL) continue;
+            int rho, z;
+            key_rz(c.key, rho, z);
+            const uint32_t pos = o_occ++;
+            mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+            mlm_gp(P.hl_t)[pos] = c.tmin;
+            mlm_gp(P.hl_vt)[pos] = c.tmin;
+            if (__popc(c.kmask) > 1) {
+                const uint32_t m = o_multi++;
+                mlm_gp(P.mt_list)[m] = pos;
+                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, c.cnt, c.tmin};
+                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.gcnt};
+                mlm_gp(P.hl_base)[pos] = o_subs;
+                mlm_gp(P.hl_cnt)[pos] = c.cnt;
+                c.gpos = o_refs;
+                o_refs += c.gcnt;
+                o_subs += (c.cnt + 15u) & ~15u;
             } else {
-                // slow exact path (a contribution outside the bitmap window, or a huge cell): write every contribution's
-                // work item into the cell's segment of `contrib`, then rank by counting straight from memory
-                MLM_GLOBAL uint32_t *K = mlm_gp(P.contrib) + soff;
-                uint32_t base = 0;
-                for (uint32_t p0 = 0; p0 < n_refs * 8u; p0 += 64) {
-                    uint32_t b, px, sb;
-                    load_pair(p0 + lane, b, px, sb);
-                    const uint32_t cb = (uint32_t)__popc(b);
-                    const uint32_t incl = mlm_wave_incl_scan(cb);
-                    uint32_t at = base + incl - cb;
-                    while (b) {
-                        const int bit = __ffs((int)b) - 1;
-                        b &= b - 1;
-                        K[at++] = ((px + (uint32_t)bit) << 5) | sb;
-                    }
-                    base += mlm_readlane(incl, 63);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t j = lane; j < n; j += 64) {
-                    const uint32_t my = __hip_atomic_load(&K[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t r = 0;
-                    for (uint32_t q = 0; q < n; ++q) r += __hip_atomic_load(&K[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my;
-                    S[r] = (uint8_t)(my & 31u);
-                }
+                // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
+                const float a = mlm_contribution_odd(P, s_odds, rho, __ffs((int)c.kmask) - 1);
+                float p = a;
+                for (uint32_t j = 1; j < c.cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
+                mlm_gp(P.hl_odd)[pos] = p;
+                mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
+                mlm_gp(P.hl_cnt)[pos] = 0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int j = lane; j < used; j += 64) rows[j] = 0ull; // clean for the next cell
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            double wx, wy, wz;
+            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+            int gx, gy, gz, cid;
+            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
+            const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+            mlm_gp(P.hl_bkey)[pos] = bkey;
+            mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
+            mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
         }
     }
-    __syncthreads();
+    MLM_PHASE(4);
+    // ---- references of the multi-kind cells (their fill cursors were set above)
+    if (n_multi) for_records(1);
     MLM_PHASE(5);
-    // ---- replay update_odds_hashmap (map_awareness.h:147-154) over the ordered kinds: one lane per multi-kind cell; the
-    //      result goes into the segment's header next to the cell's hit-list index
-    for (uint32_t m = threadIdx.x; m < n_multi; m += MLM_SEC_THREADS) {
-        const MlmSecCell &c = s_tab[s_multi[m]];
-        const int rho_c = (int)(c.key % (uint32_t)P.nRho);
-        const uint32_t n = c.cnt;
-        MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + c.aux; // 16-byte aligned segments
-        float p = 0.0f;
-        bool first = true;
-        mlm_u32x4 nxt = *(const MLM_GLOBAL mlm_u32x4 *)S;
-        for (uint32_t j0 = 0; j0 < n && p != 1.0f; j0 += 16) {
-            const mlm_u32x4 v = nxt;
-            if (j0 + 16 < n) nxt = *(const MLM_GLOBAL mlm_u32x4 *)(S + j0 + 16); // one segment ahead
-            const uint32_t word[4] = {v.x, v.y, v.z, v.w};
-            float a[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int sub = (int)((word[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
-                if (j0 + q >= n) sub = 0; // padding bytes are not kinds
-                a[q] = mlm_contribution_odd(P, s_odds, rho_c, sub);
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (j0 + q < n) {
-                    if (first) {
-                        p = a[q];
-                        first = false;
-                    } else {
-                        p = 1 - (1 - p) * (1 - a[q]);
-                    }
-                }
-            }
-        }
-        *(MLM_GLOBAL uint32_t *)(S - 12) = __float_as_uint(p);
-    }
-    __syncthreads();
-    MLM_PHASE(6);
-    // ---- the column's unique hits: cell, first-touch time, odd, increment, world voxel + speculative block slot
-    //      (what k_collect_hits / k_chain / k_prepare_voxels leave behind on the cell-table path)
-    for (uint32_t e = threadIdx.x; e < TAB; e += MLM_SEC_THREADS) {
-        const MlmSecCell c = s_tab[e];
-        if (c.key == MLM_NIL) continue;
-        const int z = (int)(c.key / (uint32_t)P.nRho);
-        const int rho = (int)(c.key - (uint32_t)z * (uint32_t)P.nRho);
-        uint32_t pos = c.aux, pbits = c.gcnt;
-        if (__popc(c.kmask) > 1) {
-            const mlm_u32x2 hd = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.subs) + (c.aux - 16u));
-            pos = hd.x;
-            pbits = hd.y;
-        }
-        const float p = __uint_as_float(pbits);
-        mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
-        mlm_gp(P.hl_t)[pos] = c.tmin;
-        mlm_gp(P.hl_vt)[pos] = c.tmin;
-        mlm_gp(P.hl_odd)[pos] = p;
-        mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
-        double wx, wy, wz;
-        mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-        int gx, gy, gz, cid;
-        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-        const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
-        mlm_gp(P.hl_bkey)[pos] = bkey;
-        mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
-        mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
-    }
-    MLM_PHASE(7);
     // ---- the column's unique miss cells (its bit mask) with their world voxels, appended to sub-list (column & 7)
     {
         const unsigned int sl = blockIdx.x & 7;
-        uint32_t v = 0;
-        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) v += (uint32_t)__popc(s_miss[w]);
+        uint32_t vm = 0;
+        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) vm += (uint32_t)__popc(s_miss[w]);
         uint32_t total;
-        mlm_block_excl_scan(v, s_w, &total); // (only the total is needed: positions are re-derived per 64-word group)
+        mlm_block_excl_scan(vm, s_w, &total); // (only the total is needed: positions are re-derived per 64-word group)
         if (threadIdx.x == 0) {
-            s_base[2] = total ? g_atomic_add(&mlm_gp(P.ctr)->mc_cnt[sl][0], total) : 0u;
-            s_base[3] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
+            s_base[4] = total ? g_atomic_add(&mlm_gp(P.ctr)->mc_cnt[sl][0], total) : 0u;
+            s_base[5] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
             mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
         }
         __syncthreads();
         if (total) {
             // groups of 64 words, one per wave at a time; the offset of a group = bits in the groups before it
-            uint32_t group_base = s_base[2];
-            const uint32_t rec_base = s_base[3];
+            uint32_t group_base = s_base[4];
+            const uint32_t rec_base = s_base[5];
             const int half = lane >> 5, b = lane & 31;
             for (uint32_t w0 = 0; w0 < NMISS; w0 += 64) {
                 const uint32_t w = w0 + lane;
@@ -780,7 +607,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                             const uint32_t within = my_off + (uint32_t)__popc(my_bits & ((1u << b) - 1u));
                             const uint32_t pos = group_base + within;
                             if (P.record_awareness)
-                                mlm_gp(P.ml_cell)[rec_base + (pos - s_base[2])] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+                                mlm_gp(P.ml_cell)[rec_base + (pos - s_base[4])] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
                             if (pos < P.mc_cap) {
                                 const size_t at = (size_t)sl * P.mc_cap + pos;
                                 mlm_gp(P.mc_bkey)[at] = bkey;
@@ -794,6 +621,187 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             }
         }
     }
-    MLM_PHASE(8);
+    MLM_PHASE(6);
     MLM_PHASE_END
+}
+
+// One wave per multi-kind hit cell: order the cell's contributions by insertion time (= pixel order: a pixel contributes
+// to a cell at most once) and store their kinds in that order for k_chain.  Bitmap ranking as k_sort_contribs, but fed with
+// the records' 8x8 lane masks (eight row bytes per (record, kind) reference) instead of one key per contribution.
+// tile_w > 0: dense 8x8 pixel tiles of an image of that width; 0: linear work items (see MlmNode).  row_w, div_m, div_s:
+// rows of the ranking bitmap and the exact division by row_w.
+__global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s) {
+    MLM_SLOT_SETUP
+    __shared__ __attribute__((aligned(16))) unsigned long long s_rows[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
+    __shared__ uint16_t s_pref[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
+    const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long *rows = s_rows[wid];
+    volatile uint16_t *pref = s_pref[wid];
+    for (int j = lane; j < MLM_SEC_RANK_WORDS; j += 64) rows[j] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
+    const MLM_GLOBAL uint32_t *refs = mlm_gp(P.refs);
+    // (record, row) pair p of a cell: the row's byte of the record's lane mask, the work item of the row's first lane, kind
+    auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &pix, uint32_t &sub) {
+        bits = 0;
+        pix = 0;
+        sub = 0;
+        if (p < rf.y * 8u) {
+            const uint32_t ref = refs[rf.x + (p >> 3)], row = p & 7u;
+            const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + (ref >> 5));
+            const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
+            bits = (uint32_t)(mask >> (8 * row)) & 0xFFu;
+            pix = (rp[2] & 0x07FFFFFFu) + (tile_w > 0 ? row * (uint32_t)tile_w : row * 8u);
+            sub = ref & 31u;
+        }
+    };
+    auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_pix)[4],
+                       const uint32_t (&r_sub)[4]) {
+        const uint32_t soff = rec.y, n = rec.z, n_refs = rf.y;
+        const uint32_t pix0 = rec.w / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
+        const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
+        const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64; // multiple of 8: a record's row byte never straddles a word
+        MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + soff;
+        bool bad = n > 0xFFFFu;
+        auto locate = [&](uint32_t pix, uint32_t &wi, uint32_t &sh) -> bool {
+            const uint32_t y = (uint32_t)(((unsigned long long)pix * div_m) >> div_s);
+            const int dx = (int)(pix - y * (uint32_t)row_w) - xlo;
+            const uint32_t dy = y - y0;
+            wi = 2 * dy + ((uint32_t)dx >> 6);
+            sh = (uint32_t)dx & 63u;
+            return dx >= 0 && dx <= 120 && dy < MLM_BMP_ROWS;
+        };
+        uint32_t l_wi[4], l_sh[4];
+        if (!bad) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                l_wi[q] = 0;
+                l_sh[q] = 0;
+                if (r_bits[q]) {
+                    if (locate(r_pix[q], l_wi[q], l_sh[q])) atomicOr(&rows[l_wi[q]], (unsigned long long)r_bits[q] << l_sh[q]);
+                    else bad = true;
+                }
+            }
+            for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
+                uint32_t b, px, sb, wi, sh;
+                load_pair(rf, p, b, px, sb);
+                if (b) {
+                    if (locate(px, wi, sh)) atomicOr(&rows[wi], (unsigned long long)b << sh);
+                    else bad = true;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bad = __any(bad);
+        uint32_t carry = 0;
+        int used = MLM_SEC_RANK_WORDS;
+        if (!bad) {
+            int j0 = 0;
+            for (; j0 < MLM_SEC_RANK_WORDS && carry < n; j0 += 64) {
+                const uint32_t cw = (uint32_t)__popcll(((volatile unsigned long long *)rows)[j0 + lane]);
+                const uint32_t incl = mlm_wave_incl_scan(cw);
+                pref[j0 + lane] = (uint16_t)(carry + incl - cw);
+                carry += mlm_readlane(incl, 63);
+            }
+            if (carry == n) used = j0;
+            else bad = true; // (two contributions on one pixel cannot happen; a count mismatch means a window miss)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!bad) {
+            auto place = [&](uint32_t bits, uint32_t wi, uint32_t sh, uint32_t sub) {
+                if (!bits) return;
+                const unsigned long long word = ((volatile unsigned long long *)rows)[wi];
+                const uint32_t before = pref[wi] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull));
+                const uint32_t seg = (uint32_t)(word >> sh) & 0xFFu; // every record's bits of this 8-pixel segment
+                while (bits) { // the row's own set bits, in pixel order; other records' bits may lie between them
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    S[before + (uint32_t)__popc(seg & ((1u << b) - 1u))] = (uint8_t)sub;
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q]);
+            for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
+                uint32_t b, px, sb, wi, sh;
+                load_pair(rf, p, b, px, sb);
+                if (b) {
+                    locate(px, wi, sh);
+                    place(b, wi, sh, sb);
+                }
+            }
+        } else {
+            // slow exact path (a contribution outside the bitmap window, or a huge cell): write every contribution's
+            // work item into the cell's segment of `contrib`, then rank by counting straight from memory
+            MLM_GLOBAL uint32_t *K = mlm_gp(P.contrib) + soff;
+            uint32_t base = 0;
+            for (uint32_t p0 = 0; p0 < n_refs * 8u; p0 += 64) {
+                uint32_t b, px, sb;
+                load_pair(rf, p0 + lane, b, px, sb);
+                const uint32_t cb = (uint32_t)__popc(b);
+                const uint32_t incl = mlm_wave_incl_scan(cb);
+                uint32_t at = base + incl - cb;
+                while (b) {
+                    const int bit = __ffs((int)b) - 1;
+                    b &= b - 1;
+                    K[at++] = ((px + (uint32_t)bit) << 5) | sb;
+                }
+                base += mlm_readlane(incl, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < n; j += 64) {
+                const uint32_t my = __hip_atomic_load(&K[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                uint32_t r = 0;
+                for (uint32_t q = 0; q < n; ++q) r += __hip_atomic_load(&K[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my;
+                S[r] = (uint8_t)(my & 31u);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < used; j += 64) rows[j] = 0ull; // clean for the next cell
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // one cell ahead: descriptors two cells ahead, the first four rounds of (record, row) pairs one cell ahead — a cell is
+    // otherwise a chain of four dependent memory round trips (descriptor, references, records, store)
+    mlm_u32x4 rec_cur = mlm_u32x4{0u, 0u, 0u, 0u}, rec_nxt = rec_cur;
+    mlm_u32x2 rf_cur = mlm_u32x2{0u, 0u}, rf_nxt = rf_cur;
+    uint32_t b_cur[4] = {0, 0, 0, 0}, p_cur[4] = {0, 0, 0, 0}, s_cur[4] = {0, 0, 0, 0}, b_nxt[4] = {0, 0, 0, 0}, p_nxt[4] = {0, 0, 0, 0},
+             s_nxt[4] = {0, 0, 0, 0};
+    auto load_desc = [&](unsigned int w, mlm_u32x4 &rec, mlm_u32x2 &rf) {
+        rec = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + w);
+        rf = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)w);
+    };
+    if (wave < n_cells) {
+        load_desc(wave, rec_cur, rf_cur);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_pair(rf_cur, (uint32_t)lane + 64u * q, b_cur[q], p_cur[q], s_cur[q]);
+    }
+    if (wave + n_waves < n_cells) load_desc(wave + n_waves, rec_nxt, rf_nxt);
+    for (unsigned int w = wave; w < n_cells; w += n_waves) {
+        mlm_u32x4 rec_nn = mlm_u32x4{0u, 0u, 0u, 0u};
+        mlm_u32x2 rf_nn = mlm_u32x2{0u, 0u};
+        if (w + n_waves < n_cells) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) load_pair(rf_nxt, (uint32_t)lane + 64u * q, b_nxt[q], p_nxt[q], s_nxt[q]);
+        }
+        if (w + 2 * n_waves < n_cells) load_desc(w + 2 * n_waves, rec_nn, rf_nn);
+        process(rec_cur, rf_cur, b_cur, p_cur, s_cur);
+        rec_cur = rec_nxt;
+        rf_cur = rf_nxt;
+        rec_nxt = rec_nn;
+        rf_nxt = rf_nn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            b_cur[q] = b_nxt[q];
+            p_cur[q] = p_nxt[q];
+            s_cur[q] = s_nxt[q];
+        }
+    }
 }

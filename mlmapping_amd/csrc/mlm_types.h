@@ -23,7 +23,7 @@ struct MlmCounters {
     unsigned int n_big;       // multi-kind cells with more than 1024 contributions
     unsigned int n_groups;    // contribution groups kept in the blocks' own slices of `bnodes` (folded by k_collect_hits)
     unsigned int sector_overflow; // sector path: an LDS table of some column overflowed -> the frame is redone by the cell-table path
-    unsigned int pad_b[1];
+    unsigned int n_refs;      // sector path: (record, kind) references of the multi-kind cells
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
@@ -184,8 +184,10 @@ struct MlmDev {
     unsigned int *col_cnt;     // [nPhi] chunk descriptors handed to each column this frame (reset by k_sector)
     uint32_t *col_chunks;      // [nPhi][chunk_cap][2] {first record in `bnodes`, record count} per (bin block, column) run
     unsigned int chunk_cap;
-    unsigned int sec_tab, sec_refs, sec_rcap, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two),
-                               // reference slots, records of one column kept in LDS
+    unsigned int sec_tab, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two)
+    unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
+    uint32_t *refs;            // [contrib_cap] (record index in `bnodes` << 5 | kind) per contribution group of a multi-kind cell
+    uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count}
     MlmCounters *ctr;          // this slot's per-frame counters
     MlmGlobal *g;
 };

@@ -395,8 +395,15 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         unsigned long long dm;
         int ds;
         div_magic((unsigned int)row_w, dm, ds);
+        unsigned long long rm;
+        int rs;
+        div_magic((unsigned int)P.nRho, rm, rs);
         tlaunch(h, "k_sector", k_sector, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
-                h->d_frame_tab, base, mode == 0 ? F.width : 0, row_w, dm, ds, (int)nb);
+                h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs);
+        tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->sort_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
+                mode == 0 ? F.width : 0, row_w, dm, ds);
+        tlaunch(h, "k_chain", k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab,
+                h->d_frame_tab, base, 0xFFFFFFFFu);
     }
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
@@ -898,6 +905,8 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
     if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
     if ((rc = dev_alloc(h, &P.col_chunks, h->use_sectors ? 2 * (size_t)P.nPhi * P.chunk_cap : 2))) return rc;
+    if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? (size_t)P.contrib_cap : 1))) return rc;
+    if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
     HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
     if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_t, NC))) return rc;
@@ -1120,11 +1129,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         while (tab < 12u * (unsigned int)P.nRho && tab < 2048u) tab <<= 1;
         if (const char *e = getenv("MLM_SEC_TAB")) tab = (unsigned int)std::max(MLM_SEC_THREADS, atoi(e)); // power of two
         P.sec_tab = tab;
-        P.sec_refs = tab == 1024 ? 4096u : 16384u;
-        P.sec_rcap = tab == 1024 ? 1280u : 2048u; // (references carry an 11-bit record index)
-        if (const char *e = getenv("MLM_SEC_REFS")) P.sec_refs = (unsigned int)std::max(64, atoi(e));
-        if (const char *e = getenv("MLM_SEC_RCAP")) P.sec_rcap = (unsigned int)std::min(2048, std::max(64, atoi(e)));
-        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, P.sec_refs, P.sec_rcap, (unsigned int)(P.nZ * P.RW), (unsigned int)P.nRho).total;
+        if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
+        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * P.RW), (unsigned int)P.nRho).total;
         h->use_sectors = !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u;
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         if (h->use_sectors)

@@ -707,7 +707,7 @@ def test_callback_query_interleaving(mods):
     gpu.close()
 
 
-@pytest.mark.parametrize("env", [{"MLM_SEC_REFS": "64"}, {"MLM_SEC_TAB": "512", "MLM_SEC_REFS": "2048"}, {"MLM_SECTORS": "0"}])
+@pytest.mark.parametrize("env", [{"MLM_SEC_FAIL_EVERY": "1"}, {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_TAB": "512"}, {"MLM_SECTORS": "0"}])
 def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
     """Stage A by azimuth sector falls back to the cell-table path frame by frame when a column overflows its LDS tables
     (forced here by shrinking them); MLM_SECTORS=0 runs the cell-table path alone.  Results must not change."""
@@ -731,8 +731,10 @@ def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
         _awareness_equal(gpu, cpu)
         compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{env} frame {k}")
     st = gpu.frame_stats()
-    if "MLM_SEC_REFS" in env and env["MLM_SEC_REFS"] == "64":
-        assert st["n_sector_fallbacks"] >= n - 1, st
+    if env.get("MLM_SEC_FAIL_EVERY") == "1":
+        assert st["n_sector_fallbacks"] == n, st
+    if env.get("MLM_SEC_FAIL_EVERY") == "3":
+        assert st["n_sector_fallbacks"] >= n // 3, st
     if "MLM_SECTORS" in env:
         assert st["n_sector_fallbacks"] == 0
     gpu.close()
