@@ -128,7 +128,13 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
         const unsigned int k = atomicAdd(&s_nnode, 1u); // <= 256: a lane belongs to exactly one record
         MlmNode nd;
         nd.cell = leader ? (uint32_t)c0 : (uint32_t)rho;
-        nd.pos = leader ? 0u : (uint32_t)zi;
+        // hit records carry their tile's origin (row << 11 | column of lane 0; list modes: 64 items = one row) for k_rank
+        uint32_t yx = i00 >> 6 << 11;
+        if (MODE == 0) {
+            const uint32_t y0 = i00 / (uint32_t)F.width;
+            yx = (y0 << 11) | (i00 - y0 * (uint32_t)F.width);
+        }
+        nd.pos = leader ? yx : (uint32_t)zi;
         nd.i00_sub = i00 | (leader ? 0u : (MLM_SEC_OUTER << 27));
         nd.pad = (uint32_t)phi;
         nd.mask = my_mask;
@@ -259,7 +265,7 @@ __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int ph
 
 // LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
-    uint32_t tab, miss, odds, sigma, rays, chunk, total;
+    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, total;
 };
 __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho) {
     MlmSecLds L;
@@ -270,6 +276,8 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
     L.sigma = o;    o += ((n_rho + 3u) & ~3u) * 4u;
     L.miss = o;     o += ((n_miss + 3u) & ~3u) * 4u;
     L.rays = o;     o += TAB * 2u;                       // table entries that start a ray
+    L.occ = o;      o += TAB * 2u;                       // occupied table entries (= the column's unique hits)
+    L.multi = o;    o += TAB * 2u;                       // ... those that received several kinds
     L.total = (o + 15u) & ~15u;
     return L;
 }
@@ -309,10 +317,12 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     float *s_odds = (float *)(s_dyn + L.odds);
     float *s_sigma = (float *)(s_dyn + L.sigma);
     uint16_t *s_rays = (uint16_t *)(s_dyn + L.rays);
+    uint16_t *s_occ = (uint16_t *)(s_dyn + L.occ);
+    uint16_t *s_multi = (uint16_t *)(s_dyn + L.multi);
     uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.chunk);
     uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
-    __shared__ uint32_t s_base[6];
+    __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter;
     for (uint32_t e = threadIdx.x; e < TAB; e += MLM_SEC_THREADS) {
         s_tab[e].key = MLM_NIL;
@@ -347,8 +357,25 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         return s_chunk_first[lo] + (r - s_chunk_start[lo]);
     };
     // pass = 0: book every record's contributions on the cells of the column (and walk the rays of points outside the
-    // map); pass = 1: write a (record, kind) reference for every contribution group of a multi-kind cell
+    // map); pass = 1: write a (record, kind) reference for every contribution group of a multi-kind cell.  A thread
+    // keeps the record it handled first: a column with at most MLM_SEC_THREADS records (the usual case) is not read twice.
+    uint32_t keep_cell = MLM_NIL, keep_gi = 0, keep_total = 0xFFFFFFFFu;
+    auto refs_of = [&](uint32_t cell, uint32_t gi) {
+        const int z = (int)(cell / (uint32_t)P.nRhoPhi);
+        const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
+        mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub) {
+            const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
+            if (e >= 0 && __popc(s_tab[e].kmask) > 1) {
+                const uint32_t at = atomicAdd(&s_tab[e].gpos, 1u);
+                if (at < P.contrib_cap) mlm_gp(P.refs)[at] = (gi << 5) | (uint32_t)sub;
+            }
+        });
+    };
     auto for_records = [&](int pass) {
+        if (pass == 1 && nch <= MLM_SEC_CHUNKS && keep_total <= MLM_SEC_THREADS) {
+            if (keep_cell != MLM_NIL) refs_of(keep_cell, keep_gi);
+            return;
+        }
         for (uint32_t c0 = 0; c0 < nch; c0 += MLM_SEC_CHUNKS) {
             const uint32_t n_staged = min(nch - c0, (uint32_t)MLM_SEC_CHUNKS);
             __syncthreads();
@@ -386,9 +413,17 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                     continue;
                 }
                 const uint32_t cell = a.x;
+                if (pass == 1) {
+                    refs_of(cell, gi);
+                    continue;
+                }
                 const int z = (int)(cell / (uint32_t)P.nRhoPhi);
                 const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
-                if (pass == 0) {
+                if (c0 == 0 && r == threadIdx.x) {
+                    keep_cell = cell;
+                    keep_gi = gi;
+                }
+                {
                     const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
                     const uint32_t i_first = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
@@ -404,16 +439,9 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                         atomicAdd(&s_tab[e].cnt, cnt);
                         atomicAdd(&s_tab[e].gcnt, 1u);
                     });
-                } else {
-                    mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub) {
-                        const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
-                        if (e >= 0 && __popc(s_tab[e].kmask) > 1) {
-                            const uint32_t at = atomicAdd(&s_tab[e].gpos, 1u);
-                            if (at < P.contrib_cap) mlm_gp(P.refs)[at] = (gi << 5) | (uint32_t)sub;
-                        }
-                    });
                 }
             }
+            if (pass == 0 && c0 == 0) keep_total = total;
         }
     };
     __syncthreads();
@@ -421,68 +449,142 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for_records(0);
     __syncthreads();
     MLM_PHASE(1);
-    // ---- per cell: slots in the hit list / multi-kind list / reference array / ordered-kinds array
+    // ---- lists of the occupied entries (= the column's unique hits), of those with several kinds, of the ray starts;
+    //      the column's reservations in the frame's lists (one round trip)
     const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread
-    uint32_t v[4] = {0u, 0u, 0u, 0u}, v_rays = 0; // occupied, multi, references, ordered-kinds slots
+    uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, multi, ray starts, -
+    uint32_t w_refs = 0, w_subs = 0;  // references / ordered-kinds slots of this thread's multi-kind cells
     for (uint32_t q = 0; q < per; ++q) {
         const MlmSecCell &c = s_tab[threadIdx.x * per + q];
         if (c.key == MLM_NIL) continue;
         ++v[0];
-        v_rays += c.kmask & 1u;
+        v[2] += c.kmask & 1u;
         if (__popc(c.kmask) > 1) {
             ++v[1];
-            v[2] += c.gcnt;
-            v[3] += (c.cnt + 15u) & ~15u;
+            w_refs += c.gcnt;
+            w_subs += (c.cnt + 15u) & ~15u;
         }
     }
-    uint32_t tot[4];
-    mlm_block_excl_scan4(v, s_w, tot);
-    uint32_t tot_rays;
-    uint32_t o_rays = mlm_block_excl_scan(v_rays, s_w, &tot_rays);
-    const uint32_t n_multi = tot[1], n_rays = P.visibility ? tot_rays : 0u;
-    // the four list reservations of this column: one round trip, issued now, awaited after the rays (which do not need them)
-    uint32_t r_hit = 0, r_multi = 0, r_refs = 0, r_subs = 0;
-    if (threadIdx.x == 0) {
-        if (tot[0]) r_hit = g_atomic_add(&mlm_gp(P.ctr)->u_hit, tot[0]);
-        if (tot[1]) r_multi = g_atomic_add(&mlm_gp(P.ctr)->n_multi, tot[1]);
-        if (tot[2]) r_refs = g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot[2]);
-        if (tot[3]) r_subs = g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot[3]);
+    for (int off = 32; off > 0; off >>= 1) {
+        w_refs += __shfl_xor(w_refs, off, 64);
+        w_subs += __shfl_xor(w_subs, off, 64);
     }
-    for (uint32_t q = 0; q < per; ++q) { // list of the cells that hold a hit centre
-        const uint32_t e = threadIdx.x * per + q;
-        if (s_tab[e].key != MLM_NIL && (s_tab[e].kmask & 1u)) s_rays[o_rays++] = (uint16_t)e;
+    if (threadIdx.x < 2) s_base[4 + threadIdx.x] = 0;
+    uint32_t tot[4];
+    mlm_block_excl_scan4(v, s_w, tot); // (its first barrier also orders the zeroing above)
+    if (lane == 0) {
+        if (w_refs) atomicAdd(&s_base[4], w_refs);
+        if (w_subs) atomicAdd(&s_base[5], w_subs);
+    }
+    {
+        uint32_t o_occ = v[0], o_multi = v[1], o_rays = v[2];
+        for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t e = threadIdx.x * per + q;
+            MlmSecCell &c = s_tab[e];
+            if (c.key == MLM_NIL) continue;
+            if (c.kmask & 1u) s_rays[o_rays++] = (uint16_t)e;
+            if (__popc(c.kmask) > 1) {
+                s_multi[o_multi++] = (uint16_t)e;
+                c.gpos = o_occ; // (its place in the hit list, until the reference cursor replaces it below)
+            }
+            s_occ[o_occ++] = (uint16_t)e;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_occ = tot[0], n_multi = tot[1], n_rays = P.visibility ? tot[2] : 0u;
+    const uint32_t tot_refs = s_base[4], tot_subs = s_base[5];
+    if (threadIdx.x == 0) {
+        s_base[0] = n_occ ? g_atomic_add(&mlm_gp(P.ctr)->u_hit, n_occ) : 0u;
+        s_base[1] = n_multi ? g_atomic_add(&mlm_gp(P.ctr)->n_multi, n_multi) : 0u;
+        s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
+        s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
+        if (s_base[2] + tot_refs > P.contrib_cap || s_base[3] + tot_subs > P.contrib_cap) s_fail = 1;
     }
     __syncthreads();
     MLM_PHASE(2);
+    if (s_fail) { // a table of this column overflowed: the frame is redone by the cell-table path (uniform branch)
+        if (threadIdx.x == 0) {
+            mlm_sector_fail(P, F);
+            mlm_gp(P.col_cnt)[phi] = 0;
+        }
+        return;
+    }
+    // ---- multi-kind cells: segments in `refs` and `subs`, descriptors for k_rank / k_chain
+    {
+        uint32_t carry_refs = s_base[2], carry_subs = s_base[3];
+        for (uint32_t j0 = 0; j0 < n_multi; j0 += MLM_SEC_THREADS) { // (one round unless the column holds > 512 such cells)
+            const uint32_t j = j0 + threadIdx.x;
+            uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
+            uint32_t e = 0;
+            if (j < n_multi) {
+                e = s_multi[j];
+                a[0] = s_tab[e].gcnt;
+                a[1] = (s_tab[e].cnt + 15u) & ~15u;
+            }
+            mlm_block_excl_scan4(a, s_w, t4);
+            if (j < n_multi) {
+                MlmSecCell &c = s_tab[e];
+                const uint32_t pos = s_base[0] + c.gpos, m = s_base[1] + j, o_refs = carry_refs + a[0], o_subs = carry_subs + a[1];
+                mlm_gp(P.mt_list)[m] = pos;
+                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, c.cnt, c.tmin};
+                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.gcnt};
+                mlm_gp(P.hl_base)[pos] = o_subs;
+                mlm_gp(P.hl_cnt)[pos] = c.cnt;
+                c.gpos = o_refs;
+            }
+            carry_refs += t4[0];
+            carry_subs += t4[1];
+        }
+    }
     // ---- rays of the cells that hold a hit centre (every point of one (rho,phi,z) cell casts the identical ray,
-    //      map_awareness.cpp:243-274: once per cell), one ray per LANE.  z' = round(z - k (z - zc) / rho) for k = 1 ..
-    //      rho-1 is followed by an integer DDA on N_k = 2 (z rho - k (z - zc)) + rho: z' = floor(N_k / 2 rho) unless
-    //      N_k is a multiple of 2 rho — the exact value is then a half-integer and only the reference's own FP64
-    //      sequence (slope = dz / rho rounded, k * slope rounded, z - .. rounded, round half away) says which way it
-    //      goes; everywhere else that sequence is at most ~1e-12 away from the exact value, which is at least 1 / (2 rho)
-    //      away from the next half-integer.  Consecutive steps that fall into one word of the mask are merged in a register.
-    for (uint32_t k0 = wid * 64; k0 < n_rays; k0 += MLM_SEC_THREADS) {
-        const uint32_t kk = k0 + lane;
+    //      map_awareness.cpp:243-274: once per cell), FOUR LANES per ray, each a quarter of its steps.
+    //      z' = round(z - k (z - zc) / rho) for k = 1 .. rho-1 is followed by an integer DDA on
+    //      N_k = 2 (z rho - k (z - zc)) + rho: z' = floor(N_k / 2 rho) unless N_k is a multiple of 2 rho — the exact value
+    //      is then a half-integer and only the reference's own FP64 sequence (slope = dz / rho rounded, k * slope rounded,
+    //      z - .. rounded, round half away) says which way it goes (those steps are collected and evaluated afterwards);
+    //      everywhere else that sequence is at most ~1e-12 away from the exact value, which is at least 1 / (2 rho) away
+    //      from the next half-integer.  Consecutive steps that fall into one word of the mask are merged in a register.
+    for (uint32_t i0 = 0; i0 < 4u * n_rays; i0 += MLM_SEC_THREADS) {
+        const uint32_t it = i0 + threadIdx.x;
         int rho = 0, z = 0;
-        if (kk < n_rays) key_rz(s_tab[s_rays[kk]].key, rho, z);
+        if (it < 4u * n_rays) key_rz(s_tab[s_rays[it >> 2]].key, rho, z);
+        const int seg = (rho + 2) >> 2; // steps k = 1 .. rho-1 in four segments of `seg`
+        const int k_lo = 1 + (int)(it & 3u) * seg, k_hi = min(rho, k_lo + seg); // [k_lo, k_hi)
         const int dz = z - P.zc, two_rho = 2 * rho;
-        const double slope = (rho > 0) ? dz / (rho * 1.0) : 0.0; // (rho < nRho: no clamp for in-range starts)
-        int q = z, rem = rho; // N_0 = 2 z rho + rho
+        // per step: N -= 2 dz = sq * 2 rho + fr with 0 <= fr < 2 rho
+        int sq = 0, fr = 0, q = 0, rem = 0;
+        if (k_lo < k_hi) {
+            auto floor_div = [&](int a, int &quo, int &r) { // a = quo * two_rho + r, 0 <= r < two_rho (|a| < 2^24)
+                quo = (int)floorf((float)a / (float)two_rho);
+                r = a - quo * two_rho;
+                if (r < 0) {
+                    r += two_rho;
+                    --quo;
+                } else if (r >= two_rho) {
+                    r -= two_rho;
+                    ++quo;
+                }
+            };
+            floor_div(2 * dz, sq, fr);
+            floor_div(rho * (2 * z + 1) - (k_lo - 1) * 2 * dz, q, rem); // N at k_lo - 1
+        }
         int cur_w = -1;
         uint32_t cur_bits = 0;
-        for (int k = 1; k < rho; ++k) {
+        unsigned long long ties = 0;
+        for (int k = k_lo; k < k_hi; ++k) {
             const int r = rho - k;
-            rem -= 2 * dz;
-            while (rem < 0) {
+            rem -= fr;
+            q -= sq;
+            if (rem < 0) {
                 rem += two_rho;
                 --q;
             }
-            while (rem >= two_rho) {
-                rem -= two_rho;
-                ++q;
+            if (rem == 0) { // exact tie: the reference's FP64 sequence decides (below)
+                ties |= 1ull << ((k - k_lo) & 63);
+                if (k - k_lo < 64) continue;
             }
             int zr = q;
-            if (rem == 0) zr = mlm_cvt_int(round(z - (k * slope))); // exact tie: the reference's FP64 sequence decides
+            if (rem == 0) zr = mlm_cvt_int(round(z - (k * (dz / (rho * 1.0))))); // (segments longer than 64 steps: nRho > 256)
             const int w = (0 <= zr && zr < P.nZ) ? zr * P.RW + (r >> 5) : -1;
             if (w != cur_w) {
                 if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
@@ -492,64 +594,46 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             cur_bits |= 1u << (r & 31);
         }
         if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
-    }
-    if (threadIdx.x == 0) {
-        s_base[0] = r_hit;
-        s_base[1] = r_multi;
-        s_base[2] = r_refs;
-        s_base[3] = r_subs;
-        if (r_refs + tot[2] > P.contrib_cap || r_subs + tot[3] > P.contrib_cap) s_fail = 1;
-    }
-    __syncthreads();
-    MLM_PHASE(3);
-    if (s_fail) { // a table of this column overflowed: the frame is redone by the cell-table path (uniform branch)
-        if (threadIdx.x == 0) {
-            mlm_sector_fail(P, F);
-            mlm_gp(P.col_cnt)[phi] = 0;
-        }
-        return;
-    }
-    // ---- the column's unique hits: cell, first-touch time, world voxel + speculative block slot; single-kind cells get
-    //      their odd and increment here, multi-kind cells a descriptor for k_rank / k_chain
-    {
-        uint32_t o_occ = s_base[0] + v[0], o_multi = s_base[1] + v[1], o_refs = s_base[2] + v[2], o_subs = s_base[3] + v[3];
-        for (uint32_t q = 0; q < per; ++q) {
-            MlmSecCell &c = s_tab[threadIdx.x * per + q];
-            if (c.key == MLM_NIL) continue;
-            int rho, z;
-            key_rz(c.key, rho, z);
-            const uint32_t pos = o_occ++;
-            mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
-            mlm_gp(P.hl_t)[pos] = c.tmin;
-            mlm_gp(P.hl_vt)[pos] = c.tmin;
-            if (__popc(c.kmask) > 1) {
-                const uint32_t m = o_multi++;
-                mlm_gp(P.mt_list)[m] = pos;
-                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, c.cnt, c.tmin};
-                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.gcnt};
-                mlm_gp(P.hl_base)[pos] = o_subs;
-                mlm_gp(P.hl_cnt)[pos] = c.cnt;
-                c.gpos = o_refs;
-                o_refs += c.gcnt;
-                o_subs += (c.cnt + 15u) & ~15u;
-            } else {
-                // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
-                const float a = mlm_contribution_odd(P, s_odds, rho, __ffs((int)c.kmask) - 1);
-                float p = a;
-                for (uint32_t j = 1; j < c.cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
-                mlm_gp(P.hl_odd)[pos] = p;
-                mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
-                mlm_gp(P.hl_cnt)[pos] = 0;
+        if (__any(ties != 0)) {
+            const double slope = (rho > 0) ? dz / (rho * 1.0) : 0.0;
+            while (ties) {
+                const int k = k_lo + __ffsll((long long)ties) - 1;
+                ties &= ties - 1;
+                const int r = rho - k;
+                const int zr = mlm_cvt_int(round(z - (k * slope)));
+                if (0 <= zr && zr < P.nZ) atomicOr(&s_miss[zr * P.RW + (r >> 5)], 1u << (r & 31));
             }
-            double wx, wy, wz;
-            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-            int gx, gy, gz, cid;
-            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-            const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
-            mlm_gp(P.hl_bkey)[pos] = bkey;
-            mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
-            mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
         }
+    }
+    __syncthreads(); // (the miss mask is complete)
+    MLM_PHASE(3);
+    // ---- the column's unique hits: cell, first-touch time, world voxel + speculative block slot; single-kind cells get
+    //      their odd and increment here (multi-kind cells: k_rank / k_chain)
+    for (uint32_t i = threadIdx.x; i < n_occ; i += MLM_SEC_THREADS) {
+        const MlmSecCell c = s_tab[s_occ[i]];
+        int rho, z;
+        key_rz(c.key, rho, z);
+        const uint32_t pos = s_base[0] + i;
+        mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+        mlm_gp(P.hl_t)[pos] = c.tmin;
+        mlm_gp(P.hl_vt)[pos] = c.tmin;
+        if (__popc(c.kmask) == 1) {
+            // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
+            const float a = mlm_contribution_odd(P, s_odds, rho, __ffs((int)c.kmask) - 1);
+            float p = a;
+            for (uint32_t j = 1; j < c.cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
+            mlm_gp(P.hl_odd)[pos] = p;
+            mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
+            mlm_gp(P.hl_cnt)[pos] = 0;
+        }
+        double wx, wy, wz;
+        mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+        int gx, gy, gz, cid;
+        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
+        const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+        mlm_gp(P.hl_bkey)[pos] = bkey;
+        mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
+        mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
     }
     MLM_PHASE(4);
     // ---- references of the multi-kind cells (their fill cursors were set above)
@@ -563,16 +647,16 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         uint32_t total;
         mlm_block_excl_scan(vm, s_w, &total); // (only the total is needed: positions are re-derived per 64-word group)
         if (threadIdx.x == 0) {
-            s_base[4] = total ? g_atomic_add(&mlm_gp(P.ctr)->mc_cnt[sl][0], total) : 0u;
-            s_base[5] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
+            s_base[6] = total ? g_atomic_add(&mlm_gp(P.ctr)->mc_cnt[sl][0], total) : 0u;
+            s_base[7] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
             mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
         }
         __syncthreads();
         if (total) {
             // groups of 64 words, one per wave at a time; the offset of a group = bits in the groups before it
-            uint32_t group_base = s_base[4];
-            const uint32_t rec_base = s_base[5];
+            uint32_t group_base = s_base[6];
+            const uint32_t rec_base = s_base[7];
             const int half = lane >> 5, b = lane & 31;
             for (uint32_t w0 = 0; w0 < NMISS; w0 += 64) {
                 const uint32_t w = w0 + lane;
@@ -607,7 +691,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                             const uint32_t within = my_off + (uint32_t)__popc(my_bits & ((1u << b) - 1u));
                             const uint32_t pos = group_base + within;
                             if (P.record_awareness)
-                                mlm_gp(P.ml_cell)[rec_base + (pos - s_base[4])] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+                                mlm_gp(P.ml_cell)[rec_base + (pos - s_base[6])] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
                             if (pos < P.mc_cap) {
                                 const size_t at = (size_t)sl * P.mc_cap + pos;
                                 mlm_gp(P.mc_bkey)[at] = bkey;
@@ -634,6 +718,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) unsigned long long s_rows[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
     __shared__ uint16_t s_pref[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
+    __shared__ __attribute__((aligned(16))) uint8_t s_kinds[MLM_BLOCK / 64][1024]; // ordered kinds of cells with n <= 1024
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -645,32 +730,35 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
     __builtin_amdgcn_wave_barrier();
     const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
     const MLM_GLOBAL uint32_t *refs = mlm_gp(P.refs);
-    // (record, row) pair p of a cell: the row's byte of the record's lane mask, the work item of the row's first lane, kind
-    auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &pix, uint32_t &sub) {
+    // (record, row) pair p of a cell: the row's byte of the record's lane mask, the position (row << 11 | column) of the
+    // row's first lane, kind
+    auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &yx, uint32_t &sub) {
         bits = 0;
-        pix = 0;
+        yx = 0;
         sub = 0;
         if (p < rf.y * 8u) {
             const uint32_t ref = refs[rf.x + (p >> 3)], row = p & 7u;
             const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + (ref >> 5));
             const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
             bits = (uint32_t)(mask >> (8 * row)) & 0xFFu;
-            pix = (rp[2] & 0x07FFFFFFu) + (tile_w > 0 ? row * (uint32_t)tile_w : row * 8u);
+            yx = rp[1] + (tile_w > 0 ? row << 11 : row * 8u);
             sub = ref & 31u;
         }
     };
-    auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_pix)[4],
+    auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],
                        const uint32_t (&r_sub)[4]) {
         const uint32_t soff = rec.y, n = rec.z, n_refs = rf.y;
         const uint32_t pix0 = rec.w / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
         const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64; // multiple of 8: a record's row byte never straddles a word
         MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + soff;
+        volatile uint8_t *SL = s_kinds[wid];
+        const bool staged = n <= 1024u; // kinds are collected in LDS and leave as whole dwords
+        const int rounds = (int)min(4u, (n_refs * 8u + 63u) >> 6); // (uniform) rounds of 64 pairs held in registers
         bool bad = n > 0xFFFFu;
-        auto locate = [&](uint32_t pix, uint32_t &wi, uint32_t &sh) -> bool {
-            const uint32_t y = (uint32_t)(((unsigned long long)pix * div_m) >> div_s);
-            const int dx = (int)(pix - y * (uint32_t)row_w) - xlo;
-            const uint32_t dy = y - y0;
+        auto locate = [&](uint32_t yx, uint32_t &wi, uint32_t &sh) -> bool {
+            const int dx = (int)(yx & 2047u) - xlo;
+            const uint32_t dy = (yx >> 11) - y0;
             wi = 2 * dy + ((uint32_t)dx >> 6);
             sh = (uint32_t)dx & 63u;
             return dx >= 0 && dx <= 120 && dy < MLM_BMP_ROWS;
@@ -681,8 +769,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
             for (int q = 0; q < 4; ++q) {
                 l_wi[q] = 0;
                 l_sh[q] = 0;
-                if (r_bits[q]) {
-                    if (locate(r_pix[q], l_wi[q], l_sh[q])) atomicOr(&rows[l_wi[q]], (unsigned long long)r_bits[q] << l_sh[q]);
+                if (q < rounds && r_bits[q]) {
+                    if (locate(r_yx[q], l_wi[q], l_sh[q])) atomicOr(&rows[l_wi[q]], (unsigned long long)r_bits[q] << l_sh[q]);
                     else bad = true;
                 }
             }
@@ -722,11 +810,14 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
                 while (bits) { // the row's own set bits, in pixel order; other records' bits may lie between them
                     const int b = __ffs((int)bits) - 1;
                     bits &= bits - 1;
-                    S[before + (uint32_t)__popc(seg & ((1u << b) - 1u))] = (uint8_t)sub;
+                    const uint32_t at = before + (uint32_t)__popc(seg & ((1u << b) - 1u));
+                    if (staged) SL[at] = (uint8_t)sub;
+                    else S[at] = (uint8_t)sub;
                 }
             };
 #pragma unroll
-            for (int q = 0; q < 4; ++q) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q]);
+            for (int q = 0; q < 4; ++q)
+                if (q < rounds) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q]);
             for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
                 uint32_t b, px, sb, wi, sh;
                 load_pair(rf, p, b, px, sb);
@@ -735,21 +826,28 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
                     place(b, wi, sh, sb);
                 }
             }
+            if (staged) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t j = lane; j < (n + 3u) >> 2; j += 64) // (segments are padded to 16 bytes)
+                    ((MLM_GLOBAL uint32_t *)S)[j] = ((volatile uint32_t *)SL)[j];
+            }
         } else {
             // slow exact path (a contribution outside the bitmap window, or a huge cell): write every contribution's
-            // work item into the cell's segment of `contrib`, then rank by counting straight from memory
+            // position into the cell's segment of `contrib`, then rank by counting straight from memory
             MLM_GLOBAL uint32_t *K = mlm_gp(P.contrib) + soff;
             uint32_t base = 0;
             for (uint32_t p0 = 0; p0 < n_refs * 8u; p0 += 64) {
                 uint32_t b, px, sb;
                 load_pair(rf, p0 + lane, b, px, sb);
+                const uint32_t item = (px >> 11) * (uint32_t)row_w + (px & 2047u); // work item of the row's first lane
                 const uint32_t cb = (uint32_t)__popc(b);
                 const uint32_t incl = mlm_wave_incl_scan(cb);
                 uint32_t at = base + incl - cb;
                 while (b) {
                     const int bit = __ffs((int)b) - 1;
                     b &= b - 1;
-                    K[at++] = ((px + (uint32_t)bit) << 5) | sb;
+                    K[at++] = ((item + (uint32_t)bit) << 5) | sb;
                 }
                 base += mlm_readlane(incl, 63);
             }

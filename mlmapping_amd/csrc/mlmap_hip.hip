@@ -619,7 +619,9 @@ int submit_batch(mlm_handle *h, int base, int n) {
     int rc;
     {
         Timed t(h, h->stream_as[set], "stage_a_batch");
-        rc = h->use_sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
+        // (the sector path packs a tile's image column into 11 bits)
+        const bool sectors = h->use_sectors && h->slots[(size_t)base].F.width <= 2040;
+        rc = sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
     }
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
