@@ -40,6 +40,19 @@ struct MlmSecCell {
     uint32_t gpos;  // multi-kind cells: fill cursor into MlmDev::refs (starts at the cell's segment)
 };
 
+#define MLM_SEC_CNT_BITS 20 // MlmSecCell::cnt: contributions in the low bits (mlm_limits.max_points < 2^20 on this path)
+#define MLM_SEC_CNT_MASK ((1u << MLM_SEC_CNT_BITS) - 1u)
+// Does the float noisy-OR chain of the cell (update_odds_hashmap, map_awareness.h:147-154: p <- 1 - (1 - p)(1 - a), each
+// operation rounded) depend on the order of its contributions?  Not with one kind only.  And not once 14 of them have
+// a >= 0.75, whatever the other kinds and the order: the first such step puts p into [0.5, 1], where 1 - p is exact, an
+// integer k <= 2^23 in units of 2^-24; p never decreases; a step with 1 - a <= 0.25 maps k to at most k / 4 + 0.625
+// (product rounded to float, then 1 - m rounded to the grid), every other step to at most k; thirteen quarterings bring
+// any k <= 2^23 to 0, i.e. p == 1.0f, which is absorbing.  Such cells are finished without ranking their contributions.
+#define MLM_SEC_STRONG_ENOUGH 14u
+__device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
+    return __popc(c.kmask) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH;
+}
+
 __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
     mlm_gp(P.ctr)->sector_overflow = 1u;
     g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
@@ -249,17 +262,17 @@ __device__ __forceinline__ uint32_t mlm_block_excl_scan(uint32_t v, uint32_t *s_
 }
 
 // The targets of a hit-centre record: its own cell (kind 0) and the +-d neighbours (kinds 2d-1, 2d), update_hits
-// map_awareness.cpp:135-171.  f(column-local key, kind).  s3 = 3 * sigma_in_dr(rho).
+// map_awareness.cpp:135-171.  f(column-local key, kind, rho of the target).  s3 = 3 * sigma_in_dr(rho).
 template <class F>
 __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int phi, int zi, float s3, F &&f) {
-    f((uint32_t)(zi * P.nRho + rho), 0);
+    f((uint32_t)(zi * P.nRho + rho), 0, rho);
     const double slope = rho > 0 ? (zi - P.zc) / (rho * 1.0) : 0.0;
     for (int d = 1; mlm_spread_active(P, rho, d, s3); ++d) {
         // neighbour cells of step d (mlm_spread_cells), as column-local keys
         int rz = mlm_cvt_int(round(zi + (d * slope)));
-        if (0 <= rz && rz < P.nZ) f((uint32_t)(rz * P.nRho + rho + d), 2 * d - 1);
+        if (0 <= rz && rz < P.nZ) f((uint32_t)(rz * P.nRho + rho + d), 2 * d - 1, rho + d);
         rz = mlm_cvt_int(round(zi - (d * slope)));
-        if (0 <= rz && rz < P.nZ && rho - d >= 0) f((uint32_t)(rz * P.nRho + rho - d), 2 * d);
+        if (0 <= rz && rz < P.nZ && rho - d >= 0) f((uint32_t)(rz * P.nRho + rho - d), 2 * d, rho - d);
     }
 }
 
@@ -359,21 +372,23 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     // pass = 0: book every record's contributions on the cells of the column (and walk the rays of points outside the
     // map); pass = 1: write a (record, kind) reference for every contribution group of a multi-kind cell.  A thread
     // keeps the record it handled first: a column with at most MLM_SEC_THREADS records (the usual case) is not read twice.
-    uint32_t keep_cell = MLM_NIL, keep_gi = 0, keep_total = 0xFFFFFFFFu;
-    auto refs_of = [&](uint32_t cell, uint32_t gi) {
+    uint32_t keep_cell = MLM_NIL, keep_yx = 0, keep_total = 0xFFFFFFFFu;
+    unsigned long long keep_mask = 0;
+    auto refs_of = [&](uint32_t cell, uint32_t yx, unsigned long long mask) {
         const int z = (int)(cell / (uint32_t)P.nRhoPhi);
         const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
-        mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub) {
+        mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int) {
             const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
-            if (e >= 0 && __popc(s_tab[e].kmask) > 1) {
+            if (e >= 0 && mlm_sec_needs_order(s_tab[e])) {
                 const uint32_t at = atomicAdd(&s_tab[e].gpos, 1u);
-                if (at < P.contrib_cap) mlm_gp(P.refs)[at] = (gi << 5) | (uint32_t)sub;
+                if (at < P.refs_cap) // a reference carries what k_rank needs of the record: one round trip there
+                    *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.refs) + 4 * (size_t)at) = mlm_u32x4{(uint32_t)mask, (uint32_t)(mask >> 32), yx, (uint32_t)sub};
             }
         });
     };
     auto for_records = [&](int pass) {
         if (pass == 1 && nch <= MLM_SEC_CHUNKS && keep_total <= MLM_SEC_THREADS) {
-            if (keep_cell != MLM_NIL) refs_of(keep_cell, keep_gi);
+            if (keep_cell != MLM_NIL) refs_of(keep_cell, keep_yx, keep_mask);
             return;
         }
         for (uint32_t c0 = 0; c0 < nch; c0 += MLM_SEC_CHUNKS) {
@@ -414,21 +429,22 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                 }
                 const uint32_t cell = a.x;
                 if (pass == 1) {
-                    refs_of(cell, gi);
+                    refs_of(cell, a.y, *(const MLM_GLOBAL unsigned long long *)(rp + 4));
                     continue;
                 }
                 const int z = (int)(cell / (uint32_t)P.nRhoPhi);
                 const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
-                if (c0 == 0 && r == threadIdx.x) {
-                    keep_cell = cell;
-                    keep_gi = gi;
-                }
                 {
                     const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
+                    if (c0 == 0 && r == threadIdx.x) {
+                        keep_cell = cell;
+                        keep_yx = a.y;
+                        keep_mask = mask;
+                    }
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
                     const uint32_t i_first = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
                     const uint32_t cnt = (uint32_t)__popcll(mask);
-                    mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub) {
+                    mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int rho_t) {
                         const int e = mlm_sec_entry<true>(s_tab, tab_mask, key);
                         if (e < 0) {
                             s_fail = 1;
@@ -436,7 +452,9 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                         }
                         atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
                         atomicOr(&s_tab[e].kmask, 1u << sub);
-                        atomicAdd(&s_tab[e].cnt, cnt);
+                        // contributions, and in the upper 12 bits (mod 4096) those whose odd is >= 0.75
+                        const bool strong = mlm_contribution_odd(P, s_odds, rho_t, sub) >= 0.75f;
+                        atomicAdd(&s_tab[e].cnt, cnt | (strong ? cnt << MLM_SEC_CNT_BITS : 0u));
                         atomicAdd(&s_tab[e].gcnt, 1u);
                     });
                 }
@@ -459,10 +477,10 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         if (c.key == MLM_NIL) continue;
         ++v[0];
         v[2] += c.kmask & 1u;
-        if (__popc(c.kmask) > 1) {
+        if (mlm_sec_needs_order(c)) {
             ++v[1];
             w_refs += c.gcnt;
-            w_subs += (c.cnt + 15u) & ~15u;
+            w_subs += ((c.cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -483,7 +501,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             MlmSecCell &c = s_tab[e];
             if (c.key == MLM_NIL) continue;
             if (c.kmask & 1u) s_rays[o_rays++] = (uint16_t)e;
-            if (__popc(c.kmask) > 1) {
+            if (mlm_sec_needs_order(c)) {
                 s_multi[o_multi++] = (uint16_t)e;
                 c.gpos = o_occ; // (its place in the hit list, until the reference cursor replaces it below)
             }
@@ -498,7 +516,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         s_base[1] = n_multi ? g_atomic_add(&mlm_gp(P.ctr)->n_multi, n_multi) : 0u;
         s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
         s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
-        if (s_base[2] + tot_refs > P.contrib_cap || s_base[3] + tot_subs > P.contrib_cap) s_fail = 1;
+        if (s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap) s_fail = 1;
     }
     __syncthreads();
     MLM_PHASE(2);
@@ -519,17 +537,17 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             if (j < n_multi) {
                 e = s_multi[j];
                 a[0] = s_tab[e].gcnt;
-                a[1] = (s_tab[e].cnt + 15u) & ~15u;
+                a[1] = ((s_tab[e].cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
             }
             mlm_block_excl_scan4(a, s_w, t4);
             if (j < n_multi) {
                 MlmSecCell &c = s_tab[e];
                 const uint32_t pos = s_base[0] + c.gpos, m = s_base[1] + j, o_refs = carry_refs + a[0], o_subs = carry_subs + a[1];
                 mlm_gp(P.mt_list)[m] = pos;
-                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, c.cnt, c.tmin};
+                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, c.cnt & MLM_SEC_CNT_MASK, c.tmin};
                 *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.gcnt};
                 mlm_gp(P.hl_base)[pos] = o_subs;
-                mlm_gp(P.hl_cnt)[pos] = c.cnt;
+                mlm_gp(P.hl_cnt)[pos] = c.cnt & MLM_SEC_CNT_MASK;
                 c.gpos = o_refs;
             }
             carry_refs += t4[0];
@@ -617,11 +635,12 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
         mlm_gp(P.hl_t)[pos] = c.tmin;
         mlm_gp(P.hl_vt)[pos] = c.tmin;
-        if (__popc(c.kmask) == 1) {
-            // cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154); 1.0f is absorbing
+        if (!mlm_sec_needs_order(c)) {
+            // one kind: cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154), 1.0f is absorbing;
+            // several kinds with enough strong contributions: 1.0f in any order (mlm_sec_needs_order)
             const float a = mlm_contribution_odd(P, s_odds, rho, __ffs((int)c.kmask) - 1);
-            float p = a;
-            for (uint32_t j = 1; j < c.cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
+            float p = __popc(c.kmask) > 1 ? 1.0f : a;
+            for (uint32_t j = 1; j < (c.cnt & MLM_SEC_CNT_MASK) && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
             mlm_gp(P.hl_odd)[pos] = p;
             mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
             mlm_gp(P.hl_cnt)[pos] = 0;
@@ -728,7 +747,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
     for (int j = lane; j < MLM_SEC_RANK_WORDS; j += 64) rows[j] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
     const MLM_GLOBAL uint32_t *refs = mlm_gp(P.refs);
     // (record, row) pair p of a cell: the row's byte of the record's lane mask, the position (row << 11 | column) of the
     // row's first lane, kind
@@ -737,12 +755,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
         yx = 0;
         sub = 0;
         if (p < rf.y * 8u) {
-            const uint32_t ref = refs[rf.x + (p >> 3)], row = p & 7u;
-            const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + (ref >> 5));
-            const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
-            bits = (uint32_t)(mask >> (8 * row)) & 0xFFu;
-            yx = rp[1] + (tile_w > 0 ? row << 11 : row * 8u);
-            sub = ref & 31u;
+            const mlm_u32x4 ref = *(const MLM_GLOBAL mlm_u32x4 *)(refs + 4 * (size_t)(rf.x + (p >> 3)));
+            const uint32_t row = p & 7u;
+            bits = ((row & 4u ? ref.y : ref.x) >> (8 * (row & 3u))) & 0xFFu;
+            yx = ref.z + (tile_w > 0 ? row << 11 : row * 8u);
+            sub = ref.w;
         }
     };
     auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],

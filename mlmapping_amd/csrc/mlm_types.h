@@ -186,7 +186,9 @@ struct MlmDev {
     unsigned int chunk_cap;
     unsigned int sec_tab, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two)
     unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
-    uint32_t *refs;            // [contrib_cap] (record index in `bnodes` << 5 | kind) per contribution group of a multi-kind cell
+    uint32_t *refs;            // [refs_cap][4] {lane mask lo, hi, tile origin (row << 11 | column), kind} per contribution group of a
+                               // multi-kind cell
+    unsigned int refs_cap;
     uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count}
     MlmCounters *ctr;          // this slot's per-frame counters
     MlmGlobal *g;

@@ -907,7 +907,8 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
     if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
     if ((rc = dev_alloc(h, &P.col_chunks, h->use_sectors ? 2 * (size_t)P.nPhi * P.chunk_cap : 2))) return rc;
-    if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? (size_t)P.contrib_cap : 1))) return rc;
+    P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, 2 * (size_t)h->lim.max_points); // (more groups than that: cell-table path)
+    if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? 4 * (size_t)P.refs_cap : 4))) return rc;
     if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
     HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
     if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
@@ -1133,7 +1134,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         P.sec_tab = tab;
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
         P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * P.RW), (unsigned int)P.nRho).total;
-        h->use_sectors = !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u;
+        h->use_sectors = !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS);
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         if (h->use_sectors)
             HIPCHK(h, hipFuncSetAttribute((const void *)k_sector, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
