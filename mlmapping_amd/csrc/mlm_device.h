@@ -136,7 +136,7 @@ __device__ __forceinline__ void mlm_cell_center_w(const MlmDev &P, const double 
 // get_global_idx / get_subbox_id, map_local.h:148-152,167-173: two independent divisions per axis; a cell
 // coordinate outside [0,n) maps to id 0 (operator[] default-inserts in the reference).
 __device__ __forceinline__ void mlm_voxel_of(const MlmDev &P, double x, double y, double z, int &gx, int &gy,
-                                             int &gz, int &cid) {
+                                             int &gz, int &cid, int *c3 = nullptr) {
     bool exact = true;
     const double qgx = mlm_quot(x, P.inv_d_glb, exact), qgy = mlm_quot(y, P.inv_d_glb, exact), qgz = mlm_quot(z, P.inv_d_glb, exact);
     const double qsx = mlm_quot(x, P.inv_d_sub, exact), qsy = mlm_quot(y, P.inv_d_sub, exact), qsz = mlm_quot(z, P.inv_d_sub, exact);
@@ -156,10 +156,17 @@ __device__ __forceinline__ void mlm_voxel_of(const MlmDev &P, double x, double y
             cz = mlm_cvt_int(floor(z / P.d_sub) - gz * P.n);
         }
     }
-    if (cx < 0 || cy < 0 || cz < 0 || cx >= P.n || cy >= P.n || cz >= P.n)
+    if (cx < 0 || cy < 0 || cz < 0 || cx >= P.n || cy >= P.n || cz >= P.n) {
         cid = 0;
-    else
+        cx = cy = cz = 0;
+    } else {
         cid = cz * P.n * P.n + cy * P.n + cx;
+    }
+    if (c3) { // cell coordinates inside the block, consistent with cid
+        c3[0] = cx;
+        c3[1] = cy;
+        c3[2] = cz;
+    }
 }
 
 // ---- hashed block table -------------------------------------------------------------------------------------

@@ -276,6 +276,28 @@ __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int ph
     }
 }
 
+// frame-local index of a voxel (MlmDev::lv_state); -1 outside the grid (cannot happen for cells of the awareness cylinder:
+// the grid is sized from its radius and height plus a margin — the frame then falls back)
+__device__ __forceinline__ int mlm_local_voxel(const MlmDev &P, const MlmFrame &F, int gx, int gy, int gz, const int c3[3]) {
+    const int x = gx * P.n + c3[0] - F.lv_o[0], y = gy * P.n + c3[1] - F.lv_o[1], z = gz * P.n + c3[2] - F.lv_o[2];
+    if ((unsigned)x >= (unsigned)P.lv_nx || (unsigned)y >= (unsigned)P.lv_ny || (unsigned)z >= (unsigned)P.lv_nz) return -1;
+    return (z * P.lv_ny + y) * P.lv_nx + x;
+}
+// Slot `at` of sub-list `sl` of the frame's voxel queue: the record of a first-touched voxel, or a hole (kind 2) when the
+// item was not its voxel's first — every hit and every miss cell owns one slot (reserved per column with one atomic), so
+// no reservation depends on what the voxel atomics return
+__device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl, unsigned int at, bool first, int lv, unsigned long long bkey,
+                                                int cid, uint32_t kind) {
+    if (at >= P.tv_cap) return;
+    const size_t i = (size_t)sl * P.tv_cap + at;
+    if (first) {
+        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, (uint32_t)mlm_block_find_k(P, bkey), kind};
+        mlm_gp(P.tv_key)[i] = bkey;
+    } else {
+        mlm_gp(P.tv_rec)[4 * i + 3] = 2u;
+    }
+}
+
 // LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
     uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, total;
@@ -296,7 +318,7 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
 }
 
 __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
-                                                            int rho_s) {
+                                                            int rho_s, unsigned long long n_bkt) {
     MLM_SLOT_SETUP
     const int phi = (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -516,6 +538,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         s_base[1] = n_multi ? g_atomic_add(&mlm_gp(P.ctr)->n_multi, n_multi) : 0u;
         s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
         s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
+        s_base[6] = n_occ ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[blockIdx.x & 7][0], n_occ) : 0u; // voxel-queue slots of the hits
         if (s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap) s_fail = 1;
     }
     __syncthreads();
@@ -627,7 +650,13 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     MLM_PHASE(3);
     // ---- the column's unique hits: cell, first-touch time, world voxel + speculative block slot; single-kind cells get
     //      their odd and increment here (multi-kind cells: k_rank / k_chain)
-    for (uint32_t i = threadIdx.x; i < n_occ; i += MLM_SEC_THREADS) {
+    const unsigned int sl = blockIdx.x & 7;
+    for (uint32_t i0 = 0; i0 < n_occ; i0 += MLM_SEC_THREADS) { // (uniform)
+        const uint32_t i = i0 + threadIdx.x;
+        bool first = false;
+        int lv = -1, h_cid = 0;
+        unsigned long long h_bkey = 0;
+        if (i < n_occ) {
         const MlmSecCell c = s_tab[s_occ[i]];
         int rho, z;
         key_rz(c.key, rho, z);
@@ -645,36 +674,52 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
             mlm_gp(P.hl_cnt)[pos] = 0;
         }
+        // its world voxel: pushed on the voxel's pending list in the frame-local grid (grouping by voxel needs no map);
+        // the first hit of a voxel queues it for the kernel that applies the frame.  Bucket-first time of the emulated
+        // container (iteration order, see Stage B in mlm_kernels.h) for the bucket count the frame was submitted with.
         double wx, wy, wz;
         mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-        int gx, gy, gz, cid;
-        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-        const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
-        mlm_gp(P.hl_bkey)[pos] = bkey;
-        mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
-        mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
+        int gx, gy, gz, cid, c3[3];
+        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid, c3);
+        lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
+        if (lv >= 0) {
+            const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
+            mlm_gp(P.hl_bkt)[pos] = (uint32_t)b;
+            if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
+            const uint32_t prev = __hip_atomic_exchange((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv), pos + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mlm_gp(P.hl_next)[pos] = (int)prev - 1;
+            first = prev == 0u;
+            h_bkey = mlm_pack_key(gx, gy, gz);
+            h_cid = cid;
+        } else {
+            s_fail = 1;
+        }
+            mlm_queue_voxel(P, sl, s_base[6] + i, first, lv, h_bkey, h_cid, 0u);
+        }
     }
     MLM_PHASE(4);
     // ---- references of the multi-kind cells (their fill cursors were set above)
     if (n_multi) for_records(1);
     MLM_PHASE(5);
-    // ---- the column's unique miss cells (its bit mask) with their world voxels, appended to sub-list (column & 7)
+    // ---- the column's unique miss cells (its bit mask): each counts one miss on its world voxel in the frame-local grid
+    //      (every miss adds the same constant, map_local.cpp:188-192: only the count per voxel matters); the first miss of
+    //      a voxel queues it for the kernel that applies the frame
     {
-        const unsigned int sl = blockIdx.x & 7;
         uint32_t vm = 0;
         for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) vm += (uint32_t)__popc(s_miss[w]);
         uint32_t total;
-        mlm_block_excl_scan(vm, s_w, &total); // (only the total is needed: positions are re-derived per 64-word group)
+        mlm_block_excl_scan(vm, s_w, &total);
         if (threadIdx.x == 0) {
-            s_base[6] = total ? g_atomic_add(&mlm_gp(P.ctr)->mc_cnt[sl][0], total) : 0u;
+            if (total) g_atomic_add(&mlm_gp(P.ctr)->umiss_part[sl][0], total);
+            s_base[5] = total ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[sl][0], total) : 0u; // voxel-queue slots of the miss cells
             s_base[7] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
             mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
         }
         __syncthreads();
         if (total) {
-            // groups of 64 words, one per wave at a time; the offset of a group = bits in the groups before it
-            uint32_t group_base = s_base[6];
+            // groups of 64 words, one per wave at a time; two words are expanded at once (lane = bit)
+            uint32_t group_base = 0;
             const uint32_t rec_base = s_base[7];
             const int half = lane >> 5, b = lane & 31;
             for (uint32_t w0 = 0; w0 < NMISS; w0 += 64) {
@@ -700,23 +745,25 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                         const uint32_t my_off = half ? mlm_readlane(excl, sb) : mlm_readlane(excl, sa);
                         const int wi_all = (int)w0 + (half ? sb : sa);
                         if ((my_bits >> b) & 1u) {
+                            bool first = false;
+                            int lv = -1, m_cid = 0;
+                            unsigned long long m_bkey = 0;
+                            const uint32_t within = group_base + my_off + (uint32_t)__popc(my_bits & ((1u << b) - 1u));
                             const int z = wi_all / P.RW;
                             const int rho = (wi_all - z * P.RW) * 32 + b;
                             double wx, wy, wz;
                             mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-                            int gx, gy, gz, cid;
-                            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-                            const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
-                            const uint32_t within = my_off + (uint32_t)__popc(my_bits & ((1u << b) - 1u));
-                            const uint32_t pos = group_base + within;
-                            if (P.record_awareness)
-                                mlm_gp(P.ml_cell)[rec_base + (pos - s_base[6])] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
-                            if (pos < P.mc_cap) {
-                                const size_t at = (size_t)sl * P.mc_cap + pos;
-                                mlm_gp(P.mc_bkey)[at] = bkey;
-                                mlm_gp(P.mc_cid)[at] = (uint32_t)cid;
-                                mlm_gp(P.mc_slot)[at] = mlm_block_find_k(P, bkey);
+                            int gx, gy, gz, c3[3];
+                            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, m_cid, c3);
+                            lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
+                            if (P.record_awareness) mlm_gp(P.ml_cell)[rec_base + within] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+                            if (lv >= 0) {
+                                m_bkey = mlm_pack_key(gx, gy, gz);
+                                first = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u) == 0u;
+                            } else {
+                                s_fail = 1;
                             }
+                            mlm_queue_voxel(P, sl, s_base[5] + within, first, lv, m_bkey, m_cid, 1u);
                         }
                     }
                 }
@@ -724,6 +771,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_fail) mlm_sector_fail(P, F); // (a voxel outside the frame-local grid)
     MLM_PHASE(6);
     MLM_PHASE_END
 }
@@ -918,5 +967,147 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
             p_cur[q] = p_nxt[q];
             s_cur[q] = s_nxt[q];
         }
+    }
+}
+
+// The part of a frame that needs the map (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237), sector
+// path: ONE launch per frame, one first-touched voxel per lane (blockIdx.y = sub-list).  Stage A has already grouped the
+// frame's hits and misses by voxel in the frame-local grid, so all that is left is: block lookup / creation
+// (allocate_ram, map_local.h:215-231), the voxel's hits in the reference's iteration order (descending key,
+// map_local.cpp:157-171), then its misses (map_local.cpp:188-203) — the reference runs all hits before all misses.
+// A voxel that has hits is owned by the record of its first hit; a record of a first miss skips such a voxel.
+// explicit_keys: hl_key holds the exact iteration-order keys (rehash frames, order_hits_exact); otherwise the key is
+// (bucket-first time from this slot's table, insertion time), valid if the frame fits the emulated container without a
+// rehash — else the frame is flagged (g->fail_frame) and replayed by the host.
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const MlmFrame F, int explicit_keys) {
+    __builtin_amdgcn_s_setprio(3); // the serial chain of the pipeline: its few waves issue ahead of Stage A's
+    const unsigned int sl = blockIdx.y;
+    const int frame_idx = F.seq;
+    const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    const MLM_GLOBAL uint32_t *recs = mlm_gp(P.tv_rec) + 4 * (size_t)sl * P.tv_cap;
+    const MLM_GLOBAL unsigned long long *keys = mlm_gp(P.tv_key) + (size_t)sl * P.tv_cap;
+    // speculative loads of item i0 (in bounds of the arrays, whatever the list length turns out to be)
+    mlm_u32x4 p_rec = mlm_u32x4{0u, 0u, 0xFFFFFFFFu, 2u};
+    unsigned long long p_key = 0;
+    if (i0 < P.tv_cap) {
+        p_rec = *(const MLM_GLOBAL mlm_u32x4 *)(recs + 4 * (size_t)i0);
+        p_key = keys[i0];
+    }
+    const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int n = min(mlm_gp(P.ctr)->mvox_cnt[sl][0], P.tv_cap);
+    const unsigned int n_hits = mlm_gp(P.ctr)->u_hit;
+    if (ff <= frame_idx) return;
+    if (!explicit_keys && n_hits > F.rehash_thr) { // speculation miss: the frame needs a rehash of the emulated container
+        if (i0 == 0 && sl == 0) atomicMin(&P.g->fail_frame, frame_idx);
+        return;
+    }
+    for (unsigned int i = i0; i < n; i += stride) {
+        if (i != i0) {
+            p_rec = *(const MLM_GLOBAL mlm_u32x4 *)(recs + 4 * (size_t)i);
+            p_key = keys[i];
+        }
+        if (p_rec.w >= 2u) continue; // a hole: the item was not its voxel's first
+        MLM_GLOBAL unsigned long long *st = mlm_gp(P.lv_state) + p_rec.x;
+        int slot = (int)p_rec.z;
+        // the voxel's pending state, and (the block being known already in the common case) its map state: one round trip
+        const unsigned long long state = *st;
+        float L = 0.0f;
+        uint8_t o = 'u';
+        size_t v = 0;
+        if (slot >= 0) {
+            v = (size_t)slot * P.cells + p_rec.y;
+            L = mlm_gp(P.log_odds)[v];
+            o = mlm_gp(P.occ)[v];
+        }
+        const uint32_t head1 = (uint32_t)state, km = (uint32_t)(state >> 32);
+        if (p_rec.w == 1u && head1 != 0u) continue; // the owner of the voxel's hits applies its misses too
+        if (head1 == 0u && km == 0u) continue;      // (consumed already: never write a stale value back)
+        *st = 0ull;
+        if (slot < 0) {
+            slot = mlm_block_slot(P, p_key);
+            if (slot < 0) continue; // block pool full (error flag set)
+            v = (size_t)slot * P.cells + p_rec.y;
+            L = mlm_gp(P.log_odds)[v];
+            o = mlm_gp(P.occ)[v];
+        }
+        if (head1) {
+            const int head = (int)head1 - 1;
+            const int nxt = mlm_gp(P.hl_next)[head];
+            const float inc = mlm_gp(P.hl_inc)[head]; // (same round trip as the link)
+            if (nxt < 0) { // the common case: a single contribution
+                if (L < P.lo_max) {
+                    L = L + inc;
+                    L = L > P.lo_max ? P.lo_max : L;
+                }
+                if (L > P.lo_sh && o != 'o') o = 'o';
+            } else {
+                auto key_of = [&](int j) -> unsigned long long {
+                    if (explicit_keys) return mlm_gp(P.hl_key)[j];
+                    const unsigned long long first = mlm_gp(P.sbkt)[mlm_gp(P.hl_bkt)[j]] & 0xFFFFFFFFull;
+                    return ((first + 1ull) << 32) | (unsigned long long)mlm_gp(P.hl_vt)[j];
+                };
+                // one walk over the list collects (key, increment) into registers kept in descending key order; lists
+                // longer than that fall back to repeated selection straight from memory
+                unsigned long long ks[MLM_APPLY_REGS];
+                float vs[MLM_APPLY_REGS];
+#pragma unroll
+                for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                    ks[q] = 0; // real keys are never 0
+                    vs[q] = 0.0f;
+                }
+                int cnt = 0;
+                for (int j = head; j >= 0; j = mlm_gp(P.hl_next)[j]) {
+                    unsigned long long k = key_of(j);
+                    float inc = mlm_gp(P.hl_inc)[j];
+                    ++cnt;
+#pragma unroll
+                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                        if (k > ks[q]) {
+                            const unsigned long long tk = ks[q];
+                            const float tv = vs[q];
+                            ks[q] = k;
+                            vs[q] = inc;
+                            k = tk;
+                            inc = tv;
+                        }
+                    }
+                }
+                if (cnt <= MLM_APPLY_REGS) {
+#pragma unroll
+                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                        if (q < cnt) {
+                            if (L < P.lo_max) {
+                                L = L + vs[q];
+                                L = L > P.lo_max ? P.lo_max : L;
+                            }
+                            if (L > P.lo_sh && o != 'o') o = 'o';
+                        }
+                    }
+                } else {
+                    unsigned long long last = ~0ull;
+                    for (;;) {
+                        int best = -1;
+                        unsigned long long bestkey = 0;
+                        for (int j = head; j >= 0; j = mlm_gp(P.hl_next)[j]) {
+                            const unsigned long long k = key_of(j);
+                            if (k < last && (best < 0 || k > bestkey)) {
+                                best = j;
+                                bestkey = k;
+                            }
+                        }
+                        if (best < 0) break;
+                        if (L < P.lo_max) {
+                            L = L + mlm_gp(P.hl_inc)[best];
+                            L = L > P.lo_max ? P.lo_max : L;
+                        }
+                        if (L > P.lo_sh && o != 'o') o = 'o';
+                        last = bestkey;
+                    }
+                }
+            }
+        }
+        mlm_apply_misses(P, L, o, km);
+        mlm_gp(P.log_odds)[v] = L;
+        mlm_gp(P.occ)[v] = o;
     }
 }

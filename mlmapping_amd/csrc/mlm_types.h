@@ -190,6 +190,16 @@ struct MlmDev {
                                // multi-kind cell
     unsigned int refs_cap;
     uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count}
+    // frame-local voxel grid: the voxels the awareness cylinder can reach, addressed relative to MlmFrame::lv_o, so
+    // that hits and misses are grouped by voxel in Stage A without knowing the map (block slots)
+    unsigned long long *lv_state; // [lv_nx*lv_ny*lv_nz] low word: 1 + index of the voxel's newest pending hit (0 = none), high
+                               // word: misses of the frame; reset by the kernel that applies the frame
+    int lv_nx, lv_ny, lv_nz;
+    uint32_t *tv_rec;          // [MLM_RAY_LISTS][tv_cap][4] first-touched voxels: {lv, cell id, block slot or -1, 0 hit / 1 miss}
+    unsigned long long *tv_key;// [MLM_RAY_LISTS][tv_cap] ... packed block key          (counts: MlmCounters::mvox_cnt)
+    unsigned int tv_cap;
+    unsigned long long *sbkt;  // [sbkt_cap] this slot's bucket-first table of the emulated hit container: (~seq << 32 | time),
+    unsigned int sbkt_cap;     // never cleared (a newer frame's entries win the min)
     MlmCounters *ctr;          // this slot's per-frame counters
     MlmGlobal *g;
 };
@@ -206,4 +216,6 @@ struct MlmFrame {
     int n;                 // work items: pixels (dense), list length (indexed) or points
     int seq;               // sequence number of the frame (speculation bookkeeping)
     unsigned int rehash_thr; // the emulated hit container takes this many elements without a rehash (speculative Stage B)
+    int lv_o[3];           // origin of the frame-local voxel grid (MlmDev::lv_state) in voxel coordinates
+    int pad2;
 };

@@ -48,6 +48,7 @@ struct MlmSlot {
     int seq = 0;              // sequence number of the frame it currently holds
     unsigned int nb = 0;      // k_bin_points blocks
     unsigned int ex_um = 0;   // frontier mode: unique miss cells of the frame it holds
+    bool sector = false;      // the frame it holds went through the sector path (Stage A and the frame-local voxel grid)
     uint16_t *d_img = nullptr; // staging for host images
     size_t img_cap = 0;
     int32_t *d_pix = nullptr;
@@ -216,6 +217,12 @@ inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 b
 void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb_in[3], MlmFrame &F) {
     frame_pose(h->q_bs, h->t_bs, q_wb_in, t_wb_in, F.q_ls, F.t_ls, F.t_wa);
     F.rehash_thr = 0xFFFFFFFFu; // only the speculative Stage B arms the check (submit_batch)
+    // origin of the frame-local voxel grid: the awareness cylinder around t_wa with a margin of four voxels
+    const MlmDev &P = h->P;
+    const double R = P.nRho * P.dRho;
+    F.lv_o[0] = (int)std::floor((F.t_wa[0] - R) / P.d_sub) - 4;
+    F.lv_o[1] = (int)std::floor((F.t_wa[1] - R) / P.d_sub) - 4;
+    F.lv_o[2] = (int)std::floor((F.t_wa[2] + P.z_border_min) / P.d_sub) - 4;
 }
 
 std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
@@ -399,7 +406,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         int rs;
         div_magic((unsigned int)P.nRho, rm, rs);
         tlaunch(h, "k_sector", k_sector, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
-                h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs);
+                h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
         tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->sort_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
                 mode == 0 ? F.width : 0, row_w, dm, ds);
         tlaunch(h, "k_chain", k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab,
@@ -451,7 +458,8 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
     const MlmDev &P = S.P;
     bool over = c.n_contrib > P.contrib_cap;
     for (int k = 0; k < MLM_RAY_LISTS; ++k)
-        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mc_cnt[k][0] > P.mc_cap;
+        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mc_cnt[k][0] > P.mc_cap ||
+               (S.sector && c.mvox_cnt[k][0] > P.tv_cap);
     if (over) {
         h->err = "a per-frame device queue overflowed (raise mlm_limits.max_points)";
         return MLM_ERR_CAPACITY;
@@ -617,15 +625,29 @@ int submit_batch(mlm_handle *h, int base, int n) {
         S.F.rehash_thr = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
     }
     int rc;
+    // (the sector path packs a tile's image column into 11 bits; its bucket-first tables hold sbkt_cap buckets)
+    const bool sectors = h->use_sectors && h->slots[(size_t)base].F.width <= 2040 && h->hit_n_bkt <= h->slots[(size_t)base].P.sbkt_cap;
+    for (int j = 0; j < n; ++j) h->slots[(size_t)(base + j)].sector = sectors;
     {
         Timed t(h, h->stream_as[set], "stage_a_batch");
-        // (the sector path packs a tile's image column into 11 bits)
-        const bool sectors = h->use_sectors && h->slots[(size_t)base].F.width <= 2040;
         rc = sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
     }
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
-    {
+    if (sectors) {
+        // one launch per frame: Stage A has grouped the frame's hits and misses by voxel already (k_apply_frame)
+        Timed t(h, h->stream, "stage_bc_batch");
+        unsigned int scg = h->sc_grid;
+        if (!h->sc_grid_fixed) { // one first-touched voxel per thread for a frame like the last confirmed one
+            const long long items = (h->stats.n_hit_cells + h->stats.n_miss_cells) / MLM_RAY_LISTS;
+            scg = (unsigned int)std::min<long long>(1024, std::max<long long>(8, (items + MLM_BLOCK - 1) / MLM_BLOCK));
+        }
+        for (int j = 0; j < n; ++j) {
+            MlmSlot &S = h->slots[(size_t)(base + j)];
+            tlaunch(h, "k_apply_frame", k_apply_frame, dim3(scg * (MLM_BLOCK / h->sc_block), MLM_RAY_LISTS), dim3(h->sc_block), 0, h->stream, S.P, S.F, 0);
+            h->pending.push_back(&S);
+        }
+    } else {
         // launch j = k_apply of frame j-1 + k_voxelize of frame j (see k_apply_voxelize): n+1 launches for n frames
         Timed t(h, h->stream, "stage_bc_batch");
         // blocks per list: one item per thread for a frame like the last confirmed one (grid-stride loops take the rest)
@@ -682,20 +704,41 @@ int drain(mlm_handle *h) {
         MlmSlot &S = *h->pending.front();
         h->h_g->fail_frame = 0x7FFFFFFF;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        if (S.h_ctr->sector_overflow) {
-            h->n_sector_fallbacks++;
-            const int si = (int)(&S - h->slots.data());
-            const int set = si / ((int)h->slots.size() / MLM_SETS);
-            HIPCHK(h, hipStreamSynchronize(h->stream)); // fail_frame is re-armed before the cell-table kernels may flag it again
-            rc = launch_stage_a_batch(h, si, 1);
-            if (rc) return rc;
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
-            HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        } else {
-            h->n_spec_miss++;
+        if (S.sector) {
+            // Sector path: the frames in flight were binned into buckets with the bucket count of their submission, which
+            // the rehash changes — every pending frame is finished with exact keys, in order (no further speculation).
+            for (size_t j = 0; j < h->pending.size(); ++j) {
+                MlmSlot &R = *h->pending[j];
+                if (R.h_ctr->sector_overflow) {
+                    h->n_sector_fallbacks++;
+                    const int si = (int)(&R - h->slots.data());
+                    const int set = si / ((int)h->slots.size() / MLM_SETS);
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    // the frame-local grid holds what the sectors that did finish pushed: wipe it, then the cell-table path
+                    HIPCHK(h, hipMemsetAsync(R.P.lv_state, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * sizeof(unsigned long long), h->stream_as[set]));
+                    rc = launch_stage_a_batch(h, si, 1);
+                    if (rc) return rc;
+                    HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
+                    HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+                    R.sector = false;
+                } else if (j == 0) {
+                    h->n_spec_miss++;
+                }
+                rc = check_queues(h, R);
+                if (rc) return rc;
+                rc = order_hits_exact(h, R, R.h_ctr->u_hit, R.seq);
+                if (rc) return rc;
+                if (R.sector)
+                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(160, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1);
+                else
+                    launch_stage_bc(h, R, 0);
+                HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+            }
+            continue; // (the loop's synchronisation confirms them)
         }
+        h->n_spec_miss++;
         rc = check_queues(h, S);
         if (rc) return rc;
         rc = order_hits_exact(h, S, S.h_ctr->u_hit, S.seq);
@@ -706,7 +749,7 @@ int drain(mlm_handle *h) {
         // the new policy state (their unique-hit counts are known), then resubmit their Stage B/C
         int ff = 0x7FFFFFFF;
         for (size_t j = h->pending.size(); j-- > 1;)
-            if (h->pending[j]->h_ctr->sector_overflow || h->pending[j]->h_ctr->u_hit > h->hit_pol._M_next_resize) ff = h->pending[j]->seq;
+            if (h->pending[j]->h_ctr->u_hit > h->hit_pol._M_next_resize) ff = h->pending[j]->seq;
         HIPCHK(h, hipStreamSynchronize(h->stream)); // h_g is about to be rewritten
         h->h_g->fail_frame = ff;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -907,6 +950,19 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
     if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
     if ((rc = dev_alloc(h, &P.col_chunks, h->use_sectors ? 2 * (size_t)P.nPhi * P.chunk_cap : 2))) return rc;
+    if (h->use_sectors) {
+        const size_t nlv = (size_t)P.lv_nx * P.lv_ny * P.lv_nz;
+        if ((rc = dev_alloc(h, &P.lv_state, nlv))) return rc;
+        HIPCHK(h, hipMemset(P.lv_state, 0, nlv * sizeof(unsigned long long)));
+        P.tv_cap = (unsigned int)(((size_t)P.nMissWords * 32 + NC) / MLM_RAY_LISTS + 4096);
+        if ((rc = dev_alloc(h, &P.tv_rec, 4 * (size_t)MLM_RAY_LISTS * P.tv_cap))) return rc;
+        if ((rc = dev_alloc(h, &P.tv_key, (size_t)MLM_RAY_LISTS * P.tv_cap))) return rc;
+        // bucket-first table of this slot: room for the emulated container of a frame with up to 2 * max_points unique
+        // hit cells (more: the handle continues on the cell-table path)
+        P.sbkt_cap = (unsigned int)std::min<size_t>(h->max_buckets, std::__detail::_Prime_rehash_policy()._M_next_bkt(4 * (size_t)h->lim.max_points + 2));
+        if ((rc = dev_alloc(h, &P.sbkt, (size_t)P.sbkt_cap))) return rc;
+        HIPCHK(h, hipMemset(P.sbkt, 0xFF, (size_t)P.sbkt_cap * sizeof(unsigned long long)));
+    }
     P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, 2 * (size_t)h->lim.max_points); // (more groups than that: cell-table path)
     if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? 4 * (size_t)P.refs_cap : 4))) return rc;
     if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
@@ -1134,7 +1190,13 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         P.sec_tab = tab;
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
         P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * P.RW), (unsigned int)P.nRho).total;
-        h->use_sectors = !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS);
+        {
+            // frame-local voxel grid: the awareness cylinder (radius nRho*dRho, height nZ*dZ) plus four voxels each side
+            const double R = P.nRho * P.dRho;
+            P.lv_nx = P.lv_ny = 2 * (int)std::ceil(R / P.d_sub) + 10;
+            P.lv_nz = (int)std::ceil(P.nZ * P.dZ / P.d_sub) + 10;
+        }
+        h->use_sectors = (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26) && !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS);
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         if (h->use_sectors)
             HIPCHK(h, hipFuncSetAttribute((const void *)k_sector, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
