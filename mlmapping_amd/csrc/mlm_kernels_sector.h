@@ -291,7 +291,7 @@ __device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl
     if (at >= P.tv_cap) return;
     const size_t i = (size_t)sl * P.tv_cap + at;
     if (first) {
-        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, (uint32_t)mlm_block_find_k(P, bkey), kind};
+        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, P.sec_probe ? (uint32_t)mlm_block_find_k(P, bkey) : 0xFFFFFFFFu, kind};
         mlm_gp(P.tv_key)[i] = bkey;
     } else {
         mlm_gp(P.tv_rec)[4 * i + 3] = 2u;
