@@ -102,6 +102,7 @@ typedef struct mlm_frame_stats {
     int64_t n_groups;        /* (wave, cell, kind) contribution groups (merged per cell in LDS before any global atomic) */
     int64_t n_rays;          /* rays walked after de-duplication */
     int64_t n_spec_replays;  /* frames so far whose Stage B had to be replayed with a rehash plan */
+    int64_t n_device_atomics;   /* device-scope atomics the frame's Stage A issued, counted by the kernels (0 on the cell-table path) */
     int64_t n_sector_fallbacks; /* frames so far redone by the cell-table path (an azimuth sector overflowed its LDS tables) */
 } mlm_frame_stats;
 

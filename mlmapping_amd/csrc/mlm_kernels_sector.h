@@ -714,6 +714,9 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             s_base[5] = total ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[sl][0], total) : 0u; // voxel-queue slots of the miss cells
             s_base[7] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
+            // device-scope atomics on account of this column: its chunk descriptors (k_bin_sectors), the list reservations
+            // above and here (up to 10, this one included), a bucket-min and a push per hit, a count per miss cell
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][1], nch_all + 10u + 2u * n_occ + total);
             mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
         }
         __syncthreads();

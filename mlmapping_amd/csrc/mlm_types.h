@@ -25,7 +25,8 @@ struct MlmCounters {
     unsigned int sector_overflow; // sector path: an LDS table of some column overflowed -> the frame is redone by the cell-table path
     unsigned int n_refs;      // sector path: (record, kind) references of the multi-kind cells
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
-    unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart
+    unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart;
+                                 // [k][1] = device-scope atomics the frame's kernels issued (sector path, counted by k_sector)
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells

@@ -442,11 +442,13 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
     h->stats.n_multi_cells = c.n_multi;
     h->stats.n_contrib_slots = c.n_contrib;
-    int64_t ng = c.n_groups, nr = 0;
+    int64_t ng = c.n_groups, nr = 0, na = 0;
     for (int k = 0; k < MLM_RAY_LISTS; ++k) {
         ng += c.node_cnt[k][0];
         nr += c.ray_cnt[k][0];
+        na += c.ray_cnt[k][1];
     }
+    h->stats.n_device_atomics = na;
     h->stats.n_groups = ng;
     h->stats.n_rays = nr;
     h->stats.n_spec_replays = h->n_spec_miss;
