@@ -721,56 +721,42 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         }
         __syncthreads();
         if (total) {
-            // groups of 64 words, one per wave at a time; two words are expanded at once (lane = bit)
-            uint32_t group_base = 0;
+            // one miss cell per thread: item i lives in the word w with off[w] <= i < off[w + 1] (exclusive prefix of the
+            // words' popcounts, in the idle chunk-staging area) and is that word's (i - off[w])-th set bit — so that the
+            // voxel atomics of all the column's miss cells are in flight together instead of one round trip per word pair
+            uint32_t *s_off = s_chunk_first; // [NMISS] (NMISS < 2 * MLM_SEC_CHUNKS, checked by the host)
+            uint32_t run = 0;
+            for (uint32_t w0 = 0; w0 < NMISS; w0 += MLM_SEC_THREADS) {
+                const uint32_t w = w0 + threadIdx.x;
+                uint32_t tot_w;
+                const uint32_t off = mlm_block_excl_scan(w < NMISS ? (uint32_t)__popc(s_miss[w]) : 0u, s_w, &tot_w);
+                if (w < NMISS) s_off[w] = run + off;
+                run += tot_w;
+            }
+            __syncthreads();
             const uint32_t rec_base = s_base[7];
-            const int half = lane >> 5, b = lane & 31;
-            for (uint32_t w0 = 0; w0 < NMISS; w0 += 64) {
-                const uint32_t w = w0 + lane;
-                const uint32_t bits = w < NMISS ? s_miss[w] : 0u;
-                const uint32_t cnt = (uint32_t)__popc(bits);
-                const uint32_t incl = mlm_wave_incl_scan(cnt);
-                const uint32_t gtot = mlm_readlane(incl, 63);
-                if ((w0 >> 6) % MLM_SEC_WAVES == (uint32_t)wid && gtot) {
-                    const uint32_t excl = incl - cnt;
-                    unsigned long long nz = __ballot(bits != 0);
-                    while (nz) {
-                        const int sa = __ffsll((long long)nz) - 1;
-                        nz &= nz - 1;
-                        int sb = sa;
-                        uint32_t bits_b = 0;
-                        if (nz) {
-                            sb = __ffsll((long long)nz) - 1;
-                            nz &= nz - 1;
-                            bits_b = mlm_readlane(bits, sb);
-                        }
-                        const uint32_t my_bits = half ? bits_b : mlm_readlane(bits, sa);
-                        const uint32_t my_off = half ? mlm_readlane(excl, sb) : mlm_readlane(excl, sa);
-                        const int wi_all = (int)w0 + (half ? sb : sa);
-                        if ((my_bits >> b) & 1u) {
-                            bool first = false;
-                            int lv = -1, m_cid = 0;
-                            unsigned long long m_bkey = 0;
-                            const uint32_t within = group_base + my_off + (uint32_t)__popc(my_bits & ((1u << b) - 1u));
-                            const int z = wi_all / P.RW;
-                            const int rho = (wi_all - z * P.RW) * 32 + b;
-                            double wx, wy, wz;
-                            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-                            int gx, gy, gz, c3[3];
-                            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, m_cid, c3);
-                            lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
-                            if (P.record_awareness) mlm_gp(P.ml_cell)[rec_base + within] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
-                            if (lv >= 0) {
-                                m_bkey = mlm_pack_key(gx, gy, gz);
-                                first = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u) == 0u;
-                            } else {
-                                s_fail = 1;
-                            }
-                            mlm_queue_voxel(P, sl, s_base[5] + within, first, lv, m_bkey, m_cid, 1u);
-                        }
-                    }
+            for (uint32_t i = threadIdx.x; i < total; i += MLM_SEC_THREADS) {
+                uint32_t lo = 0, hi = NMISS; // largest w with off[w] <= i
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= i) lo = mid;
+                    else hi = mid;
                 }
-                group_base += gtot;
+                uint32_t bits = s_miss[lo];
+                for (uint32_t k = i - s_off[lo]; k > 0; --k) bits &= bits - 1;
+                const int b = __ffs((int)bits) - 1;
+                const int z = (int)lo / P.RW;
+                const int rho = ((int)lo - z * P.RW) * 32 + b;
+                double wx, wy, wz;
+                mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+                int gx, gy, gz, m_cid, c3[3];
+                mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, m_cid, c3);
+                const int lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
+                if (P.record_awareness) mlm_gp(P.ml_cell)[rec_base + i] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+                bool first = false;
+                if (lv >= 0) first = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u) == 0u;
+                else s_fail = 1;
+                mlm_queue_voxel(P, sl, s_base[5] + i, first, lv, mlm_pack_key(gx, gy, gz), m_cid, 1u);
             }
         }
     }

@@ -1200,7 +1200,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             P.lv_nx = P.lv_ny = 2 * (int)std::ceil(R / P.d_sub) + 10;
             P.lv_nz = (int)std::ceil(P.nZ * P.dZ / P.d_sub) + 10;
         }
-        h->use_sectors = (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26) && !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS);
+        h->use_sectors = (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26) && P.nZ * P.RW < 2 * MLM_SEC_CHUNKS && !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS);
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         if (h->use_sectors)
             HIPCHK(h, hipFuncSetAttribute((const void *)k_sector, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));

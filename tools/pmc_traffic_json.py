@@ -20,7 +20,7 @@ def load(path, name):
 
 f = load(sys.argv[1], "FETCH_SIZE")
 w = load(sys.argv[2], "WRITE_SIZE")
-n_frames = max(v[1] for k, v in f.items() if k == "k_bin_points")
+n_frames = max(v[1] for k, v in f.items() if k in ("k_bin_points", "k_bin_sectors"))
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over tools/pmc_workload.py "
                  "(one launch = one VGA frame of the bench workload)",
        "unit": "bytes per frame (Stage A kernels are launched once per batch in bench.py: multiply by frames_per_launch)",

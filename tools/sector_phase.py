@@ -11,8 +11,8 @@ from mlmapping_amd import mlmap as mm
 from mlmapping_amd import synthetic as syn
 from mlmapping_amd.config import S1, S3
 
-NAMES = ["0 LDS init", "1 pass 0: book records on cells", "2 per-cell scans", "3 rays into the LDS mask (DDA)",
-         "4 hit write-out, single-kind odds, voxels", "5 pass 1: references", "6 miss expansion + voxels", "7 -", "8 -"]
+NAMES = ["0 LDS init", "1 pass 0: book records on cells", "2 lists + reservations + multi-kind descriptors", "3 rays into the LDS mask (DDA)",
+         "4 hit list, single-kind odds, voxel pushes", "5 pass 1: references", "6 miss cells: voxel counts + queue", "7 -", "8 -"]
 L = mm.load_library(os.path.join(os.path.dirname(mm.LIB_PATH), "libmlmap_hip_prof.so"))
 L.mlm_debug_phases.argtypes = [ctypes.c_void_p]
 mm._lib = L
