@@ -30,7 +30,8 @@ extern "C" int mlm_sort_pairs_u64_u32(void *temp, size_t temp_bytes, const unsig
 
 namespace {
 
-#define MLM_SETS 2 // slot sets: one being filled while the other drains (3 measured slower: 34.1k vs 35.7k frames/s)
+#define MLM_SETS 3 // slot sets: batches in flight (one being filled, one in Stage A, one draining).  Measured on config 2 with the sector
+                   // path: 44.7k frames/s with 2, 48.4k with 3, 45.3k with 4
 
 struct KernelTime {
     const char *name;
