@@ -80,7 +80,8 @@ typedef struct mlm_limits {
     int32_t max_blocks;      /* capacity of the hashed block pool (n^3 cells each); 0 = default 65536 */
     int32_t max_points;      /* largest point count of one frame; 0 = 1280*720 */
     int32_t max_batch;       /* frames integrated per launch sequence (batch entry points); 0 = 8, at most 64;
-                              * every frame in flight owns ~0.3 GB (S1) .. 2 GB (S3) of scratch, two sets of them */
+                              * every frame in flight owns ~0.35 GB (S1) .. 2.2 GB (S3) of scratch, three sets of them
+                              * (one being filled, one in the map-independent stage, one draining) */
     int32_t record_awareness;/* keep per-frame hit/miss lists readable via mlm_get_awareness_* (tests) */
 } mlm_limits;
 

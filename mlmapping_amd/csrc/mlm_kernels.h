@@ -1,4 +1,7 @@
-// mlm_kernels.h — HIP kernels of the per-frame map update (gfx950, wave64).
+// mlm_kernels.h — HIP kernels of the per-frame map update (gfx950, wave64): the CELL-TABLE path of Stage A and its
+// two-kernel Stage B+C (frontier mode, images wider than 2040 pixels, and the fall-back of frames in which an azimuth
+// sector overflows its LDS tables), the rehash-replay kernels, k_chain, queries, inflation, exports.  The default Stage A
+// (by azimuth sector) and its one-launch-per-frame apply kernel are in mlm_kernels_sector.h.
 //
 // Stage A  (awareness_map_cylindrical::input_pc_pose, map_awareness.cpp:173-282)
 //   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions as wave groups, de-duplicated ray walk

@@ -1,8 +1,8 @@
 // mlmap_hip.hip — host side of libmlmap_hip.so: the C ABI of include/mlmap_hip.h.
 //
-// Host work per frame is O(1): the pose composition T_ls (map_awareness.cpp:184-186), the bookkeeping of the
-// emulated libstdc++ rehash policy of hit_idx_odds_hashmap, and kernel launches.  All per-point / per-cell /
-// per-voxel work runs in the kernels of mlm_kernels.h.  There is no CPU fallback: every entry point fails with
+// Host work per frame is O(1): the pose composition T_ls (map_awareness.cpp:184-186, mlm_host.h), the bookkeeping of
+// the emulated libstdc++ rehash policy of hit_idx_odds_hashmap, and kernel launches.  All per-point / per-cell /
+// per-voxel work runs in the kernels of mlm_kernels_sector.h (default path) and mlm_kernels.h / mlm_kernels_explore.h.  There is no CPU fallback: every entry point fails with
 // MLM_ERR_HIP when the device is unavailable.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>

@@ -16,7 +16,9 @@
  * Eigen / PCL / ROS (forbidden), so no oracle/_ref build exists.  What pins the oracle
  * instead: the known-answer counts recorded in SURVEY.md §8d (hit/miss/block/'o'/'f'
  * cell counts for configs 1, 3 and the reference-default sampler case, including the
- * iteration-order dependent frame-19 counts), reproduced by tests/test_oracle_kat.py.
+ * iteration-order dependent frame-19 counts), reproduced by tests/test_oracle_kat.py, and
+ * the property tests the reference holds for Sophus (test_so3.cpp, test_se3.cpp), to which
+ * tests/test_host_math.py holds the SO3 / SE3 restatements below.
  */
 #ifndef MLMAP_ORACLE_H
 #define MLMAP_ORACLE_H
