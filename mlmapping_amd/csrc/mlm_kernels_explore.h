@@ -71,6 +71,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_collect_misses(MLM_SLOT_ARGS) 
             P.ex_cell[pos] = (uint32_t)c;
             P.ex_t[pos] = t;
             P.ex_vt[pos] = t;
+            // its world voxel (pure geometry: here in the batched stage rather than in the per-frame chain)
+            int rho, phi, z;
+            mlm_cell_rpz(P, (uint32_t)c, rho, phi, z);
+            double wx, wy, wz;
+            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+            int gx, gy, gz, cid;
+            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
+            P.ex_bkey[pos] = mlm_pack_key(gx, gy, gz);
+            P.ex_cid[pos] = (uint32_t)cid;
         }
         __syncthreads();
     }
@@ -118,6 +127,50 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_make_keys(const MlmDev P, unsi
     }
 }
 
+__device__ __forceinline__ void mlm_ex_apply_misses_body(const MlmDev &P);
+__device__ __forceinline__ void mlm_ex_release_body(const MlmDev &P);
+// Both containers in one launch when neither rehashes this frame (the usual case): blockIdx.y = 0 the hit container
+// (hashed (rho,phi,z) keys), 1 the miss container (identity hash).  The bucket-first tables are the two copies of bkt64,
+// tagged with a per-frame counter (newest frame's smallest time wins the min): no clearing between frames.
+// blockIdx.y = 2 (when launched with three rows): the miss phase of the PREVIOUS frame (k_ex_apply_misses), which nothing in
+// this frame's ordering depends on — the per-frame chain is two launches shorter (see also k_ex_order_keys).
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_min(const MlmDev P, unsigned int n_hit, unsigned int n_miss, unsigned long long nb_hit,
+                                                            unsigned long long nb_miss, int tag, const MlmDev Pprev) {
+    const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (blockIdx.y == 2) {
+        mlm_ex_apply_misses_body(Pprev);
+    } else if (blockIdx.y == 0) {
+        for (unsigned int i = i0; i < n_hit; i += stride) {
+            int rho, phi, z;
+            mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+            atomicMin(&P.bkt64[mlm_hash_rpz(rho, phi, z) % nb_hit], mlm_bkt_entry(tag, P.hl_vt[i]));
+        }
+    } else {
+        for (unsigned int i = i0; i < n_miss; i += stride)
+            atomicMin(&P.bkt64[P.bkt_stride + (unsigned long long)P.ex_cell[i] % nb_miss], mlm_bkt_entry(tag, P.ex_vt[i]));
+    }
+}
+// blockIdx.y = 2: the release scan of the PREVIOUS frame (after its miss phase, which ran with k_ex_order_min)
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_keys(const MlmDev P, unsigned int n_hit, unsigned int n_miss, unsigned long long nb_hit,
+                                                             unsigned long long nb_miss, const MlmDev Pprev) {
+    const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (blockIdx.y == 2) {
+        mlm_ex_release_body(Pprev);
+    } else if (blockIdx.y == 0) {
+        for (unsigned int i = i0; i < n_hit; i += stride) {
+            int rho, phi, z;
+            mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+            const unsigned long long first = P.bkt64[mlm_hash_rpz(rho, phi, z) % nb_hit] & 0xFFFFFFFFull;
+            P.hl_key[i] = ((first + 1ull) << 32) | (unsigned long long)P.hl_vt[i];
+        }
+    } else {
+        for (unsigned int i = i0; i < n_miss; i += stride) {
+            const unsigned long long first = P.bkt64[P.bkt_stride + (unsigned long long)P.ex_cell[i] % nb_miss] & 0xFFFFFFFFull;
+            P.ex_key[i] = ((first + 1ull) << 32) | (unsigned long long)P.ex_vt[i];
+        }
+    }
+}
+
 // ---- Stage C, miss side --------------------------------------------------------------------------------------------
 // allocate_ram as the update loops use it (map_local.h:215-231): false for a released block
 __device__ __forceinline__ int mlm_ex_block_slot(const MlmDev &P, unsigned long long key) {
@@ -126,25 +179,28 @@ __device__ __forceinline__ int mlm_ex_block_slot(const MlmDev &P, unsigned long 
     return slot;
 }
 
-// one unique miss cell per lane: its voxel, the voxel's miss count and tau = key of its first miss in iteration order
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_miss_tau(const MlmDev P, const MlmFrame F) {
+// one unique miss cell per lane: its voxel (computed in Stage A), the voxel's miss count and tau = key of its first miss in
+// iteration order.  ex_vox[i] = voxel address, or -1 - address when the cell is not its voxel's first miss of the frame
+// (k_ex_apply_misses takes the first ones), or INT_MIN when the block is unavailable.
+__device__ __forceinline__ void mlm_ex_miss_tau_body(const MlmDev &P) {
     const unsigned int n = P.ctr->n_ex_miss;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int rho, phi, z;
-        mlm_cell_rpz(P, P.ex_cell[i], rho, phi, z);
-        double wx, wy, wz;
-        mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-        int gx, gy, gz, cid;
-        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid);
-        const int slot = mlm_ex_block_slot(P, mlm_pack_key(gx, gy, gz));
-        int v = -1;
+        const int slot = mlm_ex_block_slot(P, P.ex_bkey[i]);
+        int v = (int)0x80000000;
         if (slot >= 0) {
-            v = slot * P.cells + cid;
+            v = slot * P.cells + (int)P.ex_cid[i];
             atomicMax(&P.vox_tau[v], P.ex_key[i]);
-            if (atomicAdd(&P.vox_miss[v], 1u) == 0) P.miss_vox[atomicAdd(&P.ctr->n_ex_vox, 1u)] = v;
+            if (atomicAdd(&P.vox_miss[v], 1u) != 0) v = -1 - v;
         }
         P.ex_vox[i] = v;
     }
+}
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_miss_tau(const MlmDev P, const MlmFrame F) { mlm_ex_miss_tau_body(P); }
+// the hit push (k_voxelize's hit side, explicit keys) and the miss registration of a frame in ONE launch: they touch
+// different per-voxel words (blockIdx.y = 0 hits, 1 misses)
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_register(const MlmDev P, const MlmFrame F) {
+    if (blockIdx.y == 0) mlm_voxelize_body(P, F, 0ull, 0u);
+    else mlm_ex_miss_tau_body(P);
 }
 
 __device__ __forceinline__ bool mlm_inside_exp_bd(double x, double y, double z) { // map_local.h:160-165, map_local.cpp:124
@@ -156,8 +212,9 @@ __device__ __forceinline__ bool mlm_inside_exp_bd(double x, double y, double z) 
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_observe(const MlmDev P, const MlmFrame F) {
     const unsigned int n = P.ctr->n_ex_miss;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int v = P.ex_vox[i];
-        if (v < 0) continue;
+        int v = P.ex_vox[i];
+        if (v == (int)0x80000000) continue;
+        if (v < 0) v = -1 - v;
         const unsigned long long tau = P.vox_tau[v];
         if (P.ex_key[i] != tau || P.occ[v] != 'u') continue;
         int rho, phi, z;
@@ -236,11 +293,13 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_observe(const MlmDev P, const 
     }
 }
 
-// per touched voxel: k misses (map_local.cpp:188-203); a cell that turns 'f' leaves the frontier
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) {
-    const unsigned int n = P.ctr->n_ex_vox;
+// per touched voxel (the miss cell that was its first this frame): k misses (map_local.cpp:188-203); a cell that turns
+// 'f' leaves the frontier
+__device__ __forceinline__ void mlm_ex_apply_misses_body(const MlmDev &P) {
+    const unsigned int n = P.ctr->n_ex_miss;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int v = P.miss_vox[i];
+        const int v = P.ex_vox[i];
+        if (v < 0) continue;
         const uint32_t k = P.vox_miss[v];
         P.vox_miss[v] = 0;
         P.vox_tau[v] = 0;
@@ -253,10 +312,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) {
         if (o == 'f' && o0 != 'f') P.frnt[v] = 0;
     }
 }
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) { mlm_ex_apply_misses_body(P); }
 
 // release scan (map_local.cpp:208-232): one workgroup per allocated block; blocks observed this frame whose frontier is
 // empty and whose occupancy is uniform are collapsed (they stop accepting updates; element 0 answers queries)
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) {
+__device__ __forceinline__ void mlm_ex_release_body(const MlmDev &P) {
     __shared__ int s_bad;
     const unsigned int n_blocks = min(P.g->n_blocks, (unsigned int)P.max_blocks); // read on the device: no host sync
     for (unsigned int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
@@ -278,6 +338,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) {
         }
     }
 }
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) { mlm_ex_release_body(P); }
 
 // frontier read-out: (gx,gy,gz,cell) of every frontier cell
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_export_frontier(const MlmDev P, unsigned int n_blocks, int32_t *out,

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -124,6 +125,14 @@ struct mlm_handle {
     hipEvent_t inputs_ready = nullptr;       // caller-supplied stream only: orders Stage A after the caller's work on it
     MlmGlobal *h_gb[MLM_SETS] = {}; // pinned snapshots of P.g taken at the end of each batch
     bool use_sectors = true;   // Stage A by azimuth sector (mlm_kernels_sector.h); MLM_SECTORS=0: the cell-table path
+    struct ExBatch {
+        int set, n;
+        bool bc_enqueued;
+    };
+    std::deque<ExBatch> ex_q;   // frontier mode, asynchronous submission: batches in flight, oldest first
+    hipEvent_t ex_counts[MLM_SETS] = {}, ex_bc_done[MLM_SETS] = {};
+    MlmSlot *ex_tail = nullptr; // frontier mode: the frame whose miss phase + release scan ride with the next frame's ordering launches
+    int ex_tag = 0;            // frontier mode: per-frame tag of the bucket-first tables (k_ex_order_min)
     long long n_sector_fallbacks = 0; // frames redone by the cell-table path because a sector's LDS tables overflowed
     std::recursive_mutex mu;   // serialises the entry points of this handle (see MLM_LOCK)
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
@@ -515,6 +524,15 @@ int order_misses_exact(mlm_handle *h, MlmSlot &S, unsigned int U) {
 // Frontier mode, the part of a frame that needs the map (main stream, no host synchronisation): exact iteration order
 // of both containers (the host replays the two rehash policies from the frame's counts in S.h_ctr), hits, then the
 // miss-side frontier bookkeeping and the release scan.  Ends with the asynchronous read-back of the counters.
+// the deferred tail of the previous frame as launches of its own (end of a batch, or before a general ordering replay)
+void explore_flush_tail(mlm_handle *h) {
+    if (!h->ex_tail) return;
+    const dim3 blk(MLM_BLOCK);
+    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, h->stream, h->ex_tail->P);
+    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, h->stream, h->ex_tail->P);
+    h->ex_tail = nullptr;
+}
+
 int explore_stage_bc(mlm_handle *h, int slot_index) {
     MlmSlot &S = h->slots[(size_t)slot_index];
     const MlmDev &P = S.P;
@@ -522,18 +540,49 @@ int explore_stage_bc(mlm_handle *h, int slot_index) {
     const dim3 blk(MLM_BLOCK);
     const unsigned int U = S.h_ctr->u_hit, UM = S.h_ctr->n_ex_miss;
     S.ex_um = UM;
-    int rc = order_hits_exact(h, S, U, 0);
-    if (rc) return rc;
-    rc = order_misses_exact(h, S, UM);
-    if (rc) return rc;
-    tlaunch(h, "k_voxelize", k_voxelize, dim3(64, 1), blk, 0, st, P, S.F, 0ull);   // hits: push on voxel lists (explicit keys)
+    // iteration-order keys of both containers.  Neither rehashes in a typical frame: then one fused pair of launches
+    // (tagged bucket-first tables, nothing to clear) that also carries the previous frame's miss phase and release scan;
+    // otherwise the general epoch-by-epoch replay per container.
+    int rc = MLM_OK;
+    {
+        std::__detail::_Prime_rehash_policy hp = h->hit_pol, mp = h->miss_pol;
+        size_t hn = h->hit_n_bkt, mn = h->miss_n_bkt;
+        const auto eh = plan_epochs_for(hp, hn, U);
+        const auto em = plan_epochs_for(mp, mn, UM);
+        if (eh.size() == 1 && em.size() == 1 && hn <= h->max_buckets && mn <= h->max_buckets) {
+            h->hit_pol = hp;
+            h->miss_pol = mp;
+            h->hit_n_bkt = hn;
+            h->miss_n_bkt = mn;
+            h->stats.n_rehash_epochs = 1;
+            const int tag = h->ex_tag++;
+            if (h->ex_tag > 0x3FFFFFFF) { // tags restart: the tables must forget them
+                h->ex_tag = 0;
+                HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long), st));
+            }
+            const MlmDev &Pp = h->ex_tail ? h->ex_tail->P : P;
+            const unsigned int rows = h->ex_tail ? 3u : 2u;
+            tlaunch(h, "k_ex_order_min", k_ex_order_min, dim3(kListGrid, rows), blk, 0, st, P, U, UM, (unsigned long long)hn, (unsigned long long)mn, tag, Pp);
+            tlaunch(h, "k_ex_order_keys", k_ex_order_keys, dim3(kListGrid, rows), blk, 0, st, P, U, UM, (unsigned long long)hn, (unsigned long long)mn, Pp);
+            h->ex_tail = nullptr;
+        } else {
+            explore_flush_tail(h);
+            rc = order_hits_exact(h, S, U, 0);
+            if (rc) return rc;
+            rc = order_misses_exact(h, S, UM);
+            if (rc) return rc;
+        }
+    }
+    tlaunch(h, "k_ex_register", k_ex_register, dim3(4 * kListGrid, 2), blk, 0, st, P, S.F); // hits: push on voxel lists; misses: count + tau
     tlaunch(h, "k_apply", k_apply, dim3(64, 1), blk, 0, st, P, 0, 1);           // hits: ordered replay, frontier erase on 'o'
-    tlaunch(h, "k_ex_miss_tau", k_ex_miss_tau, dim3(4 * kListGrid), blk, 0, st, P, S.F);
     tlaunch(h, "k_ex_observe", k_ex_observe, dim3(4 * kListGrid), blk, 0, st, P, S.F);
-    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, st, P);
-    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, st, P);
-    HIPCHK(h, hipMemcpyAsync(h->h_g, P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
+    h->ex_tail = &S; // its miss phase and release scan ride with the next frame's ordering launches (or explore_flush_tail)
+    return MLM_OK;
+}
+// end of a batch (or of a single frame): the last frame's tail, the map-wide counters
+int explore_end_batch(mlm_handle *h) {
+    explore_flush_tail(h);
+    HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
     return MLM_OK;
 }
 // after the stream has been synchronised
@@ -545,6 +594,52 @@ int explore_finish(mlm_handle *h, int slot_index) {
     fill_stats(h, S);
     h->stats.n_miss_cells = S.ex_um;
     h->stats.hit_bucket_count = (int64_t)h->hit_n_bkt;
+    return MLM_OK;
+}
+
+// Frontier mode, asynchronous submission: Stage A of a batch runs while the map-dependent part of the batch before it is
+// enqueued — the host needs the frames' hit / miss counts (it replays both containers' rehash policies) before it can
+// enqueue that part, so a batch's second half is always one call behind its first.
+int explore_enqueue_bc(mlm_handle *h, mlm_handle::ExBatch &b) {
+    const int K = (int)h->slots.size() / MLM_SETS, base = b.set * K;
+    HIPCHK(h, hipEventSynchronize(h->ex_counts[b.set])); // the frames' counters are on the host
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[b.set], 0));
+    for (int j = 0; j < b.n; ++j) {
+        const int rc = explore_stage_bc(h, base + j);
+        if (rc) return rc;
+    }
+    {
+        const int rc = explore_end_batch(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->set_free[b.set], h->stream));
+    HIPCHK(h, hipEventRecord(h->ex_bc_done[b.set], h->stream));
+    b.bc_enqueued = true;
+    return MLM_OK;
+}
+int explore_confirm_front(mlm_handle *h) {
+    const mlm_handle::ExBatch b = h->ex_q.front();
+    h->ex_q.pop_front();
+    const int K = (int)h->slots.size() / MLM_SETS;
+    HIPCHK(h, hipEventSynchronize(h->ex_bc_done[b.set]));
+    HIPCHK(h, hipGetLastError());
+    for (int j = 0; j < b.n; ++j) {
+        const int rc = explore_finish(h, b.set * K + j);
+        if (rc) return rc;
+    }
+    return MLM_OK;
+}
+int drain_explore(mlm_handle *h) {
+    for (auto &b : h->ex_q)
+        if (!b.bc_enqueued) {
+            const int rc = explore_enqueue_bc(h, b);
+            if (rc) return rc;
+        }
+    while (!h->ex_q.empty()) {
+        const int rc = explore_confirm_front(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return MLM_OK;
 }
 
@@ -604,6 +699,8 @@ int run_frame_explore(mlm_handle *h, int slot_index) {
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     int rc = explore_stage_bc(h, slot_index);
+    if (rc) return rc;
+    rc = explore_end_batch(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
@@ -692,6 +789,7 @@ int confirm_front(mlm_handle *h, int count) {
 
 // Wait for everything submitted, replay frames whose speculation failed, leave nothing pending.
 int drain(mlm_handle *h) {
+    if (h->P.explore) return drain_explore(h);
     for (;;) {
         HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -809,6 +907,37 @@ int run_slots(mlm_handle *h, int n) {
     if (h->P.explore) { // frontier mode: exact ordering of both containers, no speculation
         const int K = (int)h->slots.size() / MLM_SETS;
         const int base = h->cur_set * K;
+        if (h->async_mode) {
+            const int set = h->cur_set;
+            for (int j = 0; j < n; ++j) {
+                h->slots[(size_t)(base + j)].seq = 0;
+                h->slots[(size_t)(base + j)].F.seq = 0;
+            }
+            int rc = launch_stage_a_batch(h, base, n);
+            if (rc == MLM_OK) {
+                hipError_t e = hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost,
+                                              h->stream_as[set]);
+                if (e == hipSuccess) e = hipEventRecord(h->ex_counts[set], h->stream_as[set]);
+                if (e != hipSuccess) {
+                    h->err = std::string("frontier batch: ") + hipGetErrorString(e);
+                    rc = MLM_ERR_HIP;
+                }
+            }
+            if (rc == MLM_OK) {
+                h->ex_q.push_back(mlm_handle::ExBatch{set, n, false});
+                for (size_t k = 0; k + 1 < h->ex_q.size() && rc == MLM_OK; ++k) // everything but the batch just submitted
+                    if (!h->ex_q[k].bc_enqueued) rc = explore_enqueue_bc(h, h->ex_q[k]);
+                h->cur_set = (set + 1) % MLM_SETS;
+                // the set that is filled next must have been confirmed (its host-side counters are reused)
+                while (rc == MLM_OK && !h->ex_q.empty() && h->ex_q.front().set == h->cur_set) rc = explore_confirm_front(h);
+            }
+            if (rc != MLM_OK) {
+                hipDeviceSynchronize();
+                h->ex_q.clear();
+                clear_device_error(h);
+            }
+            return rc;
+        }
         if (n == 1) return run_frame_explore(h, base);
         // a batch: Stage A of all frames in one launch sequence (it does not depend on the map), one synchronisation to
         // learn the frames' hit/miss counts, then the map-dependent part frame by frame without further synchronisation
@@ -825,6 +954,8 @@ int run_slots(mlm_handle *h, int n) {
             rc = explore_stage_bc(h, base + j);
             if (rc) return rc;
         }
+        rc = explore_end_batch(h);
+        if (rc) return rc;
         HIPCHK(h, hipEventRecord(h->set_free[h->cur_set], h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
@@ -1001,6 +1132,8 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         if ((rc = dev_alloc(h, &P.ex_arr, NC))) return rc;
         if ((rc = dev_alloc(h, &P.ex_key, NC))) return rc;
         if ((rc = dev_alloc(h, &P.ex_vox, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_bkey, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.ex_cid, NC))) return rc;
         HIPCHK(h, hipMemset(P.start_t, 0xFF, NC * sizeof(uint32_t)));
         HIPCHK(h, hipMemset(P.miss_t, 0xFF, NC * sizeof(uint32_t)));
     }
@@ -1313,6 +1446,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         for (int k = 0; k < MLM_SETS; ++k) HIPCHK(h, hipStreamCreateWithFlags(&h->stream_as[k], hipStreamNonBlocking));
     }
     for (int k = 0; k < MLM_SETS; ++k) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->ex_counts[k], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ex_bc_done[k], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->stage_a_done[k], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->set_free[k], hipEventDisableTiming));
     }
@@ -1344,6 +1479,8 @@ int mlm_destroy(mlm_handle *h) {
     if (h->h_frame_tab) hipHostFree(h->h_frame_tab);
     for (int k = 0; k < MLM_SETS; ++k) {
         if (h->stage_a_done[k]) hipEventDestroy(h->stage_a_done[k]);
+        if (h->ex_counts[k]) hipEventDestroy(h->ex_counts[k]);
+        if (h->ex_bc_done[k]) hipEventDestroy(h->ex_bc_done[k]);
         if (h->set_free[k]) hipEventDestroy(h->set_free[k]);
     }
     for (int k = 0; k < MLM_SETS; ++k)

@@ -155,6 +155,17 @@ def test_frontier_mode_batch(mods):
     compare_maps(ea, cpu.export_blocks(), "frontier batch vs oracle")
     assert np.array_equal(a.export_frontier(), cpu.export_frontier())
     assert a.frame_stats()["n_miss_cells"] == b.frame_stats()["n_miss_cells"]
+    # asynchronous submission: Stage A of a batch overlaps the map-dependent part of the batch before it
+    c = MLMap(cfg, max_blocks=8192, max_batch=3)
+    c.set_async(True)
+    for k0 in (0, 3, 6):
+        c.update_map_batch(frames[k0:k0 + 3], q[k0:k0 + 3], t[k0:k0 + 3])
+    c.update_map(frames[9], q[9], t[9])
+    ec = c.export_blocks()  # (exports wait for everything submitted)
+    for key in ("keys", "occ", "infl", "collapsed"):
+        assert np.array_equal(ec[key], eb[key]), key
+    assert np.array_equal(ec["log_odds"], eb["log_odds"])
+    assert np.array_equal(c.export_frontier(), b.export_frontier())
 
 
 def test_config3_720p(mods):
