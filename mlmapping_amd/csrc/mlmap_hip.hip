@@ -133,6 +133,8 @@ struct mlm_handle {
     hipEvent_t ex_counts[MLM_SETS] = {}, ex_bc_done[MLM_SETS] = {};
     MlmSlot *ex_tail = nullptr; // frontier mode: the frame whose miss phase + release scan ride with the next frame's ordering launches
     int ex_tag = 0;            // frontier mode: per-frame tag of the bucket-first tables (k_ex_order_min)
+    int sector_backoff_len = 16; // (MLM_SEC_BACKOFF)
+    int sector_backoff = 0;    // batches that go straight to the cell-table path after a sector overflow (the scene does not fit the sectors' LDS tables: do not pay for both paths)
     long long n_sector_fallbacks = 0; // frames redone by the cell-table path because a sector's LDS tables overflowed
     std::recursive_mutex mu;   // serialises the entry points of this handle (see MLM_LOCK)
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
@@ -726,7 +728,9 @@ int submit_batch(mlm_handle *h, int base, int n) {
     }
     int rc;
     // (the sector path packs a tile's image column into 11 bits; its bucket-first tables hold sbkt_cap buckets)
-    const bool sectors = h->use_sectors && h->slots[(size_t)base].F.width <= 2040 && h->hit_n_bkt <= h->slots[(size_t)base].P.sbkt_cap;
+    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040 &&
+                         h->hit_n_bkt <= h->slots[(size_t)base].P.sbkt_cap;
+    if (h->sector_backoff > 0) --h->sector_backoff;
     for (int j = 0; j < n; ++j) h->slots[(size_t)(base + j)].sector = sectors;
     {
         Timed t(h, h->stream_as[set], "stage_a_batch");
@@ -812,6 +816,7 @@ int drain(mlm_handle *h) {
                 MlmSlot &R = *h->pending[j];
                 if (R.h_ctr->sector_overflow) {
                     h->n_sector_fallbacks++;
+                    h->sector_backoff = h->sector_backoff_len;
                     const int si = (int)(&R - h->slots.data());
                     const int set = si / ((int)h->slots.size() / MLM_SETS);
                     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1326,6 +1331,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         P.sec_tab = tab;
         P.sec_probe = 0; // (measured on config 2: 42.8k vs 41.5k frames/s with the lookups in k_sector)
         if (const char *e = getenv("MLM_SEC_PROBE")) P.sec_probe = atoi(e) != 0;
+        if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
         P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * P.RW), (unsigned int)P.nRho).total;
         {

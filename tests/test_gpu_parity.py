@@ -718,7 +718,8 @@ def test_callback_query_interleaving(mods):
     gpu.close()
 
 
-@pytest.mark.parametrize("env", [{"MLM_SEC_FAIL_EVERY": "1"}, {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_TAB": "512"}, {"MLM_SECTORS": "0"}])
+@pytest.mark.parametrize("env", [{"MLM_SEC_FAIL_EVERY": "1", "MLM_SEC_BACKOFF": "0"}, {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_TAB": "512", "MLM_SEC_BACKOFF": "0"},
+                                 {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "2"}, {"MLM_SECTORS": "0"}])
 def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
     """Stage A by azimuth sector falls back to the cell-table path frame by frame when a column overflows its LDS tables
     (forced here by shrinking them); MLM_SECTORS=0 runs the cell-table path alone.  Results must not change."""
@@ -746,6 +747,8 @@ def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
         assert st["n_sector_fallbacks"] == n, st
     if env.get("MLM_SEC_FAIL_EVERY") == "3":
         assert st["n_sector_fallbacks"] >= n // 3, st
+    if env.get("MLM_SEC_FAIL_EVERY") == "4":  # after a fall-back the next batches skip the sector attempt, then it is retried
+        assert 1 <= st["n_sector_fallbacks"] < n // 2, st
     if "MLM_SECTORS" in env:
         assert st["n_sector_fallbacks"] == 0
     gpu.close()
