@@ -19,6 +19,7 @@ atomics counted by the kernels themselves.  `cpu_baseline` is the CPU oracle on 
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -105,11 +106,15 @@ def time_stream(m, cfg, d_frames, q, t, B, K, W, distinct, sync, collect=None):
     for s in range(W):
         run_step(s, False)
     sync()
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for s in range(W, W + K):
         run_step(s, True)
     sync()
-    return time.perf_counter() - t0, run_step
+    dt = time.perf_counter() - t0
+    gc.enable()
+    return dt, run_step
 
 
 def main():
@@ -173,7 +178,7 @@ def main():
     _, run_step = time_stream(m, cfg, d_frames, q, t, B, 0, W, args.distinct, barrier)
     ktime_c, ktime = {}, {}
     n_c = min(K, 6)
-    n_settle = 2
+    n_settle = 24  # untimed batches between the instrumented ones and the timed region (see below)
     timed_kernel, timed_every = None, 1
     if not args.no_kernel_timing:
         m.enable_kernel_timing(2)
@@ -189,16 +194,30 @@ def main():
         timed_every = 8 if per_frame else 1
         m.set_timed_kernel(timed_kernel, timed_every)
         m.enable_kernel_timing(3)
-        for s in range(n_settle):  # settle back into the pipelined regime (their launches are bracketed as well)
-            run_step(s, False)
+        # settle back into the pipelined regime (their launches are bracketed as well).  Two dozen batches: the HIP runtime
+        # grows its pools of signals / kernel-argument buffers while the first few dozen asynchronous batches are in
+        # flight (several ms each time, seen at the 3rd, 5th, 9th and ~18th submission of a process)
+        for s in range(n_settle):
+            run_step(s % max(1, W), False)
         barrier()
     stats = []
+    step_t = []
+    # (the interpreter's cyclic garbage collector stays out of the timed region: a generation-2 pass over the modules
+    # loaded here takes ~40 ms — more than many a timed region — at a point that depends on the allocation count)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for s in range(W, W + K):
         run_step(s, True)
         stats.append(m.frame_stats())
+        step_t.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("MLM_BENCH_STEP_TIMES"):  # diagnostic: host time of every submission call of the timed region
+        d = np.diff(np.array([t0] + step_t)) * 1e3
+        print("step ms:", [(i, round(float(x), 2)) for i, x in enumerate(d) if x > 1.5], "final barrier", round((t0 + dt - step_t[-1]) * 1e3, 2),
+              file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

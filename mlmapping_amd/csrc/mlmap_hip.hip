@@ -807,6 +807,9 @@ int drain(mlm_handle *h) {
         // pending.front() does not fit the emulated container without a rehash (replay its Stage B exactly), or one of
         // its azimuth sectors overflowed its LDS tables (redo its Stage A on the cell-table path first)
         MlmSlot &S = *h->pending.front();
+        if (getenv("MLM_DEBUG_DRAIN"))
+            fprintf(stderr, "[drain] fail at seq %d: u_hit %u thr %zu n_bkt %zu pending %zu overflow %u\n", S.seq, S.h_ctr->u_hit,
+                    (size_t)h->hit_pol._M_next_resize, h->hit_n_bkt, h->pending.size(), S.h_ctr->sector_overflow);
         h->h_g->fail_frame = 0x7FFFFFFF;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (S.sector) {
@@ -975,11 +978,11 @@ int run_slots(mlm_handle *h, int n) {
     const int set = h->cur_set;
     int rc = submit_batch(h, set * K, n);
     if (rc == MLM_OK) {
-        if (h->async_mode) {
+        if (h->async_mode && h->hit_n_bkt > 1) {
             // confirm the OLDEST batch in flight (the set that will be refilled next); the newer ones keep the GPU busy
             h->cur_set = (set + 1) % MLM_SETS;
             rc = finish_set(h, h->cur_set);
-        } else {
+        } else { // (also the very first batch of a stream: its first frame always grows the emulated container from empty)
             rc = drain(h);
         }
     }
