@@ -311,7 +311,8 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
     L.sigma = o;    o += ((n_rho + 3u) & ~3u) * 4u;
     L.miss = o;     o += ((n_miss + 3u) & ~3u) * 4u;
     L.rays = o;     o += TAB * 2u;                       // table entries that start a ray
-    L.occ = o;      o += TAB * 2u;                       // occupied table entries (= the column's unique hits)
+    L.occ = L.chunk;                                     // occupied table entries (= the column's unique hits): in the chunk
+                                                         // staging, idle between the first record pass and the second
     L.multi = o;    o += TAB * 2u;                       // ... those that received several kinds
     L.total = (o + 15u) & ~15u;
     return L;
