@@ -50,6 +50,7 @@ struct MlmSlot {
     int seq = 0;              // sequence number of the frame it currently holds
     unsigned int nb = 0;      // k_bin_points blocks
     unsigned int ex_um = 0;   // frontier mode: unique miss cells of the frame it holds
+    size_t alloc_end = 0;     // mlm_handle::allocs.size() once this slot was allocated
     bool sector = false;      // the frame it holds went through the sector path (Stage A and the frame-local voxel grid)
     uint16_t *d_img = nullptr; // staging for host images
     size_t img_cap = 0;
@@ -106,6 +107,7 @@ struct mlm_handle {
     unsigned int sc_grid = 80;               // blocks per list of k_apply_voxelize (grid-stride loops; 40..120 measured equal, 160 3 % slower)
     std::string timed_kernel = "k_bin_points"; // the kernel bracketed in timing mode 3 ...
     unsigned int timed_every = 1, timed_count = 0; // ... on every timed_every-th launch
+    int n_sets = MLM_SETS;     // slot sets in use (2 when three do not fit the device memory)
     int set_pending[MLM_SETS] = {};
     bool async_mode = false;
     int cu_split = 0;
@@ -303,7 +305,7 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     const MlmDev &P = S0.P;
     const MlmFrame &F = S0.F;
     const int mode = S0.mode;
-    const int set = base / ((int)h->slots.size() / MLM_SETS);
+    const int set = base / (h->lim.max_batch);
     hipStream_t st = h->stream_as[set];
     // the previous user of this slot set must have been consumed by the main stream
     HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
@@ -384,7 +386,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
     const MlmDev &P = S0.P;
     const MlmFrame &F = S0.F;
     const int mode = S0.mode;
-    const int set = base / ((int)h->slots.size() / MLM_SETS);
+    const int set = base / (h->lim.max_batch);
     hipStream_t st = h->stream_as[set];
     HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
     if (!h->own_stream) { // see launch_stage_a_batch
@@ -603,7 +605,7 @@ int explore_finish(mlm_handle *h, int slot_index) {
 // enqueued — the host needs the frames' hit / miss counts (it replays both containers' rehash policies) before it can
 // enqueue that part, so a batch's second half is always one call behind its first.
 int explore_enqueue_bc(mlm_handle *h, mlm_handle::ExBatch &b) {
-    const int K = (int)h->slots.size() / MLM_SETS, base = b.set * K;
+    const int K = h->lim.max_batch, base = b.set * K;
     HIPCHK(h, hipEventSynchronize(h->ex_counts[b.set])); // the frames' counters are on the host
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[b.set], 0));
     for (int j = 0; j < b.n; ++j) {
@@ -622,7 +624,7 @@ int explore_enqueue_bc(mlm_handle *h, mlm_handle::ExBatch &b) {
 int explore_confirm_front(mlm_handle *h) {
     const mlm_handle::ExBatch b = h->ex_q.front();
     h->ex_q.pop_front();
-    const int K = (int)h->slots.size() / MLM_SETS;
+    const int K = h->lim.max_batch;
     HIPCHK(h, hipEventSynchronize(h->ex_bc_done[b.set]));
     HIPCHK(h, hipGetLastError());
     for (int j = 0; j < b.n; ++j) {
@@ -719,7 +721,7 @@ int submit_batch(mlm_handle *h, int base, int n) {
         h->err = "emulated bucket count exceeds capacity";
         return MLM_ERR_CAPACITY;
     }
-    const int set = base / ((int)h->slots.size() / MLM_SETS);
+    const int set = base / (h->lim.max_batch);
     for (int j = 0; j < n; ++j) {
         MlmSlot &S = h->slots[(size_t)(base + j)];
         S.seq = h->next_seq++;
@@ -821,7 +823,7 @@ int drain(mlm_handle *h) {
                     h->n_sector_fallbacks++;
                     h->sector_backoff = h->sector_backoff_len;
                     const int si = (int)(&R - h->slots.data());
-                    const int set = si / ((int)h->slots.size() / MLM_SETS);
+                    const int set = si / (h->lim.max_batch);
                     HIPCHK(h, hipStreamSynchronize(h->stream));
                     // the frame-local grid holds what the sectors that did finish pushed: wipe it, then the cell-table path
                     HIPCHK(h, hipMemsetAsync(R.P.lv_state, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * sizeof(unsigned long long), h->stream_as[set]));
@@ -913,7 +915,7 @@ int run_slots(mlm_handle *h, int n) {
         h->kpool_used = 0;
     }
     if (h->P.explore) { // frontier mode: exact ordering of both containers, no speculation
-        const int K = (int)h->slots.size() / MLM_SETS;
+        const int K = h->lim.max_batch;
         const int base = h->cur_set * K;
         if (h->async_mode) {
             const int set = h->cur_set;
@@ -935,7 +937,7 @@ int run_slots(mlm_handle *h, int n) {
                 h->ex_q.push_back(mlm_handle::ExBatch{set, n, false});
                 for (size_t k = 0; k + 1 < h->ex_q.size() && rc == MLM_OK; ++k) // everything but the batch just submitted
                     if (!h->ex_q[k].bc_enqueued) rc = explore_enqueue_bc(h, h->ex_q[k]);
-                h->cur_set = (set + 1) % MLM_SETS;
+                h->cur_set = (set + 1) % h->n_sets;
                 // the set that is filled next must have been confirmed (its host-side counters are reused)
                 while (rc == MLM_OK && !h->ex_q.empty() && h->ex_q.front().set == h->cur_set) rc = explore_confirm_front(h);
             }
@@ -974,13 +976,13 @@ int run_slots(mlm_handle *h, int n) {
         return MLM_OK;
     }
     h->stats.n_rehash_epochs = 1;
-    const int K = (int)h->slots.size() / MLM_SETS;
+    const int K = h->lim.max_batch;
     const int set = h->cur_set;
     int rc = submit_batch(h, set * K, n);
     if (rc == MLM_OK) {
         if (h->async_mode && h->hit_n_bkt > 1) {
             // confirm the OLDEST batch in flight (the set that will be refilled next); the newer ones keep the GPU busy
-            h->cur_set = (set + 1) % MLM_SETS;
+            h->cur_set = (set + 1) % h->n_sets;
             rc = finish_set(h, h->cur_set);
         } else { // (also the very first batch of a stream: its first frame always grows the emulated container from empty)
             rc = drain(h);
@@ -994,7 +996,7 @@ int run_slots(mlm_handle *h, int n) {
     }
     return rc;
 }
-inline MlmSlot &cur_slot(mlm_handle *h, int j) { return h->slots[(size_t)(h->cur_set * ((int)h->slots.size() / MLM_SETS) + j)]; }
+inline MlmSlot &cur_slot(mlm_handle *h, int j) { return h->slots[(size_t)(h->cur_set * (h->lim.max_batch) + j)]; }
 
 int ensure_img(mlm_handle *h, MlmSlot &S, size_t n_px) {
     if (n_px <= S.img_cap) return MLM_OK;
@@ -1155,6 +1157,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = ensure_img(h, S, (size_t)h->lim.max_points))) return rc;
     if ((rc = dev_alloc(h, &S.d_pix, (size_t)h->lim.max_points))) return rc;
     if ((rc = dev_alloc(h, &S.d_pts, (size_t)h->lim.max_points * 3))) return rc;
+    S.alloc_end = h->allocs.size();
     return MLM_OK;
 }
 
@@ -1433,7 +1436,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes))) return rc;
 
     // frame slots
-    const size_t NS = (size_t)h->lim.max_batch * MLM_SETS; // one set being filled while the others drain
+    if (const char *e = getenv("MLM_SLOT_SETS")) h->n_sets = std::min(MLM_SETS, std::max(2, atoi(e)));
+    size_t NS = (size_t)h->lim.max_batch * h->n_sets; // one set being filled while the others are in flight
     h->slots.resize(NS);
     if ((rc = dev_alloc(h, &h->d_ctr_all, NS))) return rc;
     if ((rc = dev_alloc(h, &h->d_slot_tab, NS))) return rc;
@@ -1460,8 +1464,36 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         HIPCHK(h, hipEventCreateWithFlags(&h->stage_a_done[k], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->set_free[k], hipEventDisableTiming));
     }
-    for (size_t i = 0; i < NS; ++i)
-        if ((rc = alloc_slot(h, h->slots[i], i, sigma3))) return rc;
+    {
+        // the frame slots are most of the footprint (S1 ~0.35 GB, S3 ~3 GB each): three sets of max_batch if they fit the
+        // device memory, else two (a quarter less throughput on config 2), else the error says what would be needed
+        const size_t mark = h->allocs.size();
+        size_t got = 0;
+        for (; got < NS; ++got)
+            if ((rc = alloc_slot(h, h->slots[got], got, sigma3))) break;
+        if (rc && got >= 2 * (size_t)h->lim.max_batch && h->n_sets > 2) {
+            (void)hipGetLastError();
+            // (keep the first two sets; give the partial third one back)
+            size_t keep = mark;
+            for (size_t i = 0; i < 2 * (size_t)h->lim.max_batch; ++i) keep = h->slots[i].alloc_end;
+            for (size_t a = keep; a < h->allocs.size(); ++a) hipFree(h->allocs[a]);
+            h->allocs.resize(keep);
+            for (size_t i = 2 * (size_t)h->lim.max_batch; i < NS; ++i)
+                if (h->slots[i].d_img) {
+                    hipFree(h->slots[i].d_img);
+                    h->slots[i].d_img = nullptr;
+                }
+            h->n_sets = 2;
+            NS = 2 * (size_t)h->lim.max_batch;
+            h->slots.resize(NS);
+            h->err.clear();
+            rc = MLM_OK;
+        }
+        if (rc) {
+            h->err += " (frame slots: lower mlm_limits.max_batch or max_points)";
+            return rc;
+        }
+    }
     {
         std::vector<MlmDev> tab(NS);
         for (size_t i = 0; i < NS; ++i) tab[i] = h->slots[i].P;
@@ -1536,7 +1568,7 @@ int mlm_integrate_depth_batch_dev(mlm_handle *h, const uint16_t *img_dev, int n_
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    const int K = (int)h->slots.size() / MLM_SETS;
+    const int K = h->lim.max_batch;
     for (int k0 = 0; k0 < n_frames; k0 += K) {
         const int n = std::min(K, n_frames - k0);
         for (int j = 0; j < n; ++j) {
@@ -1566,7 +1598,7 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    const int K = (int)h->slots.size() / MLM_SETS;
+    const int K = h->lim.max_batch;
     const size_t n_px = (size_t)row_stride * height;
     for (int k0 = 0; k0 < n_frames; k0 += K) {
         const int n = std::min(K, n_frames - k0);

@@ -252,3 +252,24 @@ def test_merge_over_rccl_world_size_1(mods):
         assert np.array_equal(e3["occ"][sel], cls) and np.array_equal(e3["log_odds"][sel].view(np.uint32), lo_g.view(np.uint32))
     finally:
         dist.destroy_process_group()
+
+
+def test_two_slot_sets(mods, monkeypatch):
+    """The handle falls back to two slot sets when three do not fit the device memory; forced here (MLM_SLOT_SETS=2): the
+    asynchronous batch pipeline must give the same map."""
+    MLMap, OracleMap = mods
+    monkeypatch.setenv("MLM_SLOT_SETS", "2")
+    cfg = S1
+    n = 20
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
+    poses = syn.random_poses(n, 42)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=4), OracleMap(cfg)
+    gpu.set_async(True)
+    for k0 in range(0, n, 4):
+        gpu.update_map_batch(frames[k0:k0 + 4], q[k0:k0 + 4], t[k0:k0 + 4])
+    gpu.sync()
+    for k in range(n):
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "two slot sets")
