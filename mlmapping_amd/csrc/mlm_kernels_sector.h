@@ -10,12 +10,17 @@
 //                   with one returning atomic (a chunk descriptor).  Nothing else leaves the block.
 //   k_sector        one workgroup per column: per-cell hit bookkeeping (first-touch time, kinds, counts) in an LDS hash
 //                   table, the column's miss bit mask in LDS (rays walked by an integer DDA), the unique-hit list
-//                   (cells that received ONE kind of contribution get their odd right away) with world voxels, the unique
-//                   miss cells with their world voxels, and for every cell that received several kinds the list of
-//                   (record, kind) references.  No global atomics except one list reservation per workgroup and list.
+//                   (cells that received ONE kind of contribution get their odd right away), and for every cell that
+//                   received several kinds the list of (record, kind) references.  Every unique hit is pushed on the pending
+//                   list of its world voxel, every unique miss cell counted on its world voxel, in a FRAME-LOCAL voxel grid
+//                   (which voxel a cell falls into is geometry; only the block's pool slot needs the map); first touches
+//                   queue the voxel.  Global atomics: list reservations per workgroup, one push + one bucket-min per hit,
+//                   one count per miss cell.
 //   k_rank          one wave per multi-kind cell: order its contributions by pixel (bitmap ranking fed with the records'
 //                   8x8 lane masks) and store the kinds in that order; k_chain (mlm_kernels.h) then replays the float
 //                   noisy-OR chain.
+//   k_apply_frame   the part that needs the map, ONE launch per frame: one queued voxel per lane — block lookup /
+//                   creation, the voxel's hits in the reference's iteration order, its misses, store.
 //
 // Compared with the cell-table path this removes every per-cell and per-miss-word device-scope atomic (they are executed
 // at the memory side, ~34 G/s for the whole chip), the 8 global copies of the miss mask and their scan, and the
