@@ -1,5 +1,5 @@
-// mlm_kernels_sector.h — Stage A by azimuth sector (the default path; mlm_kernels.h keeps the cell-table path that
-// frontier mode uses and that a frame falls back to when a sector's LDS tables overflow).
+// mlm_kernels_sector.h — Stage A by azimuth sector (the default path; mlm_kernels.h keeps the cell-table path that a
+// frame falls back to when a sector's LDS tables overflow and that takes images wider than 2040 pixels).
 //
 // Everything awareness_map_cylindrical::input_pc_pose does to one azimuth column phi stays inside that column: the noise
 // spread of a hit moves along rho (and z) at the point's phi (map_awareness.cpp:149-168) and its ray runs radially inwards
@@ -21,6 +21,10 @@
 //                   noisy-OR chain.
 //   k_apply_frame   the part that needs the map, ONE launch per frame: one queued voxel per lane — block lookup /
 //                   creation, the voxel's hits in the reference's iteration order, its misses, store.
+//
+// Frontier mode (use_exploration_frontiers) uses k_bin_sectors, k_sector<true>, k_rank and k_chain and continues with its
+// own map-dependent part (mlm_kernels_explore.h): there the miss container's iteration order matters as well, so the
+// column keeps the first insertion time of every miss cell in LDS instead of a bit.
 //
 // Compared with the cell-table path this removes every per-cell and per-miss-word device-scope atomic (they are executed
 // at the memory side, ~34 G/s for the whole chip), the 8 global copies of the miss mask and their scan, and the
@@ -60,7 +64,8 @@ __device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
 
 __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
     mlm_gp(P.ctr)->sector_overflow = 1u;
-    g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
+    // (frontier mode does not speculate: its host reads the flag before it enqueues what depends on the map)
+    if (!P.explore) g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
 }
 
 template <int MODE>
@@ -305,9 +310,10 @@ __device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl
 
 // LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
-    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, total;
+    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, total;
 };
-__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho) {
+// n_miss: words of the column's miss table (bit mask: nZ * RW; frontier mode keeps insertion times: nZ * nRho)
+__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, bool explore) {
     MlmSecLds L;
     uint32_t o = 0;
     L.tab = o;      o += TAB * (uint32_t)sizeof(MlmSecCell);
@@ -319,10 +325,16 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
     L.occ = L.chunk;                                     // occupied table entries (= the column's unique hits): in the chunk
                                                          // staging, idle between the first record pass and the second
     L.multi = o;    o += TAB * 2u;                       // ... those that received several kinds
+    L.ray_p0 = o;   if (explore) o += TAB * 4u;          // frontier mode: first point of every ray start
     L.total = (o + 15u) & ~15u;
     return L;
 }
 
+// EX: frontier mode (use_exploration_frontiers).  The miss container's iteration order matters there (mlm_kernels_explore.h),
+// so a miss cell keeps its first insertion time — point index * 256 + step of the ray, map_awareness.cpp:266-274 — instead
+// of a bit, and the map-dependent part is frontier mode's own (explore_stage_bc): the kernel ends with the unique hit list
+// (+ world voxels) and the unique miss list (cell, time, world voxel), no frame-local grid.
+template <bool EX>
 __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
                                                             int rho_s, unsigned long long n_bkt) {
     MLM_SLOT_SETUP
@@ -351,8 +363,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     if (nch_all == 0) return; // nothing fell into this column (uniform)
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    const uint32_t TAB = P.sec_tab, NMISS = (uint32_t)(P.nZ * P.RW);
-    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho);
+    const uint32_t TAB = P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
+    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, EX);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
     float *s_odds = (float *)(s_dyn + L.odds);
@@ -362,6 +374,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     uint16_t *s_multi = (uint16_t *)(s_dyn + L.multi);
     uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.chunk);
     uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
+    uint32_t *s_ray_p0 = (uint32_t *)(s_dyn + L.ray_p0); // (EX only)
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter;
@@ -371,12 +384,13 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         s_tab[e].kmask = 0;
         s_tab[e].cnt = 0;
         s_tab[e].gcnt = 0;
+        if (EX) s_tab[e].gpos = MLM_EMPTY_T; // (until the lists are built: first point whose centre is the cell)
     }
-    for (uint32_t e = threadIdx.x; e < NMISS; e += MLM_SEC_THREADS) s_miss[e] = 0;
+    for (uint32_t e = threadIdx.x; e < NMISS; e += MLM_SEC_THREADS) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
     for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_odds[e] = mlm_gp(P.odds_table)[e];
     for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_sigma[e] = mlm_gp(P.sigma3)[e];
     if (threadIdx.x == 0) {
-        s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)F.seq % P.sec_fail_every == 0)) ? 1u : 0u;
+        s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
         s_nouter = 0;
     }
     MLM_PHASE_BEGIN
@@ -447,9 +461,17 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                             z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
                             rho = P.nRho - 1;
                         }
+                        uint32_t p0 = 0;
+                        if (EX) { // the record's first point (several records may start the same ray: the minimum wins)
+                            const int l0 = __ffsll((long long)*(const MLM_GLOBAL unsigned long long *)(rp + 4)) - 1;
+                            p0 = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
+                        }
                         for (int rr = 1; rr < rho; ++rr) {
                             const int zr = mlm_cvt_int(round(z - ((rho - rr) * slope)));
-                            if (0 <= zr && zr < P.nZ) atomicOr(&s_miss[zr * P.RW + (rr >> 5)], 1u << (rr & 31));
+                            if (0 <= zr && zr < P.nZ) {
+                                if (EX) atomicMin(&s_miss[zr * P.nRho + rr], p0 * 256u + (uint32_t)(rho - rr - 1));
+                                else atomicOr(&s_miss[zr * P.RW + (rr >> 5)], 1u << (rr & 31));
+                            }
                         }
                         atomicAdd(&s_nouter, 1u);
                     }
@@ -484,6 +506,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                         const bool strong = mlm_contribution_odd(P, s_odds, rho_t, sub) >= 0.75f;
                         atomicAdd(&s_tab[e].cnt, cnt | (strong ? cnt << MLM_SEC_CNT_BITS : 0u));
                         atomicAdd(&s_tab[e].gcnt, 1u);
+                        if (EX && sub == 0) atomicMin(&s_tab[e].gpos, i_first);
                     });
                 }
             }
@@ -528,7 +551,10 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             const uint32_t e = threadIdx.x * per + q;
             MlmSecCell &c = s_tab[e];
             if (c.key == MLM_NIL) continue;
-            if (c.kmask & 1u) s_rays[o_rays++] = (uint16_t)e;
+            if (c.kmask & 1u) {
+                if (EX) s_ray_p0[o_rays] = c.gpos;
+                s_rays[o_rays++] = (uint16_t)e;
+            }
             if (mlm_sec_needs_order(c)) {
                 s_multi[o_multi++] = (uint16_t)e;
                 c.gpos = o_occ; // (its place in the hit list, until the reference cursor replaces it below)
@@ -544,7 +570,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         s_base[1] = n_multi ? g_atomic_add(&mlm_gp(P.ctr)->n_multi, n_multi) : 0u;
         s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
         s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
-        s_base[6] = n_occ ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[blockIdx.x & 7][0], n_occ) : 0u; // voxel-queue slots of the hits
+        s_base[6] = (n_occ && !EX) ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[blockIdx.x & 7][0], n_occ) : 0u; // voxel-queue slots of the hits
         if (s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap) s_fail = 1;
     }
     __syncthreads();
@@ -594,7 +620,11 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for (uint32_t i0 = 0; i0 < 4u * n_rays; i0 += MLM_SEC_THREADS) {
         const uint32_t it = i0 + threadIdx.x;
         int rho = 0, z = 0;
-        if (it < 4u * n_rays) key_rz(s_tab[s_rays[it >> 2]].key, rho, z);
+        uint32_t t0 = 0; // EX: insertion time of the ray's step k is t0 + k - 1
+        if (it < 4u * n_rays) {
+            key_rz(s_tab[s_rays[it >> 2]].key, rho, z);
+            if (EX) t0 = s_ray_p0[it >> 2] * 256u;
+        }
         const int seg = (rho + 2) >> 2; // steps k = 1 .. rho-1 in four segments of `seg`
         const int k_lo = 1 + (int)(it & 3u) * seg, k_hi = min(rho, k_lo + seg); // [k_lo, k_hi)
         const int dz = z - P.zc, two_rho = 2 * rho;
@@ -632,6 +662,10 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             }
             int zr = q;
             if (rem == 0) zr = mlm_cvt_int(round(z - (k * (dz / (rho * 1.0))))); // (segments longer than 64 steps: nRho > 256)
+            if (EX) {
+                if (0 <= zr && zr < P.nZ) atomicMin(&s_miss[zr * P.nRho + r], t0 + (uint32_t)(k - 1));
+                continue;
+            }
             const int w = (0 <= zr && zr < P.nZ) ? zr * P.RW + (r >> 5) : -1;
             if (w != cur_w) {
                 if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
@@ -640,7 +674,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             }
             cur_bits |= 1u << (r & 31);
         }
-        if (cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
+        if (!EX && cur_w >= 0) atomicOr(&s_miss[cur_w], cur_bits);
         if (__any(ties != 0)) {
             const double slope = (rho > 0) ? dz / (rho * 1.0) : 0.0;
             while (ties) {
@@ -648,7 +682,10 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                 ties &= ties - 1;
                 const int r = rho - k;
                 const int zr = mlm_cvt_int(round(z - (k * slope)));
-                if (0 <= zr && zr < P.nZ) atomicOr(&s_miss[zr * P.RW + (r >> 5)], 1u << (r & 31));
+                if (0 <= zr && zr < P.nZ) {
+                    if (EX) atomicMin(&s_miss[zr * P.nRho + r], t0 + (uint32_t)(k - 1));
+                    else atomicOr(&s_miss[zr * P.RW + (r >> 5)], 1u << (r & 31));
+                }
             }
         }
     }
@@ -687,6 +724,13 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
         int gx, gy, gz, cid, c3[3];
         mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid, c3);
+        if (EX) { // frontier mode: the hit's world voxel + speculative block slot, as k_prepare_voxels leaves them
+            const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+            mlm_gp(P.hl_bkey)[pos] = bkey;
+            mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
+            mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
+            continue;
+        }
         lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
         if (lv >= 0) {
             const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
@@ -710,7 +754,38 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     // ---- the column's unique miss cells (its bit mask): each counts one miss on its world voxel in the frame-local grid
     //      (every miss adds the same constant, map_local.cpp:188-192: only the count per voxel matters); the first miss of
     //      a voxel queues it for the kernel that applies the frame
-    {
+    if (EX) {
+        // frontier mode: the unique miss list with insertion times and world voxels (what k_ex_collect_misses leaves);
+        // a thread's cells take consecutive places
+        uint32_t vm = 0;
+        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) vm += s_miss[w] != MLM_EMPTY_T ? 1u : 0u;
+        uint32_t total;
+        const uint32_t my_off = mlm_block_excl_scan(vm, s_w, &total);
+        if (threadIdx.x == 0) {
+            s_base[5] = total ? g_atomic_add(&mlm_gp(P.ctr)->n_ex_miss, total) : 0u;
+            if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][1], nch_all + 8u); // device-scope atomics on account of this column
+            mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
+        }
+        __syncthreads();
+        uint32_t at = s_base[5] + my_off;
+        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) {
+            const uint32_t t = s_miss[w];
+            if (t == MLM_EMPTY_T) continue;
+            int rho, z;
+            key_rz(w, rho, z);
+            double wx, wy, wz;
+            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
+            int gx, gy, gz, m_cid;
+            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, m_cid);
+            mlm_gp(P.ex_cell)[at] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
+            mlm_gp(P.ex_t)[at] = t;
+            mlm_gp(P.ex_vt)[at] = t;
+            mlm_gp(P.ex_bkey)[at] = mlm_pack_key(gx, gy, gz);
+            mlm_gp(P.ex_cid)[at] = (uint32_t)m_cid;
+            ++at;
+        }
+    } else {
         uint32_t vm = 0;
         for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) vm += (uint32_t)__popc(s_miss[w]);
         uint32_t total;

@@ -221,5 +221,5 @@ struct MlmFrame {
     int seq;               // sequence number of the frame (speculation bookkeeping)
     unsigned int rehash_thr; // the emulated hit container takes this many elements without a rehash (speculative Stage B)
     int lv_o[3];           // origin of the frame-local voxel grid (MlmDev::lv_state) in voxel coordinates
-    int pad2;
+    int pad2;                  // frontier mode: running frame number (test hook MLM_SEC_FAIL_EVERY; seq stays 0 there)
 };

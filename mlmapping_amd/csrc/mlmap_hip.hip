@@ -135,6 +135,7 @@ struct mlm_handle {
     hipEvent_t ex_counts[MLM_SETS] = {}, ex_bc_done[MLM_SETS] = {};
     MlmSlot *ex_tail = nullptr; // frontier mode: the frame whose miss phase + release scan ride with the next frame's ordering launches
     int ex_tag = 0;            // frontier mode: per-frame tag of the bucket-first tables (k_ex_order_min)
+    unsigned int ex_frame_no = 0; // frontier mode: frames submitted (MlmFrame::pad2)
     int sector_backoff_len = 16; // (MLM_SEC_BACKOFF)
     int sector_backoff = 0;    // batches that go straight to the cell-table path after a sector overflow (the scene does not fit the sectors' LDS tables: do not pay for both paths)
     long long n_sector_fallbacks = 0; // frames redone by the cell-table path because a sector's LDS tables overflowed
@@ -419,8 +420,12 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         unsigned long long rm;
         int rs;
         div_magic((unsigned int)P.nRho, rm, rs);
-        tlaunch(h, "k_sector", k_sector, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
-                h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
+        if (P.explore)
+            tlaunch(h, "k_sector", k_sector<true>, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull);
+        else
+            tlaunch(h, "k_sector", k_sector<false>, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
         tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->sort_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
                 mode == 0 ? F.width : 0, row_w, dm, ds);
         tlaunch(h, "k_chain", k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab,
@@ -604,9 +609,14 @@ int explore_finish(mlm_handle *h, int slot_index) {
 // Frontier mode, asynchronous submission: Stage A of a batch runs while the map-dependent part of the batch before it is
 // enqueued — the host needs the frames' hit / miss counts (it replays both containers' rehash policies) before it can
 // enqueue that part, so a batch's second half is always one call behind its first.
+int explore_redo_overflows(mlm_handle *h, int base, int n);
 int explore_enqueue_bc(mlm_handle *h, mlm_handle::ExBatch &b) {
     const int K = h->lim.max_batch, base = b.set * K;
     HIPCHK(h, hipEventSynchronize(h->ex_counts[b.set])); // the frames' counters are on the host
+    {
+        const int rc = explore_redo_overflows(h, base, b.n);
+        if (rc) return rc;
+    }
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[b.set], 0));
     for (int j = 0; j < b.n; ++j) {
         const int rc = explore_stage_bc(h, base + j);
@@ -647,68 +657,42 @@ int drain_explore(mlm_handle *h) {
     return MLM_OK;
 }
 
-int run_frame_explore(mlm_handle *h, int slot_index) {
-    MlmSlot &S = h->slots[(size_t)slot_index];
-    const MlmDev &P = S.P;
-    hipStream_t st = h->stream;
-    // the frame's inputs were uploaded on the slot set's Stage A stream: order this stream after them
-    // (device inputs produced on a caller-supplied stream are ordered by that stream itself: everything below runs on it)
-    HIPCHK(h, hipEventRecord(h->stage_a_done[h->cur_set], h->stream_as[h->cur_set]));
-    HIPCHK(h, hipStreamWaitEvent(st, h->stage_a_done[h->cur_set], 0));
-    S.seq = 0;
-    S.F.seq = 0;
-    h->h_frame_tab[slot_index] = S.F;
-    HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + slot_index, h->h_frame_tab + slot_index, sizeof(MlmFrame), hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemsetAsync(P.ctr, 0, sizeof(MlmCounters), st));
-    const MlmFrame &F = S.F;
-    unsigned int nb = 0;
-    const dim3 blk(MLM_BLOCK);
-    if (F.n > 0) {
-        nb = bin_grid(P, F, S.mode);
-        if (nb > (unsigned int)h->lim.max_points / 64 + 1024) {
-            h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
-            return MLM_ERR_CAPACITY;
-        }
-        if (S.mode == 0)
-            hipLaunchKernelGGL(k_bin_points<0>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
-        else if (S.mode == 1)
-            hipLaunchKernelGGL(k_bin_points<1>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
-        else
-            hipLaunchKernelGGL(k_bin_points<2>, dim3(nb, 1, 1), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, slot_index);
+// Frontier mode, Stage A of the slots base..base+n: by azimuth sector when the handle can (k_sector<true>), else (and for
+// frames whose sector tables overflowed, explore_redo_overflows) on the cell-table path.
+int explore_stage_a(mlm_handle *h, int base, int n) {
+    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040;
+    if (h->sector_backoff > 0) --h->sector_backoff;
+    for (int j = 0; j < n; ++j) {
+        MlmSlot &S = h->slots[(size_t)(base + j)];
+        S.seq = 0;
+        S.F.seq = 0;
+        S.F.pad2 = (int)(h->ex_frame_no++ & 0x3FFFFFFF); // (frame counter for the MLM_SEC_FAIL_EVERY test hook)
+        S.sector = sectors;
     }
-    const int tile_w = S.mode == 0 ? F.width : 0;
-    if (nb) {
-        int tx, ty;
-        const unsigned int ng = book_grid(P, F, S.mode, (int)nb, tx, ty);
-        hipLaunchKernelGGL(k_book_cells, dim3(ng, 1, 1), dim3(MLM_BOOK_THREADS), 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tx, ty, (int)nb);
+    Timed t(h, h->stream_as[base / h->lim.max_batch], "stage_a_batch");
+    return sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
+}
+// The frames' counters are on the host: those with an overflowed sector table get their Stage A redone on the cell-table
+// path (nothing that depends on the map has been enqueued for them yet).  Returns with their new counters on the host.
+int explore_redo_overflows(mlm_handle *h, int base, int n) {
+    const int set = base / h->lim.max_batch;
+    bool any = false;
+    for (int j = 0; j < n; ++j) {
+        MlmSlot &S = h->slots[(size_t)(base + j)];
+        if (!S.sector || !S.h_ctr->sector_overflow) continue;
+        h->n_sector_fallbacks++;
+        h->sector_backoff = h->sector_backoff_len;
+        S.sector = false;
+        const int rc = launch_stage_a_batch(h, base + j, 1);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream_as[set]));
+        any = true;
     }
-    hipLaunchKernelGGL(k_assign_nodes, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w);
-    hipLaunchKernelGGL(k_ex_walk_rays, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
-    hipLaunchKernelGGL(k_collect_hits, dim3(64, MLM_RAY_LISTS, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, (int)nb);
-    hipLaunchKernelGGL(k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, tile_w,
-                       (int)nb);
-    {
-        const int row_w = S.mode == 0 ? F.width : 64;
-        unsigned long long dm;
-        int ds;
-        div_magic((unsigned int)row_w, dm, ds);
-        hipLaunchKernelGGL(k_sort_contribs<1024>, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 0u, row_w, dm, ds);
-        hipLaunchKernelGGL(k_sort_contribs<4096>, dim3(128, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index, 1024u, row_w, dm, ds);
+    if (any) {
+        HIPCHK(h, hipStreamSynchronize(h->stream_as[set]));
+        HIPCHK(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_chain, dim3(256, 1, 1), blk, (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
-                       slot_index, 0xFFFFFFFFu);
-    hipLaunchKernelGGL(k_prepare_voxels, dim3(256, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index); // hits only
-    hipLaunchKernelGGL(k_ex_collect_misses, dim3(1024, 1, 1), blk, 0, st, h->d_slot_tab, h->d_frame_tab, slot_index);
-    HIPCHK(h, hipMemcpyAsync(S.h_ctr, P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    HIPCHK(h, hipGetLastError());
-    int rc = explore_stage_bc(h, slot_index);
-    if (rc) return rc;
-    rc = explore_end_batch(h);
-    if (rc) return rc;
-    HIPCHK(h, hipStreamSynchronize(st));
-    HIPCHK(h, hipGetLastError());
-    return explore_finish(h, slot_index);
+    return MLM_OK;
 }
 
 // ---- submission / confirmation ---------------------------------------------------------------------------------
@@ -919,11 +903,7 @@ int run_slots(mlm_handle *h, int n) {
         const int base = h->cur_set * K;
         if (h->async_mode) {
             const int set = h->cur_set;
-            for (int j = 0; j < n; ++j) {
-                h->slots[(size_t)(base + j)].seq = 0;
-                h->slots[(size_t)(base + j)].F.seq = 0;
-            }
-            int rc = launch_stage_a_batch(h, base, n);
+            int rc = explore_stage_a(h, base, n);
             if (rc == MLM_OK) {
                 hipError_t e = hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost,
                                               h->stream_as[set]);
@@ -948,18 +928,16 @@ int run_slots(mlm_handle *h, int n) {
             }
             return rc;
         }
-        if (n == 1) return run_frame_explore(h, base);
-        // a batch: Stage A of all frames in one launch sequence (it does not depend on the map), one synchronisation to
-        // learn the frames' hit/miss counts, then the map-dependent part frame by frame without further synchronisation
-        for (int j = 0; j < n; ++j) {
-            h->slots[(size_t)(base + j)].seq = 0;
-            h->slots[(size_t)(base + j)].F.seq = 0;
-        }
-        int rc = launch_stage_a_batch(h, base, n);
+        // Stage A of all frames in one launch sequence (it does not depend on the map), one synchronisation to learn the
+        // frames' hit/miss counts, then the map-dependent part frame by frame without further synchronisation
+        int rc = explore_stage_a(h, base, n);
         if (rc) return rc;
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[h->cur_set], 0));
         HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        rc = explore_redo_overflows(h, base, n);
+        if (rc) return rc;
         for (int j = 0; j < n; ++j) {
             rc = explore_stage_bc(h, base + j);
             if (rc) return rc;
@@ -1094,7 +1072,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
     if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
     if ((rc = dev_alloc(h, &P.col_chunks, h->use_sectors ? 2 * (size_t)P.nPhi * P.chunk_cap : 2))) return rc;
-    if (h->use_sectors) {
+    if (h->use_sectors && !P.explore) { // (frontier mode's own Stage B+C takes over after k_sector: no frame-local grid)
         const size_t nlv = (size_t)P.lv_nx * P.lv_ny * P.lv_nz;
         if ((rc = dev_alloc(h, &P.lv_state, nlv))) return rc;
         HIPCHK(h, hipMemset(P.lv_state, 0, nlv * sizeof(unsigned long long)));
@@ -1339,17 +1317,24 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (const char *e = getenv("MLM_SEC_PROBE")) P.sec_probe = atoi(e) != 0;
         if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
-        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * P.RW), (unsigned int)P.nRho).total;
+        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, P.explore).total;
         {
             // frame-local voxel grid: the awareness cylinder (radius nRho*dRho, height nZ*dZ) plus four voxels each side
             const double R = P.nRho * P.dRho;
             P.lv_nx = P.lv_ny = 2 * (int)std::ceil(R / P.d_sub) + 10;
             P.lv_nz = (int)std::ceil(P.nZ * P.dZ / P.d_sub) + 10;
         }
-        h->use_sectors = (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26) && P.nZ * P.RW < 2 * MLM_SEC_CHUNKS && !P.explore && P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS);
+        // (frontier mode: no frame-local grid, no prefix of the mask words in the chunk staging area; its insertion times
+        // hold point index * 256 + ray step in 32 bits)
+        h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) &&
+                         (P.explore ? P.nRho <= 256 : ((long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26) && P.nZ * P.RW < 2 * MLM_SEC_CHUNKS));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
-        if (h->use_sectors)
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_sector, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+        if (h->use_sectors) {
+            if (P.explore)
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+            else
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+        }
     }
     std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
     for (int p = 0; p < P.nPhi; ++p) {

@@ -752,3 +752,49 @@ def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
     if "MLM_SECTORS" in env:
         assert st["n_sector_fallbacks"] == 0
     gpu.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"MLM_SEC_FAIL_EVERY": "1", "MLM_SEC_BACKOFF": "0"}, {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_BACKOFF": "0"},
+                                 {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "1"}, {"MLM_SECTORS": "0"}])
+def test_frontier_mode_sector_path(mods, monkeypatch, env):
+    """Frontier mode runs Stage A by azimuth sector too (insertion times of the miss cells kept in LDS); a frame whose sector
+    tables overflow redoes Stage A on the cell-table path before anything that depends on the map is enqueued.  Single
+    frames, batches and asynchronous batches against the oracle: map, frontier set, awareness lists."""
+    MLMap, OracleMap = mods
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = S1.with_(use_exploration_frontiers=True)
+    n = 11
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
+    poses = syn.random_poses(n, 7)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=4, record_awareness=True), OracleMap(cfg)
+    for k in range(3):  # single frames
+        gpu.update_map(frames[k], q[k], t[k])
+        cpu.update_depth(frames[k], q[k], t[k])
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{env} frame {k}")
+        assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"{env} frontier, frame {k}"
+    gpu.update_map_batch(frames[3:8], q[3:8], t[3:8])  # 4 + 1
+    for k in range(3, 8):
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{env} batch")
+    assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"{env} frontier after the batch"
+    gpu.set_async(True)
+    gpu.update_map_batch(frames[8:10], q[8:10], t[8:10])
+    gpu.update_map(frames[10], q[10], t[10])
+    for k in range(8, n):
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{env} async")
+    assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"{env} frontier after the async batches"
+    st = gpu.frame_stats()
+    if not env or "MLM_SECTORS" in env:
+        assert st["n_sector_fallbacks"] == 0, st
+    if env.get("MLM_SEC_FAIL_EVERY") == "1":
+        assert st["n_sector_fallbacks"] == n, st
+    if env.get("MLM_SEC_FAIL_EVERY") == "3":
+        assert st["n_sector_fallbacks"] == 4, st  # frames 0, 3, 6, 9
+    if env.get("MLM_SEC_FAIL_EVERY") == "4":
+        assert 1 <= st["n_sector_fallbacks"] <= 3, st
+    gpu.close()
