@@ -19,6 +19,10 @@
 // wrappers are the device-scope relaxed atomics of HIP's atomicOr/atomicAdd/atomicMin on such pointers.
 #define MLM_GLOBAL __attribute__((address_space(1)))
 template <class T> __device__ __forceinline__ MLM_GLOBAL T *mlm_gp(T *p) { return (MLM_GLOBAL T *)p; }
+// The same for LDS: a generic pointer to __shared__ memory (e.g. a volatile one used for wave-synchronous exchange)
+// compiles to FLAT instructions with 64-bit address arithmetic; mlm_lp() re-types it as address space 3 (DS instructions).
+#define MLM_LDS __attribute__((address_space(3)))
+template <class T> __device__ __forceinline__ MLM_LDS T *mlm_lp(T *p) { return (MLM_LDS T *)p; }
 template <class T> __device__ __forceinline__ T g_atomic_or(MLM_GLOBAL T *p, T v) {
     return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

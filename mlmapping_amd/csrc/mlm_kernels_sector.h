@@ -856,13 +856,13 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) unsigned long long s_rows[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
     __shared__ uint16_t s_pref[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
-    __shared__ __attribute__((aligned(16))) uint8_t s_kinds[MLM_BLOCK / 64][1024]; // ordered kinds of cells with n <= 1024
+    __shared__ __attribute__((aligned(16))) uint8_t s_kinds[MLM_BLOCK / 64][1024 + 64]; // ordered kinds of cells with n <= 1024 (+ a spare byte per lane)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
-    unsigned long long *rows = s_rows[wid];
-    volatile uint16_t *pref = s_pref[wid];
+    MLM_LDS unsigned long long *rows = mlm_lp(s_rows[wid]);
+    volatile MLM_LDS uint16_t *pref = mlm_lp(s_pref[wid]);
     for (int j = lane; j < MLM_SEC_RANK_WORDS; j += 64) rows[j] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -883,12 +883,14 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
     };
     auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],
                        const uint32_t (&r_sub)[4]) {
-        const uint32_t soff = rec.y, n = rec.z, n_refs = rf.y;
-        const uint32_t pix0 = rec.w / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
+        // (the descriptor is the same in every lane: scalar registers, uniform branches)
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z),
+                       n_refs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rf.y);
+        const uint32_t pix0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
         const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64; // multiple of 8: a record's row byte never straddles a word
         MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + soff;
-        volatile uint8_t *SL = s_kinds[wid];
+        volatile MLM_LDS uint8_t *SL = mlm_lp(s_kinds[wid]);
         const bool staged = n <= 1024u; // kinds are collected in LDS and leave as whole dwords
         const int rounds = (int)min(4u, (n_refs * 8u + 63u) >> 6); // (uniform) rounds of 64 pairs held in registers
         bool bad = n > 0xFFFFu;
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
                 l_wi[q] = 0;
                 l_sh[q] = 0;
                 if (q < rounds && r_bits[q]) {
-                    if (locate(r_yx[q], l_wi[q], l_sh[q])) atomicOr(&rows[l_wi[q]], (unsigned long long)r_bits[q] << l_sh[q]);
+                    if (locate(r_yx[q], l_wi[q], l_sh[q])) __hip_atomic_fetch_or(&rows[l_wi[q]], (unsigned long long)r_bits[q] << l_sh[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else bad = true;
                 }
             }
@@ -914,7 +916,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
                 uint32_t b, px, sb, wi, sh;
                 load_pair(rf, p, b, px, sb);
                 if (b) {
-                    if (locate(px, wi, sh)) atomicOr(&rows[wi], (unsigned long long)b << sh);
+                    if (locate(px, wi, sh)) __hip_atomic_fetch_or(&rows[wi], (unsigned long long)b << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else bad = true;
                 }
             }
@@ -927,7 +929,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
         if (!bad) {
             int j0 = 0;
             for (; j0 < MLM_SEC_RANK_WORDS && carry < n; j0 += 64) {
-                const uint32_t cw = (uint32_t)__popcll(((volatile unsigned long long *)rows)[j0 + lane]);
+                const uint32_t cw = (uint32_t)__popcll(((volatile MLM_LDS unsigned long long *)rows)[j0 + lane]);
                 const uint32_t incl = mlm_wave_incl_scan(cw);
                 pref[j0 + lane] = (uint16_t)(carry + incl - cw);
                 carry += mlm_readlane(incl, 63);
@@ -938,35 +940,53 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (!bad) {
-            auto place = [&](uint32_t bits, uint32_t wi, uint32_t sh, uint32_t sub) {
-                if (!bits) return;
-                const unsigned long long word = ((volatile unsigned long long *)rows)[wi];
+            // a row's own set bits, in pixel order (other records' bits may lie between them): rank of bit b = contributions
+            // before the segment + set bits of the segment below b
+            auto place = [&](uint32_t bits, uint32_t wi, uint32_t sh, uint32_t sub, auto &&store) {
+                const unsigned long long word = ((volatile MLM_LDS unsigned long long *)rows)[wi];
                 const uint32_t before = pref[wi] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull));
                 const uint32_t seg = (uint32_t)(word >> sh) & 0xFFu; // every record's bits of this 8-pixel segment
-                while (bits) { // the row's own set bits, in pixel order; other records' bits may lie between them
-                    const int b = __ffs((int)bits) - 1;
-                    bits &= bits - 1;
+                store(bits, before, seg, sub);
+            };
+            // staged (n <= 1024, the usual case): by bit position, eight straight-line steps without branches — a lane whose
+            // bit is clear writes to a spare byte of its own behind the staged kinds
+            auto store_lds = [&](uint32_t bits, uint32_t before, uint32_t seg, uint32_t sub) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
                     const uint32_t at = before + (uint32_t)__popc(seg & ((1u << b) - 1u));
-                    if (staged) SL[at] = (uint8_t)sub;
-                    else S[at] = (uint8_t)sub;
+                    SL[(bits >> b) & 1u ? at : 1024u + (uint32_t)lane] = (uint8_t)sub;
                 }
             };
+            auto store_glb = [&](uint32_t bits, uint32_t before, uint32_t seg, uint32_t sub) {
+                while (bits) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    S[before + (uint32_t)__popc(seg & ((1u << b) - 1u))] = (uint8_t)sub;
+                }
+            };
+            if (staged) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q < rounds) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q]);
+                for (int q = 0; q < 4; ++q)
+                    if (q < rounds) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q], store_lds);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < rounds) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q], store_glb);
+            }
             for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
                 uint32_t b, px, sb, wi, sh;
                 load_pair(rf, p, b, px, sb);
                 if (b) {
                     locate(px, wi, sh);
-                    place(b, wi, sh, sb);
+                    if (staged) place(b, wi, sh, sb, store_lds);
+                    else place(b, wi, sh, sb, store_glb);
                 }
             }
             if (staged) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t j = lane; j < (n + 3u) >> 2; j += 64) // (segments are padded to 16 bytes)
-                    ((MLM_GLOBAL uint32_t *)S)[j] = ((volatile uint32_t *)SL)[j];
+                    ((MLM_GLOBAL uint32_t *)S)[j] = ((volatile MLM_LDS uint32_t *)SL)[j];
             }
         } else {
             // slow exact path (a contribution outside the bitmap window, or a huge cell): write every contribution's
