@@ -736,9 +736,16 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
             mlm_gp(P.hl_bkt)[pos] = (uint32_t)b;
             if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
-            const uint32_t prev = __hip_atomic_exchange((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv), pos + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mlm_gp(P.hl_next)[pos] = (int)prev - 1;
-            first = prev == 0u;
+            // hit number k of its voxel: the first ones into the voxel's slots, the rest on a list headed by the last slot
+            const uint32_t k = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv), 1u);
+            MLM_GLOBAL uint32_t *hs = mlm_gp(P.lv_hits) + (size_t)lv * MLM_LV_SLOTS;
+            if (k < MLM_LV_SLOTS - 1u) {
+                hs[k] = pos;
+            } else {
+                const uint32_t prev = __hip_atomic_exchange(hs + (MLM_LV_SLOTS - 1), pos + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mlm_gp(P.hl_next)[pos] = (int)prev - 1;
+            }
+            first = k == 0u;
             h_bkey = mlm_pack_key(gx, gy, gz);
             h_cid = cid;
         } else {
@@ -861,6 +868,17 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
     const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
+    if (!P.explore) {
+        // Iteration-order keys of the frame's unique hits, valid if the frame fits the emulated container without a rehash
+        // (k_apply_frame checks): (first insertion time of the hit's bucket, its own insertion time) — the bucket-first
+        // table of this slot is complete now that every column of the frame has been through k_sector
+        const unsigned int n_hit = mlm_gp(P.ctr)->u_hit;
+        for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hit; i += gridDim.x * blockDim.x) {
+            const uint32_t b = mlm_gp(P.hl_bkt)[i];
+            const unsigned long long first = b < P.sbkt_cap ? mlm_gp(P.sbkt)[b] & 0xFFFFFFFFull : 0ull;
+            mlm_gp(P.hl_key)[i] = ((first + 1ull) << 32) | (unsigned long long)mlm_gp(P.hl_vt)[i];
+        }
+    }
     MLM_LDS unsigned long long *rows = mlm_lp(s_rows[wid]);
     volatile MLM_LDS uint16_t *pref = mlm_lp(s_pref[wid]);
     for (int j = lane; j < MLM_SEC_RANK_WORDS; j += 64) rows[j] = 0ull;
@@ -1065,8 +1083,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
 // frame's hits and misses by voxel in the frame-local grid, so all that is left is: block lookup / creation
 // (allocate_ram, map_local.h:215-231), the voxel's hits in the reference's iteration order (descending key,
 // map_local.cpp:157-171), then its misses (map_local.cpp:188-203) — the reference runs all hits before all misses.
-// A voxel that has hits is owned by the record of its first hit; a record of a first miss skips such a voxel.
-// explicit_keys: hl_key holds the exact iteration-order keys (rehash frames, order_hits_exact); otherwise the key is
+// A voxel that has hits is owned by the record of its first hit; a record of a first miss skips such a voxel.  Three
+// dependent round trips per voxel: queue entry -> (pending state, hit slots, log-odds, class) -> (keys, increments).
+// explicit_keys: hl_key holds the exact iteration-order keys (rehash frames, order_hits_exact); otherwise k_rank's
 // (bucket-first time from this slot's table, insertion time), valid if the frame fits the emulated container without a
 // rehash — else the frame is flagged (g->fail_frame) and replayed by the host.
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const MlmFrame F, int explicit_keys) {
@@ -1098,9 +1117,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
         }
         if (p_rec.w >= 2u) continue; // a hole: the item was not its voxel's first
         MLM_GLOBAL unsigned long long *st = mlm_gp(P.lv_state) + p_rec.x;
+        MLM_GLOBAL uint32_t *hs = mlm_gp(P.lv_hits) + (size_t)p_rec.x * MLM_LV_SLOTS;
         int slot = (int)p_rec.z;
-        // the voxel's pending state, and (the block being known already in the common case) its map state: one round trip
+        // the voxel's pending state and hit slots, and (the block being known already in the common case) its map state:
+        // one round trip
         const unsigned long long state = *st;
+        const mlm_u32x4 h0 = *(const MLM_GLOBAL mlm_u32x4 *)hs, h1 = *(const MLM_GLOBAL mlm_u32x4 *)(hs + 4);
         float L = 0.0f;
         uint8_t o = 'u';
         size_t v = 0;
@@ -1109,10 +1131,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
             L = mlm_gp(P.log_odds)[v];
             o = mlm_gp(P.occ)[v];
         }
-        const uint32_t head1 = (uint32_t)state, km = (uint32_t)(state >> 32);
-        if (p_rec.w == 1u && head1 != 0u) continue; // the owner of the voxel's hits applies its misses too
-        if (head1 == 0u && km == 0u) continue;      // (consumed already: never write a stale value back)
+        const uint32_t nh = (uint32_t)state, km = (uint32_t)(state >> 32);
+        if (p_rec.w == 1u && nh != 0u) continue; // the owner of the voxel's hits applies its misses too
+        if (nh == 0u && km == 0u) continue;      // (consumed already: never write a stale value back)
         *st = 0ull;
+        if (nh >= MLM_LV_SLOTS) hs[MLM_LV_SLOTS - 1] = 0u; // (the list of the hits beyond the direct slots)
         if (slot < 0) {
             slot = mlm_block_slot(P, p_key);
             if (slot < 0) continue; // block pool full (error flag set)
@@ -1120,79 +1143,79 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
             L = mlm_gp(P.log_odds)[v];
             o = mlm_gp(P.occ)[v];
         }
-        if (head1) {
-            const int head = (int)head1 - 1;
-            const int nxt = mlm_gp(P.hl_next)[head];
-            const float inc = mlm_gp(P.hl_inc)[head]; // (same round trip as the link)
-            if (nxt < 0) { // the common case: a single contribution
-                if (L < P.lo_max) {
-                    L = L + inc;
-                    L = L > P.lo_max ? P.lo_max : L;
+        auto hit = [&](float inc) { // map_local.cpp:157-171
+            if (L < P.lo_max) {
+                L = L + inc;
+                L = L > P.lo_max ? P.lo_max : L;
+            }
+            if (L > P.lo_sh && o != 'o') o = 'o';
+        };
+        if (nh == 1u) { // the common case: a single contribution
+            hit(mlm_gp(P.hl_inc)[h0.x]);
+        } else if (nh) {
+            // (key, increment) of all its hits in one gather — hl_key: k_rank's speculative keys or the exact ones of
+            // order_hits_exact — kept in registers in descending key order (the reference's iteration order)
+            const uint32_t ps[MLM_LV_SLOTS - 1] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z};
+            const uint32_t nd = min(nh, (uint32_t)(MLM_LV_SLOTS - 1));
+            unsigned long long gk[MLM_LV_SLOTS - 1];
+            float gv[MLM_LV_SLOTS - 1];
+#pragma unroll
+            for (int q = 0; q < MLM_LV_SLOTS - 1; ++q) {
+                gk[q] = 0;
+                gv[q] = 0.0f;
+                if ((uint32_t)q < nd) {
+                    gk[q] = mlm_gp(P.hl_key)[ps[q]];
+                    gv[q] = mlm_gp(P.hl_inc)[ps[q]];
                 }
-                if (L > P.lo_sh && o != 'o') o = 'o';
-            } else {
-                auto key_of = [&](int j) -> unsigned long long {
-                    if (explicit_keys) return mlm_gp(P.hl_key)[j];
-                    const unsigned long long first = mlm_gp(P.sbkt)[mlm_gp(P.hl_bkt)[j]] & 0xFFFFFFFFull;
-                    return ((first + 1ull) << 32) | (unsigned long long)mlm_gp(P.hl_vt)[j];
-                };
-                // one walk over the list collects (key, increment) into registers kept in descending key order; lists
-                // longer than that fall back to repeated selection straight from memory
-                unsigned long long ks[MLM_APPLY_REGS];
-                float vs[MLM_APPLY_REGS];
+            }
+            unsigned long long ks[MLM_APPLY_REGS];
+            float vs[MLM_APPLY_REGS];
+#pragma unroll
+            for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                ks[q] = 0; // real keys are never 0
+                vs[q] = 0.0f;
+            }
+            auto insert = [&](unsigned long long k, float inc) {
 #pragma unroll
                 for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                    ks[q] = 0; // real keys are never 0
-                    vs[q] = 0.0f;
-                }
-                int cnt = 0;
-                for (int j = head; j >= 0; j = mlm_gp(P.hl_next)[j]) {
-                    unsigned long long k = key_of(j);
-                    float inc = mlm_gp(P.hl_inc)[j];
-                    ++cnt;
-#pragma unroll
-                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                        if (k > ks[q]) {
-                            const unsigned long long tk = ks[q];
-                            const float tv = vs[q];
-                            ks[q] = k;
-                            vs[q] = inc;
-                            k = tk;
-                            inc = tv;
-                        }
+                    if (k > ks[q]) {
+                        const unsigned long long tk = ks[q];
+                        const float tv = vs[q];
+                        ks[q] = k;
+                        vs[q] = inc;
+                        k = tk;
+                        inc = tv;
                     }
                 }
-                if (cnt <= MLM_APPLY_REGS) {
+            };
 #pragma unroll
-                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                        if (q < cnt) {
-                            if (L < P.lo_max) {
-                                L = L + vs[q];
-                                L = L > P.lo_max ? P.lo_max : L;
-                            }
-                            if (L > P.lo_sh && o != 'o') o = 'o';
+            for (int q = 0; q < MLM_LV_SLOTS - 1; ++q)
+                if ((uint32_t)q < nd) insert(gk[q], gv[q]);
+            const int over = (int)h1.w - 1; // head of the list of the hits beyond the slots (nh >= MLM_LV_SLOTS)
+            if (nh >= MLM_LV_SLOTS)
+                for (int j = over; j >= 0; j = mlm_gp(P.hl_next)[j]) insert(mlm_gp(P.hl_key)[j], mlm_gp(P.hl_inc)[j]);
+            if (nh <= MLM_APPLY_REGS) {
+#pragma unroll
+                for (int q = 0; q < MLM_APPLY_REGS; ++q)
+                    if ((uint32_t)q < nh) hit(vs[q]);
+            } else {
+                // more hits than registers: repeated selection of the next key straight from memory
+                unsigned long long last = ~0ull;
+                for (;;) {
+                    int best = -1;
+                    unsigned long long bestkey = 0;
+                    auto consider = [&](int j) {
+                        const unsigned long long k = mlm_gp(P.hl_key)[j];
+                        if (k < last && (best < 0 || k > bestkey)) {
+                            best = j;
+                            bestkey = k;
                         }
-                    }
-                } else {
-                    unsigned long long last = ~0ull;
-                    for (;;) {
-                        int best = -1;
-                        unsigned long long bestkey = 0;
-                        for (int j = head; j >= 0; j = mlm_gp(P.hl_next)[j]) {
-                            const unsigned long long k = key_of(j);
-                            if (k < last && (best < 0 || k > bestkey)) {
-                                best = j;
-                                bestkey = k;
-                            }
-                        }
-                        if (best < 0) break;
-                        if (L < P.lo_max) {
-                            L = L + mlm_gp(P.hl_inc)[best];
-                            L = L > P.lo_max ? P.lo_max : L;
-                        }
-                        if (L > P.lo_sh && o != 'o') o = 'o';
-                        last = bestkey;
-                    }
+                    };
+                    for (int q = 0; q < MLM_LV_SLOTS - 1; ++q) consider((int)ps[q]);
+                    for (int j = over; j >= 0; j = mlm_gp(P.hl_next)[j]) consider(j);
+                    if (best < 0) break;
+                    hit(mlm_gp(P.hl_inc)[best]);
+                    last = bestkey;
                 }
             }
         }

@@ -79,6 +79,7 @@ struct MlmCell {
     uint32_t seg;  // start of the cell's segment in `contrib` (MLM_NIL for single-kind cells)
 };
 
+#define MLM_LV_SLOTS 8
 struct MlmDev {
     // ---- awareness map constants (map_awareness.cpp:19-82)
     double dRho, dPhi, dZ, z_border_min;
@@ -130,7 +131,7 @@ struct MlmDev {
     uint32_t *hl_vt;           // virtual insertion time (== hl_t when no rehash happened this frame)
     uint32_t *hl_arr;          // arrival index (rank of hl_t), only valid on rehash frames
     uint64_t *hl_key;          // iteration-order key: (bucket_first << 32) | vt ; larger = earlier in iteration
-    int *hl_next;              // per-voxel pending list link
+    int *hl_next;              // per-voxel pending list link (sector path: only hits beyond the voxel's direct slots, lv_hits)
     int *hl_vox;               // voxel address (slot*cells + cell id)
     uint32_t *bkt_first;       // [max buckets] min vt per hash bucket (exact path on rehash frames)
     unsigned long long *bkt64; // [max buckets] (~seq << 32 | min vt): speculative path, never cleared
@@ -196,8 +197,11 @@ struct MlmDev {
     uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count}
     // frame-local voxel grid: the voxels the awareness cylinder can reach, addressed relative to MlmFrame::lv_o, so
     // that hits and misses are grouped by voxel in Stage A without knowing the map (block slots)
-    unsigned long long *lv_state; // [lv_nx*lv_ny*lv_nz] low word: 1 + index of the voxel's newest pending hit (0 = none), high
-                               // word: misses of the frame; reset by the kernel that applies the frame
+    unsigned long long *lv_state; // [lv_nx*lv_ny*lv_nz] low word: pending hits of the frame, high word: its misses; reset by
+                               // the kernel that applies the frame
+    uint32_t *lv_hits;         // [..][MLM_LV_SLOTS] the voxel's pending hits (indices into hl_*): hit k < MLM_LV_SLOTS-1 in slot
+                               // k; the last slot heads a list (1 + index, links in hl_next) of the hits beyond — one gather
+                               // instead of a list walk for the kernel that applies the frame
     int lv_nx, lv_ny, lv_nz;
     uint32_t *tv_rec;          // [MLM_RAY_LISTS][tv_cap][4] first-touched voxels: {lv, cell id, block slot or -1, 0 hit / 1 miss}
     unsigned long long *tv_key;// [MLM_RAY_LISTS][tv_cap] ... packed block key          (counts: MlmCounters::mvox_cnt)

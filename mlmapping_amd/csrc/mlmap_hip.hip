@@ -811,6 +811,7 @@ int drain(mlm_handle *h) {
                     HIPCHK(h, hipStreamSynchronize(h->stream));
                     // the frame-local grid holds what the sectors that did finish pushed: wipe it, then the cell-table path
                     HIPCHK(h, hipMemsetAsync(R.P.lv_state, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * sizeof(unsigned long long), h->stream_as[set]));
+                    HIPCHK(h, hipMemsetAsync(R.P.lv_hits, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * MLM_LV_SLOTS * sizeof(uint32_t), h->stream_as[set]));
                     rc = launch_stage_a_batch(h, si, 1);
                     if (rc) return rc;
                     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
@@ -1076,6 +1077,8 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         const size_t nlv = (size_t)P.lv_nx * P.lv_ny * P.lv_nz;
         if ((rc = dev_alloc(h, &P.lv_state, nlv))) return rc;
         HIPCHK(h, hipMemset(P.lv_state, 0, nlv * sizeof(unsigned long long)));
+        if ((rc = dev_alloc(h, &P.lv_hits, nlv * MLM_LV_SLOTS))) return rc;
+        HIPCHK(h, hipMemset(P.lv_hits, 0, nlv * MLM_LV_SLOTS * sizeof(uint32_t)));
         P.tv_cap = (unsigned int)(((size_t)P.nMissWords * 32 + NC) / MLM_RAY_LISTS + 4096);
         if ((rc = dev_alloc(h, &P.tv_rec, 4 * (size_t)MLM_RAY_LISTS * P.tv_cap))) return rc;
         if ((rc = dev_alloc(h, &P.tv_key, (size_t)MLM_RAY_LISTS * P.tv_cap))) return rc;
