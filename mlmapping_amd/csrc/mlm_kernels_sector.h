@@ -1122,7 +1122,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
         // the voxel's pending state and hit slots, and (the block being known already in the common case) its map state:
         // one round trip
         const unsigned long long state = *st;
-        const mlm_u32x4 h0 = *(const MLM_GLOBAL mlm_u32x4 *)hs, h1 = *(const MLM_GLOBAL mlm_u32x4 *)(hs + 4);
+        mlm_u32x4 h0 = mlm_u32x4{0u, 0u, 0u, 0u}, h1 = h0;
+        if (p_rec.w == 0u) { // (the record of a first miss never applies hits: see below)
+            h0 = *(const MLM_GLOBAL mlm_u32x4 *)hs;
+            h1 = *(const MLM_GLOBAL mlm_u32x4 *)(hs + 4);
+        }
         float L = 0.0f;
         uint8_t o = 'u';
         size_t v = 0;
