@@ -173,6 +173,28 @@ __device__ __forceinline__ void mlm_voxel_of(const MlmDev &P, double x, double y
     }
 }
 
+// One axis of mlm_voxel_of (the axes are independent: a quotient that passes mlm_quot's check has the integer part of the
+// true division, so recomputing only the failing axis gives what recomputing all six gives)
+__device__ __forceinline__ void mlm_voxel_axis(const MlmDev &P, double x, int &g, int &c) {
+    bool exact = true;
+    const double qg = mlm_quot(x, P.inv_d_glb, exact), qs = mlm_quot(x, P.inv_d_sub, exact);
+    g = (int)floor(qg);
+    c = (int)(floor(qs) - g * P.n);
+    if (!exact) {
+        g = mlm_cvt_int(floor(x / P.d_glb));
+        c = mlm_cvt_int(floor(x / P.d_sub) - g * P.n);
+    }
+}
+// ... and their combination: block indices, cell id and in-block coordinates from the three (block index, cell coordinate) pairs
+__device__ __forceinline__ void mlm_voxel_combine(const MlmDev &P, int &cx, int &cy, int &cz, int &cid) {
+    if (cx < 0 || cy < 0 || cz < 0 || cx >= P.n || cy >= P.n || cz >= P.n) {
+        cid = 0;
+        cx = cy = cz = 0;
+    } else {
+        cid = cz * P.n * P.n + cy * P.n + cx;
+    }
+}
+
 // ---- hashed block table -------------------------------------------------------------------------------------
 // key: three 21-bit biased block indices.  Blocks are never freed (the reference only ever "collapses" them).
 __device__ __forceinline__ unsigned long long mlm_pack_key(int gx, int gy, int gz) {
@@ -195,10 +217,13 @@ __device__ __forceinline__ void mlm_unpack_key(unsigned long long key, int &gx, 
 }
 // lookup only; -1 if absent
 __device__ __forceinline__ int mlm_block_find_k(const MlmDev &P, unsigned long long key) {
+    // (key and slot of a probe position are fetched together: one round trip when the first probe decides, the usual case
+    // with a table four times the pool)
     uint32_t h = mlm_mix(key) & P.ht_mask;
     for (uint32_t probe = 0; probe <= P.ht_mask; ++probe) {
-        const unsigned long long k = P.ht_keys[h];
-        if (k == key) return P.ht_slot[h];
+        const unsigned long long k = mlm_gp(P.ht_keys)[h];
+        const int s = mlm_gp(P.ht_slot)[h];
+        if (k == key) return s;
         if (k == MLM_HT_EMPTY) return -1;
         h = (h + 1) & P.ht_mask;
     }

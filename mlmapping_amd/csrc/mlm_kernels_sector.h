@@ -295,13 +295,14 @@ __device__ __forceinline__ int mlm_local_voxel(const MlmDev &P, const MlmFrame &
 }
 // Slot `at` of sub-list `sl` of the frame's voxel queue: the record of a first-touched voxel, or a hole (kind 2) when the
 // item was not its voxel's first — every hit and every miss cell owns one slot (reserved per column with one atomic), so
-// no reservation depends on what the voxel atomics return
+// no reservation depends on what the voxel atomics return.  spec_slot: the block's pool slot if the block exists already
+// (looked up by the caller while its voxel atomic is in flight), else -1: k_apply_frame resolves it.
 __device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl, unsigned int at, bool first, int lv, unsigned long long bkey,
-                                                int cid, uint32_t kind) {
+                                                int cid, uint32_t kind, int spec_slot) {
     if (at >= P.tv_cap) return;
     const size_t i = (size_t)sl * P.tv_cap + at;
     if (first) {
-        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, P.sec_probe ? (uint32_t)mlm_block_find_k(P, bkey) : 0xFFFFFFFFu, kind};
+        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, (uint32_t)spec_slot, kind};
         mlm_gp(P.tv_key)[i] = bkey;
     } else {
         mlm_gp(P.tv_rec)[4 * i + 3] = 2u;
@@ -310,10 +311,10 @@ __device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl
 
 // LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
-    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, total;
+    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, vox, total;
 };
 // n_miss: words of the column's miss table (bit mask: nZ * RW; frontier mode keeps insertion times: nZ * nRho)
-__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, bool explore) {
+__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, uint32_t n_z, bool explore) {
     MlmSecLds L;
     uint32_t o = 0;
     L.tab = o;      o += TAB * (uint32_t)sizeof(MlmSecCell);
@@ -326,6 +327,8 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
                                                          // staging, idle between the first record pass and the second
     L.multi = o;    o += TAB * 2u;                       // ... those that received several kinds
     L.ray_p0 = o;   if (explore) o += TAB * 4u;          // frontier mode: first point of every ray start
+    o = (o + 7u) & ~7u;
+    L.vox = o;      o += (2u * n_rho + n_z) * 8u;        // world voxel (block index, cell coordinate) per axis: x, y by rho; z by z
     L.total = (o + 15u) & ~15u;
     return L;
 }
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t TAB = P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
-    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, EX);
+    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, EX);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
     float *s_odds = (float *)(s_dyn + L.odds);
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.chunk);
     uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
     uint32_t *s_ray_p0 = (uint32_t *)(s_dyn + L.ray_p0); // (EX only)
+    int2 *s_vox = (int2 *)(s_dyn + L.vox);
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter;
@@ -389,6 +393,29 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for (uint32_t e = threadIdx.x; e < NMISS; e += MLM_SEC_THREADS) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
     for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_odds[e] = mlm_gp(P.odds_table)[e];
     for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_sigma[e] = mlm_gp(P.sigma3)[e];
+    // Which world voxel a cell of this column falls into (get_global_idx / get_subbox_id of its centre moved by T_wa,
+    // map_local.cpp:151,180) separates by axis: x and y depend on rho only (phi is the column's), z on z only.  One
+    // evaluation of the FP64 sequences per rho and per z instead of one per hit and miss cell.
+    for (uint32_t e = threadIdx.x; e < 2u * (uint32_t)P.nRho + (uint32_t)P.nZ; e += MLM_SEC_THREADS) {
+        const int axis = e < (uint32_t)P.nRho ? 0 : (e < 2u * (uint32_t)P.nRho ? 1 : 2);
+        const int idx = (int)e - (axis == 0 ? 0 : (axis == 1 ? P.nRho : 2 * P.nRho));
+        double wx, wy, wz;
+        mlm_cell_center_w(P, F.t_wa, axis == 2 ? 0 : idx, phi, axis == 2 ? idx : 0, wx, wy, wz);
+        int g, c;
+        mlm_voxel_axis(P, axis == 0 ? wx : (axis == 1 ? wy : wz), g, c);
+        s_vox[e] = make_int2(g, c);
+    }
+    // world voxel of cell (rho, z) of this column: what mlm_voxel_of(mlm_cell_center_w(...)) gives
+    auto cell_voxel = [&](int rho, int z, int &gx, int &gy, int &gz, int &cid, int (&c3)[3]) {
+        const int2 vx = s_vox[rho], vy = s_vox[P.nRho + rho], vz = s_vox[2 * P.nRho + z];
+        gx = vx.x;
+        gy = vy.x;
+        gz = vz.x;
+        c3[0] = vx.y;
+        c3[1] = vy.y;
+        c3[2] = vz.y;
+        mlm_voxel_combine(P, c3[0], c3[1], c3[2], cid);
+    };
     if (threadIdx.x == 0) {
         s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
         s_nouter = 0;
@@ -697,7 +724,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for (uint32_t i0 = 0; i0 < n_occ; i0 += MLM_SEC_THREADS) { // (uniform)
         const uint32_t i = i0 + threadIdx.x;
         bool first = false;
-        int lv = -1, h_cid = 0;
+        int lv = -1, h_cid = 0, h_spec = -1;
         unsigned long long h_bkey = 0;
         if (i < n_occ) {
         const MlmSecCell c = s_tab[s_occ[i]];
@@ -720,10 +747,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         // its world voxel: pushed on the voxel's pending list in the frame-local grid (grouping by voxel needs no map);
         // the first hit of a voxel queues it for the kernel that applies the frame.  Bucket-first time of the emulated
         // container (iteration order, see Stage B in mlm_kernels.h) for the bucket count the frame was submitted with.
-        double wx, wy, wz;
-        mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
         int gx, gy, gz, cid, c3[3];
-        mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, cid, c3);
+        cell_voxel(rho, z, gx, gy, gz, cid, c3);
         if (EX) { // frontier mode: the hit's world voxel + speculative block slot, as k_prepare_voxels leaves them
             const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
             mlm_gp(P.hl_bkey)[pos] = bkey;
@@ -738,6 +763,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
             // hit number k of its voxel: the first ones into the voxel's slots, the rest on a list headed by the last slot
             const uint32_t k = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv), 1u);
+            h_bkey = mlm_pack_key(gx, gy, gz);
+            if (P.sec_probe) h_spec = mlm_block_find_k(P, h_bkey); // (in flight together with the atomic)
             MLM_GLOBAL uint32_t *hs = mlm_gp(P.lv_hits) + (size_t)lv * MLM_LV_SLOTS;
             if (k < MLM_LV_SLOTS - 1u) {
                 hs[k] = pos;
@@ -746,12 +773,11 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                 mlm_gp(P.hl_next)[pos] = (int)prev - 1;
             }
             first = k == 0u;
-            h_bkey = mlm_pack_key(gx, gy, gz);
             h_cid = cid;
         } else {
             s_fail = 1;
         }
-            mlm_queue_voxel(P, sl, s_base[6] + i, first, lv, h_bkey, h_cid, 0u);
+            mlm_queue_voxel(P, sl, s_base[6] + i, first, lv, h_bkey, h_cid, 0u, h_spec);
         }
     }
     MLM_PHASE(4);
@@ -781,10 +807,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             if (t == MLM_EMPTY_T) continue;
             int rho, z;
             key_rz(w, rho, z);
-            double wx, wy, wz;
-            mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
-            int gx, gy, gz, m_cid;
-            mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, m_cid);
+            int gx, gy, gz, m_cid, c3[3];
+            cell_voxel(rho, z, gx, gy, gz, m_cid, c3);
             mlm_gp(P.ex_cell)[at] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
             mlm_gp(P.ex_t)[at] = t;
             mlm_gp(P.ex_vt)[at] = t;
@@ -835,16 +859,21 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                 const int b = __ffs((int)bits) - 1;
                 const int z = (int)lo / P.RW;
                 const int rho = ((int)lo - z * P.RW) * 32 + b;
-                double wx, wy, wz;
-                mlm_cell_center_w(P, F.t_wa, rho, phi, z, wx, wy, wz);
                 int gx, gy, gz, m_cid, c3[3];
-                mlm_voxel_of(P, wx, wy, wz, gx, gy, gz, m_cid, c3);
+                cell_voxel(rho, z, gx, gy, gz, m_cid, c3);
                 const int lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
                 if (P.record_awareness) mlm_gp(P.ml_cell)[rec_base + i] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
                 bool first = false;
-                if (lv >= 0) first = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u) == 0u;
-                else s_fail = 1;
-                mlm_queue_voxel(P, sl, s_base[5] + i, first, lv, mlm_pack_key(gx, gy, gz), m_cid, 1u);
+                int spec = -1;
+                const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
+                if (lv >= 0) {
+                    const uint32_t before = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u);
+                    if (P.sec_probe) spec = mlm_block_find_k(P, bkey); // (in flight together with the atomic)
+                    first = before == 0u;
+                } else {
+                    s_fail = 1;
+                }
+                mlm_queue_voxel(P, sl, s_base[5] + i, first, lv, bkey, m_cid, 1u, spec);
             }
         }
     }
