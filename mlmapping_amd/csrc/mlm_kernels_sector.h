@@ -35,7 +35,8 @@
 #define MLM_SEC_THREADS 512
 #define MLM_SEC_WAVES (MLM_SEC_THREADS / 64)
 #define MLM_SEC_COLS 64     // distinct columns one k_bin_sectors block can feed (more: the frame falls back)
-#define MLM_SEC_CHUNKS 512  // chunk descriptors staged per pass of k_sector (= MLM_SEC_THREADS: one per thread)
+#define MLM_SEC_CHUNKS 256  // chunk descriptors staged per pass of k_sector (a column of a VGA frame has ~50)
+#define MLM_SEC_COMBOS 512  // most blocks one column may reach (MlmDev::sec_combos; = MLM_SEC_THREADS: one lookup per thread)
 #define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
 #define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
 
@@ -286,24 +287,17 @@ __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int ph
     }
 }
 
-// frame-local index of a voxel (MlmDev::lv_state); -1 outside the grid (cannot happen for cells of the awareness cylinder:
-// the grid is sized from its radius and height plus a margin — the frame then falls back)
-__device__ __forceinline__ int mlm_local_voxel(const MlmDev &P, const MlmFrame &F, int gx, int gy, int gz, const int c3[3]) {
-    const int x = gx * P.n + c3[0] - F.lv_o[0], y = gy * P.n + c3[1] - F.lv_o[1], z = gz * P.n + c3[2] - F.lv_o[2];
-    if ((unsigned)x >= (unsigned)P.lv_nx || (unsigned)y >= (unsigned)P.lv_ny || (unsigned)z >= (unsigned)P.lv_nz) return -1;
-    return (z * P.lv_ny + y) * P.lv_nx + x;
-}
 // Slot `at` of sub-list `sl` of the frame's voxel queue: the record of a first-touched voxel, or a hole (kind 2) when the
 // item was not its voxel's first — every hit and every miss cell owns one slot (reserved per column with one atomic), so
-// no reservation depends on what the voxel atomics return.  spec_slot: the block's pool slot if the block exists already
-// (looked up by the caller while its voxel atomic is in flight), else -1: k_apply_frame resolves it.
-__device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl, unsigned int at, bool first, int lv, unsigned long long bkey,
+// no reservation depends on what the voxel atomics return.  spec_slot: the block's pool slot if the block existed when the
+// column looked its blocks up, else -1: k_apply_frame resolves it.
+__device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl, unsigned int at, bool first, int lv, int gx, int gy, int gz,
                                                 int cid, uint32_t kind, int spec_slot) {
     if (at >= P.tv_cap) return;
     const size_t i = (size_t)sl * P.tv_cap + at;
     if (first) {
         *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, (uint32_t)spec_slot, kind};
-        mlm_gp(P.tv_key)[i] = bkey;
+        mlm_gp(P.tv_key)[i] = mlm_pack_key(gx, gy, gz);
     } else {
         mlm_gp(P.tv_rec)[4 * i + 3] = 2u;
     }
@@ -311,14 +305,23 @@ __device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl
 
 // LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
-    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, vox, total;
+    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, vox, vrep, bslot, total;
 };
 // n_miss: words of the column's miss table (bit mask: nZ * RW; frontier mode keeps insertion times: nZ * nRho)
-__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, uint32_t n_z, bool explore) {
+// n_combos: (rho run, z run) blocks the column may reach (MlmDev::sec_combos)
+__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, uint32_t n_z, uint32_t n_combos, bool explore) {
     MlmSecLds L;
     uint32_t o = 0;
     L.tab = o;      o += TAB * (uint32_t)sizeof(MlmSecCell);
-    L.chunk = o;    o += 2u * MLM_SEC_CHUNKS * 4u;       // staged chunk descriptors of the record passes
+    {
+        // staged chunk descriptors of the record passes; later the list of occupied table entries (L.occ), then the prefix of
+        // the miss mask's words
+        uint32_t b = 2u * MLM_SEC_CHUNKS * 4u;
+        if (b < TAB * 2u) b = TAB * 2u;
+        if (!explore && b < n_miss * 4u) b = n_miss * 4u;
+        L.chunk = o;
+        o += (b + 15u) & ~15u;
+    }
     L.odds = o;     o += (2u * MLM_DIFF_RANGE + 1u) * n_rho * 4u;
     L.sigma = o;    o += ((n_rho + 3u) & ~3u) * 4u;
     L.miss = o;     o += ((n_miss + 3u) & ~3u) * 4u;
@@ -328,7 +331,10 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
     L.multi = o;    o += TAB * 2u;                       // ... those that received several kinds
     L.ray_p0 = o;   if (explore) o += TAB * 4u;          // frontier mode: first point of every ray start
     o = (o + 7u) & ~7u;
-    L.vox = o;      o += (2u * n_rho + n_z) * 8u;        // world voxel (block index, cell coordinate) per axis: x, y by rho; z by z
+    o = (o + 15u) & ~15u;
+    L.vox = o;      o += (n_rho + n_z) * 16u;            // world voxel per axis (block index, cell coordinate, block run): x, y by rho; z by z
+    L.vrep = o;     o += ((n_rho + n_z + 1u) & ~1u) * 2u; // first rho / z of every block run
+    L.bslot = o;    o += n_combos * 4u;                  // speculative pool slot of every (rho run, z run) block of the column
     L.total = (o + 15u) & ~15u;
     return L;
 }
@@ -338,7 +344,7 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
 // of a bit, and the map-dependent part is frontier mode's own (explore_stage_bc): the kernel ends with the unique hit list
 // (+ world voxels) and the unique miss list (cell, time, world voxel), no frame-local grid.
 template <bool EX>
-__global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
+__global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
                                                             int rho_s, unsigned long long n_bkt) {
     MLM_SLOT_SETUP
     const int phi = (int)blockIdx.x;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t TAB = P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
-    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, EX);
+    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, P.sec_combos, EX);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
     float *s_odds = (float *)(s_dyn + L.odds);
@@ -378,7 +384,10 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.chunk);
     uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
     uint32_t *s_ray_p0 = (uint32_t *)(s_dyn + L.ray_p0); // (EX only)
-    int2 *s_vox = (int2 *)(s_dyn + L.vox);
+    int4 *s_vr = (int4 *)(s_dyn + L.vox), *s_vz = s_vr + P.nRho;
+    uint16_t *s_rrep = (uint16_t *)(s_dyn + L.vrep), *s_zrep = s_rrep + P.nRho;
+    int *s_bslot = (int *)(s_dyn + L.bslot);
+    __shared__ int s_kr, s_kz;
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter;
@@ -395,29 +404,72 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_sigma[e] = mlm_gp(P.sigma3)[e];
     // Which world voxel a cell of this column falls into (get_global_idx / get_subbox_id of its centre moved by T_wa,
     // map_local.cpp:151,180) separates by axis: x and y depend on rho only (phi is the column's), z on z only.  One
-    // evaluation of the FP64 sequences per rho and per z instead of one per hit and miss cell.
-    for (uint32_t e = threadIdx.x; e < 2u * (uint32_t)P.nRho + (uint32_t)P.nZ; e += MLM_SEC_THREADS) {
-        const int axis = e < (uint32_t)P.nRho ? 0 : (e < 2u * (uint32_t)P.nRho ? 1 : 2);
-        const int idx = (int)e - (axis == 0 ? 0 : (axis == 1 ? P.nRho : 2 * P.nRho));
+    // evaluation of the FP64 sequences per rho and per z instead of one per hit and miss cell:
+    //   s_vr[rho] = {gx, gy, cx | cy << 8 | out-of-range << 16, run of equal (gx, gy) along rho}
+    //   s_vz[z]   = {gz, cz | out-of-range << 16, run of equal gz along z, -}
+    // and the blocks the column can reach are the (rho run, z run) pairs: their pool slots are looked up once per column.
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(P.nRho + P.nZ); e += MLM_SEC_THREADS) {
         double wx, wy, wz;
-        mlm_cell_center_w(P, F.t_wa, axis == 2 ? 0 : idx, phi, axis == 2 ? idx : 0, wx, wy, wz);
-        int g, c;
-        mlm_voxel_axis(P, axis == 0 ? wx : (axis == 1 ? wy : wz), g, c);
-        s_vox[e] = make_int2(g, c);
+        if (e < (uint32_t)P.nRho) {
+            mlm_cell_center_w(P, F.t_wa, (int)e, phi, 0, wx, wy, wz);
+            int gx, gy, cx, cy;
+            mlm_voxel_axis(P, wx, gx, cx);
+            mlm_voxel_axis(P, wy, gy, cy);
+            const bool bad = cx < 0 || cy < 0 || cx >= P.n || cy >= P.n;
+            s_vr[e] = make_int4(gx, gy, bad ? 0x10000 : (cx | cy << 8), 0);
+        } else {
+            const int z = (int)e - P.nRho;
+            mlm_cell_center_w(P, F.t_wa, 0, phi, z, wx, wy, wz);
+            int gz, cz;
+            mlm_voxel_axis(P, wz, gz, cz);
+            const bool bad = cz < 0 || cz >= P.n;
+            s_vz[z] = make_int4(gz, bad ? 0x10000 : cz, 0, 0);
+        }
     }
-    // world voxel of cell (rho, z) of this column: what mlm_voxel_of(mlm_cell_center_w(...)) gives
-    auto cell_voxel = [&](int rho, int z, int &gx, int &gy, int &gz, int &cid, int (&c3)[3]) {
-        const int2 vx = s_vox[rho], vy = s_vox[P.nRho + rho], vz = s_vox[2 * P.nRho + z];
-        gx = vx.x;
-        gy = vy.x;
+    __syncthreads();
+    if (wid < 2) { // wave 0: runs along rho, wave 1: runs along z (ballot scan over the change flags)
+        const int n_ax = wid == 0 ? P.nRho : P.nZ;
+        int carry = 0;
+        for (int i0 = 0; i0 < n_ax; i0 += 64) {
+            const int i = i0 + lane;
+            bool change = false;
+            if (i < n_ax) {
+                if (wid == 0) change = i == 0 || s_vr[i].x != s_vr[i - 1].x || s_vr[i].y != s_vr[i - 1].y;
+                else change = i == 0 || s_vz[i].x != s_vz[i - 1].x;
+            }
+            const unsigned long long m = __ballot(change);
+            const int id = carry + (int)__popcll(m & ((2ull << lane) - 1ull)) - 1;
+            if (i < n_ax) {
+                if (wid == 0) s_vr[i].w = id;
+                else s_vz[i].z = id;
+                if (change) (wid == 0 ? s_rrep : s_zrep)[id] = (uint16_t)i;
+            }
+            carry += (int)__popcll(m);
+        }
+        if (lane == 0) (wid == 0 ? s_kr : s_kz) = carry;
+    }
+    __syncthreads();
+    const int n_zrun = s_kz, n_combo = s_kr * n_zrun;
+    // world voxel of cell (rho, z) of this column — what mlm_voxel_of(mlm_cell_center_w(...)) gives — as block indices, cell id,
+    // index in the frame-local grid (-1: outside) and the block's speculative pool slot (-1: not known)
+    auto cell_voxel = [&](int rho, int z, int &gx, int &gy, int &gz, int &cid, int &lv, int &spec) {
+        const int4 vr = s_vr[rho], vz = s_vz[z];
+        gx = vr.x;
+        gy = vr.y;
         gz = vz.x;
-        c3[0] = vx.y;
-        c3[1] = vy.y;
-        c3[2] = vz.y;
-        mlm_voxel_combine(P, c3[0], c3[1], c3[2], cid);
+        int cx = vr.z & 0xFF, cy = (vr.z >> 8) & 0xFF, cz = vz.y & 0xFF;
+        if ((vr.z | vz.y) >> 16) cx = cy = cz = 0; // a coordinate outside [0, n): id 0 (mlm_voxel_of)
+        cid = cz * P.n * P.n + cy * P.n + cx;
+        spec = P.sec_probe ? s_bslot[vr.w * n_zrun + vz.z] : -1;
+        if (EX) {
+            lv = 0;
+        } else {
+            const int x = gx * P.n + cx - F.lv_o[0], y = gy * P.n + cy - F.lv_o[1], zz = gz * P.n + cz - F.lv_o[2];
+            lv = ((unsigned)x >= (unsigned)P.lv_nx || (unsigned)y >= (unsigned)P.lv_ny || (unsigned)zz >= (unsigned)P.lv_nz) ? -1 : (zz * P.lv_ny + y) * P.lv_nx + x;
+        }
     };
     if (threadIdx.x == 0) {
-        s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
+        s_fail = (nch_all > P.chunk_cap || n_combo > (int)P.sec_combos || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
         s_nouter = 0;
     }
     MLM_PHASE_BEGIN
@@ -644,6 +696,14 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     //      z - .. rounded, round half away) says which way it goes (those steps are collected and evaluated afterwards);
     //      everywhere else that sequence is at most ~1e-12 away from the exact value, which is at least 1 / (2 rho) away
     //      from the next half-integer.  Consecutive steps that fall into one word of the mask are merged in a register.
+    // (the pool slots of the column's blocks, one per thread, are fetched while the rays are walked: nothing below touches
+    // global memory until the hit list)
+    int my_bslot = -1;
+    if (P.sec_probe && (int)threadIdx.x < n_combo && threadIdx.x < P.sec_combos) {
+        const int r = (int)threadIdx.x / n_zrun, zr = (int)threadIdx.x - r * n_zrun;
+        const int4 vr = s_vr[s_rrep[r]];
+        my_bslot = mlm_block_find(P, vr.x, vr.y, s_vz[s_zrep[zr]].x);
+    }
     for (uint32_t i0 = 0; i0 < 4u * n_rays; i0 += MLM_SEC_THREADS) {
         const uint32_t it = i0 + threadIdx.x;
         int rho = 0, z = 0;
@@ -716,6 +776,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             }
         }
     }
+    if (threadIdx.x < P.sec_combos) s_bslot[threadIdx.x] = my_bslot;
     __syncthreads(); // (the miss mask is complete)
     MLM_PHASE(3);
     // ---- the column's unique hits: cell, first-touch time, world voxel + speculative block slot; single-kind cells get
@@ -724,8 +785,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
     for (uint32_t i0 = 0; i0 < n_occ; i0 += MLM_SEC_THREADS) { // (uniform)
         const uint32_t i = i0 + threadIdx.x;
         bool first = false;
-        int lv = -1, h_cid = 0, h_spec = -1;
-        unsigned long long h_bkey = 0;
+        int lv = -1, h_cid = 0, h_spec = -1, gx = 0, gy = 0, gz = 0;
         if (i < n_occ) {
         const MlmSecCell c = s_tab[s_occ[i]];
         int rho, z;
@@ -747,24 +807,20 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         // its world voxel: pushed on the voxel's pending list in the frame-local grid (grouping by voxel needs no map);
         // the first hit of a voxel queues it for the kernel that applies the frame.  Bucket-first time of the emulated
         // container (iteration order, see Stage B in mlm_kernels.h) for the bucket count the frame was submitted with.
-        int gx, gy, gz, cid, c3[3];
-        cell_voxel(rho, z, gx, gy, gz, cid, c3);
+        int cid;
+        cell_voxel(rho, z, gx, gy, gz, cid, lv, h_spec);
         if (EX) { // frontier mode: the hit's world voxel + speculative block slot, as k_prepare_voxels leaves them
-            const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
-            mlm_gp(P.hl_bkey)[pos] = bkey;
+            mlm_gp(P.hl_bkey)[pos] = mlm_pack_key(gx, gy, gz);
             mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
-            mlm_gp(P.hl_slot)[pos] = mlm_block_find_k(P, bkey);
+            mlm_gp(P.hl_slot)[pos] = h_spec;
             continue;
         }
-        lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
         if (lv >= 0) {
             const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
             mlm_gp(P.hl_bkt)[pos] = (uint32_t)b;
             if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
             // hit number k of its voxel: the first ones into the voxel's slots, the rest on a list headed by the last slot
             const uint32_t k = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv), 1u);
-            h_bkey = mlm_pack_key(gx, gy, gz);
-            if (P.sec_probe) h_spec = mlm_block_find_k(P, h_bkey); // (in flight together with the atomic)
             MLM_GLOBAL uint32_t *hs = mlm_gp(P.lv_hits) + (size_t)lv * MLM_LV_SLOTS;
             if (k < MLM_LV_SLOTS - 1u) {
                 hs[k] = pos;
@@ -777,7 +833,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         } else {
             s_fail = 1;
         }
-            mlm_queue_voxel(P, sl, s_base[6] + i, first, lv, h_bkey, h_cid, 0u, h_spec);
+            mlm_queue_voxel(P, sl, s_base[6] + i, first, lv, gx, gy, gz, h_cid, 0u, h_spec);
         }
     }
     MLM_PHASE(4);
@@ -807,8 +863,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
             if (t == MLM_EMPTY_T) continue;
             int rho, z;
             key_rz(w, rho, z);
-            int gx, gy, gz, m_cid, c3[3];
-            cell_voxel(rho, z, gx, gy, gz, m_cid, c3);
+            int gx, gy, gz, m_cid, lv_unused, spec_unused;
+            cell_voxel(rho, z, gx, gy, gz, m_cid, lv_unused, spec_unused);
             mlm_gp(P.ex_cell)[at] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
             mlm_gp(P.ex_t)[at] = t;
             mlm_gp(P.ex_vt)[at] = t;
@@ -833,10 +889,12 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
         }
         __syncthreads();
         if (total) {
-            // one miss cell per thread: item i lives in the word w with off[w] <= i < off[w + 1] (exclusive prefix of the
-            // words' popcounts, in the idle chunk-staging area) and is that word's (i - off[w])-th set bit — so that the
-            // voxel atomics of all the column's miss cells are in flight together instead of one round trip per word pair
-            uint32_t *s_off = s_chunk_first; // [NMISS] (NMISS < 2 * MLM_SEC_CHUNKS, checked by the host)
+            // One miss cell per thread, so that the voxel atomics of all the column's miss cells are in flight together.
+            // The cells are listed first (column-local keys z * nRho + rho, in the cell table's space, which is idle by now):
+            // a thread takes a byte of a mask word and writes its set bits at off[word] + bits below — off = exclusive prefix
+            // of the words' popcounts (in the idle chunk-staging area).
+            uint32_t *s_off = s_chunk_first; // [NMISS] (the staging area is sized for it, mlm_sec_lds)
+            uint16_t *s_cells = (uint16_t *)s_tab; // [total] (NMISS * 64 bytes <= the table's, checked by the host)
             uint32_t run = 0;
             for (uint32_t w0 = 0; w0 < NMISS; w0 += MLM_SEC_THREADS) {
                 const uint32_t w = w0 + threadIdx.x;
@@ -846,34 +904,32 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector(MLM_SLOT_ARGS, int t
                 run += tot_w;
             }
             __syncthreads();
+            for (uint32_t q0 = 0; q0 < 4u * NMISS; q0 += MLM_SEC_THREADS) {
+                const uint32_t q = q0 + threadIdx.x, w = q >> 2, sh = (q & 3u) * 8u;
+                if (w >= NMISS) break;
+                const uint32_t bits = s_miss[w];
+                uint32_t byte = (bits >> sh) & 0xFFu;
+                if (!byte) continue;
+                const uint32_t z = w / (uint32_t)P.RW;
+                const uint32_t key0 = z * (uint32_t)P.nRho + (w - z * (uint32_t)P.RW) * 32u + sh;
+                uint32_t at = s_off[w] + (uint32_t)__popc(bits & ((1u << sh) - 1u));
+                while (byte) {
+                    s_cells[at++] = (uint16_t)(key0 + (uint32_t)__ffs((int)byte) - 1u);
+                    byte &= byte - 1;
+                }
+            }
+            __syncthreads();
             const uint32_t rec_base = s_base[7];
             for (uint32_t i = threadIdx.x; i < total; i += MLM_SEC_THREADS) {
-                uint32_t lo = 0, hi = NMISS; // largest w with off[w] <= i
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_off[mid] <= i) lo = mid;
-                    else hi = mid;
-                }
-                uint32_t bits = s_miss[lo];
-                for (uint32_t k = i - s_off[lo]; k > 0; --k) bits &= bits - 1;
-                const int b = __ffs((int)bits) - 1;
-                const int z = (int)lo / P.RW;
-                const int rho = ((int)lo - z * P.RW) * 32 + b;
-                int gx, gy, gz, m_cid, c3[3];
-                cell_voxel(rho, z, gx, gy, gz, m_cid, c3);
-                const int lv = mlm_local_voxel(P, F, gx, gy, gz, c3);
+                int rho, z;
+                key_rz(s_cells[i], rho, z);
+                int gx, gy, gz, m_cid, lv, spec;
+                cell_voxel(rho, z, gx, gy, gz, m_cid, lv, spec);
                 if (P.record_awareness) mlm_gp(P.ml_cell)[rec_base + i] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
                 bool first = false;
-                int spec = -1;
-                const unsigned long long bkey = mlm_pack_key(gx, gy, gz);
-                if (lv >= 0) {
-                    const uint32_t before = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u);
-                    if (P.sec_probe) spec = mlm_block_find_k(P, bkey); // (in flight together with the atomic)
-                    first = before == 0u;
-                } else {
-                    s_fail = 1;
-                }
-                mlm_queue_voxel(P, sl, s_base[5] + i, first, lv, bkey, m_cid, 1u, spec);
+                if (lv >= 0) first = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u) == 0u;
+                else s_fail = 1;
+                mlm_queue_voxel(P, sl, s_base[5] + i, first, lv, gx, gy, gz, m_cid, 1u, spec);
             }
         }
     }

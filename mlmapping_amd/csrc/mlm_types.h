@@ -190,6 +190,7 @@ struct MlmDev {
     unsigned int chunk_cap;
     unsigned int sec_tab, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two)
     unsigned int sec_probe;              // 1: k_sector looks the block slot of a queued voxel up (speculatively), 0: left to k_apply_frame
+    unsigned int sec_combos;   // most blocks a column may reach: runs of equal block index along rho x runs along z (k_sector)
     unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
     uint32_t *refs;            // [refs_cap][4] {lane mask lo, hi, tile origin (row << 11 | column), kind} per contribution group of a
                                // multi-kind cell

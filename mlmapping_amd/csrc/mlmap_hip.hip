@@ -1320,7 +1320,13 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (const char *e = getenv("MLM_SEC_PROBE")) P.sec_probe = atoi(e) != 0;
         if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
-        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
+        {
+            // a ray of length R crosses at most R (|cos| + |sin|) / D block boundaries in x or y, the column's height H / D in z
+            const double D = P.n * P.d_sub;
+            const unsigned int kr = (unsigned int)std::ceil(P.nRho * P.dRho * std::sqrt(2.0) / D) + 3, kz = (unsigned int)std::ceil(P.nZ * P.dZ / D) + 2;
+            P.sec_combos = std::min<unsigned int>(MLM_SEC_COMBOS, kr * kz);
+        }
+        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.sec_combos, P.explore).total;
         {
             // frame-local voxel grid: the awareness cylinder (radius nRho*dRho, height nZ*dZ) plus four voxels each side
             const double R = P.nRho * P.dRho;
@@ -1329,9 +1335,14 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         }
         // (frontier mode: no frame-local grid, no prefix of the mask words in the chunk staging area; its insertion times
         // hold point index * 256 + ray step in 32 bits)
-        h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) &&
-                         (P.explore ? P.nRho <= 256 : ((long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26) && P.nZ * P.RW < 2 * MLM_SEC_CHUNKS));
+        // (k_sector packs in-block cell coordinates into bytes and lists a column's miss cells in its cell table's space)
+        h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
+                         (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
+                         (P.explore ? P.nRho <= 256 : (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
+        if (getenv("MLM_DEBUG_CREATE"))
+            fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries, %u blocks), frame-local grid %d x %d x %d\n", (int)h->use_sectors,
+                    P.sec_lds_bytes, P.sec_tab, P.sec_combos, P.lv_nx, P.lv_ny, P.lv_nz);
         if (h->use_sectors) {
             if (P.explore)
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
