@@ -53,12 +53,18 @@ struct MlmSecCell {
 #define MLM_SEC_CNT_BITS 20 // MlmSecCell::cnt: contributions in the low bits (mlm_limits.max_points < 2^20 on this path)
 #define MLM_SEC_CNT_MASK ((1u << MLM_SEC_CNT_BITS) - 1u)
 // Does the float noisy-OR chain of the cell (update_odds_hashmap, map_awareness.h:147-154: p <- 1 - (1 - p)(1 - a), each
-// operation rounded) depend on the order of its contributions?  Not with one kind only.  And not once 14 of them have
-// a >= 0.75, whatever the other kinds and the order: the first such step puts p into [0.5, 1], where 1 - p is exact, an
-// integer k <= 2^23 in units of 2^-24; p never decreases; a step with 1 - a <= 0.25 maps k to at most k / 4 + 0.625
-// (product rounded to float, then 1 - m rounded to the grid), every other step to at most k; thirteen quarterings bring
-// any k <= 2^23 to 0, i.e. p == 1.0f, which is absorbing.  Such cells are finished without ranking their contributions.
-#define MLM_SEC_STRONG_ENOUGH 14u
+// operation rounded) depend on the order of its contributions?  Not with one kind only.  And not once the contributions
+// are strong enough to end at exactly 1.0f in ANY order.  Call a contribution with a >= 0.5 strong, of strength
+// s = 1 (a < 0.75), 2 (a < 0.875) or 3: b = 1 - a is exact and <= 2^-s.  The first strong step of any order puts p into
+// [0.5, 1], where 1 - p is exact: an integer k <= 2^24 in units of 2^-24.  From then on p never decreases; a strong step maps
+// k to at most k (1 + 2^-24) / 2^s + 0.5 (the product m = k 2^-24 b is rounded to float, then 1 - m to the grid), any other
+// step to at most k.  Unrolled over the strong steps before the LAST one of the order (fewer than 2^20, strengths summing
+// to at least S - 3 with S the sum of all): k <= 1.07 (2^24 / 2^(S - 3) + 1), i.e. k <= 1 once S >= 28; the last strong step
+// turns k <= 1 into m <= 2^-25 (exact), and 1 - m rounds to 1.0f (ties to even), which is absorbing.
+// Such cells are finished without ranking their contributions (S is summed mod 4096 next to the count: a wrap only
+// makes a cell look weaker than it is).
+#define MLM_SEC_STRONG_ENOUGH 28u
+__device__ __forceinline__ uint32_t mlm_sec_strength(float a) { return a >= 0.875f ? 3u : (a >= 0.75f ? 2u : (a >= 0.5f ? 1u : 0u)); }
 __device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
     return __popc(c.kmask) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH;
 }
@@ -581,9 +587,9 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
                         }
                         atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
                         atomicOr(&s_tab[e].kmask, 1u << sub);
-                        // contributions, and in the upper 12 bits (mod 4096) those whose odd is >= 0.75
-                        const bool strong = mlm_contribution_odd(P, s_odds, rho_t, sub) >= 0.75f;
-                        atomicAdd(&s_tab[e].cnt, cnt | (strong ? cnt << MLM_SEC_CNT_BITS : 0u));
+                        // contributions, and in the upper 12 bits (mod 4096) the sum of their strengths (mlm_sec_needs_order)
+                        const uint32_t strength = mlm_sec_strength(mlm_contribution_odd(P, s_odds, rho_t, sub));
+                        atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
                         atomicAdd(&s_tab[e].gcnt, 1u);
                         if (EX && sub == 0) atomicMin(&s_tab[e].gpos, i_first);
                     });
