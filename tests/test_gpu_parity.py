@@ -798,3 +798,33 @@ def test_frontier_mode_sector_path(mods, monkeypatch, env):
     if env.get("MLM_SEC_FAIL_EVERY") == "4":
         assert 1 <= st["n_sector_fallbacks"] <= 3, st
     gpu.close()
+
+
+@pytest.mark.parametrize("d_sub", [0.3, 0.5])
+def test_many_hits_per_voxel(mods, d_sub):
+    """Voxels several awareness cells wide collect dozens of hit cells each: more than the seven direct hit slots of a voxel
+    in the frame-local grid (list behind the last slot) and more than k_apply_frame orders in registers (selection from
+    memory).  The order of a voxel's hits matters through the clamp at log_odds_max and the float additions."""
+    MLMap, OracleMap = mods
+    cfg = S1.with_(subbox_d_xyz=d_sub, subbox_n=4, lm_log_odds_max=2.5, lm_measurement_hit=0.4)
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=4, record_awareness=True), OracleMap(cfg)
+    frames = list(syn.stream(cfg, "room_jitter", "random", 6))
+    for k, (img, (q, t)) in enumerate(frames[:2]):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"d_sub {d_sub} frame {k}")
+        if k == 0:  # hit cells per voxel that received hits (those are the voxels above 0 after the first frame)
+            ratio = gpu.frame_stats()["n_hit_cells"] / max(1, int((cpu.export_blocks()["log_odds"] > 0).sum()))
+            print(f"d_sub {d_sub}: {ratio:.1f} hit cells per hit voxel")
+            assert ratio > (5 if d_sub < 0.4 else 12), ratio
+    imgs = np.stack([f[0] for f in frames[2:]])
+    q = np.stack([f[1][0] for f in frames[2:]])
+    t = np.stack([f[1][1] for f in frames[2:]])
+    gpu.update_map_batch(imgs, q, t)
+    for img, (qq, tt) in frames[2:]:
+        cpu.update_depth(img, qq, tt)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"d_sub {d_sub} batch")
+    st = gpu.frame_stats()
+    assert st["n_sector_fallbacks"] == 0, st
+    gpu.close()
