@@ -124,9 +124,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step (one batched Stage A launch sequence)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step (one batched Stage A launch sequence)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
-    ap.add_argument("--distinct", type=int, default=32, help="distinct depth frames kept in HBM (cycled)")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct depth frames kept in HBM (cycled; rounded up to a multiple of --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events around the kernels")
     ap.add_argument("--no-extra", action="store_true", help="skip the short config-3 measurement")
@@ -157,6 +157,7 @@ def main():
         import dataclasses
         cfg = dataclasses.replace(cfg, use_raycasting=False)
     B, K, W = args.batch, args.steps, args.warmup
+    args.distinct = max(B, (args.distinct + B - 1) // B * B)  # whole batches: a step is always ONE batched submission
     n_total = (K + W) * B
     frames, q, t = make_inputs(cfg, args.distinct, n_total, seed=42 + rank)
     # inputs resident in HBM: torch owns the buffer (uint16 payload viewed as int16 storage)
