@@ -11,15 +11,15 @@ struct MlmCounters {
     // per-frame (zeroed at the start of every frame)
     unsigned int n_points;    // points with raw != 0
     unsigned int u_hit;       // unique hit cells
-    unsigned int u_miss;      // unique miss cells
+    unsigned int rsv0;        // (unused; keeps the 64-byte head of the block)
     unsigned int n_oor;       // "point out range"
-    unsigned int n_miss_vox;  // voxels touched by misses this frame
+    unsigned int rsv1;        // (unused)
     unsigned int n_miss_list; // entries of ml_cell (record_awareness only)
     unsigned int n_contrib;   // contributions stored for multi-type cells (segments of `contrib`)
     unsigned int n_multi;     // hit cells that received more than one kind of contribution
     unsigned int n_ex_rays;   // explore mode: queued rays
     unsigned int n_ex_miss;   // explore mode: unique miss cells
-    unsigned int n_ex_vox;    // explore mode: voxels touched by misses
+    unsigned int rsv2;        // (unused)
     unsigned int n_big;       // multi-kind cells with more than 1024 contributions
     unsigned int n_groups;    // contribution groups kept in the blocks' own slices of `bnodes` (folded by k_collect_hits)
     unsigned int sector_overflow; // sector path: an LDS table of some column overflowed -> the frame is redone by the cell-table path

@@ -523,14 +523,19 @@ def test_random_configurations(mods):
             if k == 1:  # a smooth surface as well as speckle
                 depth[:] = (1000 * 0.6 * cfg.am_n_Rho * cfg.am_d_Rho + 200 * np.sin(np.arange(320) / 25.0)[None, :]).astype(np.uint16)
             q, t = syn.random_poses(3, seed=trial)[k]
-            gpu.update_map(depth, q, t)
             cpu.update_depth(depth, q, t)
+            if cpu.block_count() > 32768:  # (tiny blocks over a long range: the pool of this test is too small — the
+                with pytest.raises(Exception, match="MLM_ERR_CAPACITY"):  # library must say so, not misbehave)
+                    gpu.update_map(depth, q, t)
+                break
+            gpu.update_map(depth, q, t)
             _awareness_equal(gpu, cpu)
             compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"fuzz trial {trial} frame {k} cfg {cfg}")
             if cfg.use_exploration_frontiers:
                 assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"fuzz trial {trial}: frontier"
-        pos = rng.uniform(-8, 8, size=(20000, 3))
-        assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+        else:
+            pos = rng.uniform(-8, 8, size=(20000, 3))
+            assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
         gpu.close()
 
 
