@@ -2,6 +2,7 @@
 same inputs: frontier mode, the ROS-free depth/odom callback (reference-default 500-sample path and dense), obstacle
 inflation, the planner queries, setFree_map_in_bound and the /global_map payload.  One JSON object on stdout.
 The oracle is used here as the CPU baseline only (like bench.py's cpu_baseline leg)."""
+import gc
 import json
 import os
 import sys
@@ -14,6 +15,8 @@ from mlmapping_amd import synthetic as syn  # noqa: E402
 from mlmapping_amd.config import S1, SDEF  # noqa: E402
 from mlmapping_amd.mlmap import MLMap  # noqa: E402
 from oracle.binding import OracleMap  # noqa: E402
+
+gc.disable()  # (a generation-2 collection is a 40 ms pause: it would land in one of the short timed loops below)
 
 
 def timeit(f, reps):
@@ -130,9 +133,14 @@ for sampled in (True, False):
     for k in range(3):
         call(gpu, k)
     t0 = time.perf_counter()
+    per = []
     for k in range(3, 33):
+        t1 = time.perf_counter()
         call(gpu, k)
+        per.append((time.perf_counter() - t1) * 1e3)
     g = 30 / (time.perf_counter() - t0)
+    if os.environ.get("MLM_ROWS_DEBUG"):
+        print("callback ms per call:", " ".join(f"{x:.2f}" for x in per), file=sys.stderr)
     n_c = 30 if sampled else 6
     t0 = time.perf_counter()
     for k in range(n_c):

@@ -1,7 +1,9 @@
+# usage: bash tools/prof_round.sh [tag]   (everything under gpurun_out/<tag>/; copy the summaries to profiles/<tag>_*)
 set -x
+TAG=${1:-r2d}
 R=$PWD
-mkdir -p gpurun_out/r2b
-O=$R/gpurun_out/r2b
+mkdir -p gpurun_out/$TAG
+O=$R/gpurun_out/$TAG
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 300 python tools/kernel_times.py > $O/kernel_times.txt 2>&1
