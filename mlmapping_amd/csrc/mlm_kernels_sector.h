@@ -197,34 +197,40 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
         }
     }
     __syncthreads();
-    if (wid == 0) { // one wave: offsets of the columns' runs inside the block's slice, one chunk descriptor per run
-        const uint32_t cnt = s_col_cnt[lane];
-        const uint32_t incl = mlm_wave_incl_scan(cnt);
-        s_col_off[lane] = incl - cnt;
-        if (cnt) {
-            const uint32_t ph = s_col_phi[lane];
-            const unsigned int k = g_atomic_add(&mlm_gp(P.col_cnt)[ph], 1u);
-            if (k < P.chunk_cap)
-                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)ph * P.chunk_cap + k)) =
-                    mlm_u32x2{blockIdx.x * 256u + (incl - cnt), cnt};
-            else
-                s_over = 1;
-        }
-        if (lane == 0) {
-            unsigned int pts = 0, oor = 0;
-            for (unsigned int w = 0; w < 4; ++w) {
-                pts += s_cnt[w] & 1023u;
-                oor += s_cnt[w] >> 10;
-            }
-            *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)blockIdx.x) = mlm_u32x4{pts, oor, nn, 0u};
-        }
+    // one wave: offsets of the columns' runs inside the block's slice; after the records are stored (the other waves are done
+    // then and do not wait for it) one chunk descriptor per run, its place in the column's list from a returning atomic
+    uint32_t run_cnt = 0, run_off = 0;
+    if (wid == 0) {
+        run_cnt = s_col_cnt[lane];
+        run_off = mlm_wave_incl_scan(run_cnt) - run_cnt;
+        s_col_off[lane] = run_off;
     }
     __syncthreads();
     if (threadIdx.x < nn && s_rec_col[threadIdx.x] != 0xFFFFu) {
         const unsigned int e = s_rec_col[threadIdx.x];
         mlm_store_node(mlm_gp(P.bnodes) + ((size_t)blockIdx.x * 256u + s_col_off[e] + s_rec_pos[threadIdx.x]), s_node[threadIdx.x]);
     }
-    if (threadIdx.x == 0 && s_over) mlm_sector_fail(P, F);
+    if (wid != 0) return;
+    bool over = false;
+    if (run_cnt) {
+        const uint32_t ph = s_col_phi[lane];
+        const unsigned int k = g_atomic_add(&mlm_gp(P.col_cnt)[ph], 1u);
+        if (k < P.chunk_cap)
+            *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)ph * P.chunk_cap + k)) = mlm_u32x2{blockIdx.x * 256u + run_off, run_cnt};
+        else
+            over = true;
+    }
+    if (lane == 0) {
+        unsigned int pts = 0, oor = 0;
+        for (unsigned int w = 0; w < 4; ++w) {
+            pts += s_cnt[w] & 1023u;
+            oor += s_cnt[w] >> 10;
+        }
+        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)blockIdx.x) = mlm_u32x4{pts, oor, nn, 0u};
+    }
+    if (__any(over) || s_over) { // (s_over: more columns than the block's table holds, set before the last barrier)
+        if (lane == 0) mlm_sector_fail(P, F);
+    }
 }
 
 // find (or with INSERT create) the table entry of a column-local cell key; -1: table full
