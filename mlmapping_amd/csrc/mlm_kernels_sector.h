@@ -690,7 +690,10 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
                 MlmSecCell &c = s_tab[e];
                 const uint32_t pos = s_base[0] + c.gpos, m = s_base[1] + j, o_refs = carry_refs + a[0], o_subs = carry_subs + a[1];
                 mlm_gp(P.mt_list)[m] = pos;
-                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, c.cnt & MLM_SEC_CNT_MASK, c.tmin};
+                int c_rho, c_z;
+                key_rz(c.key, c_rho, c_z);
+                // (contributions | rho << 20: what k_chain_lanes needs of the cell comes with one load)
+                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, (c.cnt & MLM_SEC_CNT_MASK) | ((uint32_t)c_rho << MLM_SEC_CNT_BITS), c.tmin};
                 *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.gcnt};
                 mlm_gp(P.hl_base)[pos] = o_subs;
                 mlm_gp(P.hl_cnt)[pos] = c.cnt & MLM_SEC_CNT_MASK;
@@ -999,7 +1002,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
     auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],
                        const uint32_t (&r_sub)[4]) {
         // (the descriptor is the same in every lane: scalar registers, uniform branches)
-        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z),
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z) & MLM_SEC_CNT_MASK,
                        n_refs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rf.y);
         const uint32_t pix0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
@@ -1173,6 +1176,110 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, i
             s_cur[q] = s_nxt[q];
         }
     }
+}
+
+// The float noisy-OR chains of the ranked cells (update_odds_hashmap, map_awareness.h:147-154, over the kinds k_rank put in
+// pixel order): one cell per LANE, and a lane that finishes its cell draws the next one — chains are 2 to several hundred
+// steps long, so with a fixed cell per lane a wave would run as long as its longest chain with most lanes idle.  A wave
+// reserves cells from the frame's counter 128 at a time; loads are issued one round ahead of their use (cell descriptor,
+// then 16 kinds per 16-byte load), so a round's arithmetic covers the next round's memory latency.  The odds table is kept
+// transposed in LDS ([rho][kind], 32 kinds per row): one shift-add per lookup.  p == 1.0f is absorbing and ends a chain.
+#define MLM_CHAIN_RESERVE 128u
+__global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
+    extern __shared__ float s_odds_t[]; // [nRho][32]: odd of a contribution of kind k into a cell at rho
+    for (int j = threadIdx.x; j < P.nRho * 32; j += blockDim.x) {
+        const int rho = j >> 5, k = j & 31;
+        // (kind k of a contribution into a cell at rho comes from a centre d = (k + 1) / 2 cells nearer (odd k) or farther;
+        // pairs whose centre would lie outside the map cannot occur)
+        const int d = (k + 1) >> 1, rho_s = k == 0 ? rho : ((k & 1) ? rho - d : rho + d);
+        s_odds_t[j] = (k <= 2 * MLM_DIFF_RANGE && rho_s >= 0 && rho_s < P.nRho) ? mlm_contribution_odd(P, P.odds_table, rho, k) : 0.0f;
+    }
+    __syncthreads();
+    const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    uint32_t loc_next = 0, loc_end = 0; // (uniform) the wave's reserved cells not handed to a lane yet
+    bool exhausted = false;             // (uniform) the frame's counter is past the last cell
+    int state = 0;                      // 0 idle, 1 descriptor in flight, 2 first kinds in flight, 3 running
+    mlm_u32x4 desc_in = mlm_u32x4{0u, 0u, 0u, 0u}, kinds_in = desc_in, kinds = desc_in;
+    uint32_t pos = 0, base = 0, n = 0, j0 = 0, row = 0;
+    float p = 0.0f;
+    bool first = true;
+    // a finished chain waits in its lane until enough lanes have one: the logit (an FP64 log10) then runs once for all of them
+    bool pend = false;
+    uint32_t pend_pos = 0;
+    float pend_p = 0.0f;
+    auto flush = [&]() {
+        if (pend) {
+            mlm_gp(P.hl_odd)[pend_pos] = pend_p;
+            mlm_gp(P.hl_inc)[pend_pos] = mlm_logit(pend_p);
+            pend = false;
+        }
+    };
+    for (;;) {
+        // ---- what was requested in the previous round has arrived
+        if (state == 2 || state == 3) kinds = kinds_in;
+        if (state == 2) state = 3;
+        if (state == 1) {
+            pos = desc_in.x;
+            base = desc_in.y;
+            n = desc_in.z & MLM_SEC_CNT_MASK;
+            row = (desc_in.z >> MLM_SEC_CNT_BITS) * 32u;
+            j0 = 0;
+            first = true;
+            p = 0.0f;
+            kinds_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.subs) + base);
+            state = 2;
+        } else if (state == 3 && j0 + 16u < n) {
+            kinds_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.subs) + base + j0 + 16u); // (one round ahead)
+        }
+        // ---- idle lanes draw cells
+        const unsigned long long need = __ballot(state == 0);
+        if (need && !exhausted) {
+            if (loc_next >= loc_end) {
+                uint32_t b = 0;
+                if (lane == 0) b = g_atomic_add(&mlm_gp(P.ctr)->chain_next, MLM_CHAIN_RESERVE);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                loc_next = b;
+                loc_end = min(b + MLM_CHAIN_RESERVE, n_cells);
+                exhausted = b >= n_cells;
+            }
+            if (!exhausted) {
+                const uint32_t idx = loc_next + (uint32_t)__popcll(need & lanes_below);
+                if (state == 0 && idx < loc_end) {
+                    desc_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + idx);
+                    state = 1;
+                }
+                loc_next = min(loc_end, loc_next + (uint32_t)__popcll(need));
+            }
+        }
+        if (exhausted && !__any(state != 0)) break;
+        if (__popcll(__ballot(pend)) >= 40) flush();
+        // ---- sixteen steps of the running chains
+        if (state == 3) {
+            const uint32_t rem = n - j0; // >= 1
+            const uint32_t w[4] = {kinds.x, kinds.y, kinds.z, kinds.w};
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float a = s_odds_t[row + ((w[q >> 2] >> ((q & 3) * 8)) & 31u)]; // (padding bytes: any value, not used)
+                if ((uint32_t)q < rem) {
+                    p = first ? a : 1 - (1 - p) * (1 - a);
+                    first = false;
+                }
+            }
+            j0 += 16u;
+        }
+        const bool fin = state == 3 && (j0 >= n || p == 1.0f);
+        if (__any(fin && pend)) flush();
+        if (fin) {
+            pend = true;
+            pend_pos = pos;
+            pend_p = p;
+            state = 0;
+        }
+    }
+    flush();
 }
 
 // The part of a frame that needs the map (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237), sector

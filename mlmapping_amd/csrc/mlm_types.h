@@ -11,7 +11,7 @@ struct MlmCounters {
     // per-frame (zeroed at the start of every frame)
     unsigned int n_points;    // points with raw != 0
     unsigned int u_hit;       // unique hit cells
-    unsigned int rsv0;        // (unused; keeps the 64-byte head of the block)
+    unsigned int chain_next;  // sector path: next ranked cell to hand to a wave of k_chain_lanes
     unsigned int n_oor;       // "point out range"
     unsigned int rsv1;        // (unused)
     unsigned int n_miss_list; // entries of ml_cell (record_awareness only)

@@ -101,6 +101,7 @@ struct mlm_handle {
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
     unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
+    unsigned int chain_grid = 0;             // blocks per frame of k_chain_lanes (0: from the last confirmed frame's ranked cells; MLM_CHAIN_GRID)
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
     unsigned int sc_block = 128;             // threads per k_apply_voxelize block (its duration in the pipeline: 18 us vs 27 us with 256)
     bool sc_grid_fixed = false;              // MLM_SC_GRID given: do not adapt
@@ -428,8 +429,15 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
         tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->sort_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
                 mode == 0 ? F.width : 0, row_w, dm, ds);
-        tlaunch(h, "k_chain", k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st, h->d_slot_tab,
-                h->d_frame_tab, base, 0xFFFFFFFFu);
+        // blocks per frame: about 400 ranked cells per block in a batch (a lane that finishes a chain draws the next cell; each
+        // block builds the transposed odds table in LDS), as many as the last confirmed frame had; single frames spread wider
+        unsigned int cg = h->chain_grid;
+        if (!cg) {
+            const long long cells = std::max<long long>(1, h->stats.n_multi_cells);
+            cg = n > 4 ? (unsigned int)std::min<long long>(64, std::max<long long>(8, cells / 400)) : (unsigned int)std::min<long long>(128, std::max<long long>(16, cells / 128));
+        }
+        tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
+                base);
     }
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
@@ -1186,6 +1194,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (const char *e = getenv("MLM_EXPAND_BLOCK")) h->expand_block = (unsigned int)std::max(64, atoi(e));
         if (const char *e = getenv("MLM_SORT_BLOCK")) h->sort_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
         if (const char *e = getenv("MLM_SORT_GRID")) h->sort_grid = (unsigned int)std::max(1, atoi(e));
+        if (const char *e = getenv("MLM_CHAIN_GRID")) h->chain_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_COLLECT_GRID")) h->collect_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_SC_BLOCK")) h->sc_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
         if (const char *e = getenv("MLM_SC_GRID")) {
