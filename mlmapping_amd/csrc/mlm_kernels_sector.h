@@ -17,12 +17,12 @@
 //                   queue the voxel.  Global atomics: list reservations per workgroup, one push + one bucket-min per hit,
 //                   one count per miss cell.
 //   k_rank          one wave per multi-kind cell: order its contributions by pixel (bitmap ranking fed with the records'
-//                   8x8 lane masks) and store the kinds in that order; k_chain (mlm_kernels.h) then replays the float
+//                   8x8 lane masks) and store the kinds in that order; k_chain_lanes then replays the float
 //                   noisy-OR chain.
 //   k_apply_frame   the part that needs the map, ONE launch per frame: one queued voxel per lane — block lookup /
 //                   creation, the voxel's hits in the reference's iteration order, its misses, store.
 //
-// Frontier mode (use_exploration_frontiers) uses k_bin_sectors, k_sector<true>, k_rank and k_chain and continues with its
+// Frontier mode (use_exploration_frontiers) uses k_bin_sectors, k_sector<true>, k_rank and k_chain_lanes and continues with its
 // own map-dependent part (mlm_kernels_explore.h): there the miss container's iteration order matters as well, so the
 // column keeps the first insertion time of every miss cell in LDS instead of a bit.
 //
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         return;
     }
-    // ---- multi-kind cells: segments in `refs` and `subs`, descriptors for k_rank / k_chain
+    // ---- multi-kind cells: segments in `refs` and `subs`, descriptors for k_rank / k_chain_lanes
     {
         uint32_t carry_refs = s_base[2], carry_subs = s_base[3];
         for (uint32_t j0 = 0; j0 < n_multi; j0 += MLM_SEC_THREADS) { // (one round unless the column holds > 512 such cells)
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     __syncthreads(); // (the miss mask is complete)
     MLM_PHASE(3);
     // ---- the column's unique hits: cell, first-touch time, world voxel + speculative block slot; single-kind cells get
-    //      their odd and increment here (multi-kind cells: k_rank / k_chain)
+    //      their odd and increment here (multi-kind cells: k_rank / k_chain_lanes)
     const unsigned int sl = blockIdx.x & 7;
     for (uint32_t i0 = 0; i0 < n_occ; i0 += MLM_SEC_THREADS) { // (uniform)
         const uint32_t i = i0 + threadIdx.x;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
 }
 
 // One wave per multi-kind hit cell: order the cell's contributions by insertion time (= pixel order: a pixel contributes
-// to a cell at most once) and store their kinds in that order for k_chain.  Bitmap ranking as k_sort_contribs, but fed with
+// to a cell at most once) and store their kinds in that order for k_chain_lanes.  Bitmap ranking as k_sort_contribs, but fed with
 // the records' 8x8 lane masks (eight row bytes per (record, kind) reference) instead of one key per contribution.
 // tile_w > 0: dense 8x8 pixel tiles of an image of that width; 0: linear work items (see MlmNode).  row_w, div_m, div_s:
 // rows of the ranking bitmap and the exact division by row_w.
