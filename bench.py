@@ -144,13 +144,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    # MLM_BENCH_DIST_BACKEND=gloo (test hook, tests/test_gpu_boundary.py): the launcher contract — rank environment,
+    # barrier, max over ranks, one JSON line from rank 0 — exercised on a box with fewer GPUs than ranks (ranks share
+    # devices, the collectives run on the CPU).  The measured configuration is always one rank per GPU over RCCL.
+    backend = os.environ.get("MLM_BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg = S1 if args.workload == "cfg2" else S3
     if os.environ.get("MLM_BENCH_NO_RAYCAST"):  # diagnostic only (not the BASELINE workload): hits without rays
@@ -222,7 +231,7 @@ def main():
         print("step ms:", [(i, round(float(x), 2)) for i, x in enumerate(d) if x > 1.5], "final barrier", round((t0 + dt - step_t[-1]) * 1e3, 2),
               file=sys.stderr)
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if not args.no_kernel_timing:

@@ -273,3 +273,26 @@ def test_two_slot_sets(mods, monkeypatch):
     for k in range(n):
         cpu.update_depth(frames[k], q[k], t[k])
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "two slot sets")
+
+
+def test_bench_launcher_contract_two_ranks():
+    """bench.py under `torch.distributed.run --nproc-per-node 2` exactly as the driver launches it (rank environment, barrier,
+    max over ranks, ONE JSON line from rank 0, whole-job aggregate).  This box has one GPU, so both ranks share it and the
+    collectives run over gloo (MLM_BENCH_DIST_BACKEND): the contract is what is checked, not a rate."""
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MLM_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["streams"] == 2 and d["config"]["frames_per_step"] == 8
+    # whole-job aggregate: frames of BOTH ranks over the slower rank's time
+    assert abs(d["value"] - 2 * 3 * 8 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["atomics"]["atomics_per_frame"] > 0
