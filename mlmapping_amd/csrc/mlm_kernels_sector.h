@@ -299,19 +299,26 @@ __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int ph
     }
 }
 
-// Slot `at` of sub-list `sl` of the frame's voxel queue: the record of a first-touched voxel, or a hole (kind 2) when the
-// item was not its voxel's first — every hit and every miss cell owns one slot (reserved per column with one atomic), so
-// no reservation depends on what the voxel atomics return.  spec_slot: the block's pool slot if the block existed when the
-// column looked its blocks up, else -1: k_apply_frame resolves it.
-__device__ __forceinline__ void mlm_queue_voxel(const MlmDev &P, unsigned int sl, unsigned int at, bool first, int lv, int gx, int gy, int gz,
-                                                int cid, uint32_t kind, int spec_slot) {
-    if (at >= P.tv_cap) return;
-    const size_t i = (size_t)sl * P.tv_cap + at;
+// The lanes of the calling wave whose item was the first on its voxel this frame (`first`) queue that voxel: they get
+// consecutive entries of sub-list `sl` of the frame's voxel queue from one returning atomic per wave — the queue holds
+// first-touched voxels only (a third of the hit + miss cells of a VGA frame).  Call with all the wave's active lanes.
+// spec_slot: the block's pool slot if the block existed when the column looked its blocks up, else -1 (k_apply_frame
+// resolves it).
+__device__ __forceinline__ void mlm_queue_firsts(const MlmDev &P, unsigned int sl, bool first, int lv, int gx, int gy, int gz, int cid, uint32_t kind,
+                                                 int spec_slot) {
+    const unsigned long long m = __ballot(first);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[sl][0], (uint32_t)__popcll(m));
+    base = (uint32_t)mlm_readlane((int)base, leader);
     if (first) {
-        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, (uint32_t)spec_slot, kind};
-        mlm_gp(P.tv_key)[i] = mlm_pack_key(gx, gy, gz);
-    } else {
-        mlm_gp(P.tv_rec)[4 * i + 3] = 2u;
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (at < P.tv_cap) { // (more: the frame is reported as a queue overflow, check_queues)
+            const size_t i = (size_t)sl * P.tv_cap + at;
+            *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, (uint32_t)spec_slot, kind};
+            mlm_gp(P.tv_key)[i] = mlm_pack_key(gx, gy, gz);
+        }
     }
 }
 
@@ -661,7 +668,6 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
         s_base[1] = n_multi ? g_atomic_add(&mlm_gp(P.ctr)->n_multi, n_multi) : 0u;
         s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
         s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
-        s_base[6] = (n_occ && !EX) ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[blockIdx.x & 7][0], n_occ) : 0u; // voxel-queue slots of the hits
         if (s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap) s_fail = 1;
     }
     __syncthreads();
@@ -848,8 +854,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
         } else {
             s_fail = 1;
         }
-            mlm_queue_voxel(P, sl, s_base[6] + i, first, lv, gx, gy, gz, h_cid, 0u, h_spec);
         }
+        if (!EX) mlm_queue_firsts(P, sl, first, lv, gx, gy, gz, h_cid, 0u, h_spec);
     }
     MLM_PHASE(4);
     // ---- references of the multi-kind cells (their fill cursors were set above)
@@ -894,12 +900,12 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
         mlm_block_excl_scan(vm, s_w, &total);
         if (threadIdx.x == 0) {
             if (total) g_atomic_add(&mlm_gp(P.ctr)->umiss_part[sl][0], total);
-            s_base[5] = total ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[sl][0], total) : 0u; // voxel-queue slots of the miss cells
             s_base[7] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
             // device-scope atomics on account of this column: its chunk descriptors (k_bin_sectors), the list reservations
-            // above and here (up to 10, this one included), a bucket-min and a push per hit, a count per miss cell
-            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][1], nch_all + 10u + 2u * n_occ + total);
+            // above and here (up to 8, this one included), a bucket-min and a hit number per hit, a count per miss cell, a
+            // queue reservation per wave and round of the hit list and of the miss cells
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][1], nch_all + 8u + 2u * n_occ + total + (n_occ + 63u) / 64u + (total + 63u) / 64u);
             mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
         }
         __syncthreads();
@@ -944,7 +950,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
                 bool first = false;
                 if (lv >= 0) first = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u) == 0u;
                 else s_fail = 1;
-                mlm_queue_voxel(P, sl, s_base[5] + i, first, lv, gx, gy, gz, m_cid, 1u, spec);
+                mlm_queue_firsts(P, sl, first, lv, gx, gy, gz, m_cid, 1u, spec);
             }
         }
     }
@@ -1319,7 +1325,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
             p_rec = *(const MLM_GLOBAL mlm_u32x4 *)(recs + 4 * (size_t)i);
             p_key = keys[i];
         }
-        if (p_rec.w >= 2u) continue; // a hole: the item was not its voxel's first
+        if (p_rec.w >= 2u) continue; // (no entry: the speculative load of a thread beyond the list)
         MLM_GLOBAL unsigned long long *st = mlm_gp(P.lv_state) + p_rec.x;
         MLM_GLOBAL uint32_t *hs = mlm_gp(P.lv_hits) + (size_t)p_rec.x * MLM_LV_SLOTS;
         int slot = (int)p_rec.z;

@@ -204,7 +204,7 @@ struct MlmDev {
                                // k; the last slot heads a list (1 + index, links in hl_next) of the hits beyond — one gather
                                // instead of a list walk for the kernel that applies the frame
     int lv_nx, lv_ny, lv_nz;
-    uint32_t *tv_rec;          // [MLM_RAY_LISTS][tv_cap][4] first-touched voxels: {lv, cell id, block slot or -1, 0 hit / 1 miss}
+    uint32_t *tv_rec;          // [MLM_RAY_LISTS][tv_cap][4] the frame's voxel queue, first-touched voxels only: {lv, cell id, block slot or -1, 0 first touch was a hit / 1 a miss}
     unsigned long long *tv_key;// [MLM_RAY_LISTS][tv_cap] ... packed block key          (counts: MlmCounters::mvox_cnt)
     unsigned int tv_cap;
     unsigned long long *sbkt;  // [sbkt_cap] this slot's bucket-first table of the emulated hit container: (~seq << 32 | time),

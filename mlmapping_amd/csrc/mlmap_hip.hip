@@ -101,6 +101,7 @@ struct mlm_handle {
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
     unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
+    long long last_queue = 0;                // voxels the last confirmed sector-path frame queued (sizes k_apply_frame's grid)
     unsigned int chain_grid = 0;             // blocks per frame of k_chain_lanes (0: from the last confirmed frame's ranked cells; MLM_CHAIN_GRID)
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
     unsigned int sc_block = 128;             // threads per k_apply_voxelize block (its duration in the pipeline: 18 us vs 27 us with 256)
@@ -476,6 +477,11 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
         na += c.ray_cnt[k][1];
     }
     h->stats.n_device_atomics = na;
+    if (S.sector) {
+        long long nq = 0;
+        for (int k = 0; k < MLM_RAY_LISTS; ++k) nq += c.mvox_cnt[k][0];
+        h->last_queue = nq;
+    }
     h->stats.n_groups = ng;
     h->stats.n_rays = nr;
     h->stats.n_spec_replays = h->n_spec_miss;
@@ -737,7 +743,7 @@ int submit_batch(mlm_handle *h, int base, int n) {
         Timed t(h, h->stream, "stage_bc_batch");
         unsigned int scg = h->sc_grid;
         if (!h->sc_grid_fixed) { // one first-touched voxel per thread for a frame like the last confirmed one
-            const long long items = (h->stats.n_hit_cells + h->stats.n_miss_cells) / MLM_RAY_LISTS;
+            const long long items = (h->last_queue > 0 ? h->last_queue * 5 / 4 : h->stats.n_hit_cells + h->stats.n_miss_cells) / MLM_RAY_LISTS;
             scg = (unsigned int)std::min<long long>(1024, std::max<long long>(8, (items + MLM_BLOCK - 1) / MLM_BLOCK));
         }
         for (int j = 0; j < n; ++j) {
