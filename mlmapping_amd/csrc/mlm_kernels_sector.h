@@ -10,17 +10,19 @@
 //                   with one returning atomic (a chunk descriptor).  Nothing else leaves the block.
 //   k_sector        one workgroup per column: per-cell hit bookkeeping (first-touch time, kinds, counts) in an LDS hash
 //                   table, the column's miss bit mask in LDS (rays walked by an integer DDA), the unique-hit list
-//                   (cells that received ONE kind of contribution get their odd right away), and for every cell that
-//                   received several kinds the list of (record, kind) references.  Every unique hit is pushed on the pending
-//                   list of its world voxel, every unique miss cell counted on its world voxel, in a FRAME-LOCAL voxel grid
-//                   (which voxel a cell falls into is geometry; only the block's pool slot needs the map); first touches
-//                   queue the voxel.  Global atomics: list reservations per workgroup, one push + one bucket-min per hit,
-//                   one count per miss cell.
-//   k_rank          one wave per multi-kind cell: order its contributions by pixel (bitmap ranking fed with the records'
-//                   8x8 lane masks) and store the kinds in that order; k_chain_lanes then replays the float
-//                   noisy-OR chain.
+//                   (cells that received ONE kind of contribution, or enough strong ones, get their odd right away), and
+//                   for every other cell the list of (record, kind) references.  Which world voxel a cell falls into is
+//                   geometry that separates by axis inside a column (tables per rho and per z; only the block's pool
+//                   slot needs the map): every unique hit takes a number on its voxel and a slot of the voxel's hit
+//                   list, every unique miss cell is counted on its voxel, in a FRAME-LOCAL voxel grid; first touches
+//                   queue the voxel.  Global atomics: list reservations per workgroup, one hit number + one bucket-min
+//                   per hit, one count per miss cell, one queue reservation per wave and round.
+//   k_rank          iteration-order keys of the frame's hits; one wave per multi-kind cell whose float chain depends on the
+//                   order: rank its contributions by pixel (bitmap ranking fed with the records' 8x8 lane masks) and
+//                   store the kinds in that order.
+//   k_chain_lanes   replays the float noisy-OR chains, one cell per lane, lanes drawing cells dynamically.
 //   k_apply_frame   the part that needs the map, ONE launch per frame: one queued voxel per lane — block lookup /
-//                   creation, the voxel's hits in the reference's iteration order, its misses, store.
+//                   creation, a gather of the voxel's hits, applied in the reference's iteration order, its misses, store.
 //
 // Frontier mode (use_exploration_frontiers) uses k_bin_sectors, k_sector<true>, k_rank and k_chain_lanes and continues with its
 // own map-dependent part (mlm_kernels_explore.h): there the miss container's iteration order matters as well, so the
