@@ -104,7 +104,8 @@ struct mlm_handle {
     long long last_queue = 0;                // voxels the last confirmed sector-path frame queued (sizes k_apply_frame's grid)
     unsigned int chain_grid = 0;             // blocks per frame of k_chain_lanes (0: from the last confirmed frame's ranked cells; MLM_CHAIN_GRID)
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
-    unsigned int sc_block = 128;             // threads per k_apply_voxelize block (its duration in the pipeline: 18 us vs 27 us with 256)
+    unsigned int sc_block = 64;              // threads per block of the per-frame apply kernels: single-wave blocks are placed as soon as any wave
+                                             // slot frees between Stage A's workgroups (config 2: 66.5k frames/s, 128: 64.1k, 256: 57.2k)
     bool sc_grid_fixed = false;              // MLM_SC_GRID given: do not adapt
     unsigned int sc_grid = 80;               // blocks per list of k_apply_voxelize (grid-stride loops; 40..120 measured equal, 160 3 % slower)
     std::string timed_kernel = "k_bin_points"; // the kernel bracketed in timing mode 3 ...
