@@ -1,6 +1,6 @@
 # usage: bash tools/prof_round.sh [tag]   (everything under gpurun_out/<tag>/; copy the summaries to profiles/<tag>_*)
 set -x
-TAG=${1:-r2e}
+TAG=${1:-r2f}
 R=$PWD
 mkdir -p gpurun_out/$TAG
 O=$R/gpurun_out/$TAG
