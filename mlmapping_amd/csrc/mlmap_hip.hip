@@ -101,6 +101,7 @@ struct mlm_handle {
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
     unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
+    unsigned int rank_grid = 512;            // blocks per frame of k_rank in a batch (config 2: 67.5k frames/s, 256: 66.9k, 1024: 65.2k; MLM_RANK_GRID)
     long long last_queue = 0;                // voxels the last confirmed sector-path frame queued (sizes k_apply_frame's grid)
     unsigned int chain_grid = 0;             // blocks per frame of k_chain_lanes (0: from the last confirmed frame's ranked cells; MLM_CHAIN_GRID)
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
@@ -429,7 +430,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         else
             tlaunch(h, "k_sector", k_sector<false>, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
-        tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->sort_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
+        tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->rank_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
                 mode == 0 ? F.width : 0, row_w, dm, ds);
         // blocks per frame: about 400 ranked cells per block in a batch (a lane that finishes a chain draws the next cell; each
         // block builds the transposed odds table in LDS), as many as the last confirmed frame had; single frames spread wider
@@ -1202,6 +1203,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (const char *e = getenv("MLM_SORT_BLOCK")) h->sort_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
         if (const char *e = getenv("MLM_SORT_GRID")) h->sort_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_CHAIN_GRID")) h->chain_grid = (unsigned int)std::max(1, atoi(e));
+        if (const char *e = getenv("MLM_RANK_GRID")) h->rank_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_COLLECT_GRID")) h->collect_grid = (unsigned int)std::max(1, atoi(e));
         if (const char *e = getenv("MLM_SC_BLOCK")) h->sc_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
         if (const char *e = getenv("MLM_SC_GRID")) {
