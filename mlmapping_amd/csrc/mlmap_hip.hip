@@ -102,6 +102,9 @@ struct mlm_handle {
     unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
     unsigned int rank_grid = 512;            // blocks per frame of k_rank in a batch (config 2: 67.5k frames/s, 256: 66.9k, 1024: 65.2k; MLM_RANK_GRID)
+    size_t map_bytes = 0;                    // ... of it the map, its tables and the buffers shared by all frame slots
+    bool debug_alloc = getenv("MLM_DEBUG_ALLOC") != nullptr;
+    size_t alloc_bytes = 0;                  // device memory the handle holds (MLM_DEBUG_CREATE prints it)
     long long last_queue = 0;                // voxels the last confirmed sector-path frame queued (sizes k_apply_frame's grid)
     unsigned int chain_grid = 0;             // blocks per frame of k_chain_lanes (0: from the last confirmed frame's ranked cells; MLM_CHAIN_GRID)
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
@@ -166,6 +169,8 @@ namespace {
 template <class T> int dev_alloc(mlm_handle *h, T **p, size_t n) {
     void *v = nullptr;
     HIPCHK(h, hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(T)));
+    h->alloc_bytes += std::max<size_t>(n, 1) * sizeof(T);
+    if (h->debug_alloc && n * sizeof(T) > (8u << 20)) fprintf(stderr, "[alloc] #%zu %.1f MB\n", h->allocs.size(), n * sizeof(T) / 1e6);
     h->allocs.push_back(v);
     *p = (T *)v;
     return MLM_OK;
@@ -1481,6 +1486,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         HIPCHK(h, hipEventCreateWithFlags(&h->stage_a_done[k], hipEventDisableTiming));
         HIPCHK(h, hipEventCreateWithFlags(&h->set_free[k], hipEventDisableTiming));
     }
+    h->map_bytes = h->alloc_bytes;
     {
         // the frame slots are most of the footprint (S1 ~0.35 GB, S3 ~3 GB each): three sets of max_batch if they fit the
         // device memory, else two (a quarter less throughput on config 2), else the error says what would be needed
@@ -1517,6 +1523,9 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), NS * sizeof(MlmDev), hipMemcpyHostToDevice));
     }
     HIPCHK(h, hipDeviceSynchronize());
+    if (getenv("MLM_DEBUG_CREATE"))
+        fprintf(stderr, "[create] device memory: %.2f GB (%zu frame slots in %d sets of %d, %.3f GB each; the map and the shared tables %.2f GB)\n",
+                h->alloc_bytes / 1e9, NS, h->n_sets, h->lim.max_batch, NS ? (h->alloc_bytes - h->map_bytes) / 1e9 / NS : 0.0, h->map_bytes / 1e9);
     return MLM_OK;
 }
 
