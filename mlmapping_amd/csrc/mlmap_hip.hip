@@ -913,6 +913,19 @@ void clear_device_error(mlm_handle *h) {
     for (int k = 0; k < MLM_SETS; ++k) *h->h_gb[k] = g;
 }
 
+// ... and the frame-local voxel grids: the frames that were dropped with the failed call may have left hits and misses
+// pending there (their apply kernels did not run), which the next frame in the same slot must not inherit.
+void wipe_frame_grids(mlm_handle *h) {
+    if (!h->use_sectors || h->P.explore) return;
+    for (auto &S : h->slots) {
+        const size_t nlv = (size_t)S.P.lv_nx * S.P.lv_ny * S.P.lv_nz;
+        if (!S.P.lv_state || !S.P.lv_hits) continue;
+        hipMemsetAsync(S.P.lv_state, 0, nlv * sizeof(unsigned long long), h->stream);
+        hipMemsetAsync(S.P.lv_hits, 0, nlv * MLM_LV_SLOTS * sizeof(uint32_t), h->stream);
+    }
+    hipStreamSynchronize(h->stream);
+}
+
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
 int run_slots(mlm_handle *h, int n) {
     (void)hipGetLastError(); // a stale error of unrelated HIP calls in this thread is not ours
@@ -993,6 +1006,7 @@ int run_slots(mlm_handle *h, int n) {
         h->pending.clear();
         for (int k = 0; k < MLM_SETS; ++k) h->set_pending[k] = 0;
         clear_device_error(h);
+        wipe_frame_grids(h);
     }
     return rc;
 }
