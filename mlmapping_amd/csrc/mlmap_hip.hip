@@ -1374,7 +1374,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // hold point index * 256 + ray step in 32 bits)
         // (k_sector packs in-block cell coordinates into bytes and lists a column's miss cells in its cell table's space)
         h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
-                         (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 && P.nRho < (1 << (32 - MLM_SEC_CNT_BITS)) &&
+                         (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 && P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho */ &&
                          (P.explore ? P.nRho <= 256 : (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         if (getenv("MLM_DEBUG_CREATE"))
