@@ -1345,6 +1345,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             HIPCHK(h, hipFuncSetAttribute((const void *)k_bin_points<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bin_lds_bytes));
         }
     }
+    if ((size_t)(2 * MLM_DIFF_RANGE + 1) * P.nRho * sizeof(float) > 64u * 1024u) { // (k_chain keeps the odds table in LDS)
+        h->err = "am_n_Rho above 780 is not supported";
+        return MLM_ERR_UNSUPPORTED;
+    }
     {
         // sector path: LDS tables of one azimuth column (k_sector).  Cell table: a column rarely holds more hit cells than a
         // few per range step; references: (record, kind) pairs of its multi-kind cells.  A column that needs more makes

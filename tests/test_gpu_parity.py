@@ -483,6 +483,8 @@ def test_argument_and_capacity_errors(mods):
         MLMap(bad)
     with pytest.raises(MlmError):
         MLMap(S1, device=99)
+    with pytest.raises(MlmError, match="UNSUPPORTED"):  # outside the supported envelope: said at creation, not at the first frame
+        MLMap(S1.with_(am_n_Rho=1000, depth_noise_coe=1e-6), max_blocks=64, max_points=1000)
     m = MLMap(S1, max_blocks=8, max_points=640 * 480)  # block pool far too small
     with pytest.raises(MlmError, match="CAPACITY"):
         m.update_map(syn.room_depth(S1), *syn.static_pose())
