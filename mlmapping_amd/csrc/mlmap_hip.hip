@@ -102,6 +102,13 @@ struct mlm_handle {
     unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
     unsigned int rank_grid = 512;            // blocks per frame of k_rank in a batch (config 2: 67.5k frames/s, 256: 66.9k, 1024: 65.2k; MLM_RANK_GRID)
+    // Lean frame slots (sector-path handles): the three large buffers only the cell-table Stage A uses — the block slices of
+    // contribution nodes sized for its LDS overflow, the (block, cell) pairs and the node lists — exist ONCE per handle instead
+    // of once per slot; a cell-table Stage A (a frame's fall-back, or a batch submitted while the sector path backs off) then
+    // runs one frame at a time, ordered by fb_done across the sets' streams.
+    bool lean = false;
+    MlmDev *d_slot_tab_fb = nullptr;         // the slots' constants with those three buffers pointing at the shared ones
+    hipEvent_t fb_done = nullptr;
     size_t map_bytes = 0;                    // ... of it the map, its tables and the buffers shared by all frame slots
     bool debug_alloc = getenv("MLM_DEBUG_ALLOC") != nullptr;
     size_t alloc_bytes = 0;                  // device memory the handle holds (MLM_DEBUG_CREATE prints it)
@@ -311,6 +318,14 @@ inline unsigned int book_grid(const MlmDev &P, const MlmFrame &F, int mode, int 
 // Stage A of a whole batch (slots base..base+n, same mode and image geometry) on stream_a: awareness raycast ->
 // unique hit lists (+odds) and miss masks.  One launch per kernel covers all n frames (blockIdx.z = slot).
 int launch_stage_a_batch(mlm_handle *h, int base, int n) {
+    if (h->lean && n > 1) { // the cell-table path's large buffers exist once per handle: one frame at a time
+        for (int j = 0; j < n; ++j) {
+            const int rc = launch_stage_a_batch(h, base + j, 1);
+            if (rc) return rc;
+        }
+        return MLM_OK;
+    }
+    const MlmDev *slot_tab = h->lean ? h->d_slot_tab_fb : h->d_slot_tab;
     const MlmSlot &S0 = h->slots[(size_t)base];
     const MlmDev &P = S0.P;
     const MlmFrame &F = S0.F;
@@ -331,6 +346,7 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
                              hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));
+    if (h->lean) HIPCHK(h, hipStreamWaitEvent(st, h->fb_done, 0)); // (the previous user of the shared buffers, on whatever stream)
     unsigned int nb = 0;
     if (F.n > 0) {
         nb = bin_grid(P, F, mode);
@@ -339,29 +355,29 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
             return MLM_ERR_CAPACITY;
         }
         if (mode == 0)
-            tlaunch(h, "k_bin_points", k_bin_points<0>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_points", k_bin_points<0>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, slot_tab, h->d_frame_tab, base);
         else if (mode == 1)
-            tlaunch(h, "k_bin_points", k_bin_points<1>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_points", k_bin_points<1>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, slot_tab, h->d_frame_tab, base);
         else
-            tlaunch(h, "k_bin_points", k_bin_points<2>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_points", k_bin_points<2>, dim3(nb, 1, n), dim3(P.bin_block), P.bin_lds_bytes, st, slot_tab, h->d_frame_tab, base);
     }
     if (nb) {
         int tx, ty;
         const unsigned int ng = book_grid(P, F, mode, (int)nb, tx, ty);
-        tlaunch(h, "k_book_cells", k_book_cells, dim3(ng, 1, n), dim3(MLM_BOOK_THREADS), 0, st, h->d_slot_tab, h->d_frame_tab, base, tx, ty, (int)nb);
+        tlaunch(h, "k_book_cells", k_book_cells, dim3(ng, 1, n), dim3(MLM_BOOK_THREADS), 0, st, slot_tab, h->d_frame_tab, base, tx, ty, (int)nb);
     }
     {
-        tlaunch(h, "k_assign_nodes", k_assign_nodes, dim3(8, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_assign_nodes", k_assign_nodes, dim3(8, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, slot_tab,
                            h->d_frame_tab, base, mode == 0 ? F.width : 0);
     }
     if (P.explore) // frontier mode: the queued rays are walked once every start cell's first point is known
-        tlaunch(h, "k_ex_walk_rays", k_ex_walk_rays, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        tlaunch(h, "k_ex_walk_rays", k_ex_walk_rays, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, slot_tab, h->d_frame_tab, base);
     {
-        tlaunch(h, "k_collect_hits", k_collect_hits, dim3(h->collect_grid, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_collect_hits", k_collect_hits, dim3(h->collect_grid, MLM_RAY_LISTS, n), dim3(MLM_BLOCK), 0, st, slot_tab,
                            h->d_frame_tab, base, (int)nb);
     }
     {
-        tlaunch(h, "k_expand_nodes", k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, n), dim3(h->expand_block), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_expand_nodes", k_expand_nodes, dim3(nb + 8 * MLM_RAY_LISTS, 1, n), dim3(h->expand_block), 0, st, slot_tab,
                            h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb);
     }
     {
@@ -369,23 +385,24 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
         unsigned long long dm;
         int ds;
         div_magic((unsigned int)row_w, dm, ds);
-        tlaunch(h, "k_sort_contribs", k_sort_contribs<1024>, dim3((n > 4 ? h->sort_grid : 1024) * (MLM_BLOCK / h->sort_block), 1, n), dim3(h->sort_block), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_sort_contribs", k_sort_contribs<1024>, dim3((n > 4 ? h->sort_grid : 1024) * (MLM_BLOCK / h->sort_block), 1, n), dim3(h->sort_block), 0, st, slot_tab,
                            h->d_frame_tab, base, 0u, row_w, dm, ds);
-        tlaunch(h, "k_sort_contribs", k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab,
+        tlaunch(h, "k_sort_contribs", k_sort_contribs<4096>, dim3(n > 4 ? 128 : 512, 1, n), dim3(MLM_BLOCK), 0, st, slot_tab,
                            h->d_frame_tab, base, 1024u, row_w, dm, ds);
     }
     {
         tlaunch(h, "k_chain", k_chain, dim3(n > 4 ? 64 : 256, 1, n), dim3(MLM_BLOCK), (size_t)21 * P.nRho * sizeof(float), st,
-                           h->d_slot_tab, h->d_frame_tab, base,
+                           slot_tab, h->d_frame_tab, base,
                            P.explore ? 0xFFFFFFFFu : (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu));
     }
     {
         // one 256-word slice of the miss mask per block (the unique hits, far fewer, are strided over the same blocks)
         const unsigned int pb = std::max(64u, grid_for((size_t)P.nMissWords));
-        tlaunch(h, "k_prepare_voxels", k_prepare_voxels, dim3(pb, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        tlaunch(h, "k_prepare_voxels", k_prepare_voxels, dim3(pb, 1, n), dim3(MLM_BLOCK), 0, st, slot_tab, h->d_frame_tab, base);
     }
     if (P.explore)
-        tlaunch(h, "k_ex_collect_misses", k_ex_collect_misses, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        tlaunch(h, "k_ex_collect_misses", k_ex_collect_misses, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, slot_tab, h->d_frame_tab, base);
+    if (h->lean) HIPCHK(h, hipEventRecord(h->fb_done, st));
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
 }
@@ -1078,8 +1095,9 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
     P.nb_cap = (unsigned int)((size_t)h->lim.max_points / 64 + 1024);
     if ((rc = dev_alloc(h, &P.blk_stats, 4 * (size_t)P.nb_cap))) return rc;
-    if ((rc = dev_alloc(h, &P.bnodes, (size_t)P.nb_cap * P.node_lds))) return rc;
-    if ((rc = dev_alloc(h, &P.pairs, (size_t)P.nb_cap * P.agg_lds))) return rc;
+    // (lean: k_bin_sectors writes at most 256 records per block; the cell-table path's buffers are shared, mlm_create)
+    if ((rc = dev_alloc(h, &P.bnodes, (size_t)P.nb_cap * (h->lean ? 256u : P.node_lds)))) return rc;
+    if (!h->lean && (rc = dev_alloc(h, &P.pairs, (size_t)P.nb_cap * P.agg_lds))) return rc;
     {
         // most contributions one point can make: centre + (+d,-d) while d < 3*sigma(rho) (map_awareness.cpp:149)
         int dmax = 0;
@@ -1103,7 +1121,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         if ((rc = dev_alloc(h, &P.contrib, cap_pad))) return rc;
         if ((rc = dev_alloc(h, &P.subs, cap_pad))) return rc;
         P.node_cap = (unsigned int)(cap / MLM_RAY_LISTS + 4096);
-        if ((rc = dev_alloc(h, &P.nodes, (size_t)MLM_RAY_LISTS * P.node_cap))) return rc;
+        if (!h->lean && (rc = dev_alloc(h, &P.nodes, (size_t)MLM_RAY_LISTS * P.node_cap))) return rc;
     }
     P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
     if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
@@ -1381,6 +1399,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
                          (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 && P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho */ &&
                          (P.explore ? P.nRho <= 256 : (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
+        h->lean = h->use_sectors;
+        if (const char *e = getenv("MLM_LEAN_SLOTS")) h->lean = h->lean && atoi(e) != 0;
         if (getenv("MLM_DEBUG_CREATE"))
             fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries, %u blocks), frame-local grid %d x %d x %d\n", (int)h->use_sectors,
                     P.sec_lds_bytes, P.sec_tab, P.sec_combos, P.lv_nx, P.lv_ny, P.lv_nz);
@@ -1539,6 +1559,22 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         std::vector<MlmDev> tab(NS);
         for (size_t i = 0; i < NS; ++i) tab[i] = h->slots[i].P;
         HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), NS * sizeof(MlmDev), hipMemcpyHostToDevice));
+        if (h->lean) {
+            const MlmDev &P0 = h->slots[0].P;
+            MlmNode *fb_bnodes, *fb_nodes;
+            MlmPair *fb_pairs;
+            if ((rc = dev_alloc(h, &fb_bnodes, (size_t)P0.nb_cap * P0.node_lds))) return rc;
+            if ((rc = dev_alloc(h, &fb_pairs, (size_t)P0.nb_cap * P0.agg_lds))) return rc;
+            if ((rc = dev_alloc(h, &fb_nodes, (size_t)MLM_RAY_LISTS * P0.node_cap))) return rc;
+            for (size_t i = 0; i < NS; ++i) {
+                tab[i].bnodes = fb_bnodes;
+                tab[i].pairs = fb_pairs;
+                tab[i].nodes = fb_nodes;
+            }
+            if ((rc = dev_alloc(h, &h->d_slot_tab_fb, NS))) return rc;
+            HIPCHK(h, hipMemcpy(h->d_slot_tab_fb, tab.data(), NS * sizeof(MlmDev), hipMemcpyHostToDevice));
+            HIPCHK(h, hipEventCreateWithFlags(&h->fb_done, hipEventDisableTiming));
+        }
     }
     HIPCHK(h, hipDeviceSynchronize());
     if (getenv("MLM_DEBUG_CREATE"))
@@ -1571,6 +1607,7 @@ int mlm_destroy(mlm_handle *h) {
     for (int k = 0; k < MLM_SETS; ++k)
         if (h->stream_as[k]) hipStreamDestroy(h->stream_as[k]);
     if (h->inputs_ready) hipEventDestroy(h->inputs_ready);
+    if (h->fb_done) hipEventDestroy(h->fb_done);
     if (h->d_f32) hipFree(h->d_f32);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);

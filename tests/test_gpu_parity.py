@@ -581,7 +581,8 @@ def test_long_stream_cfg2(mods):
             c2.update_depth(frames[j], q[rep * B + j], t[rep * B + j])
     d = compare_maps(g2.export_blocks(), c2.export_blocks(), "cfg2 batch_dev 100 frames")
     print("long stream worst |d odd|", worst, d)
-    assert gpu.frame_stats()["n_spec_replays"] >= 1  # the emulated container did rehash on the way
+    st = gpu.frame_stats()
+    assert st["n_spec_replays"] + st["n_sector_fallbacks"] >= 1  # the emulated container did rehash on the way
 
 
 def test_corridor_substitute(mods):
