@@ -1399,8 +1399,9 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
                          (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 && P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho */ &&
                          (P.explore ? P.nRho <= 256 : (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
-        h->lean = h->use_sectors;
-        if (const char *e = getenv("MLM_LEAN_SLOTS")) h->lean = h->lean && atoi(e) != 0;
+        // (lean slots cost the worst-case scenes their batching — every frame overflowing its sector tables: 1.3k instead of
+        // 4.4k frames/s on the "scatter" scene — so they are used on request, or when the full slots do not fit the device)
+        if (const char *e = getenv("MLM_LEAN_SLOTS")) h->lean = h->use_sectors && atoi(e) != 0;
         if (getenv("MLM_DEBUG_CREATE"))
             fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries, %u blocks), frame-local grid %d x %d x %d\n", (int)h->use_sectors,
                     P.sec_lds_bytes, P.sec_tab, P.sec_combos, P.lv_nx, P.lv_ny, P.lv_nz);
@@ -1526,12 +1527,25 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     }
     h->map_bytes = h->alloc_bytes;
     {
-        // the frame slots are most of the footprint (S1 ~0.35 GB, S3 ~3 GB each): three sets of max_batch if they fit the
-        // device memory, else two (a quarter less throughput on config 2), else the error says what would be needed
+        // the frame slots are most of the footprint (S1 ~1 GB, S3 ~3.8 GB each): three sets of max_batch if they fit the device
+        // memory, else the same with lean slots (sector-path handles), else two sets (a few percent less throughput on config
+        // 2), else the error says what would be needed
         const size_t mark = h->allocs.size();
         size_t got = 0;
         for (; got < NS; ++got)
             if ((rc = alloc_slot(h, h->slots[got], got, sigma3))) break;
+        if (rc && h->use_sectors && !h->lean) {
+            (void)hipGetLastError();
+            for (size_t a = mark; a < h->allocs.size(); ++a) hipFree(h->allocs[a]);
+            h->allocs.resize(mark);
+            h->alloc_bytes = h->map_bytes;
+            h->slots.assign(NS, MlmSlot{});
+            h->lean = true;
+            h->err.clear();
+            rc = MLM_OK;
+            for (got = 0; got < NS; ++got)
+                if ((rc = alloc_slot(h, h->slots[got], got, sigma3))) break;
+        }
         if (rc && got >= 2 * (size_t)h->lim.max_batch && h->n_sets > 2) {
             (void)hipGetLastError();
             // (keep the first two sets; give the partial third one back)

@@ -730,7 +730,8 @@ def test_callback_query_interleaving(mods):
 
 
 @pytest.mark.parametrize("env", [{"MLM_SEC_FAIL_EVERY": "1", "MLM_SEC_BACKOFF": "0"}, {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_TAB": "512", "MLM_SEC_BACKOFF": "0"},
-                                 {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "2"}, {"MLM_SECTORS": "0"}])
+                                 {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "2"}, {"MLM_SECTORS": "0"},
+                                 {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_BACKOFF": "1", "MLM_LEAN_SLOTS": "1"}])
 def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
     """Stage A by azimuth sector falls back to the cell-table path frame by frame when a column overflows its LDS tables
     (forced here by shrinking them); MLM_SECTORS=0 runs the cell-table path alone.  Results must not change."""
@@ -756,8 +757,10 @@ def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
     st = gpu.frame_stats()
     if env.get("MLM_SEC_FAIL_EVERY") == "1":
         assert st["n_sector_fallbacks"] == n, st
-    if env.get("MLM_SEC_FAIL_EVERY") == "3":
+    if env.get("MLM_SEC_FAIL_EVERY") == "3" and "MLM_LEAN_SLOTS" not in env:
         assert st["n_sector_fallbacks"] >= n // 3, st
+    if "MLM_LEAN_SLOTS" in env:  # (lean slots: fall-backs and backed-off batches run the cell-table Stage A frame by frame)
+        assert st["n_sector_fallbacks"] >= 1, st
     if env.get("MLM_SEC_FAIL_EVERY") == "4":  # after a fall-back the next batches skip the sector attempt, then it is retried
         assert 1 <= st["n_sector_fallbacks"] < n // 2, st
     if "MLM_SECTORS" in env:
@@ -766,7 +769,8 @@ def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", [{}, {"MLM_SEC_FAIL_EVERY": "1", "MLM_SEC_BACKOFF": "0"}, {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_BACKOFF": "0"},
-                                 {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "1"}, {"MLM_SECTORS": "0"}])
+                                 {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "1"}, {"MLM_SECTORS": "0"},
+                                 {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_BACKOFF": "0", "MLM_LEAN_SLOTS": "1"}])
 def test_frontier_mode_sector_path(mods, monkeypatch, env):
     """Frontier mode runs Stage A by azimuth sector too (insertion times of the miss cells kept in LDS); a frame whose sector
     tables overflow redoes Stage A on the cell-table path before anything that depends on the map is enqueued.  Single
