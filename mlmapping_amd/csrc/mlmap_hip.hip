@@ -1080,6 +1080,12 @@ int read_global(mlm_handle *h) {
 }
 
 int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float> &sigma3) {
+    if (!h->lean) // (test hook: the full slots "do not fit" from slot k on, so that the lean retry of mlm_create runs)
+        if (const char *e = getenv("MLM_DEBUG_FAIL_SLOT"))
+            if ((long long)index >= atoll(e)) {
+                h->err = "simulated allocation failure (MLM_DEBUG_FAIL_SLOT)";
+                return MLM_ERR_HIP;
+            }
     S.P = h->P;
     MlmDev &P = S.P;
     int rc;

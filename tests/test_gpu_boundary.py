@@ -296,3 +296,25 @@ def test_bench_launcher_contract_two_ranks():
     # whole-job aggregate: frames of BOTH ranks over the slower rank's time
     assert abs(d["value"] - 2 * 3 * 8 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
     assert d["roofline"]["frac"] > 0 and d["roofline"]["atomics"]["atomics_per_frame"] > 0
+
+
+def test_lean_slots_when_the_full_ones_do_not_fit(mods, monkeypatch):
+    """mlm_create retries with lean slots (the cell-table path's large buffers once per handle) when the full slots do not fit
+    the device — simulated here: the first attempt fails at the third slot.  The handle then works as usual, fall-backs to the
+    cell-table path (forced on every second frame) included."""
+    MLMap, OracleMap = mods
+    monkeypatch.setenv("MLM_DEBUG_FAIL_SLOT", "2")
+    monkeypatch.setenv("MLM_SEC_FAIL_EVERY", "2")
+    monkeypatch.setenv("MLM_SEC_BACKOFF", "0")
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=2), OracleMap(cfg)
+    frames = list(syn.stream(cfg, "room_jitter", "random", 6))
+    imgs = np.stack([f[0] for f in frames])
+    q = np.stack([f[1][0] for f in frames])
+    t = np.stack([f[1][1] for f in frames])
+    gpu.update_map_batch(imgs, q, t)  # 2 + 2 + 2
+    for img, (qq, tt) in frames:
+        cpu.update_depth(img, qq, tt)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "lean slots")
+    assert gpu.frame_stats()["n_sector_fallbacks"] == 3
+    gpu.close()
