@@ -896,10 +896,17 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             ++at;
         }
     } else {
-        uint32_t vm = 0;
-        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) vm += (uint32_t)__popc(s_miss[w]);
-        uint32_t total;
-        mlm_block_excl_scan(vm, s_w, &total);
+        // exclusive prefix of the mask words' popcounts (in the idle chunk-staging area): the column's miss cells, and where
+        // each word's cells go in the list below
+        uint32_t *s_off = s_chunk_first; // [NMISS] (the staging area is sized for it, mlm_sec_lds)
+        uint32_t total = 0;
+        for (uint32_t w0 = 0; w0 < NMISS; w0 += MLM_SEC_THREADS) {
+            const uint32_t w = w0 + threadIdx.x;
+            uint32_t tot_w;
+            const uint32_t off = mlm_block_excl_scan(w < NMISS ? (uint32_t)__popc(s_miss[w]) : 0u, s_w, &tot_w);
+            if (w < NMISS) s_off[w] = total + off;
+            total += tot_w;
+        }
         if (threadIdx.x == 0) {
             if (total) g_atomic_add(&mlm_gp(P.ctr)->umiss_part[sl][0], total);
             s_base[7] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
@@ -914,19 +921,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
         if (total) {
             // One miss cell per thread, so that the voxel atomics of all the column's miss cells are in flight together.
             // The cells are listed first (column-local keys z * nRho + rho, in the cell table's space, which is idle by now):
-            // a thread takes a byte of a mask word and writes its set bits at off[word] + bits below — off = exclusive prefix
-            // of the words' popcounts (in the idle chunk-staging area).
-            uint32_t *s_off = s_chunk_first; // [NMISS] (the staging area is sized for it, mlm_sec_lds)
+            // a thread takes a byte of a mask word and writes its set bits at off[word] + bits below.
             uint16_t *s_cells = (uint16_t *)s_tab; // [total] (NMISS * 64 bytes <= the table's, checked by the host)
-            uint32_t run = 0;
-            for (uint32_t w0 = 0; w0 < NMISS; w0 += MLM_SEC_THREADS) {
-                const uint32_t w = w0 + threadIdx.x;
-                uint32_t tot_w;
-                const uint32_t off = mlm_block_excl_scan(w < NMISS ? (uint32_t)__popc(s_miss[w]) : 0u, s_w, &tot_w);
-                if (w < NMISS) s_off[w] = run + off;
-                run += tot_w;
-            }
-            __syncthreads();
             for (uint32_t q0 = 0; q0 < 4u * NMISS; q0 += MLM_SEC_THREADS) {
                 const uint32_t q = q0 + threadIdx.x, w = q >> 2, sh = (q & 3u) * 8u;
                 if (w >= NMISS) break;
