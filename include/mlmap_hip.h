@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MLM_ABI_VERSION 2
+#define MLM_ABI_VERSION 3
 
 typedef enum mlm_status {
     MLM_OK = 0,
@@ -105,6 +105,8 @@ typedef struct mlm_frame_stats {
     int64_t n_spec_replays;  /* frames so far whose Stage B had to be replayed with a rehash plan */
     int64_t n_device_atomics;   /* device-scope atomics the frame's Stage A issued, counted by the kernels (0 on the cell-table path) */
     int64_t n_sector_fallbacks; /* frames so far redone by the cell-table path (an azimuth sector overflowed its LDS tables) */
+    int64_t logit_bit_exact;    /* 1: hit increments log10f(odd / (1 - odd)) carry the float bits of this host's libm (map_local.h:8);
+                                 * 0: unknown libm, increments are FP64 log10 rounded once (last-place differences possible) */
 } mlm_frame_stats;
 
 /* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */

@@ -33,7 +33,85 @@ MLM_HD inline int mlm_cv_f32_to_u16(float v) {
     return r > 65535.0f ? 65535 : (int)r;
 }
 
+// log10f of glibc 2.35 (Ubuntu 22.04: sysdeps/ieee754/flt-32/e_log10f.c on top of the table-driven logf of
+// sysdeps/ieee754/flt-32/e_logf.c + logf_data.c), restated operation by operation: the hit increment of the reference is
+// `logit(odd)` = log10f(odd / (1 - odd)) evaluated by the HOST's libm (map_local.h:8, map_local.cpp:159), and the log-odds
+// it accumulates decide occupancy classes at a threshold, so the device must produce the same float bits.  Every step is
+// an IEEE-754 double or float operation (no libm call), so the device result equals the host's bit for bit.  Checked
+// against this image's libm over ALL positive finite floats (2^31 - 2^23 inputs: zero mismatches, with and without
+// FMA contraction of the polynomial — the FMA ifunc variant of glibc's logf gives the same floats);
+// tests/test_host_math.py repeats a strided sweep, and mlm_create compares the host's log10f with this function on the
+// configuration's odds table and a sweep of the logit range before it lets the kernels use it (MlmDev::logit_exact).
+// Precondition of mlm_glibc_logf_core: 0.5 <= x < 2 (what log10f hands it).
+MLM_HD inline float mlm_glibc_logf_core(float x) {
+    static const double T[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+        {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+        {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+        {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+        {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+        {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+    const double Ln2 = 0x1.62e42fefa39efp-1;
+    const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+    const unsigned int ix = __builtin_bit_cast(unsigned int, x);
+    if (ix == 0x3f800000u) return 0.0f;
+    const unsigned int tmp = ix - 0x3f330000u;  // OFF
+    const int i = (int)((tmp >> (23 - 4)) % 16u);
+    const int k = (int)tmp >> 23;               // arithmetic shift
+    const unsigned int iz = ix - (tmp & (0x1ffu << 23));
+    const double invc = T[i][0], logc = T[i][1];
+    const double z = (double)__builtin_bit_cast(float, iz);
+    const double r = z * invc - 1;              // log(x) = log1p(z/c - 1) + log(c) + k ln2
+    const double y0 = logc + (double)k * Ln2;
+    const double r2 = r * r;
+    double y = A1 * r + A2;
+    y = A0 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+MLM_HD inline float mlm_glibc_log10f(float x) {
+    const float two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f, log10_2lo = 7.9034151668e-07f;
+    int hx = __builtin_bit_cast(int, x);
+    int k = 0;
+    if (hx < 0x00800000) { // x < 2^-126
+        if ((hx & 0x7fffffff) == 0) return -two25 / __builtin_fabsf(x); // log(+-0) = -inf
+        if (hx < 0) return (x - x) / (x - x);                           // log(-#) = NaN
+        k -= 25;
+        x *= two25; // subnormal: scale up
+        hx = __builtin_bit_cast(int, x);
+    }
+    if (hx >= 0x7f800000) return x + x;
+    k += (hx >> 23) - 127;
+    const int i = (int)(((unsigned int)k & 0x80000000u) >> 31);
+    hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+    const float y = (float)(k + i);
+    const float xm = __builtin_bit_cast(float, hx);
+    const float z = y * log10_2lo + ivln10 * mlm_glibc_logf_core(xm);
+    return z + y * log10_2hi;
+}
+
 namespace mlm_host {
+
+// Does this host's libm log10f (what the reference's logit macro calls) agree with mlm_glibc_log10f?  Checked on the values the
+// caller cares about (`vals`) and on a strided sweep of the positive floats between 1e-4 and 1e4 (the logit's argument for odds in
+// [0.001, 0.999] and the noisy-OR results above them).
+inline bool host_log10f_matches(const float *vals, size_t n) {
+    auto same = [](float v) {
+        const float a = ::log10f(v), b = mlm_glibc_log10f(v);
+        return __builtin_bit_cast(unsigned int, a) == __builtin_bit_cast(unsigned int, b);
+    };
+    for (size_t i = 0; i < n; ++i)
+        if (!same(vals[i])) return false;
+    const unsigned int lo = __builtin_bit_cast(unsigned int, 1e-4f), hi = __builtin_bit_cast(unsigned int, 1e4f);
+    for (unsigned int u = lo; u < hi; u += 4099u)
+        if (!same(__builtin_bit_cast(float, u))) return false;
+    const float sp[] = {0.0f, 1.0f, __builtin_inff(), 1e-45f, 1e-39f, 3.4e38f};
+    for (float v : sp)
+        if (!same(v)) return false;
+    return true;
+}
 
 // ---- Eigen::Quaterniond / Sophus::SE3 pieces of the frame setup (so3.cpp:36-96, se3.cpp:29-95) -----------------
 struct Q4 {

@@ -520,9 +520,13 @@ __device__ __forceinline__ float mlm_contribution_odd(const MlmDev &P, const flo
     }
     return table[row * P.nRho + rho_s];
 }
-// logit macro, map_local.h:8, on a float: log10f(x / (1 - x))
-__device__ __forceinline__ float mlm_logit(float p) {
+// logit macro, map_local.h:8, on a float: log10f(x / (1 - x)) — the HOST libm's log10f in the reference.  P.logit_exact:
+// mlm_create found that this host's log10f is glibc's table-driven one, restated bit for bit in mlm_glibc_log10f
+// (mlm_host.h): the increment then has the reference's float bits.  Otherwise (an unknown libm): FP64 log10 rounded once,
+// which differs from a float log10f in the last place on some inputs.
+__device__ __forceinline__ float mlm_logit(const MlmDev &P, float p) {
     const float ratio = p / (1 - p);
+    if (P.logit_exact) return mlm_glibc_log10f(ratio);
     return (float)log10((double)ratio);
 }
 
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_collect_hits(MLM_SLOT_ARGS, int n
                 float p = a;
                 for (uint32_t j = 1; j < cnt && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
                 P.hl_odd[pos] = p;
-                P.hl_inc[pos] = mlm_logit(p);
+                P.hl_inc[pos] = mlm_logit(P, p);
                 P.hl_cnt[pos] = 0;
             }
         }
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain(MLM_SLOT_ARGS, unsigned int
             }
         }
         P.hl_odd[pos] = p;
-        P.hl_inc[pos] = mlm_logit(p);
+        P.hl_inc[pos] = mlm_logit(P, p);
     }
 }
 

@@ -824,7 +824,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             float p = __popc(c.kmask) > 1 ? 1.0f : a;
             for (uint32_t j = 1; j < (c.cnt & MLM_SEC_CNT_MASK) && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
             mlm_gp(P.hl_odd)[pos] = p;
-            mlm_gp(P.hl_inc)[pos] = mlm_logit(p);
+            mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
             mlm_gp(P.hl_cnt)[pos] = 0;
         }
         // its world voxel: pushed on the voxel's pending list in the frame-local grid (grouping by voxel needs no map);
@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
     auto flush = [&]() {
         if (pend) {
             mlm_gp(P.hl_odd)[pend_pos] = pend_p;
-            mlm_gp(P.hl_inc)[pend_pos] = mlm_logit(pend_p);
+            mlm_gp(P.hl_inc)[pend_pos] = mlm_logit(P, pend_p);
             pend = false;
         }
     };

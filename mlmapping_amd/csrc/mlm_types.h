@@ -88,6 +88,7 @@ struct MlmDev {
     int RW;                    // 32-bit words per (phi,z) row of the miss bit mask = ceil(nRho/32)
     int nMissWords;
     int visibility;
+    int logit_exact;           // 1: the host's log10f equals mlm_glibc_log10f (mlm_host.h) -> hit increments with the reference's float bits
     // ---- local map constants (map_local.cpp:46-139)
     double d_sub, d_glb, d_sub_half;
     double inv_dRho, inv_dPhi, inv_dZ, inv_d_sub, inv_d_glb; // 1/d (rounded once): see mlm_quot in mlm_device.h

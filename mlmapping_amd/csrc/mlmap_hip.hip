@@ -510,6 +510,7 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_rays = nr;
     h->stats.n_spec_replays = h->n_spec_miss;
     h->stats.n_sector_fallbacks = h->n_sector_fallbacks;
+    h->stats.logit_bit_exact = h->P.logit_exact;
 }
 
 int check_queues(mlm_handle *h, const MlmSlot &S) {
@@ -681,18 +682,26 @@ int explore_confirm_front(mlm_handle *h) {
     }
     return MLM_OK;
 }
+void clear_device_error(mlm_handle *h);
+// Frontier mode after a failed call: nothing stays queued, the deferred tail is dropped, the device flags are re-armed —
+// the handle stays usable (what the default path's epilogue in run_slots does)
+void explore_fail_epilogue(mlm_handle *h) {
+    hipDeviceSynchronize();
+    h->ex_q.clear();
+    h->ex_tail = nullptr;
+    clear_device_error(h);
+}
 int drain_explore(mlm_handle *h) {
+    int rc = MLM_OK;
     for (auto &b : h->ex_q)
-        if (!b.bc_enqueued) {
-            const int rc = explore_enqueue_bc(h, b);
-            if (rc) return rc;
-        }
-    while (!h->ex_q.empty()) {
-        const int rc = explore_confirm_front(h);
-        if (rc) return rc;
+        if (!b.bc_enqueued && rc == MLM_OK) rc = explore_enqueue_bc(h, b);
+    while (rc == MLM_OK && !h->ex_q.empty()) rc = explore_confirm_front(h);
+    if (rc == MLM_OK && hipStreamSynchronize(h->stream) != hipSuccess) {
+        h->err = "hipStreamSynchronize failed";
+        rc = MLM_ERR_HIP;
     }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return MLM_OK;
+    if (rc != MLM_OK) explore_fail_epilogue(h);
+    return rc;
 }
 
 // Frontier mode, Stage A of the slots base..base+n: by azimuth sector when the handle can (k_sector<true>), else (and for
@@ -836,9 +845,13 @@ int drain(mlm_handle *h) {
                     (size_t)h->hit_pol._M_next_resize, h->hit_n_bkt, h->pending.size(), S.h_ctr->sector_overflow);
         h->h_g->fail_frame = 0x7FFFFFFF;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        if (S.sector) {
+        bool any_sector = false; // (async mode holds up to three batches: a cell-table batch may be followed by sector batches)
+        for (const MlmSlot *R : h->pending) any_sector = any_sector || R->sector;
+        if (any_sector) {
             // Sector path: the frames in flight were binned into buckets with the bucket count of their submission, which
             // the rehash changes — every pending frame is finished with exact keys, in order (no further speculation).
+            // Cell-table frames among them are finished the same way (k_voxelize would read hl_slot / hl_cid / hl_bkey,
+            // which k_sector never writes for a frame of the sector path).
             for (size_t j = 0; j < h->pending.size(); ++j) {
                 MlmSlot &R = *h->pending[j];
                 if (R.h_ctr->sector_overflow) {
@@ -973,37 +986,38 @@ int run_slots(mlm_handle *h, int n) {
                 // the set that is filled next must have been confirmed (its host-side counters are reused)
                 while (rc == MLM_OK && !h->ex_q.empty() && h->ex_q.front().set == h->cur_set) rc = explore_confirm_front(h);
             }
-            if (rc != MLM_OK) {
-                hipDeviceSynchronize();
-                h->ex_q.clear();
-                clear_device_error(h);
-            }
+            if (rc != MLM_OK) explore_fail_epilogue(h);
             return rc;
         }
         // Stage A of all frames in one launch sequence (it does not depend on the map), one synchronisation to learn the
         // frames' hit/miss counts, then the map-dependent part frame by frame without further synchronisation
-        int rc = explore_stage_a(h, base, n);
-        if (rc) return rc;
-        HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[h->cur_set], 0));
-        HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
-        rc = explore_redo_overflows(h, base, n);
-        if (rc) return rc;
-        for (int j = 0; j < n; ++j) {
-            rc = explore_stage_bc(h, base + j);
+        auto sync_path = [&]() -> int {
+            int rc = explore_stage_a(h, base, n);
             if (rc) return rc;
-        }
-        rc = explore_end_batch(h);
-        if (rc) return rc;
-        HIPCHK(h, hipEventRecord(h->set_free[h->cur_set], h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
-        for (int j = 0; j < n; ++j) {
-            rc = explore_finish(h, base + j);
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[h->cur_set], 0));
+            HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipGetLastError());
+            rc = explore_redo_overflows(h, base, n);
             if (rc) return rc;
-        }
-        return MLM_OK;
+            for (int j = 0; j < n; ++j) {
+                rc = explore_stage_bc(h, base + j);
+                if (rc) return rc;
+            }
+            rc = explore_end_batch(h);
+            if (rc) return rc;
+            HIPCHK(h, hipEventRecord(h->set_free[h->cur_set], h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipGetLastError());
+            for (int j = 0; j < n; ++j) {
+                rc = explore_finish(h, base + j);
+                if (rc) return rc;
+            }
+            return MLM_OK;
+        };
+        const int rc = sync_path();
+        if (rc != MLM_OK) explore_fail_epilogue(h); // (the handle stays usable after MLM_ERR_CAPACITY in this mode too)
+        return rc;
     }
     h->stats.n_rehash_epochs = 1;
     const int K = h->lim.max_batch;
@@ -1340,6 +1354,15 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     std::vector<float> sigma3(P.nRho);
     for (int r = 0; r < P.nRho; ++r) sigma3[r] = 3 * om.sigma_in_dr((size_t)r); // map_awareness.cpp:149
     {
+        // The hit increment is the HOST libm's log10f(odd / (1 - odd)) in the reference (map_local.h:8, map_local.cpp:159).  If this
+        // host's log10f is the one mlm_glibc_log10f restates (checked on the table's own logit arguments and a sweep of the range),
+        // the kernels evaluate that restatement and every increment has the reference's float bits; else FP64 log10 rounded once.
+        std::vector<float> ratios(h->odds_table.size());
+        for (size_t i = 0; i < ratios.size(); ++i) ratios[i] = h->odds_table[i] / (1 - h->odds_table[i]);
+        P.logit_exact = host_log10f_matches(ratios.data(), ratios.size()) ? 1 : 0;
+        if (const char *e = getenv("MLM_LOGIT_EXACT")) P.logit_exact = P.logit_exact && atoi(e) != 0;
+    }
+    {
         // a point spreads into 1 + 2*dmax cells; the wider the spread, the more groups and distinct cells a block produces
         int dmax = 0;
         for (int r = 0; r < P.nRho; ++r) {
@@ -1545,6 +1568,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             for (size_t a = mark; a < h->allocs.size(); ++a) hipFree(h->allocs[a]);
             h->allocs.resize(mark);
             h->alloc_bytes = h->map_bytes;
+            for (auto &S : h->slots) // (the image staging buffers are not in `allocs`: ensure_img)
+                if (S.d_img) hipFree(S.d_img);
             h->slots.assign(NS, MlmSlot{});
             h->lean = true;
             h->err.clear();

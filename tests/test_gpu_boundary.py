@@ -5,6 +5,7 @@ import ctypes
 import os
 import struct
 import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -157,13 +158,15 @@ def test_caller_stream_orders_device_inputs(mods):
     gpu.close()
 
 
-def test_handle_survives_capacity_error(mods):
+@pytest.mark.parametrize("explore", [False, True])
+def test_handle_survives_capacity_error(mods, explore):
     """After MLM_ERR_CAPACITY (block pool full) the handle stays usable: the blocks that exist keep accepting updates
-    and answering queries (the device error flag used to stay set, failing every later call)."""
+    and answering queries (the device error flag used to stay set, failing every later call) — also in frontier mode,
+    whose synchronous path has its own error epilogue."""
     from mlmapping_amd.mlmap import MlmError
 
     MLMap, OracleMap = mods
-    cfg = S1
+    cfg = S1.with_(use_exploration_frontiers=explore)
     gpu = MLMap(cfg, max_blocks=40)
     img = syn.room_depth(cfg)      # 116 blocks of 1 m
     near = np.full_like(img, 600)  # a wall 0.6 m ahead: a handful of blocks
@@ -254,6 +257,65 @@ def test_merge_over_rccl_world_size_1(mods):
         dist.destroy_process_group()
 
 
+def test_merge_device_maps_two_ranks_periodic(tmp_path):
+    """merge_device_maps with world size 2 (both ranks' maps on the one GPU, collectives over gloo, host staged): key union,
+    mlm_merge_pack, direct reduce-scatter (all-to-all), mlm_merge_finish, all-gather, mlm_import_blocks — and the periodic
+    case the round-2 advisor flagged: a second merge after more frames must add the ranks' INCREMENTS to the first merged
+    map, not sum maps that already contain it; a third merge with nothing new changes nothing."""
+    import subprocess
+
+    port = str(29700 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "merge_device_worker.py"), str(r), "2", port, str(tmp_path)])
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    cfg = SDEF
+    lo_min, lo_max, sh = np.float32(cfg.lm_log_odds_min), np.float32(cfg.lm_log_odds_max), np.float32(cfg.lm_occupied_sh)
+    L = lambda name, r: np.load(tmp_path / f"{name}_{r}.npz")
+
+    def union_layout(maps):
+        allk = np.unique(np.concatenate([m["keys"] for m in maps]), axis=0)
+        allk = allk[np.lexsort((allk[:, 2], allk[:, 1], allk[:, 0]))]
+        idx = {tuple(k): i for i, k in enumerate(allk)}
+        out = []
+        for m in maps:
+            lo = np.zeros((allk.shape[0], cfg.cells_per_block), np.float32)
+            seen = np.zeros(lo.shape, bool)
+            rows = [idx[tuple(k)] for k in m["keys"]]
+            lo[rows] = m["log_odds"]
+            seen[rows] = m["occ"] != ord("u")
+            out.append((lo, seen))
+        return allk, out
+
+    def classes(lo, seen):
+        c = np.where(seen, ord("f"), ord("u")).astype(np.uint8)
+        c[lo > sh] = ord("o")
+        return c
+
+    # round 1: plain sum of the two maps
+    keys1, ((a_lo, a_seen), (b_lo, b_seen)) = union_layout([L("own1", 0), L("own1", 1)])
+    exp1 = np.clip(a_lo + b_lo, lo_min, lo_max)
+    for r in range(2):
+        m = L("merged1", r)
+        assert np.array_equal(m["keys"], keys1)
+        assert np.array_equal(m["log_odds"].view(np.uint32), exp1.view(np.uint32)), f"rank {r}: first merge"
+        assert np.array_equal(m["occ"], classes(exp1, a_seen | b_seen))
+    assert keys1.shape[0] > max(L("own1", 0)["keys"].shape[0], L("own1", 1)["keys"].shape[0])
+    # round 2: M + (L_0 - M) + (L_1 - M)
+    keys2, ((a2, s_a), (b2, s_b), (m1, _)) = union_layout([L("own2", 0), L("own2", 1), L("merged1", 0)])
+    exp2 = np.clip((a2 - m1) + (b2 - m1) + m1, lo_min, lo_max)
+    for r in range(2):
+        m = L("merged2", r)
+        assert np.array_equal(m["keys"], keys2)
+        assert np.allclose(m["log_odds"], exp2, atol=2e-6), f"rank {r}: second merge"
+        assert np.array_equal(m["occ"][np.abs(exp2 - sh) > 1e-5], classes(exp2, s_a | s_b)[np.abs(exp2 - sh) > 1e-5])
+    assert np.abs(np.clip(a2 + b2, lo_min, lo_max) - exp2).max() > 0.1  # (re-summing the maps would double-count)
+    for r in range(2):
+        m2, m3 = L("merged2", r), L("merged3", r)
+        assert np.array_equal(m2["keys"], m3["keys"]) and np.array_equal(m2["occ"], m3["occ"])
+        assert np.allclose(m2["log_odds"], m3["log_odds"], atol=1e-6)
+
+
 def test_two_slot_sets(mods, monkeypatch):
     """The handle falls back to two slot sets when three do not fit the device memory; forced here (MLM_SLOT_SETS=2): the
     asynchronous batch pipeline must give the same map."""
@@ -276,26 +338,36 @@ def test_two_slot_sets(mods, monkeypatch):
 
 
 def test_bench_launcher_contract_two_ranks():
-    """bench.py under `torch.distributed.run --nproc-per-node 2` exactly as the driver launches it (rank environment, barrier,
-    max over ranks, ONE JSON line from rank 0, whole-job aggregate).  This box has one GPU, so both ranks share it and the
-    collectives run over gloo (MLM_BENCH_DIST_BACKEND): the contract is what is checked, not a rate."""
+    """`python bench.py --gpus 2` exactly as the driver invokes it when it does not wrap it in torch.distributed.run: the
+    parent starts the two ranks itself (before it touches the GPU) — rank environment, barrier, max over ranks, the timed
+    merge leg, ONE JSON line from rank 0, whole-job aggregate.  This box has one GPU, so both ranks share it and the
+    collectives run over gloo (MLM_BENCH_DIST_BACKEND): the contract is what is checked, not a rate.  Without that hook the
+    same command must fail loudly on a one-GPU box instead of reporting one stream as two GPUs."""
     import json
     import sys
 
+    import torch
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MLM_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-extra"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-extra"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "one rank per GPU" in r.stderr, (r.returncode, r.stderr[-500:])
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run(cmd, cwd=root, env=dict(env, MLM_BENCH_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["streams"] == 2 and d["config"]["frames_per_step"] == 8
+    assert d["config"]["streams"] == 2 and d["config"]["frames_per_step"] == 8 and "cfg4" in d["config"]["workload"]
     # whole-job aggregate: frames of BOTH ranks over the slower rank's time
     assert abs(d["value"] - 2 * 3 * 8 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
     assert d["roofline"]["frac"] > 0 and d["roofline"]["atomics"]["atomics_per_frame"] > 0
+    mg = d["merge"]  # the two streams have different poses: the union is larger than either map
+    assert mg["merge_ms"] > 0 and mg["union_blocks"] > mg["own_blocks"] > 0 and mg["merge_bytes_per_rank"] > 0
 
 
 def test_lean_slots_when_the_full_ones_do_not_fit(mods, monkeypatch):

@@ -815,6 +815,34 @@ def test_frontier_mode_sector_path(mods, monkeypatch, env):
     gpu.close()
 
 
+def test_async_replay_with_mixed_stage_a_paths(mods, monkeypatch):
+    """Asynchronous submission keeps up to three batches in flight.  Here a cell-table batch (submitted while the sector path
+    backs off after a forced overflow) is followed by sector batches, and a frame of the OLDER, cell-table batch turns out to
+    need a rehash of the emulated hit container (its hit count jumps from ~3 k to ~14 k): the replay must finish every
+    pending frame on the path its Stage A took (round-2 advisor finding: the sector frames were resubmitted through
+    k_voxelize, which reads per-hit fields k_sector never writes)."""
+    MLMap, OracleMap = mods
+    monkeypatch.setenv("MLM_SEC_FAIL_EVERY", "7")
+    monkeypatch.setenv("MLM_SEC_BACKOFF", "1")
+    cfg = S1
+    n = 14
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
+    frames[:3, 110:, :] = 0  # frames 0-2: only the top rows carry depth -> a small hit container
+    poses = syn.random_poses(n, 11)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=2), OracleMap(cfg)
+    gpu.set_async(True)
+    for k0 in range(0, n, 2):
+        gpu.update_map_batch(frames[k0:k0 + 2], q[k0:k0 + 2], t[k0:k0 + 2])
+    for k in range(n):
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "async, cell-table batch followed by sector batches")
+    st = gpu.frame_stats()
+    assert st["n_spec_replays"] >= 1 and st["n_sector_fallbacks"] >= 2, st
+    gpu.close()
+
+
 @pytest.mark.parametrize("d_sub", [0.3, 0.5])
 def test_many_hits_per_voxel(mods, d_sub):
     """Voxels several awareness cells wide collect dozens of hit cells each: more than the seven direct hit slots of a voxel

@@ -153,3 +153,10 @@ def test_odds_table_and_conversion_match_oracle(rec, oracle_lib):
     s = x * np.float32(1000.0)
     ref = np.clip(np.rint(s), 0, 65535).astype(np.uint16)
     assert np.array_equal(B.cv_f32_to_u16(x), ref)
+
+
+def test_log10f_restatement_matches_host_libm(rec):
+    """mlm_glibc_log10f (the device's logit) equals this host's log10f bit for bit on the driver's sweep (the driver exits
+    with an error on any mismatch); reference: logit macro map_local.h:8 evaluated by the host libm, map_local.cpp:159."""
+    n, bad = rec["log10f"][0]
+    assert n > 8e6 and bad == 0

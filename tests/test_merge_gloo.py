@@ -22,6 +22,20 @@ def _rank_blocks(rank):
     return m.export_blocks()
 
 
+def _second_round_blocks(rank, M):
+    """Rank `rank`'s map some frames after the merged map M was loaded into it: M + its own increments on a few blocks,
+    plus one block only this rank has seen."""
+    rng = np.random.default_rng(100 + rank)
+    keys, lo, occ = M["keys"].copy(), M["log_odds"].copy(), M["occ"].copy()
+    rows = rng.choice(keys.shape[0], size=max(1, keys.shape[0] // 3), replace=False)
+    lo[rows] += rng.uniform(-0.5, 0.5, size=(rows.size, lo.shape[1])).astype(np.float32)
+    occ[rows] = np.where(occ[rows] == ord("u"), ord("f"), occ[rows])
+    new_key = np.array([[1000 + rank, 0, 0]], dtype=np.int32)
+    new_lo = rng.uniform(-1, 1, size=(1, lo.shape[1])).astype(np.float32)
+    return {"keys": np.concatenate([keys, new_key]), "log_odds": np.concatenate([lo, new_lo]),
+            "occ": np.concatenate([occ, np.full((1, lo.shape[1]), ord("f"), np.uint8)])}
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch
@@ -36,6 +50,13 @@ def _worker(rank, world, port, out_dir):
     b = _rank_blocks(rank)
     merged = merge_global_map(b, SDEF)
     np.savez(os.path.join(out_dir, f"merged_{rank}.npz"), **{k: v.cpu().numpy() for k, v in merged.items()})
+    # second round (periodic merge): every rank's map is now the merged map M plus what it observed since
+    nxt = _second_round_blocks(rank, {k: v.cpu().numpy() for k, v in merged.items()})
+    merged2 = merge_global_map(nxt, SDEF, baseline=merged)
+    np.savez(os.path.join(out_dir, f"merged2_{rank}.npz"), **{k: v.cpu().numpy() for k, v in merged2.items()})
+    # third round without new observations: the maps ARE the merged map -> unchanged
+    merged3 = merge_global_map(merged2, SDEF, baseline=merged2)
+    np.savez(os.path.join(out_dir, f"merged3_{rank}.npz"), **{k: v.cpu().numpy() for k, v in merged3.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,3 +94,26 @@ def test_merge_two_ranks(tmp_path):
     assert np.allclose(m0["log_odds"], lo, atol=1e-6)
     assert np.array_equal(m0["occ"], cls)
     assert allk.shape[0] > max(b0["keys"].shape[0], b1["keys"].shape[0])  # the union is really larger
+
+    # ---- periodic merge: the second round sums the ranks' INCREMENTS on top of the first merged map (summing the maps
+    #      themselves would count the shared past twice), the third (no new observations) changes nothing
+    M = {k: m0[k] for k in ("keys", "log_odds", "occ")}
+    n0, n1 = _second_round_blocks(0, M), _second_round_blocks(1, M)
+    m20, m21 = np.load(tmp_path / "merged2_0.npz"), np.load(tmp_path / "merged2_1.npz")
+    for k in ("keys", "log_odds", "occ"):
+        assert np.array_equal(m20[k], m21[k]), f"second round: ranks disagree on {k}"
+    nM = M["keys"].shape[0]
+    assert m20["keys"].shape[0] == nM + 2
+    exp = M["log_odds"].astype(np.float32) + (n0["log_odds"][:nM] - M["log_odds"]) + (n1["log_odds"][:nM] - M["log_odds"])
+    exp = np.clip(exp, np.float32(SDEF.lm_log_odds_min), np.float32(SDEF.lm_log_odds_max))
+    pos = {tuple(k): i for i, k in enumerate(m20["keys"])}
+    got = m20["log_odds"][[pos[tuple(k)] for k in M["keys"]]]
+    assert np.allclose(got, exp, atol=1e-5)
+    naive = np.clip(n0["log_odds"][:nM] + n1["log_odds"][:nM], np.float32(SDEF.lm_log_odds_min), np.float32(SDEF.lm_log_odds_max))
+    assert np.abs(naive - exp).max() > 0.1  # (what re-summing the maps would have given)
+    for r, nb in ((0, n0), (1, n1)):  # each rank's own new block comes through unchanged (clamped)
+        assert np.allclose(m20["log_odds"][pos[(1000 + r, 0, 0)]],
+                           np.clip(nb["log_odds"][-1], np.float32(SDEF.lm_log_odds_min), np.float32(SDEF.lm_log_odds_max)), atol=1e-6)
+    m30 = np.load(tmp_path / "merged3_0.npz")
+    assert np.array_equal(m30["keys"], m20["keys"]) and np.array_equal(m30["occ"], m20["occ"])
+    assert np.allclose(m30["log_odds"], m20["log_odds"], atol=1e-6)

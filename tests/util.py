@@ -10,9 +10,11 @@ def odds_of(log_odds: np.ndarray) -> np.ndarray:
     return p / (1.0 + p)
 
 
-def compare_maps(g: dict, c: dict, what: str = "") -> dict:
+def compare_maps(g: dict, c: dict, what: str = "", exact: bool = True) -> dict:
     """GPU block dump vs oracle block dump (both sorted by key).  Integer/byte facts must be identical; the float
-    log-odds are compared as odds with the 1e-4 tolerance of the north star.  Returns diagnostics."""
+    log-odds are compared as odds with the 1e-4 tolerance of the north star AND, with `exact` (the default: the device
+    evaluates the host libm's log10f bit for bit, mlm_glibc_log10f, and adds the increments in the reference's order),
+    as float bits: not one voxel may differ.  Returns diagnostics."""
     assert g["keys"].shape == c["keys"].shape, f"{what}: block count {g['keys'].shape[0]} vs {c['keys'].shape[0]}"
     assert np.array_equal(g["keys"], c["keys"]), f"{what}: block key sets differ"
     assert np.array_equal(g["collapsed"], c["collapsed"]), f"{what}: released (collapsed) block sets differ"
@@ -27,6 +29,9 @@ def compare_maps(g: dict, c: dict, what: str = "") -> dict:
     dodd = np.abs(odds_of(g["log_odds"]) - odds_of(c["log_odds"]))
     assert dodd.max() <= ODDS_TOL, f"{what}: max |d odd| = {dodd.max():.3e}"
     dl = np.abs(g["log_odds"].astype(np.float64) - c["log_odds"].astype(np.float64))
+    if exact:
+        nb = int((g["log_odds"].view(np.uint32) != c["log_odds"].view(np.uint32)).sum())
+        assert nb == 0, f"{what}: {nb} of {g['log_odds'].size} voxels differ in log-odds bits (max |dL| {dl.max():.3e})"
     return {"blocks": int(g["keys"].shape[0]), "max_dodd": float(dodd.max()), "max_dL": float(dl.max()),
             "bit_mismatch": int((g["log_odds"].view(np.uint32) != c["log_odds"].view(np.uint32)).sum()),
             "cells": int(g["log_odds"].size)}
