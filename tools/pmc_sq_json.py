@@ -9,21 +9,34 @@ from collections import defaultdict
 
 acc = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(lambda: defaultdict(int))
+seen_in, dup = {}, set()
 for path in sys.argv[1:-1]:
+    for c, p0 in list(seen_in.items()):
+        if p0 != path:
+            dup.add((path, c))
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         if not k.startswith("k_"):
             continue
+        if (path, r["Counter_Name"]) in dup:
+            continue  # (a counter collected by two passes: the first pass counts)
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[k][r["Counter_Name"]] += 1
+        seen_in[r["Counter_Name"]] = path
 n_frames = 48.0  # tools/pmc_batch.py: three 16-frame batches
-out = {"source": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
-                 "SQ_WAIT_ANY --kernel-trace -- python3 tools/pmc_batch.py",
+out = {"source": "two rocprofv3 --pmc passes over python3 tools/pmc_batch.py (--kernel-trace only): SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS "
+                 "SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY; SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES.  WAIT_ANY (parked on s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + "
+                 "ACTIVE_INST_ANY (issuing) ~ WAVE_CYCLES (MI355X_MICROARCH.md, rocprofv3 PMC slots)",
        "unit": "per frame (48 frames of the bench workload in three batches)", "kernels": {}}
 for k, cs in acc.items():
     d = {c: v / n_frames for c, v in sorted(cs.items())}
     if d.get("SQ_WAVE_CYCLES"):
         d["wait_any_over_wave_cycles"] = d.get("SQ_WAIT_ANY", 0.0) / d["SQ_WAVE_CYCLES"]
+        for c, name in (("SQ_WAIT_INST_ANY", "wait_inst_any_over_wave_cycles"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_over_wave_cycles"),
+                        ("SQ_ACTIVE_INST_VALU", "active_inst_valu_over_wave_cycles"), ("SQ_ACTIVE_INST_LDS", "active_inst_lds_over_wave_cycles")):
+            if c in d:
+                d[name] = d[c] / d["SQ_WAVE_CYCLES"]
     d["launches"] = max(launches[k].values())
     out["kernels"][k] = d
 json.dump(out, open(sys.argv[-1], "w"), indent=1)
