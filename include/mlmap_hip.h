@@ -20,8 +20,9 @@
  *    that returned (in async mode they first wait for everything submitted).  mlm_last_error is per handle: read it
  *    on the thread that got the failure before that thread issues another call.  mlm_destroy must not race with
  *    other calls;
- *  - after MLM_ERR_CAPACITY the handle stays usable: the map keeps what the failing call applied before it ran out
- *    of room, blocks that did not fit stay absent, later frames integrate normally;
+ *  - the block pool grows on demand; after MLM_ERR_CAPACITY (device memory exhausted, a frame with more points than
+ *    mlm_limits.max_points, or a fixed pool: MLM_POOL_GROW=0) the handle stays usable: the map keeps what the failing call
+ *    applied before it ran out of room, later frames integrate normally;
  *  - poses are q_wb = (w,x,y,z) and t_wb of T_wb (body in world), exactly what mlmap.cpp:494 builds;
  *  - positions are world-frame doubles (Vec3 of include/common.h:22), n x 3 row-major.
  */
@@ -77,7 +78,10 @@ typedef struct mlm_config {
 
 /* Sizing of the device-resident state (no reference counterpart: the reference grows std containers). */
 typedef struct mlm_limits {
-    int32_t max_blocks;      /* capacity of the hashed block pool (n^3 cells each); 0 = default 65536 */
+    int32_t max_blocks;      /* INITIAL capacity of the hashed block pool (n^3 cells each); 0 = default 65536.  The pool
+                              * grows on demand (table and pool re-allocated at twice the size, blocks copied, table rebuilt
+                              * on the device) like the reference's observed_group_map; MLM_ERR_CAPACITY only when the
+                              * device cannot hold the larger pool (or with the environment's MLM_POOL_GROW=0) */
     int32_t max_points;      /* largest point count of one frame; 0 = 1280*720 */
     int32_t max_batch;       /* frames integrated per launch sequence (batch entry points); 0 = 8, at most 64;
                               * every frame in flight owns ~0.35 GB (S1) .. 2.2 GB (S3) of scratch, three sets of them
@@ -107,6 +111,8 @@ typedef struct mlm_frame_stats {
     int64_t n_sector_fallbacks; /* frames so far redone by the cell-table path (an azimuth sector overflowed its LDS tables) */
     int64_t logit_bit_exact;    /* 1: hit increments log10f(odd / (1 - odd)) carry the float bits of this host's libm (map_local.h:8);
                                  * 0: unknown libm, increments are FP64 log10 rounded once (last-place differences possible) */
+    int64_t n_pool_grows;       /* times the block pool has grown so far (allocate_ram never refuses: map_local.h:215-231) */
+    int64_t block_capacity;     /* blocks the pool holds now */
 } mlm_frame_stats;
 
 /* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */

@@ -1776,6 +1776,20 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_query_odds_at(const MlmDev P, con
 }
 
 // mlm_import_blocks: find or create the block of every imported key (allocate_ram, map_local.h:215-231) ...
+// grow_pool: re-insert the blocks' keys into the new, larger table (slot = the block's index in the pool)
+__global__ __launch_bounds__(MLM_BLOCK) void k_rehash_blocks(const MlmDev P, unsigned int n) {
+    const unsigned int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const unsigned long long key = mlm_pack_key(P.block_keys[3 * (size_t)b], P.block_keys[3 * (size_t)b + 1], P.block_keys[3 * (size_t)b + 2]);
+    uint32_t h = mlm_mix(key) & P.ht_mask;
+    for (uint32_t probe = 0; probe <= P.ht_mask; ++probe) {
+        if (atomicCAS(&P.ht_keys[h], MLM_HT_EMPTY, key) == MLM_HT_EMPTY) {
+            P.ht_slot[h] = (int)b;
+            return;
+        }
+        h = (h + 1) & P.ht_mask;
+    }
+}
 __global__ __launch_bounds__(MLM_BLOCK) void k_import_slots(const MlmDev P, const int32_t *keys, int n, int *slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -1346,15 +1346,21 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
         const uint32_t nh = (uint32_t)state, km = (uint32_t)(state >> 32);
         if (p_rec.w == 1u && nh != 0u) continue; // the owner of the voxel's hits applies its misses too
         if (nh == 0u && km == 0u) continue;      // (consumed already: never write a stale value back)
-        *st = 0ull;
-        if (nh >= MLM_LV_SLOTS) hs[MLM_LV_SLOTS - 1] = 0u; // (the list of the hits beyond the direct slots)
         if (slot < 0) {
             slot = mlm_block_slot(P, p_key);
-            if (slot < 0) continue; // block pool full (error flag set)
+            if (slot < 0) {
+                // block pool full (error flag set by the allocator): the voxel STAYS pending and the frame flags itself, so that
+                // the frames behind it do nothing; the host grows the pool and launches them again (drain), this voxel is
+                // applied then — before any later frame touches it, i.e. exactly as if the block had fitted
+                atomicMin(&P.g->fail_frame, frame_idx);
+                continue;
+            }
             v = (size_t)slot * P.cells + p_rec.y;
             L = mlm_gp(P.log_odds)[v];
             o = mlm_gp(P.occ)[v];
         }
+        *st = 0ull;
+        if (nh >= MLM_LV_SLOTS) hs[MLM_LV_SLOTS - 1] = 0u; // (the list of the hits beyond the direct slots)
         auto hit = [&](float inc) { // map_local.cpp:157-171
             if (L < P.lo_max) {
                 L = L + inc;

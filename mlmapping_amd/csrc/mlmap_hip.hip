@@ -52,6 +52,8 @@ struct MlmSlot {
     unsigned int ex_um = 0;   // frontier mode: unique miss cells of the frame it holds
     size_t alloc_end = 0;     // mlm_handle::allocs.size() once this slot was allocated
     bool sector = false;      // the frame it holds went through the sector path (Stage A and the frame-local voxel grid)
+    bool keys_exact = false;  // hl_key of the frame it holds was written by order_hits_exact (a replay must not recompute it:
+                              // the emulated container's policy state has moved on)
     uint16_t *d_img = nullptr; // staging for host images
     size_t img_cap = 0;
     int32_t *d_pix = nullptr;
@@ -155,6 +157,11 @@ struct mlm_handle {
     long long n_sector_fallbacks = 0; // frames redone by the cell-table path because a sector's LDS tables overflowed
     std::recursive_mutex mu;   // serialises the entry points of this handle (see MLM_LOCK)
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
+    bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
+    size_t frame_block_bound = 0; // most blocks one frame can create
+    long long n_pool_grows = 0;
+    MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
+    MlmPair *fb_pairs = nullptr;
 };
 
 namespace {
@@ -243,6 +250,10 @@ inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 b
         hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
     }
 }
+
+int grow_pool(mlm_handle *h, size_t want);
+int ensure_free_blocks(mlm_handle *h, size_t need);
+int ensure_free_blocks_idle(mlm_handle *h, size_t need);
 
 // T_ls and t_wa of one frame (map_awareness.cpp:184-186)
 void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb_in[3], MlmFrame &F) {
@@ -511,6 +522,8 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_spec_replays = h->n_spec_miss;
     h->stats.n_sector_fallbacks = h->n_sector_fallbacks;
     h->stats.logit_bit_exact = h->P.logit_exact;
+    h->stats.n_pool_grows = h->n_pool_grows;
+    h->stats.block_capacity = h->P.max_blocks;
 }
 
 int check_queues(mlm_handle *h, const MlmSlot &S) {
@@ -753,18 +766,25 @@ int submit_batch(mlm_handle *h, int base, int n) {
         return MLM_ERR_CAPACITY;
     }
     const int set = base / (h->lim.max_batch);
+    int rc;
+    // (the sector path packs a tile's image column into 11 bits; its bucket-first tables hold sbkt_cap buckets)
+    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040 &&
+                         h->hit_n_bkt <= h->slots[(size_t)base].P.sbkt_cap;
+    if (h->sector_backoff > 0) --h->sector_backoff;
+    if (!sectors) { // the cell-table path cannot replay a frame that ran out of blocks: room for everything in flight + this batch
+        rc = ensure_free_blocks(h, (h->pending.size() + (size_t)n) * h->frame_block_bound);
+        if (rc) return rc;
+    }
     for (int j = 0; j < n; ++j) {
         MlmSlot &S = h->slots[(size_t)(base + j)];
         S.seq = h->next_seq++;
         S.F.seq = S.seq;
         S.F.rehash_thr = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
     }
-    int rc;
-    // (the sector path packs a tile's image column into 11 bits; its bucket-first tables hold sbkt_cap buckets)
-    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040 &&
-                         h->hit_n_bkt <= h->slots[(size_t)base].P.sbkt_cap;
-    if (h->sector_backoff > 0) --h->sector_backoff;
-    for (int j = 0; j < n; ++j) h->slots[(size_t)(base + j)].sector = sectors;
+    for (int j = 0; j < n; ++j) {
+        h->slots[(size_t)(base + j)].sector = sectors;
+        h->slots[(size_t)(base + j)].keys_exact = false;
+    }
     {
         Timed t(h, h->stream_as[set], "stage_a_batch");
         rc = sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
@@ -832,10 +852,34 @@ int drain(mlm_handle *h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         const int f = h->h_g->fail_frame;
+        const bool pool_full = (h->h_g->err & 1u) && h->pool_grow;
+        if (pool_full) h->h_g->err &= ~1u; // (handled below: not an error of the frames confirmed here)
         size_t ok = 0;
         while (ok < h->pending.size() && h->pending[ok]->seq < f) ++ok;
         int rc = confirm_front(h, (int)ok);
         if (rc) return rc;
+        if (pool_full) {
+            // A frame ran out of blocks.  On the sector path it is applied voxel by voxel — the voxels whose block did not fit
+            // were left pending in the frame-local grid and the frame flagged itself, so it and the frames behind it have
+            // not touched those voxels: grow the pool and launch them again (the voxels that were applied are skipped).
+            // (Frames of the cell-table path never get here for lack of blocks: ensure_free_blocks before their submission.)
+            rc = grow_pool(h, (size_t)h->P.max_blocks + 2 * h->frame_block_bound);
+            if (rc) return rc;
+            h->h_g->fail_frame = 0x7FFFFFFF;
+            HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+            if (f == 0x7FFFFFFF) { // (no frame flagged itself: a path without replay overflowed although room was made for it)
+                h->err = "block pool overflowed on a path that cannot be replayed";
+                return MLM_ERR_CAPACITY;
+            }
+            for (MlmSlot *R : h->pending) {
+                if (R->sector)
+                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(160, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, R->P, R->F, R->keys_exact ? 1 : 0);
+                else
+                    launch_stage_bc(h, *R, R->keys_exact ? 0 : h->hit_n_bkt);
+                HIPCHK(h, hipMemcpyAsync(R->h_ctr, R->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+            }
+            continue;
+        }
         if (h->pending.empty()) break;
         // pending.front() does not fit the emulated container without a rehash (replay its Stage B exactly), or one of
         // its azimuth sectors overflowed its LDS tables (redo its Stage A on the cell-table path first)
@@ -860,6 +904,8 @@ int drain(mlm_handle *h) {
                     const int si = (int)(&R - h->slots.data());
                     const int set = si / (h->lim.max_batch);
                     HIPCHK(h, hipStreamSynchronize(h->stream));
+                    rc = ensure_free_blocks_idle(h, h->frame_block_bound); // (its k_voxelize cannot be replayed)
+                    if (rc) return rc;
                     // the frame-local grid holds what the sectors that did finish pushed: wipe it, then the cell-table path
                     HIPCHK(h, hipMemsetAsync(R.P.lv_state, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * sizeof(unsigned long long), h->stream_as[set]));
                     HIPCHK(h, hipMemsetAsync(R.P.lv_hits, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * MLM_LV_SLOTS * sizeof(uint32_t), h->stream_as[set]));
@@ -875,8 +921,11 @@ int drain(mlm_handle *h) {
                 }
                 rc = check_queues(h, R);
                 if (rc) return rc;
-                rc = order_hits_exact(h, R, R.h_ctr->u_hit, R.seq);
-                if (rc) return rc;
+                if (!R.keys_exact) {
+                    rc = order_hits_exact(h, R, R.h_ctr->u_hit, R.seq);
+                    if (rc) return rc;
+                    R.keys_exact = true;
+                }
                 if (R.sector)
                     tlaunch(h, "k_apply_frame", k_apply_frame, dim3(160, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1);
                 else
@@ -890,6 +939,7 @@ int drain(mlm_handle *h) {
         if (rc) return rc;
         rc = order_hits_exact(h, S, S.h_ctr->u_hit, S.seq);
         if (rc) return rc;
+        S.keys_exact = true;
         launch_stage_bc(h, S, 0);
         HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
         // the later frames evaluated their device-side check against the OLD threshold: re-arm it from the host with
@@ -965,6 +1015,12 @@ int run_slots(mlm_handle *h, int n) {
     }
     if (h->P.explore) { // frontier mode: exact ordering of both containers, no speculation
         const int K = h->lim.max_batch;
+        {
+            size_t in_flight = 0;
+            for (const auto &b : h->ex_q) in_flight += (size_t)b.n;
+            const int rc = ensure_free_blocks(h, (in_flight + (size_t)n) * h->frame_block_bound); // (no replay in this mode)
+            if (rc) return rc;
+        }
         const int base = h->cur_set * K;
         if (h->async_mode) {
             const int set = h->cur_set;
@@ -1091,6 +1147,179 @@ int read_global(mlm_handle *h) {
     HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return MLM_OK;
+}
+
+// The pool fields of MlmDev (everything sized by max_blocks): copied into every slot's parameter block when the pool grows
+void copy_pool_fields(MlmDev &d, const MlmDev &s) {
+    d.ht_keys = s.ht_keys;
+    d.ht_slot = s.ht_slot;
+    d.ht_mask = s.ht_mask;
+    d.max_blocks = s.max_blocks;
+    d.block_keys = s.block_keys;
+    d.log_odds = s.log_odds;
+    d.occ = s.occ;
+    d.infl = s.infl;
+    d.vox_head = s.vox_head;
+    d.vox_miss = s.vox_miss;
+    d.vox_stride = s.vox_stride;
+    d.frnt = s.frnt;
+    d.blk_collapsed = s.blk_collapsed;
+    d.blk_observed = s.blk_observed;
+    d.vox_tau = s.vox_tau;
+}
+void dev_free(mlm_handle *h, void *p, size_t bytes) {
+    if (!p) return;
+    auto it = std::find(h->allocs.begin(), h->allocs.end(), p);
+    if (it != h->allocs.end()) *it = nullptr; // (slot indices into `allocs` stay valid: MlmSlot::alloc_end)
+    hipFree(p);
+    h->alloc_bytes -= std::min(h->alloc_bytes, bytes);
+}
+// Allocate and initialise a block table + pool for `max_blocks` blocks into the pool fields of P (allocate_ram leaves a new
+// block at log_odds 0, occupancy 'u', inflate_occupancy 'u': map_local.h:215-231 — pre-initialised, so creating a block is
+// one CAS).
+int alloc_pool(mlm_handle *h, MlmDev &P, int max_blocks) {
+    int rc;
+    if (max_blocks <= 0 || (long long)max_blocks * P.cells > 0x7FFFFFFFll) { // (voxel addresses are 32-bit on the cell-table path)
+        h->err = "block pool beyond 2^31 voxels";
+        return MLM_ERR_CAPACITY;
+    }
+    P.max_blocks = max_blocks;
+    size_t ht = 1;
+    while (ht < (size_t)P.max_blocks * 4) ht <<= 1;
+    P.ht_mask = (uint32_t)(ht - 1);
+    const size_t NV = (size_t)P.max_blocks * P.cells;
+    // (only the cell-table path and frontier mode use the per-map-voxel scratch: the sector path groups by voxel in the
+    // frame-local grid)
+    if ((rc = dev_alloc(h, &P.ht_keys, ht))) return rc;
+    if ((rc = dev_alloc(h, &P.ht_slot, ht))) return rc;
+    if ((rc = dev_alloc(h, &P.block_keys, (size_t)P.max_blocks * 3))) return rc;
+    if ((rc = dev_alloc(h, &P.log_odds, NV))) return rc;
+    if ((rc = dev_alloc(h, &P.occ, NV))) return rc;
+    if ((rc = dev_alloc(h, &P.infl, NV))) return rc;
+    P.vox_stride = NV;
+    if ((rc = dev_alloc(h, &P.vox_head, 2 * NV))) return rc;
+    if ((rc = dev_alloc(h, &P.vox_miss, 2 * NV))) return rc;
+    if (P.explore) {
+        if ((rc = dev_alloc(h, &P.frnt, NV))) return rc;
+        if ((rc = dev_alloc(h, &P.vox_tau, NV))) return rc;
+        if ((rc = dev_alloc(h, &P.blk_collapsed, (size_t)P.max_blocks))) return rc;
+        if ((rc = dev_alloc(h, &P.blk_observed, (size_t)P.max_blocks))) return rc;
+        HIPCHK(h, hipMemset(P.frnt, 0, NV));
+        HIPCHK(h, hipMemset(P.vox_tau, 0, NV * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemset(P.blk_collapsed, 0, (size_t)P.max_blocks));
+        HIPCHK(h, hipMemset(P.blk_observed, 0, (size_t)P.max_blocks));
+    }
+    HIPCHK(h, hipMemset(P.ht_keys, 0xFF, ht * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(P.ht_slot, 0xFF, ht * sizeof(int)));
+    HIPCHK(h, hipMemset(P.log_odds, 0, NV * sizeof(float)));            // allocate_ram: log_odds 0
+    HIPCHK(h, hipMemset(P.occ, 'u', NV));                               //               occupancy 'u'
+    HIPCHK(h, hipMemset(P.infl, 'u', NV));                              //               inflate_occupancy 'u'
+    HIPCHK(h, hipMemset(P.vox_head, 0xFF, 2 * NV * sizeof(int)));
+    HIPCHK(h, hipMemset(P.vox_miss, 0, 2 * NV * sizeof(uint32_t)));
+    return MLM_OK;
+}
+void free_pool(mlm_handle *h, const MlmDev &P) {
+    const size_t NV = (size_t)P.max_blocks * P.cells, ht = (size_t)P.ht_mask + 1;
+    dev_free(h, P.ht_keys, ht * 8);
+    dev_free(h, P.ht_slot, ht * 4);
+    dev_free(h, P.block_keys, (size_t)P.max_blocks * 12);
+    dev_free(h, P.log_odds, NV * 4);
+    dev_free(h, P.occ, NV);
+    dev_free(h, P.infl, NV);
+    dev_free(h, P.vox_head, 2 * NV * 4);
+    dev_free(h, P.vox_miss, 2 * NV * 4);
+    if (P.explore) {
+        dev_free(h, P.frnt, NV);
+        dev_free(h, P.vox_tau, NV * 8);
+        dev_free(h, P.blk_collapsed, (size_t)P.max_blocks);
+        dev_free(h, P.blk_observed, (size_t)P.max_blocks);
+    }
+}
+// The reference's observed_group_map grows without bound (allocate_ram, map_local.h:215-231).  Here: a new table + pool of at
+// least `want` blocks, the blocks copied over, the table rebuilt on the device, every parameter block re-pointed.  Nothing
+// may be in flight (callers drain first).  MLM_ERR_CAPACITY only if the device cannot hold the larger pool.
+int grow_pool(mlm_handle *h, size_t want) {
+    MlmGlobal g{};
+    HIPCHK(h, hipMemcpy(&g, h->P.g, sizeof(g), hipMemcpyDeviceToHost));
+    const unsigned int nb = std::min<unsigned int>(g.n_blocks, (unsigned int)h->P.max_blocks);
+    const size_t cap = (size_t)(0x7FFFFFFFll / h->P.cells);
+    size_t target = std::max<size_t>(want, 2 * (size_t)h->P.max_blocks);
+    target = std::min(target, cap);
+    if (target <= (size_t)h->P.max_blocks) {
+        h->err = "block pool cannot grow further (2^31 voxels)";
+        return MLM_ERR_CAPACITY;
+    }
+    MlmDev N = h->P;
+    int rc = alloc_pool(h, N, (int)target);
+    if (rc) {
+        (void)hipGetLastError();
+        // (arrays allocated before the failure stay in `allocs` and are released by mlm_destroy)
+        h->err = "device memory exhausted while growing the block pool: " + h->err;
+        return MLM_ERR_CAPACITY;
+    }
+    const size_t C = (size_t)h->P.cells;
+    if (nb) {
+        hipStream_t st = h->stream;
+        HIPCHK(h, hipMemcpyAsync(N.block_keys, h->P.block_keys, (size_t)nb * 3 * sizeof(int), hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(N.log_odds, h->P.log_odds, nb * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(N.occ, h->P.occ, nb * C, hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(N.infl, h->P.infl, nb * C, hipMemcpyDeviceToDevice, st));
+        if (N.explore) {
+            HIPCHK(h, hipMemcpyAsync(N.frnt, h->P.frnt, nb * C, hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(N.blk_collapsed, h->P.blk_collapsed, nb, hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(N.blk_observed, h->P.blk_observed, nb, hipMemcpyDeviceToDevice, st));
+        }
+        hipLaunchKernelGGL(k_rehash_blocks, dim3(grid_for(nb)), dim3(MLM_BLOCK), 0, st, N, nb);
+        HIPCHK(h, hipGetLastError());
+    }
+    g.n_blocks = nb; // (allocations that failed had pushed the counter past the old capacity)
+    g.err &= ~1u;
+    HIPCHK(h, hipMemcpyAsync(h->P.g, &g, sizeof(g), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    free_pool(h, h->P);
+    copy_pool_fields(h->P, N);
+    *h->h_g = g;
+    for (int k = 0; k < MLM_SETS; ++k) *h->h_gb[k] = g;
+    std::vector<MlmDev> tab(h->slots.size());
+    for (size_t i = 0; i < h->slots.size(); ++i) {
+        copy_pool_fields(h->slots[i].P, N);
+        tab[i] = h->slots[i].P;
+    }
+    HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
+    if (h->lean && h->d_slot_tab_fb) {
+        for (size_t i = 0; i < tab.size(); ++i) {
+            tab[i].bnodes = h->fb_bnodes;
+            tab[i].pairs = h->fb_pairs;
+            tab[i].nodes = h->fb_nodes;
+        }
+        HIPCHK(h, hipMemcpy(h->d_slot_tab_fb, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
+    }
+    h->n_pool_grows++;
+    if (getenv("MLM_DEBUG_CREATE")) fprintf(stderr, "[pool] grown to %d blocks (%u in use)\n", h->P.max_blocks, nb);
+    return MLM_OK;
+}
+int drain(mlm_handle *h);
+// Paths that cannot replay a frame after the fact (the cell-table path's two map-dependent kernels, frontier mode, inflation,
+// imports) make sure beforehand that the pool can take what they may create at most.
+int ensure_free_blocks_idle(mlm_handle *h, size_t need) { // (nothing in flight on any stream)
+    if (!h->pool_grow) return MLM_OK;
+    HIPCHK(h, hipMemcpy(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost));
+    const size_t nb = std::min<size_t>(h->h_g->n_blocks, (size_t)h->P.max_blocks);
+    if (nb + need <= (size_t)h->P.max_blocks) return MLM_OK;
+    // (a bound beyond what a pool can ever hold — tiny voxels over a long range — is clamped: the pool then grows as far as it
+    // can and a frame that really needs more is reported as MLM_ERR_CAPACITY)
+    const size_t cap = (size_t)(0x7FFFFFFFll / h->P.cells);
+    const size_t want = std::min(cap, nb + 2 * need);
+    if (want <= (size_t)h->P.max_blocks) return MLM_OK;
+    return grow_pool(h, want);
+}
+int ensure_free_blocks(mlm_handle *h, size_t need) {
+    if (!h->pool_grow) return MLM_OK;
+    const size_t known = std::min<size_t>(h->h_g->n_blocks, (size_t)h->P.max_blocks);
+    if (known + need <= (size_t)h->P.max_blocks) return MLM_OK;
+    const int rc = drain(h);
+    if (rc) return rc;
+    return ensure_free_blocks_idle(h, need);
 }
 
 int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float> &sigma3) {
@@ -1476,43 +1705,22 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, &P.bkt64, 2 * h->max_buckets))) return rc;
     HIPCHK(h, hipMemset(P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long)));
 
-    // block table + pool (shared by all slots)
-    size_t ht = 1;
-    while (ht < (size_t)P.max_blocks * 4) ht <<= 1;
-    P.ht_mask = (uint32_t)(ht - 1);
-    const size_t NV = (size_t)P.max_blocks * P.cells;
-    if ((rc = dev_alloc(h, &P.ht_keys, ht))) return rc;
-    if ((rc = dev_alloc(h, &P.ht_slot, ht))) return rc;
-    if ((rc = dev_alloc(h, &P.block_keys, (size_t)P.max_blocks * 3))) return rc;
-    if ((rc = dev_alloc(h, &P.log_odds, NV))) return rc;
-    if ((rc = dev_alloc(h, &P.occ, NV))) return rc;
-    if ((rc = dev_alloc(h, &P.infl, NV))) return rc;
-    P.vox_stride = NV;
-    if ((rc = dev_alloc(h, &P.vox_head, 2 * NV))) return rc;
-    if ((rc = dev_alloc(h, &P.vox_miss, 2 * NV))) return rc;
+    // block table + pool (shared by all slots; grows on demand: grow_pool)
     if ((rc = dev_alloc(h, &P.g, 1))) return rc;
-    if (P.explore) {
-        if ((rc = dev_alloc(h, &P.frnt, NV))) return rc;
-        if ((rc = dev_alloc(h, &P.vox_tau, NV))) return rc;
-        if ((rc = dev_alloc(h, &P.blk_collapsed, (size_t)P.max_blocks))) return rc;
-        if ((rc = dev_alloc(h, &P.blk_observed, (size_t)P.max_blocks))) return rc;
-        if ((rc = dev_alloc(h, &P.bktm_first, h->max_buckets))) return rc;
-        HIPCHK(h, hipMemset(P.frnt, 0, NV));
-        HIPCHK(h, hipMemset(P.vox_tau, 0, NV * sizeof(unsigned long long)));
-        HIPCHK(h, hipMemset(P.blk_collapsed, 0, (size_t)P.max_blocks));
-        HIPCHK(h, hipMemset(P.blk_observed, 0, (size_t)P.max_blocks));
-    }
-    HIPCHK(h, hipMemset(P.ht_keys, 0xFF, ht * sizeof(unsigned long long)));
-    HIPCHK(h, hipMemset(P.ht_slot, 0xFF, ht * sizeof(int)));
-    HIPCHK(h, hipMemset(P.log_odds, 0, NV * sizeof(float)));            // allocate_ram: log_odds 0
-    HIPCHK(h, hipMemset(P.occ, 'u', NV));                               //               occupancy 'u'
-    HIPCHK(h, hipMemset(P.infl, 'u', NV));                              //               inflate_occupancy 'u'
-    HIPCHK(h, hipMemset(P.vox_head, 0xFF, 2 * NV * sizeof(int)));
-    HIPCHK(h, hipMemset(P.vox_miss, 0, 2 * NV * sizeof(uint32_t)));
+    if ((rc = alloc_pool(h, P, h->lim.max_blocks))) return rc;
+    if (P.explore && (rc = dev_alloc(h, &P.bktm_first, h->max_buckets))) return rc;
     {
         MlmGlobal g0{};
         g0.fail_frame = 0x7FFFFFFF;
         HIPCHK(h, hipMemcpy(P.g, &g0, sizeof(MlmGlobal), hipMemcpyHostToDevice));
+    }
+    {
+        // most blocks ONE frame can create: those that overlap the frame-local voxel grid (every cell of the awareness cylinder
+        // falls inside it, else the frame is redone / rejected)
+        auto nb = [&](int nv) { return (long long)(nv + P.n - 1) / P.n + 1; };
+        const long long b = nb(P.lv_nx) * nb(P.lv_ny) * nb(P.lv_nz);
+        h->frame_block_bound = (size_t)std::min<long long>(b, 1ll << 30);
+        if (const char *e = getenv("MLM_POOL_GROW")) h->pool_grow = atoi(e) != 0;
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
     std::memset(h->h_g, 0, sizeof(MlmGlobal));
@@ -1565,7 +1773,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             if ((rc = alloc_slot(h, h->slots[got], got, sigma3))) break;
         if (rc && h->use_sectors && !h->lean) {
             (void)hipGetLastError();
-            for (size_t a = mark; a < h->allocs.size(); ++a) hipFree(h->allocs[a]);
+            for (size_t a = mark; a < h->allocs.size(); ++a)
+                if (h->allocs[a]) hipFree(h->allocs[a]);
             h->allocs.resize(mark);
             h->alloc_bytes = h->map_bytes;
             for (auto &S : h->slots) // (the image staging buffers are not in `allocs`: ensure_img)
@@ -1582,7 +1791,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             // (keep the first two sets; give the partial third one back)
             size_t keep = mark;
             for (size_t i = 0; i < 2 * (size_t)h->lim.max_batch; ++i) keep = h->slots[i].alloc_end;
-            for (size_t a = keep; a < h->allocs.size(); ++a) hipFree(h->allocs[a]);
+            for (size_t a = keep; a < h->allocs.size(); ++a)
+                if (h->allocs[a]) hipFree(h->allocs[a]);
             h->allocs.resize(keep);
             for (size_t i = 2 * (size_t)h->lim.max_batch; i < NS; ++i)
                 if (h->slots[i].d_img) {
@@ -1606,15 +1816,13 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), NS * sizeof(MlmDev), hipMemcpyHostToDevice));
         if (h->lean) {
             const MlmDev &P0 = h->slots[0].P;
-            MlmNode *fb_bnodes, *fb_nodes;
-            MlmPair *fb_pairs;
-            if ((rc = dev_alloc(h, &fb_bnodes, (size_t)P0.nb_cap * P0.node_lds))) return rc;
-            if ((rc = dev_alloc(h, &fb_pairs, (size_t)P0.nb_cap * P0.agg_lds))) return rc;
-            if ((rc = dev_alloc(h, &fb_nodes, (size_t)MLM_RAY_LISTS * P0.node_cap))) return rc;
+            if ((rc = dev_alloc(h, &h->fb_bnodes, (size_t)P0.nb_cap * P0.node_lds))) return rc;
+            if ((rc = dev_alloc(h, &h->fb_pairs, (size_t)P0.nb_cap * P0.agg_lds))) return rc;
+            if ((rc = dev_alloc(h, &h->fb_nodes, (size_t)MLM_RAY_LISTS * P0.node_cap))) return rc;
             for (size_t i = 0; i < NS; ++i) {
-                tab[i].bnodes = fb_bnodes;
-                tab[i].pairs = fb_pairs;
-                tab[i].nodes = fb_nodes;
+                tab[i].bnodes = h->fb_bnodes;
+                tab[i].pairs = h->fb_pairs;
+                tab[i].nodes = h->fb_nodes;
             }
             if ((rc = dev_alloc(h, &h->d_slot_tab_fb, NS))) return rc;
             HIPCHK(h, hipMemcpy(h->d_slot_tab_fb, tab.data(), NS * sizeof(MlmDev), hipMemcpyHostToDevice));
@@ -1638,7 +1846,8 @@ int mlm_destroy(mlm_handle *h) {
     }
     hipSetDevice(h->device);
     hipDeviceSynchronize();
-    for (void *p : h->allocs) hipFree(p);
+    for (void *p : h->allocs)
+        if (p) hipFree(p);
     for (auto &S : h->slots)
         if (S.d_img) hipFree(S.d_img);
     if (h->h_ctr_all) hipHostFree(h->h_ctr_all);
@@ -1973,6 +2182,8 @@ int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
     }
     int rc = drain(h);
     if (rc) return rc;
+    rc = ensure_free_blocks_idle(h, (size_t)(2 * G + 3) * (2 * G + 3) * (2 * G + 3)); // (neighbour blocks are allocated: inflate_atpos)
+    if (rc) return rc;
     // get_global_idx(ct_pos) (mlmap.cpp:289, map_local.h:148-152)
     const int cgx = (int)std::floor(ct_pos[0] / h->P.d_glb), cgy = (int)std::floor(ct_pos[1] / h->P.d_glb),
               cgz = (int)std::floor(ct_pos[2] / h->P.d_glb);
@@ -2116,6 +2327,8 @@ int mlm_import_blocks(mlm_handle *h, int n, const int32_t *keys, const float *lo
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);
     if (rc || n == 0) return rc;
+    rc = ensure_free_blocks_idle(h, (size_t)n);
+    if (rc) return rc;
     const size_t C = (size_t)h->P.cells, N = (size_t)n;
     // one staging buffer: keys | slots | log_odds | occ | infl | collapsed (sources may be host or device memory)
     const size_t o_keys = 0, o_slots = o_keys + N * 12, o_lo = (o_slots + N * 4 + 15) & ~(size_t)15, o_occ = o_lo + N * C * 4,
