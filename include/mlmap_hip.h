@@ -113,6 +113,8 @@ typedef struct mlm_frame_stats {
                                  * 0: unknown libm, increments are FP64 log10 rounded once (last-place differences possible) */
     int64_t n_pool_grows;       /* times the block pool has grown so far (allocate_ram never refuses: map_local.h:215-231) */
     int64_t block_capacity;     /* blocks the pool holds now */
+    int64_t n_graph_launches;   /* single frames so far submitted as one HIP-graph replay (synchronous mode: the reference's one frame
+                                 * per depth callback, src/mlmap.cpp:463-507) */
 } mlm_frame_stats;
 
 /* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */

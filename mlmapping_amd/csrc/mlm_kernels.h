@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
             const int pix = (MODE == 1) ? mlm_gp(F.pix)[i] : i;
             const int v = pix / F.width;
             const int u = pix - v * F.width;
-            const uint16_t raw = mlm_gp(F.img)[(size_t)v * F.row_stride + u];
+            const uint16_t raw = (MODE == 1 && F.raw) ? (uint16_t)mlm_gp(F.raw)[i] : mlm_gp(F.img)[(size_t)v * F.row_stride + u];
             if (raw == 0) { // mlmap.cpp:338-341
                 have = false;
             } else {

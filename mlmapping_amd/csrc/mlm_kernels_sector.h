@@ -12,25 +12,27 @@
 //                   table, the column's miss bit mask in LDS (rays walked by an integer DDA), the unique-hit list
 //                   (cells that received ONE kind of contribution, or enough strong ones, get their odd right away), and
 //                   for every other cell the list of (record, kind) references.  Which world voxel a cell falls into is
-//                   geometry that separates by axis inside a column (tables per rho and per z; only the block's pool
-//                   slot needs the map): every unique hit takes a number on its voxel and a slot of the voxel's hit
-//                   list, every unique miss cell is counted on its voxel, in a FRAME-LOCAL voxel grid; first touches
-//                   queue the voxel.  Global atomics: list reservations per workgroup, one hit number + one bucket-min
-//                   per hit, one count per miss cell, one queue reservation per wave and round.
+//                   geometry that separates by axis inside a column (tables per rho and per z); the frame-local voxel grid
+//                   is cut into tiles, a column crosses a tile once, so the column's hits and miss cells — ordered by rho —
+//                   leave as one coalesced stream of voxel-in-tile indices plus ONE descriptor per tile it crosses.
+//                   Global atomics: list reservations per workgroup, one bucket-min per hit, one descriptor per tile run.
 //   k_rank          iteration-order keys of the frame's hits; one wave per multi-kind cell whose float chain depends on the
 //                   order: rank its contributions by pixel (bitmap ranking fed with the records' 8x8 lane masks) and
 //                   store the kinds in that order.
 //   k_chain_lanes   replays the float noisy-OR chains, one cell per lane, lanes drawing cells dynamically.
-//   k_apply_frame   the part that needs the map, ONE launch per frame: one queued voxel per lane — block lookup /
-//                   creation, a gather of the voxel's hits, applied in the reference's iteration order, its misses, store.
+//   k_tile          one workgroup per tile of the frame-local voxel grid: counts the tile's miss cells and hits per voxel in
+//                   LDS and writes ONE 32-byte record per touched voxel (block key, cell id, counts, the increment of a
+//                   single hit, the block's pool slot if it exists); the hits of voxels with several go next to each other.
+//   k_apply_frame   the part that needs the map, ONE launch per frame: one voxel record per lane — block creation if
+//                   needed, the voxel's hits in the reference's iteration order, its misses, store.  Two round trips.
 //
 // Frontier mode (use_exploration_frontiers) uses k_bin_sectors, k_sector<true>, k_rank and k_chain_lanes and continues with its
 // own map-dependent part (mlm_kernels_explore.h): there the miss container's iteration order matters as well, so the
 // column keeps the first insertion time of every miss cell in LDS instead of a bit.
 //
-// Compared with the cell-table path this removes every per-cell and per-miss-word device-scope atomic (they are executed
-// at the memory side, ~34 G/s for the whole chip), the 8 global copies of the miss mask and their scan, and the
-// scattered insertion-time stores (0.9 M per VGA frame).
+// Compared with the cell-table path this removes every per-cell, per-miss-word and per-voxel device-scope atomic (they are
+// executed at the memory side, ~34 G/s for the whole chip, and their latency is what a column's workgroup used to wait
+// for), the 8 global copies of the miss mask and their scan, and the scattered insertion-time stores (0.9 M per VGA frame).
 #pragma once
 #include "mlm_kernels.h"
 
@@ -38,7 +40,6 @@
 #define MLM_SEC_WAVES (MLM_SEC_THREADS / 64)
 #define MLM_SEC_COLS 64     // distinct columns one k_bin_sectors block can feed (more: the frame falls back)
 #define MLM_SEC_CHUNKS 256  // chunk descriptors staged per pass of k_sector (a column of a VGA frame has ~50)
-#define MLM_SEC_COMBOS 512  // most blocks one column may reach (MlmDev::sec_combos; = MLM_SEC_THREADS: one lookup per thread)
 #define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
 #define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
             const int pix = (MODE == 1) ? mlm_gp(F.pix)[i] : i;
             const int v = pix / F.width;
             const int u = pix - v * F.width;
-            const uint16_t raw = mlm_gp(F.img)[(size_t)v * F.row_stride + u];
+            const uint16_t raw = (MODE == 1 && F.raw) ? (uint16_t)mlm_gp(F.raw)[i] : mlm_gp(F.img)[(size_t)v * F.row_stride + u];
             if (raw == 0) { // mlmap.cpp:338-341
                 have = false;
             } else {
@@ -253,8 +254,9 @@ __device__ __forceinline__ int mlm_sec_entry(MlmSecCell *tab, uint32_t tab_mask,
     return -1;
 }
 
-// exclusive prefix sums over the workgroup of four values per thread at once (one pair of barriers); v[] is replaced by
-// this thread's offsets, total[] gets the sums.  s_w needs 4 * MLM_SEC_WAVES words.
+// exclusive prefix sums over a workgroup of NW waves of four values per thread at once (one pair of barriers); v[] is
+// replaced by this thread's offsets, total[] gets the sums.  s_w needs 4 * NW words.
+template <int NW = MLM_SEC_WAVES>
 __device__ __forceinline__ void mlm_block_excl_scan4(uint32_t (&v)[4], uint32_t *s_w, uint32_t (&total)[4]) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t incl[4];
@@ -270,7 +272,7 @@ __device__ __forceinline__ void mlm_block_excl_scan4(uint32_t (&v)[4], uint32_t 
     for (int k = 0; k < 4; ++k) {
         uint32_t off = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < MLM_SEC_WAVES; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const uint32_t t = s_w[4 * w + k];
             if (w < wid) off += t;
             tot += t;
@@ -301,45 +303,19 @@ __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int ph
     }
 }
 
-// The lanes of the calling wave whose item was the first on its voxel this frame (`first`) queue that voxel: they get
-// consecutive entries of sub-list `sl` of the frame's voxel queue from one returning atomic per wave — the queue holds
-// first-touched voxels only (a third of the hit + miss cells of a VGA frame).  Call with all the wave's active lanes.
-// spec_slot: the block's pool slot if the block existed when the column looked its blocks up, else -1 (k_apply_frame
-// resolves it).
-__device__ __forceinline__ void mlm_queue_firsts(const MlmDev &P, unsigned int sl, bool first, int lv, int gx, int gy, int gz, int cid, uint32_t kind,
-                                                 int spec_slot) {
-    const unsigned long long m = __ballot(first);
-    if (!m) return;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[sl][0], (uint32_t)__popcll(m));
-    base = (uint32_t)mlm_readlane((int)base, leader);
-    if (first) {
-        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (at < P.tv_cap) { // (more: the frame is reported as a queue overflow, check_queues)
-            const size_t i = (size_t)sl * P.tv_cap + at;
-            *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tv_rec) + 4 * i) = mlm_u32x4{(uint32_t)lv, (uint32_t)cid, (uint32_t)spec_slot, kind};
-            mlm_gp(P.tv_key)[i] = mlm_pack_key(gx, gy, gz);
-        }
-    }
-}
-
 // LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
-    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, vox, vrep, bslot, total;
+    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, vox, aux, total;
 };
 // n_miss: words of the column's miss table (bit mask: nZ * RW; frontier mode keeps insertion times: nZ * nRho)
-// n_combos: (rho run, z run) blocks the column may reach (MlmDev::sec_combos)
-__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, uint32_t n_z, uint32_t n_combos, bool explore) {
+__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, uint32_t n_z, bool explore) {
     MlmSecLds L;
     uint32_t o = 0;
     L.tab = o;      o += TAB * (uint32_t)sizeof(MlmSecCell);
     {
-        // staged chunk descriptors of the record passes; later the list of occupied table entries (L.occ), then the prefix of
-        // the miss mask's words
+        // staged chunk descriptors of the record passes; later the list of occupied table entries (L.occ)
         uint32_t b = 2u * MLM_SEC_CHUNKS * 4u;
         if (b < TAB * 2u) b = TAB * 2u;
-        if (!explore && b < n_miss * 4u) b = n_miss * 4u;
         L.chunk = o;
         o += (b + 15u) & ~15u;
     }
@@ -351,11 +327,10 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
                                                          // staging, idle between the first record pass and the second
     L.multi = o;    o += TAB * 2u;                       // ... those that received several kinds
     L.ray_p0 = o;   if (explore) o += TAB * 4u;          // frontier mode: first point of every ray start
-    o = (o + 7u) & ~7u;
     o = (o + 15u) & ~15u;
-    L.vox = o;      o += (n_rho + n_z) * 16u;            // world voxel per axis (block index, cell coordinate, block run): x, y by rho; z by z
-    L.vrep = o;     o += ((n_rho + n_z + 1u) & ~1u) * 2u; // first rho / z of every block run
-    L.bslot = o;    o += n_combos * 4u;                  // speculative pool slot of every (rho run, z run) block of the column
+    L.vox = o;      o += (n_rho + n_z) * 16u;            // world voxel per axis: x, y by rho; z by z (see k_sector)
+    L.aux = o;      o += n_rho * 24u;                    // per tile run along rho: tile, first rho, hits (count, offset); per rho: miss cells
+                                                         // (count -> fill cursor, offset)
     L.total = (o + 15u) & ~15u;
     return L;
 }
@@ -394,7 +369,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t TAB = P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
-    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, P.sec_combos, EX);
+    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, EX);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
     float *s_odds = (float *)(s_dyn + L.odds);
@@ -406,9 +381,11 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
     uint32_t *s_ray_p0 = (uint32_t *)(s_dyn + L.ray_p0); // (EX only)
     int4 *s_vr = (int4 *)(s_dyn + L.vox), *s_vz = s_vr + P.nRho;
-    uint16_t *s_rrep = (uint16_t *)(s_dyn + L.vrep), *s_zrep = s_rrep + P.nRho;
-    int *s_bslot = (int *)(s_dyn + L.bslot);
-    __shared__ int s_kr, s_kz;
+    // per tile run r along rho: its tile, its first rho, its hits (count, then offset in the column's hit list);
+    // per rho: its unique miss cells (count, then fill cursor) and their offset in the column's miss list
+    uint32_t *s_run_tile = (uint32_t *)(s_dyn + L.aux), *s_run_rho = s_run_tile + P.nRho, *s_run_hits = s_run_rho + P.nRho,
+             *s_run_off = s_run_hits + P.nRho, *s_rho_miss = s_run_off + P.nRho, *s_rho_off = s_rho_miss + P.nRho;
+    __shared__ int s_kr;
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter;
@@ -422,13 +399,24 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     for (uint32_t e = threadIdx.x; e < NMISS; e += MLM_SEC_THREADS) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
     for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_odds[e] = mlm_gp(P.odds_table)[e];
-    for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_sigma[e] = mlm_gp(P.sigma3)[e];
+    for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) {
+        s_sigma[e] = mlm_gp(P.sigma3)[e];
+        s_run_hits[e] = 0;
+        s_rho_miss[e] = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
+        s_nouter = 0;
+    }
+    __syncthreads();
     // Which world voxel a cell of this column falls into (get_global_idx / get_subbox_id of its centre moved by T_wa,
     // map_local.cpp:151,180) separates by axis: x and y depend on rho only (phi is the column's), z on z only.  One
-    // evaluation of the FP64 sequences per rho and per z instead of one per hit and miss cell:
-    //   s_vr[rho] = {gx, gy, cx | cy << 8 | out-of-range << 16, run of equal (gx, gy) along rho}
-    //   s_vz[z]   = {gz, cz | out-of-range << 16, run of equal gz along z, -}
-    // and the blocks the column can reach are the (rho run, z run) pairs: their pool slots are looked up once per column.
+    // evaluation of the FP64 sequences per rho and per z instead of one per hit and miss cell.
+    //   frontier mode:  s_vr[rho] = {gx, gy, cx | cy << 8 | out-of-range << 16, -},  s_vz[z] = {gz, cz | out-of-range << 16, -, -}
+    //   default:        s_vr[rho] = {tile of the frame-local grid, in-tile (y, x) bits, -, tile run},  s_vz[z] = {grid z, -, -, -}
+    //                   (a voxel-in-tile index is vt = s_vr[rho].y * lv_nz + s_vz[z].x).  A coordinate the reference's two
+    //                   independent divisions put outside [0, n) (the id-0 quirk of get_subbox_id, map_local.h:170) cannot be
+    //                   expressed per axis: such a column — one in ~1e13 evaluations — sends its frame to the cell-table path.
     for (uint32_t e = threadIdx.x; e < (uint32_t)(P.nRho + P.nZ); e += MLM_SEC_THREADS) {
         double wx, wy, wz;
         if (e < (uint32_t)P.nRho) {
@@ -437,43 +425,51 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             mlm_voxel_axis(P, wx, gx, cx);
             mlm_voxel_axis(P, wy, gy, cy);
             const bool bad = cx < 0 || cy < 0 || cx >= P.n || cy >= P.n;
-            s_vr[e] = make_int4(gx, gy, bad ? 0x10000 : (cx | cy << 8), 0);
+            if (EX) {
+                s_vr[e] = make_int4(gx, gy, bad ? 0x10000 : (cx | cy << 8), 0);
+            } else {
+                const int x = gx * P.n + cx - F.lv_o[0], y = gy * P.n + cy - F.lv_o[1], m = (1 << P.tile_sh) - 1;
+                if (bad || (unsigned)x >= (unsigned)P.lv_nx || (unsigned)y >= (unsigned)P.lv_ny) s_fail = 1;
+                s_vr[e] = make_int4((y >> P.tile_sh) * P.n_tx + (x >> P.tile_sh), ((y & m) << P.tile_sh) | (x & m), 0, 0);
+            }
         } else {
             const int z = (int)e - P.nRho;
             mlm_cell_center_w(P, F.t_wa, 0, phi, z, wx, wy, wz);
             int gz, cz;
             mlm_voxel_axis(P, wz, gz, cz);
             const bool bad = cz < 0 || cz >= P.n;
-            s_vz[z] = make_int4(gz, bad ? 0x10000 : cz, 0, 0);
+            if (EX) {
+                s_vz[z] = make_int4(gz, bad ? 0x10000 : cz, 0, 0);
+            } else {
+                const int zz = gz * P.n + cz - F.lv_o[2];
+                if (bad || (unsigned)zz >= (unsigned)P.lv_nz) s_fail = 1;
+                s_vz[z] = make_int4(zz, 0, 0, 0);
+            }
         }
     }
     __syncthreads();
-    if (wid < 2) { // wave 0: runs along rho, wave 1: runs along z (ballot scan over the change flags)
-        const int n_ax = wid == 0 ? P.nRho : P.nZ;
+    if (!EX && wid == 0) { // runs of equal tile along rho (a ray crosses a tile once): ballot scan over the change flags
         int carry = 0;
-        for (int i0 = 0; i0 < n_ax; i0 += 64) {
+        for (int i0 = 0; i0 < P.nRho; i0 += 64) {
             const int i = i0 + lane;
-            bool change = false;
-            if (i < n_ax) {
-                if (wid == 0) change = i == 0 || s_vr[i].x != s_vr[i - 1].x || s_vr[i].y != s_vr[i - 1].y;
-                else change = i == 0 || s_vz[i].x != s_vz[i - 1].x;
-            }
+            const bool change = i < P.nRho && (i == 0 || s_vr[i].x != s_vr[i - 1].x);
             const unsigned long long m = __ballot(change);
             const int id = carry + (int)__popcll(m & ((2ull << lane) - 1ull)) - 1;
-            if (i < n_ax) {
-                if (wid == 0) s_vr[i].w = id;
-                else s_vz[i].z = id;
-                if (change) (wid == 0 ? s_rrep : s_zrep)[id] = (uint16_t)i;
+            if (i < P.nRho) {
+                s_vr[i].w = id;
+                if (change) {
+                    s_run_tile[id] = (uint32_t)s_vr[i].x;
+                    s_run_rho[id] = (uint32_t)i;
+                }
             }
             carry += (int)__popcll(m);
         }
-        if (lane == 0) (wid == 0 ? s_kr : s_kz) = carry;
+        if (lane == 0) s_kr = carry;
     }
     __syncthreads();
-    const int n_zrun = s_kz, n_combo = s_kr * n_zrun;
-    // world voxel of cell (rho, z) of this column — what mlm_voxel_of(mlm_cell_center_w(...)) gives — as block indices, cell id,
-    // index in the frame-local grid (-1: outside) and the block's speculative pool slot (-1: not known)
-    auto cell_voxel = [&](int rho, int z, int &gx, int &gy, int &gz, int &cid, int &lv, int &spec) {
+    const int n_run = EX ? 0 : s_kr;
+    // frontier mode: world voxel of cell (rho, z) of this column — what mlm_voxel_of(mlm_cell_center_w(...)) gives
+    auto cell_voxel = [&](int rho, int z, int &gx, int &gy, int &gz, int &cid) {
         const int4 vr = s_vr[rho], vz = s_vz[z];
         gx = vr.x;
         gy = vr.y;
@@ -481,18 +477,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
         int cx = vr.z & 0xFF, cy = (vr.z >> 8) & 0xFF, cz = vz.y & 0xFF;
         if ((vr.z | vz.y) >> 16) cx = cy = cz = 0; // a coordinate outside [0, n): id 0 (mlm_voxel_of)
         cid = cz * P.n * P.n + cy * P.n + cx;
-        spec = P.sec_probe ? s_bslot[vr.w * n_zrun + vz.z] : -1;
-        if (EX) {
-            lv = 0;
-        } else {
-            const int x = gx * P.n + cx - F.lv_o[0], y = gy * P.n + cy - F.lv_o[1], zz = gz * P.n + cz - F.lv_o[2];
-            lv = ((unsigned)x >= (unsigned)P.lv_nx || (unsigned)y >= (unsigned)P.lv_ny || (unsigned)zz >= (unsigned)P.lv_nz) ? -1 : (zz * P.lv_ny + y) * P.lv_nx + x;
-        }
     };
-    if (threadIdx.x == 0) {
-        s_fail = (nch_all > P.chunk_cap || n_combo > (int)P.sec_combos || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
-        s_nouter = 0;
-    }
     MLM_PHASE_BEGIN
     const uint32_t tab_mask = TAB - 1;
     const MLM_GLOBAL uint32_t *chunks = mlm_gp(P.col_chunks) + 2 * (size_t)phi * P.chunk_cap;
@@ -620,10 +605,15 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     MLM_PHASE(1);
     // ---- lists of the occupied entries (= the column's unique hits), of those with several kinds, of the ray starts;
     //      the column's reservations in the frame's lists (one round trip)
-    const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread
-    uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, multi, ray starts, -
+    //      The hit list is ordered by tile run (the hits of one tile are contiguous): rank inside the run from a returning
+    //      LDS atomic, the runs' offsets from the same block scan that places the other lists.
+    const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread (per <= 4)
+    uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, multi, ray starts, hits of tile run `threadIdx.x`
     uint32_t w_refs = 0, w_subs = 0;  // references / ordered-kinds slots of this thread's multi-kind cells
-    for (uint32_t q = 0; q < per; ++q) {
+    uint32_t hk[4] = {0u, 0u, 0u, 0u}, hrun[4] = {0u, 0u, 0u, 0u}; // this thread's entries: tile run, rank among the run's hits
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        if (q >= per) break;
         const MlmSecCell &c = s_tab[threadIdx.x * per + q];
         if (c.key == MLM_NIL) continue;
         ++v[0];
@@ -633,21 +623,31 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             w_refs += c.gcnt;
             w_subs += ((c.cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
         }
+        int rho, z;
+        key_rz(c.key, rho, z);
+        hrun[q] = EX ? 0u : (uint32_t)s_vr[rho].w;
+        hk[q] = atomicAdd(&s_run_hits[hrun[q]], 1u);
     }
     for (int off = 32; off > 0; off >>= 1) {
         w_refs += __shfl_xor(w_refs, off, 64);
         w_subs += __shfl_xor(w_subs, off, 64);
     }
     if (threadIdx.x < 2) s_base[4 + threadIdx.x] = 0;
+    __syncthreads(); // (the runs' hit counts are complete)
+    if ((int)threadIdx.x < (EX ? 1 : n_run)) v[3] = s_run_hits[threadIdx.x]; // (n_run <= nRho <= MLM_SEC_THREADS)
     uint32_t tot[4];
     mlm_block_excl_scan4(v, s_w, tot); // (its first barrier also orders the zeroing above)
+    if ((int)threadIdx.x < (EX ? 1 : n_run)) s_run_off[threadIdx.x] = v[3];
     if (lane == 0) {
         if (w_refs) atomicAdd(&s_base[4], w_refs);
         if (w_subs) atomicAdd(&s_base[5], w_subs);
     }
+    __syncthreads(); // (the runs' offsets are visible)
     {
-        uint32_t o_occ = v[0], o_multi = v[1], o_rays = v[2];
-        for (uint32_t q = 0; q < per; ++q) {
+        uint32_t o_multi = v[1], o_rays = v[2];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (q >= per) break;
             const uint32_t e = threadIdx.x * per + q;
             MlmSecCell &c = s_tab[e];
             if (c.key == MLM_NIL) continue;
@@ -655,11 +655,12 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
                 if (EX) s_ray_p0[o_rays] = c.gpos;
                 s_rays[o_rays++] = (uint16_t)e;
             }
+            const uint32_t place = s_run_off[hrun[q]] + hk[q];
             if (mlm_sec_needs_order(c)) {
                 s_multi[o_multi++] = (uint16_t)e;
-                c.gpos = o_occ; // (its place in the hit list, until the reference cursor replaces it below)
+                c.gpos = place; // (its place in the hit list, until the reference cursor replaces it below)
             }
-            s_occ[o_occ++] = (uint16_t)e;
+            s_occ[place] = (uint16_t)e;
         }
     }
     __syncthreads();
@@ -719,14 +720,6 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     //      z - .. rounded, round half away) says which way it goes (those steps are collected and evaluated afterwards);
     //      everywhere else that sequence is at most ~1e-12 away from the exact value, which is at least 1 / (2 rho) away
     //      from the next half-integer.  Consecutive steps that fall into one word of the mask are merged in a register.
-    // (the pool slots of the column's blocks, one per thread, are fetched while the rays are walked: nothing below touches
-    // global memory until the hit list)
-    int my_bslot = -1;
-    if (P.sec_probe && (int)threadIdx.x < n_combo && threadIdx.x < P.sec_combos) {
-        const int r = (int)threadIdx.x / n_zrun, zr = (int)threadIdx.x - r * n_zrun;
-        const int4 vr = s_vr[s_rrep[r]];
-        my_bslot = mlm_block_find(P, vr.x, vr.y, s_vz[s_zrep[zr]].x);
-    }
     for (uint32_t i0 = 0; i0 < 4u * n_rays; i0 += MLM_SEC_THREADS) {
         const uint32_t it = i0 + threadIdx.x;
         int rho = 0, z = 0;
@@ -799,17 +792,12 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
-    if (threadIdx.x < P.sec_combos) s_bslot[threadIdx.x] = my_bslot;
     __syncthreads(); // (the miss mask is complete)
     MLM_PHASE(3);
-    // ---- the column's unique hits: cell, first-touch time, world voxel + speculative block slot; single-kind cells get
+    // ---- the column's unique hits (ordered by tile run): cell, first-touch time, voxel-in-tile index; single-kind cells get
     //      their odd and increment here (multi-kind cells: k_rank / k_chain_lanes)
     const unsigned int sl = blockIdx.x & 7;
-    for (uint32_t i0 = 0; i0 < n_occ; i0 += MLM_SEC_THREADS) { // (uniform)
-        const uint32_t i = i0 + threadIdx.x;
-        bool first = false;
-        int lv = -1, h_cid = 0, h_spec = -1, gx = 0, gy = 0, gz = 0;
-        if (i < n_occ) {
+    for (uint32_t i = threadIdx.x; i < n_occ; i += MLM_SEC_THREADS) {
         const MlmSecCell c = s_tab[s_occ[i]];
         int rho, z;
         key_rz(c.key, rho, z);
@@ -827,45 +815,25 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
             mlm_gp(P.hl_cnt)[pos] = 0;
         }
-        // its world voxel: pushed on the voxel's pending list in the frame-local grid (grouping by voxel needs no map);
-        // the first hit of a voxel queues it for the kernel that applies the frame.  Bucket-first time of the emulated
-        // container (iteration order, see Stage B in mlm_kernels.h) for the bucket count the frame was submitted with.
-        int cid;
-        cell_voxel(rho, z, gx, gy, gz, cid, lv, h_spec);
-        if (EX) { // frontier mode: the hit's world voxel + speculative block slot, as k_prepare_voxels leaves them
+        if (EX) { // frontier mode: the hit's world voxel (its kernels look the block up themselves)
+            int gx, gy, gz, cid;
+            cell_voxel(rho, z, gx, gy, gz, cid);
             mlm_gp(P.hl_bkey)[pos] = mlm_pack_key(gx, gy, gz);
             mlm_gp(P.hl_cid)[pos] = (uint32_t)cid;
-            mlm_gp(P.hl_slot)[pos] = h_spec;
+            mlm_gp(P.hl_slot)[pos] = -1;
             continue;
         }
-        if (lv >= 0) {
-            const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
-            mlm_gp(P.hl_bkt)[pos] = (uint32_t)b;
-            if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
-            // hit number k of its voxel: the first ones into the voxel's slots, the rest on a list headed by the last slot
-            const uint32_t k = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv), 1u);
-            MLM_GLOBAL uint32_t *hs = mlm_gp(P.lv_hits) + (size_t)lv * MLM_LV_SLOTS;
-            if (k < MLM_LV_SLOTS - 1u) {
-                hs[k] = pos;
-            } else {
-                const uint32_t prev = __hip_atomic_exchange(hs + (MLM_LV_SLOTS - 1), pos + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mlm_gp(P.hl_next)[pos] = (int)prev - 1;
-            }
-            first = k == 0u;
-            h_cid = cid;
-        } else {
-            s_fail = 1;
-        }
-        }
-        if (!EX) mlm_queue_firsts(P, sl, first, lv, gx, gy, gz, h_cid, 0u, h_spec);
+        // its voxel (k_tile groups the frame's hits and misses by voxel, tile by tile) and the bucket-first time of the
+        // emulated container (iteration order, see Stage B in mlm_kernels.h) for the bucket count the frame was submitted with
+        mlm_gp(P.hl_vt16)[pos] = (uint16_t)(s_vr[rho].y * P.lv_nz + s_vz[z].x);
+        const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
+        mlm_gp(P.hl_bkt)[pos] = (uint32_t)b;
+        if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
     }
     MLM_PHASE(4);
     // ---- references of the multi-kind cells (their fill cursors were set above)
     if (n_multi) for_records(1);
     MLM_PHASE(5);
-    // ---- the column's unique miss cells (its bit mask): each counts one miss on its world voxel in the frame-local grid
-    //      (every miss adds the same constant, map_local.cpp:188-192: only the count per voxel matters); the first miss of
-    //      a voxel queues it for the kernel that applies the frame
     if (EX) {
         // frontier mode: the unique miss list with insertion times and world voxels (what k_ex_collect_misses leaves);
         // a thread's cells take consecutive places
@@ -886,8 +854,8 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             if (t == MLM_EMPTY_T) continue;
             int rho, z;
             key_rz(w, rho, z);
-            int gx, gy, gz, m_cid, lv_unused, spec_unused;
-            cell_voxel(rho, z, gx, gy, gz, m_cid, lv_unused, spec_unused);
+            int gx, gy, gz, m_cid;
+            cell_voxel(rho, z, gx, gy, gz, m_cid);
             mlm_gp(P.ex_cell)[at] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
             mlm_gp(P.ex_t)[at] = t;
             mlm_gp(P.ex_vt)[at] = t;
@@ -896,64 +864,77 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
             ++at;
         }
     } else {
-        // exclusive prefix of the mask words' popcounts (in the idle chunk-staging area): the column's miss cells, and where
-        // each word's cells go in the list below
-        uint32_t *s_off = s_chunk_first; // [NMISS] (the staging area is sized for it, mlm_sec_lds)
+        // ---- the column's unique miss cells (its bit mask) leave as voxel-in-tile indices, ordered by rho and therefore by
+        //      tile run: every miss adds the same constant (map_local.cpp:188-192), only the count per voxel matters, and
+        //      k_tile counts.  Miss cells per rho (LDS atomics), their offsets (one block scan), the list in LDS (the cell
+        //      table's space is idle by now), one coalesced copy; then ONE descriptor per tile run — {first miss cell, count,
+        //      first hit, count} — handed to the tile with a returning atomic: the only per-tile global atomic of the column.
+        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) {
+            uint32_t bits = s_miss[w];
+            const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u;
+            while (bits) {
+                atomicAdd(&s_rho_miss[rho0 + (uint32_t)__ffs((int)bits) - 1u], 1u);
+                bits &= bits - 1;
+            }
+        }
+        __syncthreads();
         uint32_t total = 0;
-        for (uint32_t w0 = 0; w0 < NMISS; w0 += MLM_SEC_THREADS) {
-            const uint32_t w = w0 + threadIdx.x;
-            uint32_t tot_w;
-            const uint32_t off = mlm_block_excl_scan(w < NMISS ? (uint32_t)__popc(s_miss[w]) : 0u, s_w, &tot_w);
-            if (w < NMISS) s_off[w] = total + off;
-            total += tot_w;
+        {
+            const uint32_t c = (int)threadIdx.x < P.nRho ? s_rho_miss[threadIdx.x] : 0u; // (nRho <= MLM_SEC_THREADS on this path)
+            const uint32_t off = mlm_block_excl_scan(c, s_w, &total);
+            if ((int)threadIdx.x < P.nRho) {
+                s_rho_off[threadIdx.x] = off;
+                s_rho_miss[threadIdx.x] = 0; // (now the fill cursor)
+            }
         }
         if (threadIdx.x == 0) {
-            if (total) g_atomic_add(&mlm_gp(P.ctr)->umiss_part[sl][0], total);
+            // (the returned base is the column's place in the frame's miss list; the counter's final value = unique miss cells)
+            s_base[6] = total ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[3][0], total) : 0u;
             s_base[7] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
             // device-scope atomics on account of this column: its chunk descriptors (k_bin_sectors), the list reservations
-            // above and here (up to 8, this one included), a bucket-min and a hit number per hit, a count per miss cell, a
-            // queue reservation per wave and round of the hit list and of the miss cells
-            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][1], nch_all + 8u + 2u * n_occ + total + (n_occ + 63u) / 64u + (total + 63u) / 64u);
+            // above and here (up to 8, this one included), a bucket-min per hit, a descriptor per tile run
+            g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][1], nch_all + 8u + n_occ + (uint32_t)n_run);
             mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
         }
         __syncthreads();
-        if (total) {
-            // One miss cell per thread, so that the voxel atomics of all the column's miss cells are in flight together.
-            // The cells are listed first (column-local keys z * nRho + rho, in the cell table's space, which is idle by now):
-            // a thread takes a byte of a mask word and writes its set bits at off[word] + bits below.
-            uint16_t *s_cells = (uint16_t *)s_tab; // [total] (NMISS * 64 bytes <= the table's, checked by the host)
-            for (uint32_t q0 = 0; q0 < 4u * NMISS; q0 += MLM_SEC_THREADS) {
-                const uint32_t q = q0 + threadIdx.x, w = q >> 2, sh = (q & 3u) * 8u;
-                if (w >= NMISS) break;
-                const uint32_t bits = s_miss[w];
-                uint32_t byte = (bits >> sh) & 0xFFu;
-                if (!byte) continue;
-                const uint32_t z = w / (uint32_t)P.RW;
-                const uint32_t key0 = z * (uint32_t)P.nRho + (w - z * (uint32_t)P.RW) * 32u + sh;
-                uint32_t at = s_off[w] + (uint32_t)__popc(bits & ((1u << sh) - 1u));
-                while (byte) {
-                    s_cells[at++] = (uint16_t)(key0 + (uint32_t)__ffs((int)byte) - 1u);
-                    byte &= byte - 1;
+        const uint32_t m_base = s_base[6];
+        if (m_base + total > P.mc_list_cap) s_fail = 1; // (cannot happen: the list holds every cell of the map)
+        uint16_t *s_cells = (uint16_t *)s_tab; // [total] (nZ * nRho * 2 bytes <= the table's, checked by the host)
+        if (total && !s_fail) {
+            const uint32_t rec_base = s_base[7];
+            for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) {
+                uint32_t bits = s_miss[w];
+                const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u;
+                const uint32_t zz = (uint32_t)s_vz[z].x;
+                while (bits) {
+                    const uint32_t rho = rho0 + (uint32_t)__ffs((int)bits) - 1u;
+                    bits &= bits - 1;
+                    const uint32_t at = s_rho_off[rho] + atomicAdd(&s_rho_miss[rho], 1u);
+                    s_cells[at] = (uint16_t)((uint32_t)s_vr[rho].y * (uint32_t)P.lv_nz + zz);
+                    if (P.record_awareness) mlm_gp(P.ml_cell)[rec_base + at] = z * (uint32_t)P.nRhoPhi + (uint32_t)phi * (uint32_t)P.nRho + rho;
                 }
             }
             __syncthreads();
-            const uint32_t rec_base = s_base[7];
-            for (uint32_t i = threadIdx.x; i < total; i += MLM_SEC_THREADS) {
-                int rho, z;
-                key_rz(s_cells[i], rho, z);
-                int gx, gy, gz, m_cid, lv, spec;
-                cell_voxel(rho, z, gx, gy, gz, m_cid, lv, spec);
-                if (P.record_awareness) mlm_gp(P.ml_cell)[rec_base + i] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
-                bool first = false;
-                if (lv >= 0) first = g_atomic_add((MLM_GLOBAL uint32_t *)(mlm_gp(P.lv_state) + lv) + 1, 1u) == 0u;
-                else s_fail = 1;
-                mlm_queue_firsts(P, sl, first, lv, gx, gy, gz, m_cid, 1u, spec);
+            for (uint32_t i = threadIdx.x; i < total; i += MLM_SEC_THREADS) mlm_gp(P.mc_list)[m_base + i] = s_cells[i];
+        }
+        if ((int)threadIdx.x < n_run && !s_fail) {
+            const uint32_t r = threadIdx.x, rho_a = s_run_rho[r], rho_b = (int)r + 1 < n_run ? s_run_rho[r + 1] : (uint32_t)P.nRho;
+            const uint32_t m_first = s_rho_off[rho_a], m_cnt = (rho_b < (uint32_t)P.nRho ? s_rho_off[rho_b] : total) - m_first;
+            const uint32_t h_cnt = s_run_hits[r];
+            if (m_cnt | h_cnt) {
+                const uint32_t tile = s_run_tile[r];
+                const unsigned int k = g_atomic_add(&mlm_gp(P.tile_cnt)[tile], 1u);
+                if (k < P.tile_desc_cap)
+                    *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * ((size_t)tile * P.tile_desc_cap + k)) =
+                        mlm_u32x4{m_base + m_first, m_cnt, s_base[0] + s_run_off[r], h_cnt};
+                else
+                    s_fail = 1;
             }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_fail) mlm_sector_fail(P, F); // (a voxel outside the frame-local grid)
+    if (threadIdx.x == 0 && s_fail) mlm_sector_fail(P, F); // (a cell outside the frame-local grid, a tile with too many runs)
     MLM_PHASE(6);
     MLM_PHASE_END
 }
@@ -1286,81 +1267,270 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
     flush();
 }
 
+// floor(a / n) for n > 0
+__device__ __forceinline__ int mlm_floor_div(int a, int n) {
+    int q = a / n;
+    if ((a % n) < 0) --q;
+    return q;
+}
+
+// Group one tile's share of a frame by voxel (map independent, batched over the frames of a batch: blockIdx.z = frame slot,
+// blockIdx.x = tile).  The tile's descriptors say where the columns left its miss cells and hits; the workgroup counts them
+// per voxel in LDS (the tile's voxels are a few thousand 32-bit counters: misses in the low half, hits in the high half),
+// compacts the touched voxels and writes ONE 32-byte record per voxel — block key, cell id, miss count, hit count, the
+// increment of a single hit, the pool slot of the block if it exists already — into the frame's record list; the hits of
+// voxels with several go next to each other into vr_hit with their iteration-order keys.  The kernel that applies the frame
+// then needs two round trips per voxel: record -> (log-odds, class, hits).  Global atomics: two list reservations per tile.
+#define MLM_TILE_THREADS 256
+#define MLM_TILE_DESC 256   // descriptors staged per pass
+#define MLM_TILE_COMBOS 512 // blocks of a tile whose pool slots are looked up (more: left to the kernel that applies the frame)
+struct MlmTileLds {
+    uint32_t cnt, place, desc, slot, ztab, total;
+};
+__host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_nz) {
+    MlmTileLds L;
+    uint32_t o = 0;
+    L.cnt = o;      o += n_vox * 4u;                 // per voxel: misses | hits << 16 (the hit half doubles as the fill cursor later)
+    L.place = o;    o += n_vox * 4u;                 // per touched voxel: record index in the tile | (offset of its hits, 0xFFFF: one hit) << 16
+    o = (o + 15u) & ~15u;
+    L.desc = o;     o += MLM_TILE_DESC * 16u + MLM_TILE_DESC * 8u; // staged descriptors + exclusive prefixes (miss cells, hits)
+    L.slot = o;     o += MLM_TILE_COMBOS * 4u;
+    L.ztab = o;     o += ((lv_nz + 1u) & ~1u) * 4u;  // per grid z: block index << 8 ... (gz, cz) packed
+    L.total = (o + 15u) & ~15u;
+    return L;
+}
+__global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
+    const unsigned int tile = blockIdx.x;
+    const unsigned int nd_all = mlm_gp(P.tile_cnt)[tile];
+    if (nd_all == 0) return; // nothing of this frame fell into the tile (uniform)
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const uint32_t edge = 1u << P.tile_sh, NV = edge * edge * (uint32_t)P.lv_nz;
+    const MlmTileLds L = mlm_tile_lds(NV, (uint32_t)P.lv_nz);
+    uint32_t *s_cnt = (uint32_t *)(s_dyn + L.cnt), *s_place = (uint32_t *)(s_dyn + L.place);
+    mlm_u32x4 *s_desc = (mlm_u32x4 *)(s_dyn + L.desc);
+    uint32_t *s_dm = (uint32_t *)(s_desc + MLM_TILE_DESC), *s_dh = s_dm + MLM_TILE_DESC;
+    int *s_slot = (int *)(s_dyn + L.slot);
+    uint32_t *s_ztab = (uint32_t *)(s_dyn + L.ztab);
+    __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
+    __shared__ uint32_t s_base[4];
+    __shared__ unsigned int s_fail, s_dead;
+    if (threadIdx.x == 0) {
+        s_dead = mlm_gp(P.ctr)->sector_overflow; // set by Stage A: the frame is redone on the cell-table path — only clean up
+        s_fail = nd_all > P.tile_desc_cap ? 1u : 0u;
+    }
+    for (uint32_t v = threadIdx.x; v < NV; v += MLM_TILE_THREADS) s_cnt[v] = 0u;
+    // the tile's place in the world: grid coordinates of its corner, the blocks it overlaps
+    const int ty = (int)(tile / (unsigned int)P.n_tx), tx = (int)tile - ty * P.n_tx;
+    const int X0 = (tx << P.tile_sh) + F.lv_o[0], Y0 = (ty << P.tile_sh) + F.lv_o[1], Z0 = F.lv_o[2];
+    const int gx0 = mlm_floor_div(X0, P.n), gy0 = mlm_floor_div(Y0, P.n), gz0 = mlm_floor_div(Z0, P.n);
+    const int ngx = mlm_floor_div(X0 + (int)edge - 1, P.n) - gx0 + 1, ngy = mlm_floor_div(Y0 + (int)edge - 1, P.n) - gy0 + 1,
+              ngz = mlm_floor_div(Z0 + P.lv_nz - 1, P.n) - gz0 + 1;
+    const int n_combo = ngx * ngy * ngz;
+    const bool probe = n_combo <= MLM_TILE_COMBOS;
+    auto combo_slot = [&](int c) {
+        const int bz = c / (ngx * ngy), r = c - bz * ngx * ngy, by = r / ngx, bx = r - by * ngx;
+        return mlm_block_find(P, gx0 + bx, gy0 + by, gz0 + bz);
+    };
+    for (int z = threadIdx.x; z < P.lv_nz; z += MLM_TILE_THREADS) {
+        const int Z = Z0 + z, gz = mlm_floor_div(Z, P.n);
+        s_ztab[z] = (uint32_t)(gz - gz0) | ((uint32_t)(Z - gz * P.n) << 16);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) mlm_gp(P.tile_cnt)[tile] = 0u; // consumed: clean for the slot's next frame (every thread has read it)
+    if (s_dead) return;
+    // the pool slots of the tile's blocks (in flight while the cells are counted; a tile overlaps a few dozen blocks)
+    int slot0 = -1;
+    if (probe) {
+        if ((int)threadIdx.x < n_combo) slot0 = combo_slot((int)threadIdx.x);
+        for (int c = threadIdx.x + MLM_TILE_THREADS; c < n_combo; c += MLM_TILE_THREADS) s_slot[c] = combo_slot(c);
+    }
+    const unsigned int nd = min(nd_all, P.tile_desc_cap);
+    const MLM_GLOBAL mlm_u32x4 *descs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * (size_t)tile * P.tile_desc_cap);
+    // flat item j of the staged descriptors -> (descriptor, offset inside it); pre[] = exclusive prefix of the counts
+    auto locate = [&](const uint32_t *pre, uint32_t n_staged, uint32_t j, uint32_t &d, uint32_t &o) {
+        uint32_t lo = 0, hi = n_staged;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        d = lo;
+        o = j - pre[lo];
+    };
+    // pass over the descriptors; what == 0: count the miss cells and hits per voxel; what == 1: place the hits
+    uint32_t rec_base = 0, hit_base = 0;
+    auto for_cells = [&](int what) {
+        for (uint32_t d0 = 0; d0 < nd; d0 += MLM_TILE_DESC) {
+            const uint32_t n_staged = min(nd - d0, (uint32_t)MLM_TILE_DESC);
+            __syncthreads();
+            uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
+            mlm_u32x4 dd = mlm_u32x4{0u, 0u, 0u, 0u};
+            if (threadIdx.x < n_staged) {
+                dd = descs[d0 + threadIdx.x];
+                a[0] = dd.y;
+                a[1] = dd.w;
+            }
+            mlm_block_excl_scan4<MLM_TILE_THREADS / 64>(a, s_w, t4);
+            if (threadIdx.x < n_staged) {
+                s_desc[threadIdx.x] = dd;
+                s_dm[threadIdx.x] = a[0];
+                s_dh[threadIdx.x] = a[1];
+            }
+            __syncthreads();
+            if (what == 0)
+                for (uint32_t j = threadIdx.x; j < t4[0]; j += MLM_TILE_THREADS) { // miss cells
+                    uint32_t d, o;
+                    locate(s_dm, n_staged, j, d, o);
+                    const uint32_t v = mlm_gp(P.mc_list)[s_desc[d].x + o];
+                    if (v < NV) atomicAdd(&s_cnt[v], 1u);
+                    else s_fail = 1;
+                }
+            for (uint32_t j = threadIdx.x; j < t4[1]; j += MLM_TILE_THREADS) { // hits
+                uint32_t d, o;
+                locate(s_dh, n_staged, j, d, o);
+                const uint32_t pos = s_desc[d].z + o;
+                const uint32_t v = mlm_gp(P.hl_vt16)[pos];
+                if (v >= NV) {
+                    s_fail = 1;
+                    continue;
+                }
+                if (what == 0) {
+                    atomicAdd(&s_cnt[v], 0x10000u);
+                    continue;
+                }
+                const uint32_t pl = s_place[v];
+                if ((pl >> 16) == 0xFFFFu) { // the voxel's only hit: its increment rides in the record (the last 8 bytes are this lane's)
+                    MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + (pl & 0xFFFFu);
+                    *(MLM_GLOBAL mlm_u32x2 *)&rec->inc0 = mlm_u32x2{__float_as_uint(mlm_gp(P.hl_inc)[pos]), pos};
+                } else {
+                    const uint32_t k = (atomicSub(&s_cnt[v], 0x10000u) >> 16) - 1u; // (counts down: n_hit - 1 .. 0)
+                    MLM_GLOBAL MlmVoxHit *hh = mlm_gp(P.vr_hit) + hit_base + (pl >> 16) + k;
+                    const unsigned long long key = mlm_gp(P.hl_key)[pos];
+                    *(MLM_GLOBAL mlm_u32x4 *)hh = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), __float_as_uint(mlm_gp(P.hl_inc)[pos]), pos};
+                }
+            }
+        }
+    };
+    for_cells(0);
+    if (probe && (int)threadIdx.x < n_combo) s_slot[threadIdx.x] = slot0;
+    __syncthreads();
+    // ---- compaction: a thread's voxels are contiguous; touched voxels get consecutive records, voxels with several hits
+    //      consecutive room in vr_hit
+    const uint32_t per = (NV + MLM_TILE_THREADS - 1) / MLM_TILE_THREADS, v_lo = min(NV, threadIdx.x * per), v_hi = min(NV, v_lo + per);
+    uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
+    for (uint32_t v = v_lo; v < v_hi; ++v) {
+        const uint32_t c = s_cnt[v];
+        if (c) {
+            ++a[0];
+            if ((c >> 16) >= 2u) a[1] += c >> 16;
+        }
+    }
+    mlm_block_excl_scan4<MLM_TILE_THREADS / 64>(a, s_w, t4);
+    if (threadIdx.x == 0) {
+        if (t4[0] > 0xFFFFu || t4[1] >= 0xFFFFu) s_fail = 1; // (the packed places hold 16 bits each)
+        s_base[0] = t4[0] ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[0][0], t4[0]) : 0u;
+        s_base[1] = t4[1] ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[1][0], t4[1]) : 0u;
+        if (s_base[0] + t4[0] > P.rec_cap || s_base[1] + t4[1] > (unsigned int)P.nCells) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) { // (uniform) the frame is redone on the cell-table path
+        if (threadIdx.x == 0) mlm_sector_fail(P, F);
+        return;
+    }
+    rec_base = s_base[0];
+    hit_base = s_base[1];
+    {
+        uint32_t o_rec = a[0], o_hit = a[1];
+        const uint32_t lvz = (uint32_t)P.lv_nz;
+        uint32_t vxy = v_lo / lvz, zz = v_lo - vxy * lvz;
+        for (uint32_t v = v_lo; v < v_hi; ++v) {
+            const uint32_t c = s_cnt[v];
+            if (c) {
+                const uint32_t nh = c >> 16;
+                s_place[v] = o_rec | ((nh >= 2u ? o_hit : 0xFFFFu) << 16);
+                const int X = X0 + (int)(vxy & (edge - 1u)), Y = Y0 + (int)(vxy >> P.tile_sh);
+                const int gx = mlm_floor_div(X, P.n), gy = mlm_floor_div(Y, P.n);
+                const uint32_t zt = s_ztab[zz];
+                const int bz = (int)(zt & 0xFFFFu), cz = (int)(zt >> 16);
+                const int cid = (cz * P.n + (Y - gy * P.n)) * P.n + (X - gx * P.n);
+                const int slot = probe ? s_slot[(bz * ngy + (gy - gy0)) * ngx + (gx - gx0)] : -1;
+                const unsigned long long key = mlm_pack_key(gx, gy, gz0 + bz);
+                MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + o_rec;
+                *(MLM_GLOBAL mlm_u32x4 *)rec = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)cid, c & 0xFFFFu};
+                *(MLM_GLOBAL mlm_u32x2 *)&rec->slot = mlm_u32x2{(uint32_t)slot, nh};
+                if (nh != 1u) *(MLM_GLOBAL mlm_u32x2 *)&rec->inc0 = mlm_u32x2{0u, hit_base + o_hit}; // (one hit: written by that hit's lane)
+                ++o_rec;
+                if (nh >= 2u) o_hit += nh;
+            }
+            if (++zz == lvz) {
+                zz = 0;
+                ++vxy;
+            }
+        }
+    }
+    for_cells(1); // (its first barrier makes the places visible)
+}
+
 // The part of a frame that needs the map (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237), sector
-// path: ONE launch per frame, one first-touched voxel per lane (blockIdx.y = sub-list).  Stage A has already grouped the
-// frame's hits and misses by voxel in the frame-local grid, so all that is left is: block lookup / creation
-// (allocate_ram, map_local.h:215-231), the voxel's hits in the reference's iteration order (descending key,
-// map_local.cpp:157-171), then its misses (map_local.cpp:188-203) — the reference runs all hits before all misses.
-// A voxel that has hits is owned by the record of its first hit; a record of a first miss skips such a voxel.  Three
-// dependent round trips per voxel: queue entry -> (pending state, hit slots, log-odds, class) -> (keys, increments).
-// explicit_keys: hl_key holds the exact iteration-order keys (rehash frames, order_hits_exact); otherwise k_rank's
-// (bucket-first time from this slot's table, insertion time), valid if the frame fits the emulated container without a
-// rehash — else the frame is flagged (g->fail_frame) and replayed by the host.
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const MlmFrame F, int explicit_keys) {
+// path: ONE launch per frame, one touched voxel per lane.  k_tile has grouped the frame's hits and misses by voxel, so all
+// that is left is: block lookup / creation (allocate_ram, map_local.h:215-231) if the block did not exist when k_tile
+// looked, the voxel's hits in the reference's iteration order (descending key, map_local.cpp:157-171), then its misses
+// (map_local.cpp:188-203) — the reference runs all hits before all misses.  Two dependent round trips per voxel:
+// record -> (log-odds, class, the hits of a voxel with several).
+// explicit_keys: hl_key holds the exact iteration-order keys (rehash frames, order_hits_exact); otherwise the records carry
+// k_rank's (bucket-first time from this slot's table, insertion time), valid if the frame fits the emulated container
+// without a rehash — else the frame is flagged (g->fail_frame) and replayed by the host.
+// retry_lo < retry_hi: only the records vr_retry[retry_lo .. retry_hi) — those whose block did not fit the pool in an
+// earlier launch of this frame; the host has grown the pool since.
+__device__ __forceinline__ void mlm_apply_frame_body(const MlmDev &P, const MlmFrame &F, int explicit_keys, unsigned int retry_lo, unsigned int retry_hi) {
     __builtin_amdgcn_s_setprio(3); // the serial chain of the pipeline: its few waves issue ahead of Stage A's
-    const unsigned int sl = blockIdx.y;
     const int frame_idx = F.seq;
     const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    const MLM_GLOBAL uint32_t *recs = mlm_gp(P.tv_rec) + 4 * (size_t)sl * P.tv_cap;
-    const MLM_GLOBAL unsigned long long *keys = mlm_gp(P.tv_key) + (size_t)sl * P.tv_cap;
-    // speculative loads of item i0 (in bounds of the arrays, whatever the list length turns out to be)
-    mlm_u32x4 p_rec = mlm_u32x4{0u, 0u, 0xFFFFFFFFu, 2u};
-    unsigned long long p_key = 0;
-    if (i0 < P.tv_cap) {
-        p_rec = *(const MLM_GLOBAL mlm_u32x4 *)(recs + 4 * (size_t)i0);
-        p_key = keys[i0];
+    const bool retry = retry_hi > retry_lo;
+    const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.vr_rec);
+    // speculative loads of record i0 (in bounds of the array, whatever the list length turns out to be)
+    mlm_u32x4 r0 = mlm_u32x4{0u, 0u, 0u, 0u}, r1 = r0;
+    if (!retry && i0 < P.rec_cap) {
+        r0 = recs[2 * (size_t)i0];
+        r1 = recs[2 * (size_t)i0 + 1];
     }
     const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int n = min(mlm_gp(P.ctr)->mvox_cnt[sl][0], P.tv_cap);
+    const unsigned int n = retry ? retry_hi - retry_lo : min(mlm_gp(P.ctr)->mvox_cnt[0][0], P.rec_cap);
     const unsigned int n_hits = mlm_gp(P.ctr)->u_hit;
-    if (ff <= frame_idx) return;
+    // an EARLIER frame is to be replayed first; this frame's own flag means either that its Stage A gave up (the frame is
+    // redone on the cell-table path) or that a voxel of it found the block pool full — the other voxels are applied regardless
+    // (a voxel's update depends on nothing but the voxel), the host launches the ones on the retry list again
+    if (ff < frame_idx || mlm_gp(P.ctr)->sector_overflow) return;
     if (!explicit_keys && n_hits > F.rehash_thr) { // speculation miss: the frame needs a rehash of the emulated container
-        if (i0 == 0 && sl == 0) atomicMin(&P.g->fail_frame, frame_idx);
+        if (i0 == 0) atomicMin(&P.g->fail_frame, frame_idx);
         return;
     }
     for (unsigned int i = i0; i < n; i += stride) {
-        if (i != i0) {
-            p_rec = *(const MLM_GLOBAL mlm_u32x4 *)(recs + 4 * (size_t)i);
-            p_key = keys[i];
+        unsigned int idx = i;
+        if (retry) idx = mlm_gp(P.vr_retry)[retry_lo + i];
+        if (retry || i != i0) {
+            r0 = recs[2 * (size_t)idx];
+            r1 = recs[2 * (size_t)idx + 1];
         }
-        if (p_rec.w >= 2u) continue; // (no entry: the speculative load of a thread beyond the list)
-        MLM_GLOBAL unsigned long long *st = mlm_gp(P.lv_state) + p_rec.x;
-        MLM_GLOBAL uint32_t *hs = mlm_gp(P.lv_hits) + (size_t)p_rec.x * MLM_LV_SLOTS;
-        int slot = (int)p_rec.z;
-        // the voxel's pending state and hit slots, and (the block being known already in the common case) its map state:
-        // one round trip
-        const unsigned long long state = *st;
-        mlm_u32x4 h0 = mlm_u32x4{0u, 0u, 0u, 0u}, h1 = h0;
-        if (p_rec.w == 0u) { // (the record of a first miss never applies hits: see below)
-            h0 = *(const MLM_GLOBAL mlm_u32x4 *)hs;
-            h1 = *(const MLM_GLOBAL mlm_u32x4 *)(hs + 4);
-        }
-        float L = 0.0f;
-        uint8_t o = 'u';
-        size_t v = 0;
-        if (slot >= 0) {
-            v = (size_t)slot * P.cells + p_rec.y;
-            L = mlm_gp(P.log_odds)[v];
-            o = mlm_gp(P.occ)[v];
-        }
-        const uint32_t nh = (uint32_t)state, km = (uint32_t)(state >> 32);
-        if (p_rec.w == 1u && nh != 0u) continue; // the owner of the voxel's hits applies its misses too
-        if (nh == 0u && km == 0u) continue;      // (consumed already: never write a stale value back)
+        const unsigned long long bkey = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32);
+        const uint32_t cid = r0.z, km = r0.w, nh = r1.y, first = r1.w;
+        int slot = (int)r1.x;
         if (slot < 0) {
-            slot = mlm_block_slot(P, p_key);
+            slot = mlm_block_slot(P, bkey);
             if (slot < 0) {
-                // block pool full (error flag set by the allocator): the voxel STAYS pending and the frame flags itself, so that
-                // the frames behind it do nothing; the host grows the pool and launches them again (drain), this voxel is
-                // applied then — before any later frame touches it, i.e. exactly as if the block had fitted
+                // block pool full (error flag set by the allocator): the voxel goes on the frame's retry list and the frame flags
+                // itself, so that the frames behind it do nothing; the host grows the pool and launches them again (drain), this
+                // voxel is applied then — before any later frame touches it, i.e. exactly as if the block had fitted
+                const unsigned int at = atomicAdd(&P.ctr->mvox_cnt[2][0], 1u);
+                if (at < P.rec_cap) mlm_gp(P.vr_retry)[at] = idx;
                 atomicMin(&P.g->fail_frame, frame_idx);
                 continue;
             }
-            v = (size_t)slot * P.cells + p_rec.y;
-            L = mlm_gp(P.log_odds)[v];
-            o = mlm_gp(P.occ)[v];
         }
-        *st = 0ull;
-        if (nh >= MLM_LV_SLOTS) hs[MLM_LV_SLOTS - 1] = 0u; // (the list of the hits beyond the direct slots)
+        const size_t v = (size_t)slot * P.cells + cid;
+        float L = mlm_gp(P.log_odds)[v];
+        uint8_t o = mlm_gp(P.occ)[v];
         auto hit = [&](float inc) { // map_local.cpp:157-171
             if (L < P.lo_max) {
                 L = L + inc;
@@ -1369,70 +1539,56 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
             if (L > P.lo_sh && o != 'o') o = 'o';
         };
         if (nh == 1u) { // the common case: a single contribution
-            hit(mlm_gp(P.hl_inc)[h0.x]);
+            hit(__uint_as_float(r1.z));
         } else if (nh) {
-            // (key, increment) of all its hits in one gather — hl_key: k_rank's speculative keys or the exact ones of
-            // order_hits_exact — kept in registers in descending key order (the reference's iteration order)
-            const uint32_t ps[MLM_LV_SLOTS - 1] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z};
-            const uint32_t nd = min(nh, (uint32_t)(MLM_LV_SLOTS - 1));
-            unsigned long long gk[MLM_LV_SLOTS - 1];
-            float gv[MLM_LV_SLOTS - 1];
-#pragma unroll
-            for (int q = 0; q < MLM_LV_SLOTS - 1; ++q) {
-                gk[q] = 0;
-                gv[q] = 0.0f;
-                if ((uint32_t)q < nd) {
-                    gk[q] = mlm_gp(P.hl_key)[ps[q]];
-                    gv[q] = mlm_gp(P.hl_inc)[ps[q]];
-                }
-            }
-            unsigned long long ks[MLM_APPLY_REGS];
-            float vs[MLM_APPLY_REGS];
-#pragma unroll
-            for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                ks[q] = 0; // real keys are never 0
-                vs[q] = 0.0f;
-            }
-            auto insert = [&](unsigned long long k, float inc) {
+            // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
+            // reference's iteration order)
+            const MLM_GLOBAL mlm_u32x4 *hh = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.vr_hit) + first);
+            auto key_of = [&](const mlm_u32x4 &e) -> unsigned long long {
+                return explicit_keys ? mlm_gp(P.hl_key)[e.w] : ((unsigned long long)e.x | ((unsigned long long)e.y << 32));
+            };
+            if (nh <= MLM_APPLY_REGS) {
+                unsigned long long ks[MLM_APPLY_REGS];
+                float vs[MLM_APPLY_REGS];
 #pragma unroll
                 for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                    if (k > ks[q]) {
-                        const unsigned long long tk = ks[q];
-                        const float tv = vs[q];
-                        ks[q] = k;
-                        vs[q] = inc;
-                        k = tk;
-                        inc = tv;
+                    ks[q] = 0; // real keys are never 0
+                    vs[q] = 0.0f;
+                }
+                for (uint32_t j = 0; j < nh; ++j) {
+                    const mlm_u32x4 e = hh[j];
+                    unsigned long long k = key_of(e);
+                    float inc = __uint_as_float(e.z);
+#pragma unroll
+                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                        if (k > ks[q]) {
+                            const unsigned long long tk = ks[q];
+                            const float tv = vs[q];
+                            ks[q] = k;
+                            vs[q] = inc;
+                            k = tk;
+                            inc = tv;
+                        }
                     }
                 }
-            };
-#pragma unroll
-            for (int q = 0; q < MLM_LV_SLOTS - 1; ++q)
-                if ((uint32_t)q < nd) insert(gk[q], gv[q]);
-            const int over = (int)h1.w - 1; // head of the list of the hits beyond the slots (nh >= MLM_LV_SLOTS)
-            if (nh >= MLM_LV_SLOTS)
-                for (int j = over; j >= 0; j = mlm_gp(P.hl_next)[j]) insert(mlm_gp(P.hl_key)[j], mlm_gp(P.hl_inc)[j]);
-            if (nh <= MLM_APPLY_REGS) {
 #pragma unroll
                 for (int q = 0; q < MLM_APPLY_REGS; ++q)
                     if ((uint32_t)q < nh) hit(vs[q]);
             } else {
                 // more hits than registers: repeated selection of the next key straight from memory
                 unsigned long long last = ~0ull;
-                for (;;) {
-                    int best = -1;
+                for (uint32_t done = 0; done < nh; ++done) {
                     unsigned long long bestkey = 0;
-                    auto consider = [&](int j) {
-                        const unsigned long long k = mlm_gp(P.hl_key)[j];
-                        if (k < last && (best < 0 || k > bestkey)) {
-                            best = j;
+                    float bestinc = 0.0f;
+                    for (uint32_t j = 0; j < nh; ++j) {
+                        const mlm_u32x4 e = hh[j];
+                        const unsigned long long k = key_of(e);
+                        if (k < last && k > bestkey) {
                             bestkey = k;
+                            bestinc = __uint_as_float(e.z);
                         }
-                    };
-                    for (int q = 0; q < MLM_LV_SLOTS - 1; ++q) consider((int)ps[q]);
-                    for (int j = over; j >= 0; j = mlm_gp(P.hl_next)[j]) consider(j);
-                    if (best < 0) break;
-                    hit(mlm_gp(P.hl_inc)[best]);
+                    }
+                    hit(bestinc);
                     last = bestkey;
                 }
             }
@@ -1441,4 +1597,12 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
         mlm_gp(P.log_odds)[v] = L;
         mlm_gp(P.occ)[v] = o;
     }
+}
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const MlmFrame F, int explicit_keys, unsigned int retry_lo, unsigned int retry_hi) {
+    mlm_apply_frame_body(P, F, explicit_keys, retry_lo, retry_hi);
+}
+// the same with the parameters taken from the device-resident tables (the launch sequence of a single frame is replayed as a HIP
+// graph: its kernel arguments must not change from call to call)
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame_tab(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot) {
+    mlm_apply_frame_body(slot_tab[slot], frame_tab[slot], 0, 0u, 0u);
 }

@@ -28,7 +28,8 @@ struct MlmCounters {
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart;
                                  // [k][1] = device-scope atomics the frame's kernels issued (sector path, counted by k_sector)
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
-    unsigned int mvox_cnt[8][32];  // [k][0] = voxels touched by misses, sub-list k
+    unsigned int mvox_cnt[8][32];  // cell-table path: [k][0] = voxels touched by misses, sub-list k; sector path: [0][0] voxel records,
+                                   // [1][0] entries of vr_hit, [2][0] entries of vr_retry, [3][0] miss cells reserved in mc_list
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
     unsigned int node_cnt[8][32];  // [k][0] = contribution nodes allocated in region k
     unsigned int mc_cnt[8][32];    // [k][0] = unique miss cells queued in sub-list k
@@ -77,6 +78,25 @@ struct MlmCell {
     uint32_t cnt;  // number of contributions
     uint32_t mask; // bit s set = a contribution of insertion slot s (0 centre, 2d-1 "+d", 2d "-d")
     uint32_t seg;  // start of the cell's segment in `contrib` (MLM_NIL for single-kind cells)
+};
+
+// One voxel a frame touches (sector path, written by k_tile): everything the kernel that applies the frame needs comes with
+// one 32-byte load.  (map_local.cpp:147-207: the voxel's hits in container order, then its misses.)
+struct MlmVoxRec {
+    unsigned long long bkey; // packed block key of the voxel's block
+    uint32_t cid;            // cell id inside the block
+    uint32_t n_miss;         // unique miss cells of the frame that fall into the voxel
+    int32_t slot;            // the block's pool slot if it existed when k_tile looked, else -1
+    uint32_t n_hit;          // unique hit cells that fall into it
+    float inc0;              // n_hit == 1: that hit's log-odds increment (its order is irrelevant)
+    uint32_t first;          // n_hit == 1: the hit's index in hl_*; n_hit >= 2: first of its n_hit entries in MlmDev::vr_hit
+};
+// One hit of a voxel with several: increment, iteration-order key (k_rank's speculative one; on a replayed frame hl_key[pos]
+// holds the exact key instead)
+struct MlmVoxHit {
+    unsigned long long key;
+    float inc;
+    uint32_t pos;            // index in hl_*
 };
 
 #define MLM_LV_SLOTS 8
@@ -190,24 +210,31 @@ struct MlmDev {
     uint32_t *col_chunks;      // [nPhi][chunk_cap][2] {first record in `bnodes`, record count} per (bin block, column) run
     unsigned int chunk_cap;
     unsigned int sec_tab, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two)
-    unsigned int sec_probe;              // 1: k_sector looks the block slot of a queued voxel up (speculatively), 0: left to k_apply_frame
-    unsigned int sec_combos;   // most blocks a column may reach: runs of equal block index along rho x runs along z (k_sector)
     unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
     uint32_t *refs;            // [refs_cap][4] {lane mask lo, hi, tile origin (row << 11 | column), kind} per contribution group of a
                                // multi-kind cell
     unsigned int refs_cap;
     uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count}
-    // frame-local voxel grid: the voxels the awareness cylinder can reach, addressed relative to MlmFrame::lv_o, so
-    // that hits and misses are grouped by voxel in Stage A without knowing the map (block slots)
-    unsigned long long *lv_state; // [lv_nx*lv_ny*lv_nz] low word: pending hits of the frame, high word: its misses; reset by
-                               // the kernel that applies the frame
-    uint32_t *lv_hits;         // [..][MLM_LV_SLOTS] the voxel's pending hits (indices into hl_*): hit k < MLM_LV_SLOTS-1 in slot
-                               // k; the last slot heads a list (1 + index, links in hl_next) of the hits beyond — one gather
-                               // instead of a list walk for the kernel that applies the frame
+    // Frame-local voxel grid: the voxels the awareness cylinder can reach, addressed relative to MlmFrame::lv_o and cut into
+    // TILES of 2^tile_sh x 2^tile_sh voxels in x,y over the grid's whole height.  Which voxel — and so which tile — a cell
+    // of an azimuth column falls into is geometry (no map needed), and along a column it depends on rho only: k_sector hands
+    // every tile the runs of the column's miss cells and hits that fall into it (a descriptor per (column, tile): the
+    // column's cells leave in one coalesced stream), k_tile groups a tile's cells by voxel in LDS and writes ONE record per
+    // touched voxel, and the kernel that applies the frame reads those records.  No per-cell global atomic anywhere.
     int lv_nx, lv_ny, lv_nz;
-    uint32_t *tv_rec;          // [MLM_RAY_LISTS][tv_cap][4] the frame's voxel queue, first-touched voxels only: {lv, cell id, block slot or -1, 0 first touch was a hit / 1 a miss}
-    unsigned long long *tv_key;// [MLM_RAY_LISTS][tv_cap] ... packed block key          (counts: MlmCounters::mvox_cnt)
-    unsigned int tv_cap;
+    int tile_sh, n_tx, n_tiles;        // tile edge 2^tile_sh voxels; tiles per grid row; tiles per frame
+    uint16_t *mc_list;         // [mc_list_cap] the frame's unique miss cells as voxel-in-tile indices
+                               // vt = ((y & m) << tile_sh | (x & m)) * lv_nz + z; a column's cells are contiguous, ordered by tile
+    unsigned int mc_list_cap;
+    uint16_t *hl_vt16;         // [nCells] vt of every unique hit (a column's hits are contiguous in hl_*, ordered by tile)
+    unsigned int *tile_cnt;    // [n_tiles] descriptors handed to each tile this frame (reset by k_tile)
+    uint32_t *tile_desc;       // [n_tiles][tile_desc_cap][4] {first miss cell in mc_list, count, first hit in hl_*, count}
+    unsigned int tile_desc_cap;
+    MlmVoxRec *vr_rec;         // [rec_cap] one record per voxel the frame touches (count: MlmCounters::mvox_cnt[0][0])
+    unsigned int rec_cap;
+    MlmVoxHit *vr_hit;         // [nCells] the hits of voxels with two or more, a voxel's hits contiguous (count: mvox_cnt[1][0])
+    uint32_t *vr_retry;        // [rec_cap] records whose block did not fit the pool (count: mvox_cnt[2][0]): applied again once
+                               // the host has grown the pool
     unsigned long long *sbkt;  // [sbkt_cap] this slot's bucket-first table of the emulated hit container: (~seq << 32 | time),
     unsigned int sbkt_cap;     // never cleared (a newer frame's entries win the min)
     MlmCounters *ctr;          // this slot's per-frame counters
@@ -221,6 +248,7 @@ struct MlmFrame {
     double t_wa[3];
     const uint16_t *img;   // device
     const int32_t *pix;    // device or null
+    const int32_t *raw;    // device or null: the depth values of the listed pixels by list position (else read from img)
     const double *pts;     // device or null
     int width, height, row_stride;
     int n;                 // work items: pixels (dense), list length (indexed) or points

@@ -52,6 +52,7 @@ struct MlmSlot {
     unsigned int ex_um = 0;   // frontier mode: unique miss cells of the frame it holds
     size_t alloc_end = 0;     // mlm_handle::allocs.size() once this slot was allocated
     bool sector = false;      // the frame it holds went through the sector path (Stage A and the frame-local voxel grid)
+    unsigned int retry_done = 0; // entries of the frame's retry list (blocks that did not fit the pool) already launched again
     bool keys_exact = false;  // hl_key of the frame it holds was written by order_hits_exact (a replay must not recompute it:
                               // the emulated container's policy state has moved on)
     uint16_t *d_img = nullptr; // staging for host images
@@ -159,6 +160,23 @@ struct mlm_handle {
     long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
     bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
     size_t frame_block_bound = 0; // most blocks one frame can create
+    unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
+    // Single frames in synchronous mode — the reference's own call pattern, one frame per depth callback (mlmap.cpp:463-507) — are
+    // submitted as ONE replay of a HIP graph on the main stream (parameter upload, counter reset, six kernels, counter
+    // read-back) instead of a dozen launches and copies spread over two streams: the call's cost is launch latency, not work.
+    struct SingleGraph {
+        int mode, width, height, base;
+        unsigned int nb;
+        size_t n_bkt;
+        hipGraphExec_t exec;
+    };
+    std::vector<SingleGraph> graphs;
+    bool use_graph = true;       // (MLM_GRAPH=0: always the general submission)
+    hipStream_t last_upload = nullptr; // the stream the current call's inputs were uploaded on (run_slots orders Stage A behind it)
+    hipEvent_t upload_ev = nullptr;
+    long long n_graph_launches = 0;
+    int32_t *h_stage = nullptr;  // pinned staging of the callback's sampled pixels (indices, then raw depths)
+    size_t stage_cap = 0;
     long long n_pool_grows = 0;
     MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
     MlmPair *fb_pairs = nullptr;
@@ -251,6 +269,7 @@ inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 b
     }
 }
 
+int drain(mlm_handle *h, bool g_copied = false);
 int grow_pool(mlm_handle *h, size_t want);
 int ensure_free_blocks(mlm_handle *h, size_t need);
 int ensure_free_blocks_idle(mlm_handle *h, size_t need);
@@ -474,6 +493,9 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         }
         tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
                 base);
+        // the frame's hits and misses grouped by voxel, tile by tile (needs the increments and keys of the kernels above)
+        if (!P.explore)
+            tlaunch(h, "k_tile", k_tile, dim3((unsigned int)P.n_tiles, 1, n), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     }
     HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
@@ -512,10 +534,9 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
         na += c.ray_cnt[k][1];
     }
     h->stats.n_device_atomics = na;
-    if (S.sector) {
-        long long nq = 0;
-        for (int k = 0; k < MLM_RAY_LISTS; ++k) nq += c.mvox_cnt[k][0];
-        h->last_queue = nq;
+    if (S.sector && !h->P.explore) {
+        h->stats.n_miss_cells = c.mvox_cnt[3][0]; // (the reservation counter of the frame's miss list)
+        h->last_queue = c.mvox_cnt[0][0];         // voxel records
     }
     h->stats.n_groups = ng;
     h->stats.n_rays = nr;
@@ -523,6 +544,7 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_sector_fallbacks = h->n_sector_fallbacks;
     h->stats.logit_bit_exact = h->P.logit_exact;
     h->stats.n_pool_grows = h->n_pool_grows;
+    h->stats.n_graph_launches = h->n_graph_launches;
     h->stats.block_capacity = h->P.max_blocks;
 }
 
@@ -531,8 +553,7 @@ int check_queues(mlm_handle *h, const MlmSlot &S) {
     const MlmDev &P = S.P;
     bool over = c.n_contrib > P.contrib_cap;
     for (int k = 0; k < MLM_RAY_LISTS; ++k)
-        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mc_cnt[k][0] > P.mc_cap ||
-               (S.sector && c.mvox_cnt[k][0] > P.tv_cap);
+        over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mc_cnt[k][0] > P.mc_cap;
     if (over) {
         h->err = "a per-frame device queue overflowed (raise mlm_limits.max_points)";
         return MLM_ERR_CAPACITY;
@@ -784,6 +805,7 @@ int submit_batch(mlm_handle *h, int base, int n) {
     for (int j = 0; j < n; ++j) {
         h->slots[(size_t)(base + j)].sector = sectors;
         h->slots[(size_t)(base + j)].keys_exact = false;
+        h->slots[(size_t)(base + j)].retry_done = 0;
     }
     {
         Timed t(h, h->stream_as[set], "stage_a_batch");
@@ -794,14 +816,14 @@ int submit_batch(mlm_handle *h, int base, int n) {
     if (sectors) {
         // one launch per frame: Stage A has grouped the frame's hits and misses by voxel already (k_apply_frame)
         Timed t(h, h->stream, "stage_bc_batch");
-        unsigned int scg = h->sc_grid;
-        if (!h->sc_grid_fixed) { // one first-touched voxel per thread for a frame like the last confirmed one
-            const long long items = (h->last_queue > 0 ? h->last_queue * 5 / 4 : h->stats.n_hit_cells + h->stats.n_miss_cells) / MLM_RAY_LISTS;
-            scg = (unsigned int)std::min<long long>(1024, std::max<long long>(8, (items + MLM_BLOCK - 1) / MLM_BLOCK));
+        unsigned int scg = h->sc_grid * MLM_RAY_LISTS;
+        if (!h->sc_grid_fixed) { // one voxel record per thread for a frame like the last confirmed one
+            const long long items = h->last_queue > 0 ? h->last_queue * 5 / 4 : h->stats.n_hit_cells + h->stats.n_miss_cells;
+            scg = (unsigned int)std::min<long long>(8192, std::max<long long>(64, (items + MLM_BLOCK - 1) / MLM_BLOCK));
         }
         for (int j = 0; j < n; ++j) {
             MlmSlot &S = h->slots[(size_t)(base + j)];
-            tlaunch(h, "k_apply_frame", k_apply_frame, dim3(scg * (MLM_BLOCK / h->sc_block), MLM_RAY_LISTS), dim3(h->sc_block), 0, h->stream, S.P, S.F, 0);
+            tlaunch(h, "k_apply_frame", k_apply_frame, dim3(scg * (MLM_BLOCK / h->sc_block)), dim3(h->sc_block), 0, h->stream, S.P, S.F, 0, 0u, 0u);
             h->pending.push_back(&S);
         }
     } else {
@@ -845,10 +867,11 @@ int confirm_front(mlm_handle *h, int count) {
 }
 
 // Wait for everything submitted, replay frames whose speculation failed, leave nothing pending.
-int drain(mlm_handle *h) {
+int drain(mlm_handle *h, bool g_copied) {
     if (h->P.explore) return drain_explore(h);
     for (;;) {
-        HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+        if (!g_copied) HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+        g_copied = false;
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         const int f = h->h_g->fail_frame;
@@ -872,9 +895,16 @@ int drain(mlm_handle *h) {
                 return MLM_ERR_CAPACITY;
             }
             for (MlmSlot *R : h->pending) {
-                if (R->sector)
-                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(160, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, R->P, R->F, R->keys_exact ? 1 : 0);
-                else
+                if (R->sector) {
+                    // the frame that ran out of blocks: only the voxels it put on its retry list; the frames behind it did nothing
+                    const unsigned int n_retry = std::min(R->h_ctr->mvox_cnt[2][0], R->P.rec_cap);
+                    if (R == h->pending.front() && n_retry > R->retry_done) {
+                        tlaunch(h, "k_apply_frame", k_apply_frame, dim3(64), dim3(MLM_BLOCK), 0, h->stream, R->P, R->F, R->keys_exact ? 1 : 0, R->retry_done, n_retry);
+                        R->retry_done = n_retry;
+                    } else {
+                        tlaunch(h, "k_apply_frame", k_apply_frame, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, R->P, R->F, R->keys_exact ? 1 : 0, 0u, 0u);
+                    }
+                } else
                     launch_stage_bc(h, *R, R->keys_exact ? 0 : h->hit_n_bkt);
                 HIPCHK(h, hipMemcpyAsync(R->h_ctr, R->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
             }
@@ -906,9 +936,7 @@ int drain(mlm_handle *h) {
                     HIPCHK(h, hipStreamSynchronize(h->stream));
                     rc = ensure_free_blocks_idle(h, h->frame_block_bound); // (its k_voxelize cannot be replayed)
                     if (rc) return rc;
-                    // the frame-local grid holds what the sectors that did finish pushed: wipe it, then the cell-table path
-                    HIPCHK(h, hipMemsetAsync(R.P.lv_state, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * sizeof(unsigned long long), h->stream_as[set]));
-                    HIPCHK(h, hipMemsetAsync(R.P.lv_hits, 0, (size_t)R.P.lv_nx * R.P.lv_ny * R.P.lv_nz * MLM_LV_SLOTS * sizeof(uint32_t), h->stream_as[set]));
+                    // (k_tile has consumed the descriptors the columns that did finish handed out: nothing of the attempt is left)
                     rc = launch_stage_a_batch(h, si, 1);
                     if (rc) return rc;
                     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
@@ -927,7 +955,7 @@ int drain(mlm_handle *h) {
                     R.keys_exact = true;
                 }
                 if (R.sector)
-                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(160, MLM_RAY_LISTS), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1);
+                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1, 0u, 0u);
                 else
                     launch_stage_bc(h, R, 0);
                 HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
@@ -993,17 +1021,98 @@ void clear_device_error(mlm_handle *h) {
     for (int k = 0; k < MLM_SETS; ++k) *h->h_gb[k] = g;
 }
 
-// ... and the frame-local voxel grids: the frames that were dropped with the failed call may have left hits and misses
-// pending there (their apply kernels did not run), which the next frame in the same slot must not inherit.
+// ... and the hand-over counters of the frame slots: the frames that were dropped with the failed call may have left
+// descriptors for the columns / tiles (their consumers did not run), which the next frame in the same slot must not inherit.
 void wipe_frame_grids(mlm_handle *h) {
-    if (!h->use_sectors || h->P.explore) return;
+    if (!h->use_sectors) return;
     for (auto &S : h->slots) {
-        const size_t nlv = (size_t)S.P.lv_nx * S.P.lv_ny * S.P.lv_nz;
-        if (!S.P.lv_state || !S.P.lv_hits) continue;
-        hipMemsetAsync(S.P.lv_state, 0, nlv * sizeof(unsigned long long), h->stream);
-        hipMemsetAsync(S.P.lv_hits, 0, nlv * MLM_LV_SLOTS * sizeof(uint32_t), h->stream);
+        if (S.P.tile_cnt) hipMemsetAsync(S.P.tile_cnt, 0, (size_t)S.P.n_tiles * sizeof(unsigned int), h->stream);
+        if (S.P.col_cnt) hipMemsetAsync(S.P.col_cnt, 0, (size_t)S.P.nPhi * sizeof(unsigned int), h->stream);
     }
     hipStreamSynchronize(h->stream);
+}
+
+// Can the frame described in slot `base` go through the single-frame graph?  (sector path, the handle's own stream, synchronous
+// mode, no per-kernel timing, nothing in flight)
+bool single_fast_ok(const mlm_handle *h, int n) {
+    if (n != 1 || !h->use_graph || h->P.explore || h->async_mode || !h->own_stream || h->timing != 0 || !h->pending.empty()) return false;
+    const MlmSlot &S = h->slots[(size_t)(h->cur_set * h->lim.max_batch)];
+    return h->use_sectors && h->sector_backoff == 0 && S.F.width <= 2040 && h->hit_n_bkt <= S.P.sbkt_cap && h->hit_n_bkt > 1 && S.F.n > 0;
+}
+// the stream uploads of a call's inputs go to: the one its Stage A will run on
+inline hipStream_t upload_stream(const mlm_handle *h) {
+    const bool fast = h->use_graph && !h->P.explore && !h->async_mode && h->own_stream && h->timing == 0 && h->use_sectors && h->sector_backoff == 0 && h->hit_n_bkt > 1;
+    return fast ? h->stream : h->stream_as[h->cur_set];
+}
+int submit_single_graph(mlm_handle *h, int base) {
+    MlmSlot &S = h->slots[(size_t)base];
+    const MlmDev &P = S.P;
+    const int set = base / h->lim.max_batch;
+    S.seq = h->next_seq++;
+    S.F.seq = S.seq;
+    S.F.rehash_thr = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
+    S.sector = true;
+    S.keys_exact = false;
+    S.retry_done = 0;
+    const unsigned int nb = S.mode == 0 ? (unsigned int)(((S.F.width + 31) / 32) * ((S.F.height + 7) / 8)) : (unsigned int)(((size_t)S.F.n + 255) / 256);
+    if (nb > P.nb_cap) {
+        h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
+        return MLM_ERR_CAPACITY;
+    }
+    mlm_handle::SingleGraph *G = nullptr;
+    for (auto &g : h->graphs)
+        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.n_bkt == h->hit_n_bkt) G = &g;
+    if (!G) {
+        if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
+            for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
+            h->graphs.clear();
+        }
+        hipStream_t st = h->stream;
+        HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, sizeof(MlmFrame), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_ctr_all + base, 0, sizeof(MlmCounters), st);
+        if (e == hipSuccess) {
+            if (S.mode == 0) hipLaunchKernelGGL(k_bin_sectors<0>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            else if (S.mode == 1) hipLaunchKernelGGL(k_bin_sectors<1>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            else hipLaunchKernelGGL(k_bin_sectors<2>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            const int row_w = S.mode == 0 ? S.F.width : 64;
+            unsigned long long dm, rm;
+            int ds, rs;
+            div_magic((unsigned int)row_w, dm, ds);
+            div_magic((unsigned int)P.nRho, rm, rs);
+            hipLaunchKernelGGL(k_sector<false>, dim3((unsigned int)P.nPhi, 1, 1), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
+                               S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
+            hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
+            hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_tile, dim3((unsigned int)P.n_tiles, 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_apply_frame_tab, dim3(256), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, sizeof(MlmCounters), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st);
+        hipGraph_t graph = nullptr;
+        const hipError_t e2 = hipStreamEndCapture(st, &graph);
+        if (e != hipSuccess || e2 != hipSuccess || !graph) {
+            if (graph) hipGraphDestroy(graph);
+            h->err = std::string("single-frame graph capture: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+            return MLM_ERR_HIP;
+        }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+            return MLM_ERR_HIP;
+        }
+        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, nb, h->hit_n_bkt, exec});
+        G = &h->graphs.back();
+    }
+    h->h_frame_tab[base] = S.F;
+    HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
+    h->n_graph_launches++;
+    h->pending.push_back(&S);
+    h->set_pending[set] = 1;
+    return MLM_OK;
 }
 
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
@@ -1078,9 +1187,30 @@ int run_slots(mlm_handle *h, int n) {
     h->stats.n_rehash_epochs = 1;
     const int K = h->lim.max_batch;
     const int set = h->cur_set;
-    int rc = submit_batch(h, set * K, n);
-    if (rc == MLM_OK) {
-        if (h->async_mode && h->hit_n_bkt > 1) {
+    int rc;
+    const bool fast = single_fast_ok(h, n);
+    {
+        // the call's inputs went up on one stream, its Stage A may run on another: order it behind
+        hipStream_t target = fast ? h->stream : h->stream_as[set];
+        if (h->last_upload && h->last_upload != target) {
+            hipError_t e = hipSuccess;
+            if (!h->upload_ev) e = hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(h->upload_ev, h->last_upload);
+            if (e == hipSuccess) e = hipStreamWaitEvent(target, h->upload_ev, 0);
+            if (e != hipSuccess) {
+                h->err = std::string("ordering the upload: ") + hipGetErrorString(e);
+                return MLM_ERR_HIP;
+            }
+        }
+        h->last_upload = nullptr;
+    }
+    if (fast) {
+        rc = submit_single_graph(h, set * K);
+        if (rc == MLM_OK) rc = drain(h, true); // (the graph ends with the read-back of the map-wide flags)
+    } else {
+        rc = submit_batch(h, set * K, n);
+        if (rc != MLM_OK) {
+        } else if (h->async_mode && h->hit_n_bkt > 1) {
             // confirm the OLDEST batch in flight (the set that will be refilled next); the newer ones keep the GPU busy
             h->cur_set = (set + 1) % h->n_sets;
             rc = finish_set(h, h->cur_set);
@@ -1257,6 +1387,9 @@ int grow_pool(mlm_handle *h, size_t want) {
         h->err = "device memory exhausted while growing the block pool: " + h->err;
         return MLM_ERR_CAPACITY;
     }
+    // (alloc_pool initialises the new arrays with hipMemset on the null stream, which the handle's non-blocking streams do not
+    // wait for: the copies below must not overtake it)
+    HIPCHK(h, hipDeviceSynchronize());
     const size_t C = (size_t)h->P.cells;
     if (nb) {
         hipStream_t st = h->stream;
@@ -1298,7 +1431,6 @@ int grow_pool(mlm_handle *h, size_t want) {
     if (getenv("MLM_DEBUG_CREATE")) fprintf(stderr, "[pool] grown to %d blocks (%u in use)\n", h->P.max_blocks, nb);
     return MLM_OK;
 }
-int drain(mlm_handle *h);
 // Paths that cannot replay a frame after the fact (the cell-table path's two map-dependent kernels, frontier mode, inflation,
 // imports) make sure beforehand that the pool can take what they may create at most.
 int ensure_free_blocks_idle(mlm_handle *h, size_t need) { // (nothing in flight on any stream)
@@ -1375,15 +1507,18 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
     if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
     if ((rc = dev_alloc(h, &P.col_chunks, h->use_sectors ? 2 * (size_t)P.nPhi * P.chunk_cap : 2))) return rc;
-    if (h->use_sectors && !P.explore) { // (frontier mode's own Stage B+C takes over after k_sector: no frame-local grid)
-        const size_t nlv = (size_t)P.lv_nx * P.lv_ny * P.lv_nz;
-        if ((rc = dev_alloc(h, &P.lv_state, nlv))) return rc;
-        HIPCHK(h, hipMemset(P.lv_state, 0, nlv * sizeof(unsigned long long)));
-        if ((rc = dev_alloc(h, &P.lv_hits, nlv * MLM_LV_SLOTS))) return rc;
-        HIPCHK(h, hipMemset(P.lv_hits, 0, nlv * MLM_LV_SLOTS * sizeof(uint32_t)));
-        P.tv_cap = (unsigned int)(((size_t)P.nMissWords * 32 + NC) / MLM_RAY_LISTS + 4096);
-        if ((rc = dev_alloc(h, &P.tv_rec, 4 * (size_t)MLM_RAY_LISTS * P.tv_cap))) return rc;
-        if ((rc = dev_alloc(h, &P.tv_key, (size_t)MLM_RAY_LISTS * P.tv_cap))) return rc;
+    if (h->use_sectors && !P.explore) { // (frontier mode's own Stage B+C takes over after k_sector: no tiles)
+        P.mc_list_cap = (unsigned int)NC; // unique miss cells of a frame
+        if ((rc = dev_alloc(h, &P.mc_list, (size_t)P.mc_list_cap + 8))) return rc;
+        if ((rc = dev_alloc(h, &P.hl_vt16, NC + 8))) return rc;
+        if ((rc = dev_alloc(h, &P.tile_cnt, (size_t)P.n_tiles))) return rc;
+        HIPCHK(h, hipMemset(P.tile_cnt, 0, (size_t)P.n_tiles * sizeof(unsigned int)));
+        if ((rc = dev_alloc(h, &P.tile_desc, 4 * (size_t)P.n_tiles * P.tile_desc_cap))) return rc;
+        // a frame touches at most one voxel per awareness cell, and no more voxels than its grid has
+        P.rec_cap = (unsigned int)std::min<size_t>(NC, (size_t)P.lv_nx * P.lv_ny * P.lv_nz);
+        if ((rc = dev_alloc(h, &P.vr_rec, (size_t)P.rec_cap))) return rc;
+        if ((rc = dev_alloc(h, &P.vr_hit, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.vr_retry, (size_t)P.rec_cap))) return rc;
         // bucket-first table of this slot: room for the emulated container of a frame with up to 2 * max_points unique
         // hit cells (more: the handle continues on the cell-table path)
         P.sbkt_cap = (unsigned int)std::min<size_t>(h->max_buckets, std::__detail::_Prime_rehash_policy()._M_next_bkt(4 * (size_t)h->lim.max_points + 2));
@@ -1633,41 +1768,47 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         while (tab < 12u * (unsigned int)P.nRho && tab < 2048u) tab <<= 1;
         if (const char *e = getenv("MLM_SEC_TAB")) tab = (unsigned int)std::max(MLM_SEC_THREADS, atoi(e)); // power of two
         P.sec_tab = tab;
-        P.sec_probe = 1; // speculative block-slot lookups in k_sector (config 2, three slot sets: 49.9k frames/s vs 48.3k without)
-        if (const char *e = getenv("MLM_SEC_PROBE")) P.sec_probe = atoi(e) != 0;
         if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
+        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
         {
-            // a ray of length R crosses at most R (|cos| + |sin|) / D block boundaries in x or y, the column's height H / D in z
-            const double D = P.n * P.d_sub;
-            const unsigned int kr = (unsigned int)std::ceil(P.nRho * P.dRho * std::sqrt(2.0) / D) + 3, kz = (unsigned int)std::ceil(P.nZ * P.dZ / D) + 2;
-            P.sec_combos = std::min<unsigned int>(MLM_SEC_COMBOS, kr * kz);
-        }
-        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.sec_combos, P.explore).total;
-        {
-            // frame-local voxel grid: the awareness cylinder (radius nRho*dRho, height nZ*dZ) plus four voxels each side
+            // frame-local voxel grid: the awareness cylinder (radius nRho*dRho, height nZ*dZ) plus four voxels each side, cut
+            // into tiles over its whole height: the largest edge (8, 4, 2, 1 voxels) whose voxels k_tile can count in LDS
             const double R = P.nRho * P.dRho;
             P.lv_nx = P.lv_ny = 2 * (int)std::ceil(R / P.d_sub) + 10;
             P.lv_nz = (int)std::ceil(P.nZ * P.dZ / P.d_sub) + 10;
+            P.tile_sh = 3;
+            while (P.tile_sh > 0 && ((size_t)P.lv_nz << (2 * P.tile_sh)) > 8192) --P.tile_sh;
+            if (const char *e = getenv("MLM_TILE_SH")) P.tile_sh = std::min(3, std::max(0, atoi(e)));
+            const int edge = 1 << P.tile_sh;
+            P.n_tx = (P.lv_nx + edge - 1) / edge;
+            P.n_tiles = P.n_tx * ((P.lv_ny + edge - 1) / edge);
+            P.tile_desc_cap = (unsigned int)P.nPhi + 64u; // a column's ray crosses a tile once: one descriptor per (column, tile)
+            h->tile_lds_bytes = mlm_tile_lds((unsigned int)(edge * edge * P.lv_nz), (unsigned int)P.lv_nz).total;
         }
-        // (frontier mode: no frame-local grid, no prefix of the mask words in the chunk staging area; its insertion times
-        // hold point index * 256 + ray step in 32 bits)
-        // (k_sector packs in-block cell coordinates into bytes and lists a column's miss cells in its cell table's space)
+        // (frontier mode: no tiles; its insertion times hold point index * 256 + ray step in 32 bits)
+        // (k_sector lists a column's miss cells in its cell table's space; k_tile counts a voxel's misses and hits in 16 bits each:
+        // no voxel may collect 2^16 cells — at most (d_sub / dRho + 2) (d_sub / dZ + 2) nPhi cell centres fall into one)
+        const double cells_per_voxel = (std::ceil(P.d_sub / P.dRho) + 2) * (std::ceil(P.d_sub / P.dZ) + 2) * P.nPhi;
         h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
-                         (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 && P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho */ &&
-                         (P.explore ? P.nRho <= 256 : (long long)P.lv_nx * P.lv_ny * P.lv_nz < (1ll << 26));
+                         P.sec_tab <= 4u * MLM_SEC_THREADS && (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
+                         P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
+                         (P.explore ? P.nRho <= 256
+                                    : (((size_t)P.lv_nz << (2 * P.tile_sh)) <= 65536 && h->tile_lds_bytes <= 96u * 1024u && cells_per_voxel < 65536.0 &&
+                                       P.n_tiles < (1 << 24) && P.lv_nz < 65536));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         // (lean slots cost the worst-case scenes their batching — every frame overflowing its sector tables: 1.3k instead of
         // 4.4k frames/s on the "scatter" scene — so they are used on request, or when the full slots do not fit the device)
         if (const char *e = getenv("MLM_LEAN_SLOTS")) h->lean = h->use_sectors && atoi(e) != 0;
         if (getenv("MLM_DEBUG_CREATE"))
-            fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries, %u blocks), frame-local grid %d x %d x %d\n", (int)h->use_sectors,
-                    P.sec_lds_bytes, P.sec_tab, P.sec_combos, P.lv_nx, P.lv_ny, P.lv_nz);
+            fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries), frame-local grid %d x %d x %d in %d tiles of edge %d (%u bytes of LDS each)\n",
+                    (int)h->use_sectors, P.sec_lds_bytes, P.sec_tab, P.lv_nx, P.lv_ny, P.lv_nz, P.n_tiles, 1 << P.tile_sh, h->tile_lds_bytes);
         if (h->use_sectors) {
             if (P.explore)
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
             else
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+            if (!P.explore) HIPCHK(h, hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds_bytes));
         }
     }
     std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
@@ -1721,6 +1862,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         const long long b = nb(P.lv_nx) * nb(P.lv_ny) * nb(P.lv_nz);
         h->frame_block_bound = (size_t)std::min<long long>(b, 1ll << 30);
         if (const char *e = getenv("MLM_POOL_GROW")) h->pool_grow = atoi(e) != 0;
+        if (const char *e = getenv("MLM_GRAPH")) h->use_graph = atoi(e) != 0;
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
     std::memset(h->h_g, 0, sizeof(MlmGlobal));
@@ -1860,6 +2002,9 @@ int mlm_destroy(mlm_handle *h) {
     }
     for (int k = 0; k < MLM_SETS; ++k)
         if (h->stream_as[k]) hipStreamDestroy(h->stream_as[k]);
+    for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
+    if (h->h_stage) hipHostFree(h->h_stage);
+    if (h->upload_ev) hipEventDestroy(h->upload_ev);
     if (h->inputs_ready) hipEventDestroy(h->inputs_ready);
     if (h->fb_done) hipEventDestroy(h->fb_done);
     if (h->d_f32) hipFree(h->d_f32);
@@ -1958,8 +2103,15 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
     return MLM_OK;
 }
 
+static int integrate_u16_dev(mlm_handle *h, const uint16_t *img_dev, int width, int height, int row_stride, const int32_t *pixel_idx_dev,
+                             const int32_t *raw_dev, int n_idx, const double q_wb[4], const double t_wb[3]);
 int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int width, int height, int row_stride,
                                 const int32_t *pixel_idx_dev, int n_idx, const double q_wb[4], const double t_wb[3]) {
+    return integrate_u16_dev(h, img_dev, width, height, row_stride, pixel_idx_dev, nullptr, n_idx, q_wb, t_wb);
+}
+// raw_dev (with pixel_idx_dev): the listed pixels' depths by list position — the image itself is then never read
+static int integrate_u16_dev(mlm_handle *h, const uint16_t *img_dev, int width, int height, int row_stride, const int32_t *pixel_idx_dev,
+                             const int32_t *raw_dev, int n_idx, const double q_wb[4], const double t_wb[3]) {
     if (!h || !img_dev || width <= 0 || height <= 0 || row_stride < width || !q_wb || !t_wb) return MLM_ERR_INVALID;
     MLM_LOCK(h);
     if (pixel_idx_dev && n_idx < 0) return MLM_ERR_INVALID;
@@ -1974,6 +2126,7 @@ int mlm_integrate_depth_u16_dev(mlm_handle *h, const uint16_t *img_dev, int widt
     frame_setup(h, q_wb, t_wb, S.F);
     S.F.img = img_dev;
     S.F.pix = pixel_idx_dev;
+    S.F.raw = pixel_idx_dev ? raw_dev : nullptr;
     S.F.width = width;
     S.F.height = height;
     S.F.row_stride = row_stride;
@@ -1991,10 +2144,12 @@ int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int h
     const size_t n_px = (size_t)row_stride * height;
     int rc = ensure_img(h, S, n_px);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
+    hipStream_t up = upload_stream(h);
+    h->last_upload = up;
+    HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, up));
     if (pixel_idx) {
         if (n_idx < 0 || n_idx > h->lim.max_points) return MLM_ERR_CAPACITY;
-        HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
+        HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, up));
     }
     return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, row_stride, pixel_idx ? S.d_pix : nullptr, n_idx, q_wb,
                                        t_wb);
@@ -2025,15 +2180,26 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
     rc = ensure_img(h, S, n_px);
     if (rc) return rc;
     std::vector<int32_t> pix;
-    if (sampled && 2 * (size_t)h->cfg.sample_cnt <= (size_t)h->lim.max_points) {
+    if (sampled && h->cfg.sample_cnt > 0 && 2 * (size_t)h->cfg.sample_cnt <= (size_t)h->lim.max_points) {
         // project_depth, mlmap.cpp:311-349 (glibc rand(), v first, zeros skipped).  Only the sampled pixels are ever read
         // by the kernels, so only they travel: the host converts them (same float arithmetic as k_convert_f32_u16), a tiny
         // kernel drops them into the device image at their pixel positions.
-        std::vector<int32_t> raw;
+        // The indices and depths are staged in a pinned buffer of the handle (the call drains before it returns, so the buffer
+        // is free again at the next call) and travel in one copy; the kernels take the depths from that list.
         const size_t want = (size_t)h->cfg.sample_cnt;
+        if (h->stage_cap < 2 * want) {
+            if (h->h_stage) hipHostFree(h->h_stage);
+    if (h->upload_ev) hipEventDestroy(h->upload_ev);
+            h->h_stage = nullptr;
+            h->stage_cap = 0;
+            HIPCHK(h, hipHostMalloc((void **)&h->h_stage, 2 * want * sizeof(int32_t), hipHostMallocDefault));
+            h->stage_cap = 2 * want;
+        }
+        size_t n_s = 0;
         int cnt = 0;
         const int max_iter = 2 * h->cfg.sample_cnt;
-        while (pix.size() < want && cnt < max_iter) {
+        int32_t *st_pix = h->h_stage, *st_raw = h->h_stage + want;
+        while (n_s < want && cnt < max_iter) {
             cnt++;
             const size_t v = static_cast<size_t>(rand() % height);
             const size_t u = static_cast<size_t>(rand() % width);
@@ -2045,18 +2211,16 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
                 r = ((const uint16_t *)depth)[at];
             }
             if (r == 0) continue;
-            pix.push_back((int32_t)at);
-            raw.push_back(r);
+            st_pix[n_s] = (int32_t)at;
+            st_raw[n_s] = r;
+            ++n_s;
         }
-        if (!pix.empty()) {
-            hipStream_t st = h->stream_as[h->cur_set];
-            int32_t *d_raw = S.d_pix + h->lim.max_points / 2;
-            HIPCHK(h, hipMemcpyAsync(S.d_pix, pix.data(), pix.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            HIPCHK(h, hipMemcpyAsync(d_raw, raw.data(), raw.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_scatter_u16, dim3(grid_for(pix.size())), dim3(MLM_BLOCK), 0, st, S.d_img, S.d_pix, d_raw, (int)pix.size());
-            HIPCHK(h, hipStreamSynchronize(st)); // pix and raw are locals
+        if (n_s) {
+            hipStream_t up = upload_stream(h);
+            h->last_upload = up;
+            HIPCHK(h, hipMemcpyAsync(S.d_pix, h->h_stage, 2 * want * sizeof(int32_t), hipMemcpyHostToDevice, up));
         }
-        return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, width, S.d_pix, (int)pix.size(), qa, ta);
+        return integrate_u16_dev(h, S.d_img, width, height, width, S.d_pix, S.d_pix + want, (int)n_s, qa, ta);
     }
     std::vector<uint16_t> host_u16; // needed only by the sampler when the input is float
     if (is_f32) {
@@ -2084,6 +2248,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         }
     } else {
         HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
+        h->last_upload = h->stream_as[h->cur_set];
     }
     if (sampled) { // (sample count larger than half the point capacity: the general path)
         const uint16_t *img = is_f32 ? host_u16.data() : (const uint16_t *)depth;
@@ -2113,7 +2278,11 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
     }
     HIPCHK(h, hipSetDevice(h->device));
     MlmSlot &S = cur_slot(h, 0);
-    if (n > 0) HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
+    if (n > 0) {
+        hipStream_t up = upload_stream(h);
+        h->last_upload = up;
+        HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, up));
+    }
     S.F = MlmFrame{};
     frame_setup(h, q_wb, t_wb, S.F);
     S.F.pts = S.d_pts;

@@ -184,6 +184,36 @@ def test_config3_720p(mods):
             assert (st["n_hit_cells"], st["n_miss_cells"]) == (136766, 659944)
 
 
+def test_single_frames_go_through_the_graph(mods, monkeypatch):
+    """Synchronous single-frame calls (the reference's call pattern: one frame per depth callback, mlmap.cpp:463-507) are
+    submitted as one HIP-graph replay; the result is the general submission's (MLM_GRAPH=0) bit for bit — dense frames from a
+    host buffer, pixel lists, the callback's sampler — and the oracle's."""
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    frames = list(syn.stream(cfg, "room_jitter", "random", 8))
+    maps = []
+    for graph in ("1", "0"):
+        monkeypatch.setenv("MLM_GRAPH", graph)
+        gpu = MLMap(cfg, max_blocks=2048, max_batch=2)
+        for k, (img, (q, t)) in enumerate(frames):
+            if k % 3 == 2:
+                gpu.update_map(img, q, t, pixel_idx=np.arange(0, img.size, 7))
+            else:
+                gpu.update_map(img, q, t)
+        st = gpu.frame_stats()
+        assert (st["n_graph_launches"] >= len(frames) - 2) if graph == "1" else st["n_graph_launches"] == 0, st
+        maps.append(gpu.export_blocks())
+        gpu.close()
+    cpu = OracleMap(cfg)
+    for k, (img, (q, t)) in enumerate(frames):
+        if k % 3 == 2:
+            cpu.update_depth_indexed(img, np.arange(0, img.size, 7), q, t)
+        else:
+            cpu.update_depth(img, q, t)
+    compare_maps(maps[0], cpu.export_blocks(), "graph submission vs oracle")
+    compare_maps(maps[1], cpu.export_blocks(), "general submission vs oracle")
+
+
 def test_reference_sampler_via_pixel_list(mods):
     """The reference's 500-sample rand() path: the host draws the pixel list, both sides integrate it."""
     MLMap, OracleMap = mods
