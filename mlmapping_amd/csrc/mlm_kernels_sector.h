@@ -38,7 +38,8 @@
 
 #define MLM_SEC_THREADS 512
 #define MLM_SEC_WAVES (MLM_SEC_THREADS / 64)
-#define MLM_SEC_COLS 64     // distinct columns one k_bin_sectors block can feed (more: the frame falls back)
+#define MLM_SEC_COLS 256    // distinct columns one k_bin_sectors block can feed in the list modes: one per record at most (a pixel list
+                            // scatters over the image); a dense 32x8 pixel strip spans a handful: 64 entries bucketed by one wave
 #define MLM_SEC_CHUNKS 256  // chunk descriptors staged per pass of k_sector (a column of a VGA frame has ~50)
 #define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
 #define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
@@ -81,12 +82,13 @@ __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
+    constexpr uint32_t COLS = MODE == 0 ? 64u : (uint32_t)MLM_SEC_COLS; // entries of the block's column table
     __shared__ MlmNode s_node[256];
-    __shared__ uint32_t s_col_phi[MLM_SEC_COLS], s_col_cnt[MLM_SEC_COLS], s_col_off[MLM_SEC_COLS];
+    __shared__ uint32_t s_col_phi[COLS], s_col_cnt[COLS], s_col_off[COLS];
     __shared__ uint16_t s_rec_col[256], s_rec_pos[256];
-    __shared__ unsigned int s_cnt[4];
+    __shared__ unsigned int s_cnt[4], s_wsum[4];
     __shared__ unsigned int s_nnode, s_over;
-    if (threadIdx.x < MLM_SEC_COLS) {
+    if (threadIdx.x < COLS) {
         s_col_phi[threadIdx.x] = MLM_NIL;
         s_col_cnt[threadIdx.x] = 0;
     }
@@ -181,58 +183,66 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
     const unsigned int nn = s_nnode;
     if (threadIdx.x < nn) {
         const uint32_t ph = s_node[threadIdx.x].pad;
-        uint32_t e = (ph * 2654435761u) >> 26;
+        uint32_t e = (ph * 2654435761u) >> (MODE == 0 ? 26 : 24);
         bool placed = false;
-        for (int probe = 0; probe < MLM_SEC_COLS; ++probe) {
+        for (uint32_t probe = 0; probe < COLS; ++probe) {
             const uint32_t prev = atomicCAS(&s_col_phi[e], MLM_NIL, ph);
             if (prev == MLM_NIL || prev == ph) {
                 placed = true;
                 break;
             }
-            e = (e + 1) & (MLM_SEC_COLS - 1);
+            e = (e + 1) & (COLS - 1);
         }
         if (placed) {
             s_rec_col[threadIdx.x] = (uint16_t)e;
             s_rec_pos[threadIdx.x] = (uint16_t)atomicAdd(&s_col_cnt[e], 1u);
-        } else {
+        } else { // (dense tiles only: more than 64 columns in one 32x8 pixel strip)
             s_rec_col[threadIdx.x] = 0xFFFFu;
             s_over = 1;
         }
     }
     __syncthreads();
-    // one wave: offsets of the columns' runs inside the block's slice; after the records are stored (the other waves are done
-    // then and do not wait for it) one chunk descriptor per run, its place in the column's list from a returning atomic
+    // offsets of the columns' runs inside the block's slice; after the records are stored, one chunk descriptor per run, its
+    // place in the column's list from a returning atomic.  Dense tiles: one wave does it (the other waves are done once the
+    // records are stored and do not wait for the atomic); list modes: one table entry per thread.
     uint32_t run_cnt = 0, run_off = 0;
-    if (wid == 0) {
-        run_cnt = s_col_cnt[lane];
-        run_off = mlm_wave_incl_scan(run_cnt) - run_cnt;
-        s_col_off[lane] = run_off;
+    if (MODE == 0) {
+        if (wid == 0) {
+            run_cnt = s_col_cnt[lane];
+            run_off = mlm_wave_incl_scan(run_cnt) - run_cnt;
+            s_col_off[lane] = run_off;
+        }
+    } else {
+        run_cnt = s_col_cnt[threadIdx.x];
+        run_off = mlm_wave_incl_scan(run_cnt);
+        if (lane == 63) s_wsum[wid] = run_off;
+        __syncthreads();
+        for (int w = 0; w < wid; ++w) run_off += s_wsum[w];
+        run_off -= run_cnt;
+        s_col_off[threadIdx.x] = run_off;
     }
     __syncthreads();
     if (threadIdx.x < nn && s_rec_col[threadIdx.x] != 0xFFFFu) {
         const unsigned int e = s_rec_col[threadIdx.x];
         mlm_store_node(mlm_gp(P.bnodes) + ((size_t)blockIdx.x * 256u + s_col_off[e] + s_rec_pos[threadIdx.x]), s_node[threadIdx.x]);
     }
-    if (wid != 0) return;
-    bool over = false;
-    if (run_cnt) {
-        const uint32_t ph = s_col_phi[lane];
-        const unsigned int k = g_atomic_add(&mlm_gp(P.col_cnt)[ph], 1u);
-        if (k < P.chunk_cap)
-            *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)ph * P.chunk_cap + k)) = mlm_u32x2{blockIdx.x * 256u + run_off, run_cnt};
-        else
-            over = true;
-    }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         unsigned int pts = 0, oor = 0;
         for (unsigned int w = 0; w < 4; ++w) {
             pts += s_cnt[w] & 1023u;
             oor += s_cnt[w] >> 10;
         }
         *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)blockIdx.x) = mlm_u32x4{pts, oor, nn, 0u};
+        if (s_over) mlm_sector_fail(P, F);
     }
-    if (__any(over) || s_over) { // (s_over: more columns than the block's table holds, set before the last barrier)
-        if (lane == 0) mlm_sector_fail(P, F);
+    if (MODE == 0 && wid != 0) return;
+    if (run_cnt) {
+        const uint32_t ph = s_col_phi[MODE == 0 ? lane : (int)threadIdx.x];
+        const unsigned int k = g_atomic_add(&mlm_gp(P.col_cnt)[ph], 1u);
+        if (k < P.chunk_cap)
+            *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)ph * P.chunk_cap + k)) = mlm_u32x2{blockIdx.x * 256u + run_off, run_cnt};
+        else
+            mlm_sector_fail(P, F);
     }
 }
 
@@ -339,13 +349,15 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
 // so a miss cell keeps its first insertion time — point index * 256 + step of the ray, map_awareness.cpp:266-274 — instead
 // of a bit, and the map-dependent part is frontier mode's own (explore_stage_bc): the kernel ends with the unique hit list
 // (+ world voxels) and the unique miss list (cell, time, world voxel), no frame-local grid.
-template <bool EX>
-__global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
-                                                            int rho_s, unsigned long long n_bkt) {
-    MLM_SLOT_SETUP
-    const int phi = (int)blockIdx.x;
+// One azimuth column.  BIG: the second pass over the columns whose cell table overflowed in the first (k_sector_big: a table
+// of MlmDev::sec_tab_big entries, one workgroup per CU) — the first pass leaves such a column untouched and puts it on the
+// frame's overflow list instead of sending the whole frame to the cell-table path.
+template <bool EX, bool BIG>
+__device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFrame &F, const int phi, int tile_w, int n_bin_blocks, unsigned long long rho_m,
+                                                  int rho_s, unsigned long long n_bkt, int big_armed) {
+    constexpr int PER_MAX = BIG ? 8 : 4; // cell-table entries per thread
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && wid == 0) { // fold the per-block statistics of k_bin_sectors
+    if (!BIG && phi == 0 && wid == 0) { // fold the per-block statistics of k_bin_sectors
         unsigned int a = 0, b = 0, g = 0;
         for (int j = lane; j < n_bin_blocks; j += 64) {
             const mlm_u32x4 st = *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)j);
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     if (nch_all == 0) return; // nothing fell into this column (uniform)
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    const uint32_t TAB = P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
+    const uint32_t TAB = BIG ? P.sec_tab_big : P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
     const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, EX);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ int s_kr;
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[8];
-    __shared__ unsigned int s_fail, s_nouter;
+    __shared__ unsigned int s_fail, s_nouter, s_tab_full;
     for (uint32_t e = threadIdx.x; e < TAB; e += MLM_SEC_THREADS) {
         s_tab[e].key = MLM_NIL;
         s_tab[e].tmin = MLM_EMPTY_T;
@@ -407,6 +419,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     if (threadIdx.x == 0) {
         s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
         s_nouter = 0;
+        s_tab_full = 0;
     }
     __syncthreads();
     // Which world voxel a cell of this column falls into (get_global_idx / get_subbox_id of its centre moved by T_wa,
@@ -582,7 +595,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
                     mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int rho_t) {
                         const int e = mlm_sec_entry<true>(s_tab, tab_mask, key);
                         if (e < 0) {
-                            s_fail = 1;
+                            s_tab_full = 1;
                             return;
                         }
                         atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
@@ -602,17 +615,30 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     MLM_PHASE(0);
     for_records(0);
     __syncthreads();
+    if (s_tab_full) { // (uniform) nothing has left the workgroup yet
+        if (threadIdx.x == 0) {
+            if (!BIG && big_armed && !s_fail) { // (big_armed: k_sector_big follows this launch)
+                // the column keeps its chunk descriptors and waits for the pass with the large table
+                const unsigned int k = g_atomic_add(&mlm_gp(P.ctr)->n_ov, 1u);
+                mlm_gp(P.ov_list)[k] = (uint32_t)phi; // (k < nPhi: a column is listed once)
+            } else {
+                mlm_sector_fail(P, F);
+                mlm_gp(P.col_cnt)[phi] = 0;
+            }
+        }
+        return;
+    }
     MLM_PHASE(1);
     // ---- lists of the occupied entries (= the column's unique hits), of those with several kinds, of the ray starts;
     //      the column's reservations in the frame's lists (one round trip)
     //      The hit list is ordered by tile run (the hits of one tile are contiguous): rank inside the run from a returning
     //      LDS atomic, the runs' offsets from the same block scan that places the other lists.
-    const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread (per <= 4)
+    const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread (per <= PER_MAX)
     uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, multi, ray starts, hits of tile run `threadIdx.x`
     uint32_t w_refs = 0, w_subs = 0;  // references / ordered-kinds slots of this thread's multi-kind cells
-    uint32_t hk[4] = {0u, 0u, 0u, 0u}, hrun[4] = {0u, 0u, 0u, 0u}; // this thread's entries: tile run, rank among the run's hits
+    uint32_t hk[PER_MAX], hrun[PER_MAX]; // this thread's entries: tile run, rank among the run's hits
 #pragma unroll
-    for (uint32_t q = 0; q < 4; ++q) {
+    for (uint32_t q = 0; q < (uint32_t)PER_MAX; ++q) {
         if (q >= per) break;
         const MlmSecCell &c = s_tab[threadIdx.x * per + q];
         if (c.key == MLM_NIL) continue;
@@ -646,7 +672,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     {
         uint32_t o_multi = v[1], o_rays = v[2];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
+        for (uint32_t q = 0; q < (uint32_t)PER_MAX; ++q) {
             if (q >= per) break;
             const uint32_t e = threadIdx.x * per + q;
             MlmSecCell &c = s_tab[e];
@@ -938,13 +964,55 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu
     MLM_PHASE(6);
     MLM_PHASE_END
 }
+template <bool EX>
+__global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
+                                                            int rho_s, unsigned long long n_bkt, int big_armed) {
+    MLM_SLOT_SETUP
+    mlm_sector_column<EX, false>(P, F, (int)blockIdx.x, tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, big_armed);
+}
+// The columns on the overflow lists of a batch's frames, with the large cell table (dynamic LDS of MlmDev::sec_big_lds_bytes:
+// one workgroup per CU).  ONE launch per batch, a fixed number of workgroups that share all (frame, column) tasks.  A kernel
+// that needs most of a CU's LDS waits for the other streams' workgroups to leave, so the host launches it only while the
+// scene calls for it (it arms the pass when a frame had to fall back because of a full table, and disarms it after a
+// while without overflows); k_sector is told whether the pass follows (big_armed) — if not, a full table still sends the
+// frame to the cell-table path.  Scenes where every pixel lands
+// in a cell of its own ("scatter") overflow the small table in every column.
+template <bool EX>
+__global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector_big(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot_base,
+                                                                int n_frames, int tile_w, int n_bin_blocks, unsigned long long rho_m, int rho_s,
+                                                                unsigned long long n_bkt) {
+    __shared__ unsigned int s_first[65]; // exclusive prefix of the frames' overflow counts (n_frames <= 64)
+    if (threadIdx.x < 64) {
+        const int j = (int)threadIdx.x;
+        unsigned int c = 0;
+        if (j < n_frames) c = min(mlm_gp(slot_tab[slot_base + j].ctr)->n_ov, (unsigned int)slot_tab[slot_base + j].nPhi);
+        const unsigned int incl = mlm_wave_incl_scan(c);
+        s_first[j] = incl - c;
+        if (j == 63) s_first[64] = incl;
+    }
+    __syncthreads();
+    const unsigned int n_tasks = s_first[64];
+    for (unsigned int t = blockIdx.x; t < n_tasks; t += gridDim.x) { // (uniform)
+        int j = 0;
+        while (j + 1 < n_frames && s_first[j + 1] <= t) ++j;
+        const MlmDev &P = slot_tab[slot_base + j];
+        const MlmFrame &F = frame_tab[slot_base + j];
+        __syncthreads(); // (the previous column's shared state is no longer read)
+        mlm_sector_column<EX, true>(P, F, (int)mlm_gp(P.ov_list)[t - s_first[j]], tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, 0);
+    }
+}
 
 // One wave per multi-kind hit cell: order the cell's contributions by insertion time (= pixel order: a pixel contributes
 // to a cell at most once) and store their kinds in that order for k_chain_lanes.  Bitmap ranking as k_sort_contribs, but fed with
 // the records' 8x8 lane masks (eight row bytes per (record, kind) reference) instead of one key per contribution.
 // tile_w > 0: dense 8x8 pixel tiles of an image of that width; 0: linear work items (see MlmNode).  row_w, div_m, div_s:
 // rows of the ranking bitmap and the exact division by row_w.
-__global__ __launch_bounds__(MLM_BLOCK) void k_rank(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s) {
+#ifdef MLM_RANK_WPE // (experiment builds: make alt ALT_FLAGS=-DMLM_RANK_WPE=8)
+#define MLM_RANK_ATTR __attribute__((amdgpu_waves_per_eu(MLM_RANK_WPE)))
+#else
+#define MLM_RANK_ATTR
+#endif
+__global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s) {
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) unsigned long long s_rows[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
     __shared__ uint16_t s_pref[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
@@ -1605,4 +1673,19 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const
 // graph: its kernel arguments must not change from call to call)
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame_tab(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot) {
     mlm_apply_frame_body(slot_tab[slot], frame_tab[slot], 0, 0u, 0u);
+}
+// First and last node of the single-frame graph: the frame's parameters come from pinned host memory (one 128-thread block
+// copies them into the device-resident table and clears the slot's counters), the counters and the map-wide flags go back
+// the same way — kernel nodes with fixed arguments instead of memcpy / memset nodes.
+__global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_frame, MlmFrame *dev_frame, MlmCounters *ctr) {
+    const uint32_t *src = (const uint32_t *)host_frame;
+    uint32_t *dst = (uint32_t *)dev_frame, *c = (uint32_t *)ctr;
+    for (unsigned int i = threadIdx.x; i < sizeof(MlmFrame) / 4; i += blockDim.x) dst[i] = src[i];
+    for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) c[i] = 0u;
+}
+__global__ __launch_bounds__(128) void k_frame_epilogue(const MlmCounters *ctr, MlmCounters *host_ctr, const MlmGlobal *g, MlmGlobal *host_g) {
+    const uint32_t *src = (const uint32_t *)ctr;
+    uint32_t *dst = (uint32_t *)host_ctr;
+    for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < sizeof(MlmGlobal) / 4) ((uint32_t *)host_g)[threadIdx.x] = __hip_atomic_load((const uint32_t *)g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

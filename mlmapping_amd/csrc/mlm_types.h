@@ -13,7 +13,7 @@ struct MlmCounters {
     unsigned int u_hit;       // unique hit cells
     unsigned int chain_next;  // sector path: next ranked cell to hand to a wave of k_chain_lanes
     unsigned int n_oor;       // "point out range"
-    unsigned int rsv1;        // (unused)
+    unsigned int n_ov;        // sector path: columns whose cell table overflowed (MlmDev::ov_list), redone with the large table
     unsigned int n_miss_list; // entries of ml_cell (record_awareness only)
     unsigned int n_contrib;   // contributions stored for multi-type cells (segments of `contrib`)
     unsigned int n_multi;     // hit cells that received more than one kind of contribution
@@ -210,6 +210,8 @@ struct MlmDev {
     uint32_t *col_chunks;      // [nPhi][chunk_cap][2] {first record in `bnodes`, record count} per (bin block, column) run
     unsigned int chunk_cap;
     unsigned int sec_tab, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two)
+    unsigned int sec_tab_big, sec_big_lds_bytes; // ... of k_sector_big (0 entries: no second pass)
+    uint32_t *ov_list;         // [nPhi] columns whose cell table overflowed in k_sector (count: MlmCounters::n_ov)
     unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
     uint32_t *refs;            // [refs_cap][4] {lane mask lo, hi, tile origin (row << 11 | column), kind} per contribution group of a
                                // multi-kind cell

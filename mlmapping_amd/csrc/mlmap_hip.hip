@@ -161,17 +161,21 @@ struct mlm_handle {
     bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
     size_t frame_block_bound = 0; // most blocks one frame can create
     unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
+    unsigned int big_grid = 256;     // workgroups of k_sector_big per batch: one per CU (MLM_BIG_GRID)
+    int big_armed = 0;               // batches (single frames) for which the pass with the large cell table stays scheduled
+    int big_arm_len = 64;            // (MLM_BIG_ARM: 0 never schedules it)
     // Single frames in synchronous mode — the reference's own call pattern, one frame per depth callback (mlmap.cpp:463-507) — are
     // submitted as ONE replay of a HIP graph on the main stream (parameter upload, counter reset, six kernels, counter
     // read-back) instead of a dozen launches and copies spread over two streams: the call's cost is launch latency, not work.
     struct SingleGraph {
-        int mode, width, height, base;
+        int mode, width, height, base, big;
         unsigned int nb;
         size_t n_bkt;
         hipGraphExec_t exec;
     };
     std::vector<SingleGraph> graphs;
     bool use_graph = true;       // (MLM_GRAPH=0: always the general submission)
+    int graph_copies = 2;        // 0: issued eagerly around the graph, 2: as kernels of the graph reading / writing the pinned buffers; 1: the graph holds the parameter upload / counter reset / read-back as memcpy and memset nodes (MLM_GRAPH_COPIES=0: issued eagerly around it)
     hipStream_t last_upload = nullptr; // the stream the current call's inputs were uploaded on (run_slots orders Stage A behind it)
     hipEvent_t upload_ev = nullptr;
     long long n_graph_launches = 0;
@@ -269,6 +273,15 @@ inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 b
     }
 }
 
+// A frame's Stage A gave up on the sector path.  First answer: schedule the pass with the large cell table for the batches to come
+// (the usual reason is a column that overflowed the small table); if that pass was scheduled already, the scene does not fit
+// the sector path at all: the next batches go straight to the cell-table path for a while.
+inline void note_fallback(mlm_handle *h) {
+    if (h->P.sec_tab_big && h->big_arm_len > 0 && h->big_armed <= 0) h->big_armed = h->big_arm_len;
+    else h->sector_backoff = h->sector_backoff_len;
+}
+// lean slots of a sector-path handle outside frontier mode: the cell-table path's per-frame state exists once (alloc_slot)
+inline bool share_ct(const mlm_handle *h) { return h->lean && !h->P.explore; }
 int drain(mlm_handle *h, bool g_copied = false);
 int grow_pool(mlm_handle *h, size_t want);
 int ensure_free_blocks(mlm_handle *h, size_t need);
@@ -347,10 +360,12 @@ inline unsigned int book_grid(const MlmDev &P, const MlmFrame &F, int mode, int 
 
 // Stage A of a whole batch (slots base..base+n, same mode and image geometry) on stream_a: awareness raycast ->
 // unique hit lists (+odds) and miss masks.  One launch per kernel covers all n frames (blockIdx.z = slot).
-int launch_stage_a_batch(mlm_handle *h, int base, int n) {
+// on_main: on the main stream instead of the slot set's (lean slots whose cell-table state is shared: the frame runs alone,
+// its map-dependent kernels follow on the same stream).
+int launch_stage_a_batch(mlm_handle *h, int base, int n, bool on_main = false) {
     if (h->lean && n > 1) { // the cell-table path's large buffers exist once per handle: one frame at a time
         for (int j = 0; j < n; ++j) {
-            const int rc = launch_stage_a_batch(h, base + j, 1);
+            const int rc = launch_stage_a_batch(h, base + j, 1, on_main);
             if (rc) return rc;
         }
         return MLM_OK;
@@ -361,10 +376,10 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     const MlmFrame &F = S0.F;
     const int mode = S0.mode;
     const int set = base / (h->lim.max_batch);
-    hipStream_t st = h->stream_as[set];
+    hipStream_t st = on_main ? h->stream : h->stream_as[set];
     // the previous user of this slot set must have been consumed by the main stream
-    HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
-    if (!h->own_stream) {
+    if (!on_main) HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
+    if (!h->own_stream && !on_main) {
         // mlm_set_stream: device inputs (the *_dev entry points) may still be being produced by work the caller enqueued
         // on that stream; Stage A reads them on its own stream, so order it behind everything enqueued there so far.
         // (Costs the overlap of this batch's Stage A with the previous batch's Stage B+C; the handle's own stream,
@@ -376,7 +391,7 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
                              hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));
-    if (h->lean) HIPCHK(h, hipStreamWaitEvent(st, h->fb_done, 0)); // (the previous user of the shared buffers, on whatever stream)
+    if (h->lean && !on_main) HIPCHK(h, hipStreamWaitEvent(st, h->fb_done, 0)); // (the previous user of the shared buffers, on whatever stream)
     unsigned int nb = 0;
     if (F.n > 0) {
         nb = bin_grid(P, F, mode);
@@ -433,7 +448,7 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n) {
     if (P.explore)
         tlaunch(h, "k_ex_collect_misses", k_ex_collect_misses, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, slot_tab, h->d_frame_tab, base);
     if (h->lean) HIPCHK(h, hipEventRecord(h->fb_done, st));
-    HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
+    if (!on_main) HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
     return MLM_OK;
 }
 
@@ -476,12 +491,22 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         unsigned long long rm;
         int rs;
         div_magic((unsigned int)P.nRho, rm, rs);
+        const int big = P.sec_tab_big && h->big_armed > 0 ? 1 : 0; // the pass with the large cell table follows (see k_sector_big)
+        if (h->big_armed > 0) --h->big_armed;
         if (P.explore)
             tlaunch(h, "k_sector", k_sector<true>, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
-                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull);
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
         else
             tlaunch(h, "k_sector", k_sector<false>, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
-                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+        if (big) { // the columns whose cell table overflowed, with the large table (a few workgroups per frame walk the list)
+            if (P.explore)
+                tlaunch(h, "k_sector_big", k_sector_big<true>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, n,
+                        mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull);
+            else
+                tlaunch(h, "k_sector_big", k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, n,
+                        mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
+        }
         tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->rank_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
                 mode == 0 ? F.width : 0, row_w, dm, ds);
         // blocks per frame: about 400 ranked cells per block in a batch (a lane that finishes a chain draws the next cell; each
@@ -542,6 +567,7 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_rays = nr;
     h->stats.n_spec_replays = h->n_spec_miss;
     h->stats.n_sector_fallbacks = h->n_sector_fallbacks;
+    if (c.n_ov > 0) h->big_armed = h->big_arm_len; // the scene still overflows the small cell table: keep the second pass scheduled
     h->stats.logit_bit_exact = h->P.logit_exact;
     h->stats.n_pool_grows = h->n_pool_grows;
     h->stats.n_graph_launches = h->n_graph_launches;
@@ -762,7 +788,7 @@ int explore_redo_overflows(mlm_handle *h, int base, int n) {
         MlmSlot &S = h->slots[(size_t)(base + j)];
         if (!S.sector || !S.h_ctr->sector_overflow) continue;
         h->n_sector_fallbacks++;
-        h->sector_backoff = h->sector_backoff_len;
+        note_fallback(h);
         S.sector = false;
         const int rc = launch_stage_a_batch(h, base + j, 1);
         if (rc) return rc;
@@ -806,6 +832,24 @@ int submit_batch(mlm_handle *h, int base, int n) {
         h->slots[(size_t)(base + j)].sector = sectors;
         h->slots[(size_t)(base + j)].keys_exact = false;
         h->slots[(size_t)(base + j)].retry_done = 0;
+    }
+    if (!sectors && share_ct(h)) {
+        // the cell-table path's per-frame state exists once: every frame runs alone, Stage A and the two map-dependent kernels
+        // back to back on the main stream (behind whatever the frames before it left there)
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->set_free[set], 0));
+        for (int j = 0; j < n; ++j) {
+            MlmSlot &S = h->slots[(size_t)(base + j)];
+            rc = launch_stage_a_batch(h, base + j, 1, true);
+            if (rc) return rc;
+            launch_stage_bc(h, S, h->hit_n_bkt);
+            HIPCHK(h, hipMemcpyAsync(S.h_ctr, S.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream)); // (before the next frame's Stage A
+            h->pending.push_back(&S);                                                                              // reuses nothing of it, but for symmetry)
+        }
+        HIPCHK(h, hipMemcpyAsync(h->h_gb[set], h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipEventRecord(h->batch_done[set], h->stream));
+        HIPCHK(h, hipEventRecord(h->set_free[set], h->stream));
+        h->set_pending[set] = n;
+        return MLM_OK;
     }
     {
         Timed t(h, h->stream_as[set], "stage_a_batch");
@@ -904,8 +948,18 @@ int drain(mlm_handle *h, bool g_copied) {
                     } else {
                         tlaunch(h, "k_apply_frame", k_apply_frame, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, R->P, R->F, R->keys_exact ? 1 : 0, 0u, 0u);
                     }
-                } else
+                } else {
+                    if (share_ct(h)) { // (its Stage A outputs have been overwritten by the frames behind it)
+                        rc = launch_stage_a_batch(h, (int)(R - h->slots.data()), 1, true);
+                        if (rc) return rc;
+                        if (R->keys_exact) { // (its exact keys went with them)
+                            HIPCHK(h, hipMemcpyAsync(R->h_ctr, R->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+                            HIPCHK(h, hipStreamSynchronize(h->stream));
+                            R->keys_exact = false;
+                        }
+                    }
                     launch_stage_bc(h, *R, R->keys_exact ? 0 : h->hit_n_bkt);
+                }
                 HIPCHK(h, hipMemcpyAsync(R->h_ctr, R->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
             }
             continue;
@@ -919,7 +973,7 @@ int drain(mlm_handle *h, bool g_copied) {
                     (size_t)h->hit_pol._M_next_resize, h->hit_n_bkt, h->pending.size(), S.h_ctr->sector_overflow);
         h->h_g->fail_frame = 0x7FFFFFFF;
         HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-        bool any_sector = false; // (async mode holds up to three batches: a cell-table batch may be followed by sector batches)
+        bool any_sector = share_ct(h); // (async mode holds up to three batches: a cell-table batch may be followed by sector batches)
         for (const MlmSlot *R : h->pending) any_sector = any_sector || R->sector;
         if (any_sector) {
             // Sector path: the frames in flight were binned into buckets with the bucket count of their submission, which
@@ -928,9 +982,14 @@ int drain(mlm_handle *h, bool g_copied) {
             // which k_sector never writes for a frame of the sector path).
             for (size_t j = 0; j < h->pending.size(); ++j) {
                 MlmSlot &R = *h->pending[j];
-                if (R.h_ctr->sector_overflow) {
-                    h->n_sector_fallbacks++;
-                    h->sector_backoff = h->sector_backoff_len;
+                // a sector frame whose Stage A gave up, or (shared cell-table state) a cell-table frame: the frames behind it
+                // have run their Stage A over the same buffers since — it takes the cell-table path from its Stage A on, alone
+                if (j == 0 && !R.h_ctr->sector_overflow) h->n_spec_miss++;
+                if (R.h_ctr->sector_overflow || (!R.sector && share_ct(h))) {
+                    if (R.sector) {
+                        h->n_sector_fallbacks++;
+                        note_fallback(h);
+                    }
                     const int si = (int)(&R - h->slots.data());
                     const int set = si / (h->lim.max_batch);
                     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -944,8 +1003,6 @@ int drain(mlm_handle *h, bool g_copied) {
                     HIPCHK(h, hipStreamSynchronize(h->stream));
                     HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
                     R.sector = false;
-                } else if (j == 0) {
-                    h->n_spec_miss++;
                 }
                 rc = check_queues(h, R);
                 if (rc) return rc;
@@ -958,8 +1015,31 @@ int drain(mlm_handle *h, bool g_copied) {
                     tlaunch(h, "k_apply_frame", k_apply_frame, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1, 0u, 0u);
                 else
                     launch_stage_bc(h, R, 0);
-                HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+                // The frame is finished before the next one starts (this is the rare path): a sector frame that ran out of blocks
+                // gets the pool grown and its retry list launched right here, so that a cell-table frame behind it — whose
+                // Stage A state may be shared with the frames behind IT — never has to be replayed once more.
+                for (;;) {
+                    HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    HIPCHK(h, hipGetLastError());
+                    if (!((h->h_g->err & 1u) && h->pool_grow && R.sector)) break;
+                    const unsigned int n_retry = std::min(R.h_ctr->mvox_cnt[2][0], R.P.rec_cap);
+                    if (n_retry <= R.retry_done) break; // (nothing of this frame is waiting: reported by check_queues below)
+                    rc = grow_pool(h, (size_t)h->P.max_blocks + 2 * h->frame_block_bound);
+                    if (rc) return rc;
+                    h->h_g->fail_frame = 0x7FFFFFFF;
+                    HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
+                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(64), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1, R.retry_done, n_retry);
+                    R.retry_done = n_retry;
+                }
+                if (h->h_g->err) { // (pool full with growth off, a queue overflow)
+                    rc = check_queues(h, R);
+                    if (rc) return rc;
+                }
             }
+            h->h_g->fail_frame = 0x7FFFFFFF; // (every pending frame is applied)
+            HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
             continue; // (the loop's synchronisation confirms them)
         }
         h->n_spec_miss++;
@@ -1059,9 +1139,11 @@ int submit_single_graph(mlm_handle *h, int base) {
         h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
         return MLM_ERR_CAPACITY;
     }
+    const int big = P.sec_tab_big && h->big_armed > 0 ? 1 : 0;
+    if (h->big_armed > 0) --h->big_armed;
     mlm_handle::SingleGraph *G = nullptr;
     for (auto &g : h->graphs)
-        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.n_bkt == h->hit_n_bkt) G = &g;
+        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
     if (!G) {
         if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
             for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
@@ -1069,8 +1151,13 @@ int submit_single_graph(mlm_handle *h, int base) {
         }
         hipStream_t st = h->stream;
         HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, sizeof(MlmFrame), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemsetAsync(h->d_ctr_all + base, 0, sizeof(MlmCounters), st);
+        hipError_t e = hipSuccess;
+        if (h->graph_copies == 1) {
+            e = hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, sizeof(MlmFrame), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemsetAsync(h->d_ctr_all + base, 0, sizeof(MlmCounters), st);
+        } else if (h->graph_copies == 2) {
+            hipLaunchKernelGGL(k_frame_prologue, dim3(1), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
+        }
         if (e == hipSuccess) {
             if (S.mode == 0) hipLaunchKernelGGL(k_bin_sectors<0>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
             else if (S.mode == 1) hipLaunchKernelGGL(k_bin_sectors<1>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
@@ -1081,15 +1168,23 @@ int submit_single_graph(mlm_handle *h, int base) {
             div_magic((unsigned int)row_w, dm, ds);
             div_magic((unsigned int)P.nRho, rm, rs);
             hipLaunchKernelGGL(k_sector<false>, dim3((unsigned int)P.nPhi, 1, 1), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                               S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
+                               S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+            if (big)
+                hipLaunchKernelGGL(k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1,
+                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
             hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
             hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
             hipLaunchKernelGGL(k_tile, dim3((unsigned int)P.n_tiles, 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
             hipLaunchKernelGGL(k_apply_frame_tab, dim3(256), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, sizeof(MlmCounters), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st);
+        if (h->graph_copies == 1) {
+            if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, sizeof(MlmCounters), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st);
+        } else if (h->graph_copies == 2 && e == hipSuccess) {
+            hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(128), 0, st, (const MlmCounters *)(h->d_ctr_all + base), h->h_ctr_all + base, (const MlmGlobal *)h->P.g, h->h_g);
+            e = hipGetLastError();
+        }
         hipGraph_t graph = nullptr;
         const hipError_t e2 = hipStreamEndCapture(st, &graph);
         if (e != hipSuccess || e2 != hipSuccess || !graph) {
@@ -1104,11 +1199,19 @@ int submit_single_graph(mlm_handle *h, int base) {
             h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
             return MLM_ERR_HIP;
         }
-        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, nb, h->hit_n_bkt, exec});
+        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, h->hit_n_bkt, exec});
         G = &h->graphs.back();
     }
     h->h_frame_tab[base] = S.F;
+    if (h->graph_copies == 0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, sizeof(MlmFrame), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, sizeof(MlmCounters), h->stream));
+    }
     HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
+    if (h->graph_copies == 0) {
+        HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+    }
     h->n_graph_launches++;
     h->pending.push_back(&S);
     h->set_pending[set] = 1;
@@ -1235,6 +1338,18 @@ int ensure_img(mlm_handle *h, MlmSlot &S, size_t n_px) {
     S.d_img = nullptr;
     HIPCHK(h, hipMalloc((void **)&S.d_img, n_px * sizeof(uint16_t)));
     S.img_cap = n_px;
+    return MLM_OK;
+}
+
+// device staging of a slot's pixel list / point list, allocated at first use (mlm_limits.max_points entries)
+int ensure_pix(mlm_handle *h, MlmSlot &S) {
+    if (S.d_pix) return MLM_OK;
+    HIPCHK(h, hipMalloc((void **)&S.d_pix, std::max<size_t>((size_t)h->lim.max_points, 1) * sizeof(int32_t)));
+    return MLM_OK;
+}
+int ensure_pts(mlm_handle *h, MlmSlot &S) {
+    if (S.d_pts) return MLM_OK;
+    HIPCHK(h, hipMalloc((void **)&S.d_pts, std::max<size_t>((size_t)h->lim.max_points, 1) * 3 * sizeof(double)));
     return MLM_OK;
 }
 
@@ -1467,14 +1582,26 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     const size_t NC = (size_t)P.nCells;
     S.h_ctr = h->h_ctr_all + index;
     P.ctr = h->d_ctr_all + index;
-    if ((rc = dev_alloc(h, &P.cs, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.miss_bits, (size_t)MLM_MISS_COPIES * P.nMissWords))) return rc;
+    // Lean slots of a sector-path handle (not frontier mode, whose own map-dependent part reads them per frame): the per-frame
+    // state only the cell-table path keeps — per-cell records, miss-mask copies, queues, the voxel addresses of its two
+    // map-dependent kernels — exists ONCE, in slot 0's name; a frame that takes that path (a fall-back, a batch submitted while
+    // the sector path backs off, a frame too wide for it) runs alone from its Stage A to the end of its apply kernel.
+    const bool share = h->lean && !P.explore, own = !share || index == 0;
+#define MLM_CT_ALLOC(field, count)                                                                                    \
+    do {                                                                                                              \
+        if (!own) P.field = h->slots[0].P.field;                                                                      \
+        else if ((rc = dev_alloc(h, &P.field, (count)))) return rc;                                                   \
+    } while (0)
+    MLM_CT_ALLOC(cs, NC);
+    MLM_CT_ALLOC(miss_bits, (size_t)MLM_MISS_COPIES * P.nMissWords);
     if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
     if ((rc = dev_alloc(h, &P.mt_rec, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.mt_big, NC))) return rc;
+    MLM_CT_ALLOC(mt_big, NC);
     P.touch_cap = (unsigned int)NC;
-    if ((rc = dev_alloc(h, &P.touched, (size_t)MLM_RAY_LISTS * P.touch_cap))) return rc;
-    P.nb_cap = (unsigned int)((size_t)h->lim.max_points / 64 + 1024);
+    MLM_CT_ALLOC(touched, (size_t)MLM_RAY_LISTS * P.touch_cap);
+    size_t max_contrib = 0; // most contributions one frame can make
+    // (256 work items per bin block; image edges and short lists add blocks: twice the quotient + 256)
+    P.nb_cap = (unsigned int)((size_t)h->lim.max_points / 128 + 256);
     if ((rc = dev_alloc(h, &P.blk_stats, 4 * (size_t)P.nb_cap))) return rc;
     // (lean: k_bin_sectors writes at most 256 records per block; the cell-table path's buffers are shared, mlm_create)
     if ((rc = dev_alloc(h, &P.bnodes, (size_t)P.nb_cap * (h->lean ? 256u : P.node_lds)))) return rc;
@@ -1488,6 +1615,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
             dmax = std::max(dmax, d - 1);
         }
         const size_t cap = (size_t)h->lim.max_points * (size_t)(1 + 2 * dmax);
+        max_contrib = cap;
         if (cap > 0xFFFFFFF0ull) {
             h->err = "contribution buffer too large";
             return MLM_ERR_UNSUPPORTED;
@@ -1504,6 +1632,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         P.node_cap = (unsigned int)(cap / MLM_RAY_LISTS + 4096);
         if (!h->lean && (rc = dev_alloc(h, &P.nodes, (size_t)MLM_RAY_LISTS * P.node_cap))) return rc;
     }
+    if ((rc = dev_alloc(h, &P.ov_list, (size_t)P.nPhi))) return rc;
     P.chunk_cap = P.nb_cap; // a column can at most get one run from every bin block
     if ((rc = dev_alloc(h, &P.col_cnt, (size_t)P.nPhi))) return rc;
     if ((rc = dev_alloc(h, &P.col_chunks, h->use_sectors ? 2 * (size_t)P.nPhi * P.chunk_cap : 2))) return rc;
@@ -1525,7 +1654,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         if ((rc = dev_alloc(h, &P.sbkt, (size_t)P.sbkt_cap))) return rc;
         HIPCHK(h, hipMemset(P.sbkt, 0xFF, (size_t)P.sbkt_cap * sizeof(unsigned long long)));
     }
-    P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, 2 * (size_t)h->lim.max_points); // (more groups than that: cell-table path)
+    P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, max_contrib); // (a (record, kind) reference stands for at least one contribution)
     if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? 4 * (size_t)P.refs_cap : 4))) return rc;
     if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
     HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
@@ -1536,19 +1665,19 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if ((rc = dev_alloc(h, &P.hl_base, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_cnt, NC))) return rc;
     if ((rc = dev_alloc(h, &P.hl_vt, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_arr, NC))) return rc;
+    MLM_CT_ALLOC(hl_arr, NC);
     if ((rc = dev_alloc(h, &P.hl_key, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_next, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_vox, NC))) return rc;
+    MLM_CT_ALLOC(hl_next, NC);
+    MLM_CT_ALLOC(hl_vox, NC);
     if ((rc = dev_alloc(h, &P.hl_bkt, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_bkey, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_cid, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_slot, NC))) return rc;
+    MLM_CT_ALLOC(hl_bkey, NC);
+    MLM_CT_ALLOC(hl_cid, NC);
+    MLM_CT_ALLOC(hl_slot, NC);
     P.mc_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 4096);
-    if ((rc = dev_alloc(h, &P.mc_bkey, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
-    if ((rc = dev_alloc(h, &P.mc_cid, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
-    if ((rc = dev_alloc(h, &P.mc_slot, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
-    if ((rc = dev_alloc(h, &P.mc_vox, (size_t)MLM_RAY_LISTS * P.mc_cap))) return rc;
+    MLM_CT_ALLOC(mc_bkey, (size_t)MLM_RAY_LISTS * P.mc_cap);
+    MLM_CT_ALLOC(mc_cid, (size_t)MLM_RAY_LISTS * P.mc_cap);
+    MLM_CT_ALLOC(mc_slot, (size_t)MLM_RAY_LISTS * P.mc_cap);
+    MLM_CT_ALLOC(mc_vox, (size_t)MLM_RAY_LISTS * P.mc_cap);
     if ((rc = dev_alloc(h, &P.ml_cell, P.record_awareness ? NC : 1))) return rc;
     if (P.explore) {
         if ((rc = dev_alloc(h, &P.start_t, NC))) return rc;
@@ -1566,15 +1695,14 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         HIPCHK(h, hipMemset(P.miss_t, 0xFF, NC * sizeof(uint32_t)));
     }
     P.mvox_cap = (unsigned int)((size_t)P.nMissWords * 32 / MLM_RAY_LISTS + 512);
-    if ((rc = dev_alloc(h, &P.miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap))) return rc;
-    {
+    MLM_CT_ALLOC(miss_vox, (size_t)MLM_RAY_LISTS * P.mvox_cap);
+#undef MLM_CT_ALLOC
+    if (own) {
         std::vector<MlmCell> init(NC, MlmCell{MLM_EMPTY_T, 0u, 0u, MLM_NIL});
         HIPCHK(h, hipMemcpy(P.cs, init.data(), NC * sizeof(MlmCell), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)MLM_MISS_COPIES * P.nMissWords * sizeof(uint32_t)));
     }
-    HIPCHK(h, hipMemset(P.miss_bits, 0, (size_t)MLM_MISS_COPIES * P.nMissWords * sizeof(uint32_t)));
-    if ((rc = ensure_img(h, S, (size_t)h->lim.max_points))) return rc;
-    if ((rc = dev_alloc(h, &S.d_pix, (size_t)h->lim.max_points))) return rc;
-    if ((rc = dev_alloc(h, &S.d_pts, (size_t)h->lim.max_points * 3))) return rc;
+    // (the staging of host images, pixel lists and point lists is allocated by the calls that use it: ensure_img / ensure_list)
     S.alloc_end = h->allocs.size();
     return MLM_OK;
 }
@@ -1772,6 +1900,15 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
         P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
         {
+            // second pass for the columns that overflow that table: the largest table (up to 4096 entries = 8 per thread) that
+            // fits a CU's LDS — an S1 column has 2 665 cells in all, so no scene overflows it there
+            unsigned int big = 4096;
+            while (big > P.sec_tab && mlm_sec_lds(big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total > 159u * 1024u) big >>= 1;
+            if (const char *e = getenv("MLM_SEC_TAB_BIG")) big = (unsigned int)atoi(e); // (0 or <= MLM_SEC_TAB: no second pass)
+            P.sec_tab_big = big > P.sec_tab && big <= 8u * MLM_SEC_THREADS ? big : 0u;
+            P.sec_big_lds_bytes = P.sec_tab_big ? mlm_sec_lds(P.sec_tab_big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total : 0u;
+        }
+        {
             // frame-local voxel grid: the awareness cylinder (radius nRho*dRho, height nZ*dZ) plus four voxels each side, cut
             // into tiles over its whole height: the largest edge (8, 4, 2, 1 voxels) whose voxels k_tile can count in LDS
             const double R = P.nRho * P.dRho;
@@ -1799,6 +1936,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         // (lean slots cost the worst-case scenes their batching — every frame overflowing its sector tables: 1.3k instead of
         // 4.4k frames/s on the "scatter" scene — so they are used on request, or when the full slots do not fit the device)
+        h->lean = h->use_sectors;
         if (const char *e = getenv("MLM_LEAN_SLOTS")) h->lean = h->use_sectors && atoi(e) != 0;
         if (getenv("MLM_DEBUG_CREATE"))
             fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries), frame-local grid %d x %d x %d in %d tiles of edge %d (%u bytes of LDS each)\n",
@@ -1809,6 +1947,12 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             else
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
             if (!P.explore) HIPCHK(h, hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds_bytes));
+            if (P.sec_tab_big) {
+                if (P.explore)
+                    HIPCHK(h, hipFuncSetAttribute((const void *)k_sector_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_big_lds_bytes));
+                else
+                    HIPCHK(h, hipFuncSetAttribute((const void *)k_sector_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_big_lds_bytes));
+            }
         }
     }
     std::vector<double> cphi(P.nPhi), sphi(P.nPhi);
@@ -1863,6 +2007,9 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         h->frame_block_bound = (size_t)std::min<long long>(b, 1ll << 30);
         if (const char *e = getenv("MLM_POOL_GROW")) h->pool_grow = atoi(e) != 0;
         if (const char *e = getenv("MLM_GRAPH")) h->use_graph = atoi(e) != 0;
+        if (const char *e = getenv("MLM_BIG_GRID")) h->big_grid = (unsigned int)std::max(1, atoi(e));
+        if (const char *e = getenv("MLM_BIG_ARM")) h->big_arm_len = std::max(0, atoi(e));
+        if (const char *e = getenv("MLM_GRAPH_COPIES")) h->graph_copies = atoi(e);
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
     std::memset(h->h_g, 0, sizeof(MlmGlobal));
@@ -1990,8 +2137,11 @@ int mlm_destroy(mlm_handle *h) {
     hipDeviceSynchronize();
     for (void *p : h->allocs)
         if (p) hipFree(p);
-    for (auto &S : h->slots)
+    for (auto &S : h->slots) {
         if (S.d_img) hipFree(S.d_img);
+        if (S.d_pix) hipFree(S.d_pix);
+        if (S.d_pts) hipFree(S.d_pts);
+    }
     if (h->h_ctr_all) hipHostFree(h->h_ctr_all);
     if (h->h_frame_tab) hipHostFree(h->h_frame_tab);
     for (int k = 0; k < MLM_SETS; ++k) {
@@ -2149,6 +2299,7 @@ int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int h
     HIPCHK(h, hipMemcpyAsync(S.d_img, img, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, up));
     if (pixel_idx) {
         if (n_idx < 0 || n_idx > h->lim.max_points) return MLM_ERR_CAPACITY;
+        if ((rc = ensure_pix(h, S))) return rc;
         HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, up));
     }
     return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, row_stride, pixel_idx ? S.d_pix : nullptr, n_idx, q_wb,
@@ -2215,6 +2366,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
             st_raw[n_s] = r;
             ++n_s;
         }
+        if ((rc = ensure_pix(h, S))) return rc;
         if (n_s) {
             hipStream_t up = upload_stream(h);
             h->last_upload = up;
@@ -2262,6 +2414,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
             if (img[v * (size_t)width + u] == 0) continue;
             pix.push_back((int32_t)(v * (size_t)width + u));
         }
+        if ((rc = ensure_pix(h, S))) return rc;
         if (!pix.empty())
             HIPCHK(h, hipMemcpyAsync(S.d_pix, pix.data(), pix.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
         HIPCHK(h, hipStreamSynchronize(h->stream_as[h->cur_set])); // pix is a local
@@ -2278,6 +2431,10 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
     }
     HIPCHK(h, hipSetDevice(h->device));
     MlmSlot &S = cur_slot(h, 0);
+    {
+        const int rc = ensure_pts(h, S);
+        if (rc) return rc;
+    }
     if (n > 0) {
         hipStream_t up = upload_stream(h);
         h->last_upload = up;

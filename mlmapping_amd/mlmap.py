@@ -242,7 +242,7 @@ class MLMap:
         d = np.ascontiguousarray(depth)
         is_f32 = int(d.dtype == np.float32)
         if not is_f32:
-            d = d.astype(np.uint16)
+            d = np.ascontiguousarray(d, dtype=np.uint16)  # (no copy when it is uint16 already)
         out = np.empty(7)
         self._chk(self._L.mlm_integrate_callback(self._h, _p(d), is_f32, d.shape[1], d.shape[0], float(t_img),
                                                  _p(_f64(odom_p)), _p(_f64(odom_q)), _p(_f64(odom_v)), float(t_odom),

@@ -10,6 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def note(rank, what):
+    print(f"[merge worker {rank}] {what}", file=sys.stderr, flush=True)
+
+
 def dump(m, path):
     b = m.export_blocks()
     np.savez(path, keys=b["keys"], log_odds=b["log_odds"], occ=b["occ"])
@@ -34,16 +38,22 @@ def main():
     frames = list(syn.stream(cfg, "room_jitter", "random", 6, seed=42 + rank))
     for img, (q, t) in frames[:3]:
         m.update_map(img, q, t)
+        note(rank, f"frame integrated: {m.frame_stats()}")
     dump(m, os.path.join(out, f"own1_{rank}.npz"))
+    note(rank, "first merge")
     merge_device_maps(m, load_back=True)
     dump(m, os.path.join(out, f"merged1_{rank}.npz"))
+    note(rank, "merged map loaded back")
     for img, (q, t) in frames[3:]:
         m.update_map(img, q, t)
+        note(rank, f"frame integrated: {m.frame_stats()}")
     dump(m, os.path.join(out, f"own2_{rank}.npz"))
+    note(rank, "second merge")
     merge_device_maps(m, load_back=True)
     dump(m, os.path.join(out, f"merged2_{rank}.npz"))
     merge_device_maps(m, load_back=True)  # nothing new observed: unchanged
     dump(m, os.path.join(out, f"merged3_{rank}.npz"))
+    note(rank, "done")
     dist.barrier()
     dist.destroy_process_group()
     m.close()

@@ -373,10 +373,12 @@ def test_bench_launcher_contract_two_ranks():
 
 
 def test_lean_slots_when_the_full_ones_do_not_fit(mods, monkeypatch):
-    """mlm_create retries with lean slots (the cell-table path's large buffers once per handle) when the full slots do not fit
-    the device — simulated here: the first attempt fails at the third slot.  The handle then works as usual, fall-backs to the
-    cell-table path (forced on every second frame) included."""
+    """Full slots (MLM_LEAN_SLOTS=0: every frame slot with cell-table state of its own) are the exception now; mlm_create
+    falls back to lean slots (that state once per handle) when the full ones do not fit the device — simulated here: the first
+    attempt fails at the third slot.  The handle then works as usual, fall-backs to the cell-table path (forced on every
+    second frame) included."""
     MLMap, OracleMap = mods
+    monkeypatch.setenv("MLM_LEAN_SLOTS", "0")
     monkeypatch.setenv("MLM_DEBUG_FAIL_SLOT", "2")
     monkeypatch.setenv("MLM_SEC_FAIL_EVERY", "2")
     monkeypatch.setenv("MLM_SEC_BACKOFF", "0")

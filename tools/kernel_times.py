@@ -16,6 +16,10 @@ if os.environ.get("MLM_BENCH_NO_RAYCAST"):  # diagnostic: hits without rays
 nb = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 8
 B = int(os.environ.get("MLM_KT_BATCH", "32"))
 frames, q, t = make_inputs(cfg, B, B * (nb + 2), seed=42)
+if "scatter" in sys.argv:  # the worst-case scene: every pixel in a cell of its own
+    import numpy as np
+    from mlmapping_amd import synthetic as syn
+    frames = np.stack([f for f, _ in syn.stream(cfg, "scatter", "smooth", B)])
 m = MLMap(cfg, max_blocks=65536 if cfg is S3 else 32768, max_points=cfg.width * cfg.height, max_batch=B)
 m.set_async(False)
 for k in range(2):
