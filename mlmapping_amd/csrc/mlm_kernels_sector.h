@@ -247,10 +247,13 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
 }
 
 // find (or with INSERT create) the table entry of a column-local cell key; -1: table full
+// (an insertion gives up after 96 probes: at the load a table is meant for, probe sequences are a handful long — a table that
+// makes them longer is as good as full, and every further probe of a full table is a wasted LDS atomic)
 template <bool INSERT>
 __device__ __forceinline__ int mlm_sec_entry(MlmSecCell *tab, uint32_t tab_mask, uint32_t key) {
     uint32_t e = ((key * 2654435761u) >> 12) & tab_mask;
-    for (uint32_t probe = 0; probe <= tab_mask; ++probe) {
+    const uint32_t max_probe = INSERT ? min(tab_mask, 95u) : tab_mask;
+    for (uint32_t probe = 0; probe <= max_probe; ++probe) {
         if (INSERT) {
             const uint32_t prev = atomicCAS(&tab[e].key, MLM_NIL, key);
             if (prev == MLM_NIL || prev == key) return (int)e;
@@ -547,6 +550,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             }
             __syncthreads();
             for (uint32_t r = threadIdx.x; r < total; r += MLM_SEC_THREADS) {
+                if (pass == 0 && *(volatile unsigned int *)&s_tab_full) break; // (the column is given up: nothing more to book)
                 const uint32_t gi = rec_index(r, n_staged);
                 const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + gi);
                 const mlm_u32x4 a = *(const MLM_GLOBAL mlm_u32x4 *)rp;

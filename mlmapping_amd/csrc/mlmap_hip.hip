@@ -163,6 +163,7 @@ struct mlm_handle {
     unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
     unsigned int big_grid = 256;     // workgroups of k_sector_big per batch: one per CU (MLM_BIG_GRID)
     int big_armed = 0;               // batches (single frames) for which the pass with the large cell table stays scheduled
+    int big_armed_from = 0;          // first frame (sequence number; frontier mode: frame number) submitted after it was scheduled
     int big_arm_len = 64;            // (MLM_BIG_ARM: 0 never schedules it)
     // Single frames in synchronous mode — the reference's own call pattern, one frame per depth callback (mlmap.cpp:463-507) — are
     // submitted as ONE replay of a HIP graph on the main stream (parameter upload, counter reset, six kernels, counter
@@ -276,9 +277,15 @@ inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 b
 // A frame's Stage A gave up on the sector path.  First answer: schedule the pass with the large cell table for the batches to come
 // (the usual reason is a column that overflowed the small table); if that pass was scheduled already, the scene does not fit
 // the sector path at all: the next batches go straight to the cell-table path for a while.
-inline void note_fallback(mlm_handle *h) {
-    if (h->P.sec_tab_big && h->big_arm_len > 0 && h->big_armed <= 0) h->big_armed = h->big_arm_len;
-    else h->sector_backoff = h->sector_backoff_len;
+inline void note_fallback(mlm_handle *h, int frame_no) {
+    if (!(h->P.sec_tab_big && h->big_arm_len > 0)) {
+        h->sector_backoff = h->sector_backoff_len;
+    } else if (h->big_armed <= 0) {
+        h->big_armed = h->big_arm_len;
+        h->big_armed_from = h->P.explore ? (int)(h->ex_frame_no & 0x3FFFFFFF) : h->next_seq; // (frames submitted from now on have the pass behind them)
+    } else if (frame_no >= h->big_armed_from) {
+        h->sector_backoff = h->sector_backoff_len; // (it had the pass and gave up all the same)
+    }
 }
 // lean slots of a sector-path handle outside frontier mode: the cell-table path's per-frame state exists once (alloc_slot)
 inline bool share_ct(const mlm_handle *h) { return h->lean && !h->P.explore; }
@@ -788,7 +795,7 @@ int explore_redo_overflows(mlm_handle *h, int base, int n) {
         MlmSlot &S = h->slots[(size_t)(base + j)];
         if (!S.sector || !S.h_ctr->sector_overflow) continue;
         h->n_sector_fallbacks++;
-        note_fallback(h);
+        note_fallback(h, S.F.pad2);
         S.sector = false;
         const int rc = launch_stage_a_batch(h, base + j, 1);
         if (rc) return rc;
@@ -988,7 +995,7 @@ int drain(mlm_handle *h, bool g_copied) {
                 if (R.h_ctr->sector_overflow || (!R.sector && share_ct(h))) {
                     if (R.sector) {
                         h->n_sector_fallbacks++;
-                        note_fallback(h);
+                        note_fallback(h, R.seq);
                     }
                     const int si = (int)(&R - h->slots.data());
                     const int set = si / (h->lim.max_batch);
