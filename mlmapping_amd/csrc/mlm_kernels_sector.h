@@ -653,10 +653,15 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             w_refs += c.gcnt;
             w_subs += ((c.cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
         }
-        int rho, z;
-        key_rz(c.key, rho, z);
-        hrun[q] = EX ? 0u : (uint32_t)s_vr[rho].w;
-        hk[q] = atomicAdd(&s_run_hits[hrun[q]], 1u);
+        if (EX) { // (frontier mode has no tiles: the hits keep the table's order)
+            hrun[q] = 0u;
+            hk[q] = v[0] - 1u;
+        } else {
+            int rho, z;
+            key_rz(c.key, rho, z);
+            hrun[q] = (uint32_t)s_vr[rho].w;
+            hk[q] = atomicAdd(&s_run_hits[hrun[q]], 1u);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         w_refs += __shfl_xor(w_refs, off, 64);
@@ -664,10 +669,10 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     }
     if (threadIdx.x < 2) s_base[4 + threadIdx.x] = 0;
     __syncthreads(); // (the runs' hit counts are complete)
-    if ((int)threadIdx.x < (EX ? 1 : n_run)) v[3] = s_run_hits[threadIdx.x]; // (n_run <= nRho <= MLM_SEC_THREADS)
+    if ((int)threadIdx.x < n_run) v[3] = s_run_hits[threadIdx.x]; // (n_run <= nRho <= MLM_SEC_THREADS)
     uint32_t tot[4];
     mlm_block_excl_scan4(v, s_w, tot); // (its first barrier also orders the zeroing above)
-    if ((int)threadIdx.x < (EX ? 1 : n_run)) s_run_off[threadIdx.x] = v[3];
+    if ((int)threadIdx.x < n_run) s_run_off[threadIdx.x] = v[3];
     if (lane == 0) {
         if (w_refs) atomicAdd(&s_base[4], w_refs);
         if (w_subs) atomicAdd(&s_base[5], w_subs);
@@ -685,7 +690,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 if (EX) s_ray_p0[o_rays] = c.gpos;
                 s_rays[o_rays++] = (uint16_t)e;
             }
-            const uint32_t place = s_run_off[hrun[q]] + hk[q];
+            const uint32_t place = (EX ? v[0] : s_run_off[hrun[q]]) + hk[q];
             if (mlm_sec_needs_order(c)) {
                 s_multi[o_multi++] = (uint16_t)e;
                 c.gpos = place; // (its place in the hit list, until the reference cursor replaces it below)
