@@ -1360,7 +1360,7 @@ __device__ __forceinline__ int mlm_floor_div(int a, int n) {
 // then needs two round trips per voxel: record -> (log-odds, class, hits).  Global atomics: two list reservations per tile.
 #define MLM_TILE_THREADS 256
 #define MLM_TILE_DESC 256   // descriptors staged per pass
-#define MLM_TILE_COMBOS 512 // blocks of a tile whose pool slots are looked up (more: left to the kernel that applies the frame)
+#define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap (its pool slots are kept in LDS; the host checks the geometry)
 struct MlmTileLds {
     uint32_t cnt, place, desc, slot, ztab, total;
 };
@@ -1371,7 +1371,8 @@ __host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_n
     L.place = o;    o += n_vox * 4u;                 // per touched voxel: record index in the tile | (offset of its hits, 0xFFFF: one hit) << 16
     o = (o + 15u) & ~15u;
     L.desc = o;     o += MLM_TILE_DESC * 16u + MLM_TILE_DESC * 8u; // staged descriptors + exclusive prefixes (miss cells, hits)
-    L.slot = o;     o += MLM_TILE_COMBOS * 4u;
+    L.slot = o;     o += MLM_TILE_COMBOS * 4u + MLM_TILE_COMBOS;  // pool slot per overlapped block + "the frame touches it" flags
+    o = (o + 3u) & ~3u;
     L.ztab = o;     o += ((lv_nz + 1u) & ~1u) * 4u;  // per grid z: block index << 8 ... (gz, cz) packed
     L.total = (o + 15u) & ~15u;
     return L;
@@ -1388,6 +1389,7 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     mlm_u32x4 *s_desc = (mlm_u32x4 *)(s_dyn + L.desc);
     uint32_t *s_dm = (uint32_t *)(s_desc + MLM_TILE_DESC), *s_dh = s_dm + MLM_TILE_DESC;
     int *s_slot = (int *)(s_dyn + L.slot);
+    uint8_t *s_touch = (uint8_t *)(s_slot + MLM_TILE_COMBOS);
     uint32_t *s_ztab = (uint32_t *)(s_dyn + L.ztab);
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[4];
@@ -1403,8 +1405,9 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     const int gx0 = mlm_floor_div(X0, P.n), gy0 = mlm_floor_div(Y0, P.n), gz0 = mlm_floor_div(Z0, P.n);
     const int ngx = mlm_floor_div(X0 + (int)edge - 1, P.n) - gx0 + 1, ngy = mlm_floor_div(Y0 + (int)edge - 1, P.n) - gy0 + 1,
               ngz = mlm_floor_div(Z0 + P.lv_nz - 1, P.n) - gz0 + 1;
-    const int n_combo = ngx * ngy * ngz;
-    const bool probe = n_combo <= MLM_TILE_COMBOS;
+    const int n_combo = ngx * ngy * ngz; // (<= MLM_TILE_COMBOS: checked by the host for the grid's geometry)
+    const bool probe = true;
+    for (int c = threadIdx.x; c < n_combo; c += MLM_TILE_THREADS) s_touch[c] = 0;
     auto combo_slot = [&](int c) {
         const int bz = c / (ngx * ngy), r = c - bz * ngx * ngy, by = r / ngx, bx = r - by * ngx;
         return mlm_block_find(P, gx0 + bx, gy0 + by, gz0 + bz);
@@ -1492,9 +1495,37 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     for_cells(0);
     if (probe && (int)threadIdx.x < n_combo) s_slot[threadIdx.x] = slot0;
     __syncthreads();
+    const uint32_t per = (NV + MLM_TILE_THREADS - 1) / MLM_TILE_THREADS, v_lo = min(NV, threadIdx.x * per), v_hi = min(NV, v_lo + per);
+    const uint32_t lvz = (uint32_t)P.lv_nz;
+    auto combo_of = [&](uint32_t vxy, uint32_t zz) { // index of the block of tile voxel (vxy, zz) among the blocks the tile overlaps
+        const int X = X0 + (int)(vxy & (edge - 1u)), Y = Y0 + (int)(vxy >> P.tile_sh);
+        return ((int)(s_ztab[zz] & 0xFFFFu) * ngy + (mlm_floor_div(Y, P.n) - gy0)) * ngx + (mlm_floor_div(X, P.n) - gx0);
+    };
+    // ---- the blocks the frame touches in this tile exist before the frame is applied (allocate_ram, map_local.h:215-231: any
+    //      hit or miss cell creates its block; creating it earlier than the reference would is invisible — it stays 0 / 'u' until
+    //      the frame is applied).  A full pool flags the frame: k_apply_tiles stops in front of it, the host grows the pool and
+    //      k_alloc_retry fills in the slots.
+    {
+        uint32_t vxy = v_lo / lvz, zz = v_lo - vxy * lvz;
+        for (uint32_t v = v_lo; v < v_hi; ++v) {
+            if (s_cnt[v]) s_touch[combo_of(vxy, zz)] = 1;
+            if (++zz == lvz) {
+                zz = 0;
+                ++vxy;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_combo; c += MLM_TILE_THREADS)
+        if (s_touch[c] && s_slot[c] < 0) {
+            const int bz = c / (ngx * ngy), r = c - bz * ngx * ngy, by = r / ngx, bx = r - by * ngx;
+            const int sl = mlm_block_slot(P, mlm_pack_key(gx0 + bx, gy0 + by, gz0 + bz));
+            s_slot[c] = sl;
+            if (sl < 0) mlm_gp(P.ctr)->pool_short = 1u;
+        }
+    __syncthreads();
     // ---- compaction: a thread's voxels are contiguous; touched voxels get consecutive records, voxels with several hits
     //      consecutive room in vr_hit
-    const uint32_t per = (NV + MLM_TILE_THREADS - 1) / MLM_TILE_THREADS, v_lo = min(NV, threadIdx.x * per), v_hi = min(NV, v_lo + per);
     uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
     for (uint32_t v = v_lo; v < v_hi; ++v) {
         const uint32_t c = s_cnt[v];
@@ -1517,9 +1548,10 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     }
     rec_base = s_base[0];
     hit_base = s_base[1];
+    if (threadIdx.x == 0) // the tile's records of this frame, for the workgroup that applies the world tile (k_apply_tiles)
+        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_dir) + 4 * (size_t)tile) = mlm_u32x4{rec_base, t4[0], (uint32_t)F.seq, 0u};
     {
         uint32_t o_rec = a[0], o_hit = a[1];
-        const uint32_t lvz = (uint32_t)P.lv_nz;
         uint32_t vxy = v_lo / lvz, zz = v_lo - vxy * lvz;
         for (uint32_t v = v_lo; v < v_hi; ++v) {
             const uint32_t c = s_cnt[v];
@@ -1531,7 +1563,7 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
                 const uint32_t zt = s_ztab[zz];
                 const int bz = (int)(zt & 0xFFFFu), cz = (int)(zt >> 16);
                 const int cid = (cz * P.n + (Y - gy * P.n)) * P.n + (X - gx * P.n);
-                const int slot = probe ? s_slot[(bz * ngy + (gy - gy0)) * ngx + (gx - gx0)] : -1;
+                const int slot = s_slot[(bz * ngy + (gy - gy0)) * ngx + (gx - gx0)];
                 const unsigned long long key = mlm_pack_key(gx, gy, gz0 + bz);
                 MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + o_rec;
                 *(MLM_GLOBAL mlm_u32x4 *)rec = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)cid, c & 0xFFFFu};
@@ -1549,140 +1581,184 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     for_cells(1); // (its first barrier makes the places visible)
 }
 
-// The part of a frame that needs the map (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237), sector
-// path: ONE launch per frame, one touched voxel per lane.  k_tile has grouped the frame's hits and misses by voxel, so all
-// that is left is: block lookup / creation (allocate_ram, map_local.h:215-231) if the block did not exist when k_tile
-// looked, the voxel's hits in the reference's iteration order (descending key, map_local.cpp:157-171), then its misses
-// (map_local.cpp:188-203) — the reference runs all hits before all misses.  Two dependent round trips per voxel:
-// record -> (log-odds, class, the hits of a voxel with several).
-// explicit_keys: hl_key holds the exact iteration-order keys (rehash frames, order_hits_exact); otherwise the records carry
-// k_rank's (bucket-first time from this slot's table, insertion time), valid if the frame fits the emulated container
-// without a rehash — else the frame is flagged (g->fail_frame) and replayed by the host.
-// retry_lo < retry_hi: only the records vr_retry[retry_lo .. retry_hi) — those whose block did not fit the pool in an
-// earlier launch of this frame; the host has grown the pool since.
-__device__ __forceinline__ void mlm_apply_frame_body(const MlmDev &P, const MlmFrame &F, int explicit_keys, unsigned int retry_lo, unsigned int retry_hi) {
+// The part that needs the map (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237), sector path: ONE launch for a
+// whole batch of frames.  The frames of a stream must be applied in order, but the only thing one frame's update depends on is
+// the same VOXEL's state after the frame before — so the work is cut by space, not by time: the frame-local grids are aligned to
+// tile boundaries, a frame-local tile is a world tile, and the workgroup that owns a world tile walks the batch's frames in
+// order and applies, frame after frame, the voxel records k_tile wrote for that tile (a barrier between frames; no ordering
+// between workgroups at all — two tiles never share a voxel, and the blocks they may share were created by k_tile).
+// Per record: the voxel's hits in the reference's iteration order (descending key, map_local.cpp:157-171), then its misses
+// (map_local.cpp:188-203) — the reference runs all hits before all misses.  Two dependent round trips per frame and tile:
+// records -> (log-odds, class, the hits of a voxel with several).
+// Every workgroup stops in front of the same frame, the first one that cannot be applied as it stands: its Stage A gave up
+// (redone on the cell-table path by the host), it does not fit the emulated hit container without a rehash (the host computes
+// exact keys: MLM_FRAME_EXACT_KEYS), or k_tile could not create its blocks (the host grows the pool).  g->fail_frame tells the
+// host which (sticky: batches behind it do nothing).  f_begin: first frame of the slot range to apply (replays).
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot_base,
+                                                           int n_frames, int f_begin) {
     __builtin_amdgcn_s_setprio(3); // the serial chain of the pipeline: its few waves issue ahead of Stage A's
-    const int frame_idx = F.seq;
-    const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    const bool retry = retry_hi > retry_lo;
-    const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.vr_rec);
-    // speculative loads of record i0 (in bounds of the array, whatever the list length turns out to be)
-    mlm_u32x4 r0 = mlm_u32x4{0u, 0u, 0u, 0u}, r1 = r0;
-    if (!retry && i0 < P.rec_cap) {
-        r0 = recs[2 * (size_t)i0];
-        r1 = recs[2 * (size_t)i0 + 1];
-    }
-    const int ff = __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned int n = retry ? retry_hi - retry_lo : min(mlm_gp(P.ctr)->mvox_cnt[0][0], P.rec_cap);
-    const unsigned int n_hits = mlm_gp(P.ctr)->u_hit;
-    // an EARLIER frame is to be replayed first; this frame's own flag means either that its Stage A gave up (the frame is
-    // redone on the cell-table path) or that a voxel of it found the block pool full — the other voxels are applied regardless
-    // (a voxel's update depends on nothing but the voxel), the host launches the ones on the retry list again
-    if (ff < frame_idx || mlm_gp(P.ctr)->sector_overflow) return;
-    if (!explicit_keys && n_hits > F.rehash_thr) { // speculation miss: the frame needs a rehash of the emulated container
-        if (i0 == 0) atomicMin(&P.g->fail_frame, frame_idx);
-        return;
-    }
-    for (unsigned int i = i0; i < n; i += stride) {
-        unsigned int idx = i;
-        if (retry) idx = mlm_gp(P.vr_retry)[retry_lo + i];
-        if (retry || i != i0) {
-            r0 = recs[2 * (size_t)idx];
-            r1 = recs[2 * (size_t)idx + 1];
+    __shared__ uint32_t s_first[64], s_count[64];
+    __shared__ int s_wx0, s_wy0, s_stop, s_nwx;
+    const int lane = threadIdx.x & 63;
+    const MlmDev &P0 = slot_tab[slot_base];
+    const int sh = P0.tile_sh;
+    // the batch's box of world tiles (every workgroup derives it from the frames' grid origins: no launch argument changes from
+    // call to call, which lets a single frame's launch sequence be replayed as a graph)
+    if (threadIdx.x < 64) {
+        int wx = 0x7FFFFFFF, wy = 0x7FFFFFFF, wxm = -0x7FFFFFFF;
+        bool ok = true;
+        if (lane < n_frames) {
+            const MlmFrame &F = frame_tab[slot_base + lane];
+            const MLM_GLOBAL MlmCounters *c = mlm_gp(slot_tab[slot_base + lane].ctr);
+            wx = F.lv_o[0] >> sh;
+            wy = F.lv_o[1] >> sh;
+            wxm = wx;
+            ok = (F.flags & MLM_FRAME_SKIP) ||
+                 (c->sector_overflow == 0u && c->pool_short == 0u && ((F.flags & MLM_FRAME_EXACT_KEYS) || c->u_hit <= F.rehash_thr));
         }
-        const unsigned long long bkey = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32);
-        const uint32_t cid = r0.z, km = r0.w, nh = r1.y, first = r1.w;
-        int slot = (int)r1.x;
-        if (slot < 0) {
-            slot = mlm_block_slot(P, bkey);
-            if (slot < 0) {
-                // block pool full (error flag set by the allocator): the voxel goes on the frame's retry list and the frame flags
-                // itself, so that the frames behind it do nothing; the host grows the pool and launches them again (drain), this
-                // voxel is applied then — before any later frame touches it, i.e. exactly as if the block had fitted
-                const unsigned int at = atomicAdd(&P.ctr->mvox_cnt[2][0], 1u);
-                if (at < P.rec_cap) mlm_gp(P.vr_retry)[at] = idx;
-                atomicMin(&P.g->fail_frame, frame_idx);
-                continue;
-            }
+        for (int off = 32; off > 0; off >>= 1) {
+            wx = min(wx, __shfl_xor(wx, off, 64));
+            wy = min(wy, __shfl_xor(wy, off, 64));
+            wxm = max(wxm, __shfl_xor(wxm, off, 64));
         }
-        const size_t v = (size_t)slot * P.cells + cid;
-        float L = mlm_gp(P.log_odds)[v];
-        uint8_t o = mlm_gp(P.occ)[v];
-        auto hit = [&](float inc) { // map_local.cpp:157-171
-            if (L < P.lo_max) {
-                L = L + inc;
-                L = L > P.lo_max ? P.lo_max : L;
-            }
-            if (L > P.lo_sh && o != 'o') o = 'o';
-        };
-        if (nh == 1u) { // the common case: a single contribution
-            hit(__uint_as_float(r1.z));
-        } else if (nh) {
-            // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
-            // reference's iteration order)
-            const MLM_GLOBAL mlm_u32x4 *hh = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.vr_hit) + first);
-            auto key_of = [&](const mlm_u32x4 &e) -> unsigned long long {
-                return explicit_keys ? mlm_gp(P.hl_key)[e.w] : ((unsigned long long)e.x | ((unsigned long long)e.y << 32));
-            };
-            if (nh <= MLM_APPLY_REGS) {
-                unsigned long long ks[MLM_APPLY_REGS];
-                float vs[MLM_APPLY_REGS];
-#pragma unroll
-                for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                    ks[q] = 0; // real keys are never 0
-                    vs[q] = 0.0f;
+        const unsigned long long bad = __ballot(!ok && lane >= f_begin && lane < n_frames);
+        if (lane == 0) {
+            s_wx0 = wx;
+            s_wy0 = wy;
+            s_nwx = wxm - wx + P0.n_tx;
+            int stop = bad ? __ffsll((long long)bad) - 1 : n_frames;
+            // an EARLIER batch is to be replayed first: nothing of this one may be applied
+            const int ff = __hip_atomic_load(&P0.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ff < frame_tab[slot_base + f_begin].seq) stop = f_begin;
+            else if (stop < n_frames && blockIdx.x == 0) atomicMin(&P0.g->fail_frame, frame_tab[slot_base + stop].seq);
+            s_stop = stop;
+        }
+    }
+    __syncthreads();
+    const int f_stop = s_stop;
+    const int WX = s_wx0 + (int)(blockIdx.x % (unsigned int)s_nwx), WY = s_wy0 + (int)(blockIdx.x / (unsigned int)s_nwx);
+    // this world tile's records in every frame of the range (one lane per frame: the directory entries arrive together)
+    if (threadIdx.x < 64) {
+        uint32_t first = 0, count = 0;
+        if (lane >= f_begin && lane < f_stop) {
+            const MlmFrame &F = frame_tab[slot_base + lane];
+            const MlmDev &P = slot_tab[slot_base + lane];
+            const int tx = WX - (F.lv_o[0] >> sh), ty = WY - (F.lv_o[1] >> sh);
+            if (!(F.flags & MLM_FRAME_SKIP) && tx >= 0 && ty >= 0 && tx < P.n_tx && ty * P.n_tx + tx < P.n_tiles) {
+                const mlm_u32x4 e = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_dir) + 4 * (size_t)(ty * P.n_tx + tx));
+                if (e.z == (uint32_t)F.seq) {
+                    first = e.x;
+                    count = e.y;
                 }
-                for (uint32_t j = 0; j < nh; ++j) {
-                    const mlm_u32x4 e = hh[j];
-                    unsigned long long k = key_of(e);
-                    float inc = __uint_as_float(e.z);
+            }
+        }
+        s_first[lane] = first;
+        s_count[lane] = count;
+    }
+    __syncthreads();
+    for (int f = f_begin; f < f_stop; ++f) {
+        const uint32_t count = s_count[f];
+        if (!count) continue; // (uniform)
+        const MlmDev &P = slot_tab[slot_base + f];
+        const int explicit_keys = frame_tab[slot_base + f].flags & MLM_FRAME_EXACT_KEYS;
+        const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.vr_rec) + s_first[f]);
+        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
+            const mlm_u32x4 r0 = recs[2 * (size_t)i], r1 = recs[2 * (size_t)i + 1];
+            const uint32_t cid = r0.z, km = r0.w, nh = r1.y, first = r1.w;
+            const int slot = (int)r1.x;
+            if (slot < 0) continue; // (cannot happen: a frame whose blocks could not be created is not applied)
+            const size_t v = (size_t)slot * P.cells + cid;
+            float L = mlm_gp(P.log_odds)[v];
+            uint8_t o = mlm_gp(P.occ)[v];
+            auto hit = [&](float inc) { // map_local.cpp:157-171
+                if (L < P.lo_max) {
+                    L = L + inc;
+                    L = L > P.lo_max ? P.lo_max : L;
+                }
+                if (L > P.lo_sh && o != 'o') o = 'o';
+            };
+            if (nh == 1u) { // the common case: a single contribution
+                hit(__uint_as_float(r1.z));
+            } else if (nh) {
+                // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
+                // reference's iteration order); explicit_keys: hl_key holds the exact keys of a replayed frame
+                const MLM_GLOBAL mlm_u32x4 *hh = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.vr_hit) + first);
+                auto key_of = [&](const mlm_u32x4 &e) -> unsigned long long {
+                    return explicit_keys ? mlm_gp(P.hl_key)[e.w] : ((unsigned long long)e.x | ((unsigned long long)e.y << 32));
+                };
+                if (nh <= MLM_APPLY_REGS) {
+                    unsigned long long ks[MLM_APPLY_REGS];
+                    float vs[MLM_APPLY_REGS];
 #pragma unroll
                     for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                        if (k > ks[q]) {
-                            const unsigned long long tk = ks[q];
-                            const float tv = vs[q];
-                            ks[q] = k;
-                            vs[q] = inc;
-                            k = tk;
-                            inc = tv;
-                        }
+                        ks[q] = 0; // real keys are never 0
+                        vs[q] = 0.0f;
                     }
-                }
-#pragma unroll
-                for (int q = 0; q < MLM_APPLY_REGS; ++q)
-                    if ((uint32_t)q < nh) hit(vs[q]);
-            } else {
-                // more hits than registers: repeated selection of the next key straight from memory
-                unsigned long long last = ~0ull;
-                for (uint32_t done = 0; done < nh; ++done) {
-                    unsigned long long bestkey = 0;
-                    float bestinc = 0.0f;
                     for (uint32_t j = 0; j < nh; ++j) {
                         const mlm_u32x4 e = hh[j];
-                        const unsigned long long k = key_of(e);
-                        if (k < last && k > bestkey) {
-                            bestkey = k;
-                            bestinc = __uint_as_float(e.z);
+                        unsigned long long k = key_of(e);
+                        float inc = __uint_as_float(e.z);
+#pragma unroll
+                        for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                            if (k > ks[q]) {
+                                const unsigned long long tk = ks[q];
+                                const float tv = vs[q];
+                                ks[q] = k;
+                                vs[q] = inc;
+                                k = tk;
+                                inc = tv;
+                            }
                         }
                     }
-                    hit(bestinc);
-                    last = bestkey;
+#pragma unroll
+                    for (int q = 0; q < MLM_APPLY_REGS; ++q)
+                        if ((uint32_t)q < nh) hit(vs[q]);
+                } else {
+                    // more hits than registers: repeated selection of the next key straight from memory
+                    unsigned long long last = ~0ull;
+                    for (uint32_t done = 0; done < nh; ++done) {
+                        unsigned long long bestkey = 0;
+                        float bestinc = 0.0f;
+                        for (uint32_t j = 0; j < nh; ++j) {
+                            const mlm_u32x4 e = hh[j];
+                            const unsigned long long k = key_of(e);
+                            if (k < last && k > bestkey) {
+                                bestkey = k;
+                                bestinc = __uint_as_float(e.z);
+                            }
+                        }
+                        hit(bestinc);
+                        last = bestkey;
+                    }
                 }
             }
+            mlm_apply_misses(P, L, o, km);
+            mlm_gp(P.log_odds)[v] = L;
+            mlm_gp(P.occ)[v] = o;
         }
-        mlm_apply_misses(P, L, o, km);
-        mlm_gp(P.log_odds)[v] = L;
-        mlm_gp(P.occ)[v] = o;
+        __syncthreads(); // (this frame's stores are visible to the workgroup's loads of the next frame)
     }
 }
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame(const MlmDev P, const MlmFrame F, int explicit_keys, unsigned int retry_lo, unsigned int retry_hi) {
-    mlm_apply_frame_body(P, F, explicit_keys, retry_lo, retry_hi);
+
+// After the host has grown the block pool: the blocks a frame's voxel records still lack (k_tile found the pool full) are created
+// and their slots filled in; pool_short is cleared if every one fitted.
+__global__ __launch_bounds__(MLM_BLOCK) void k_alloc_retry(const MlmDev P) {
+    const unsigned int n = min(mlm_gp(P.ctr)->mvox_cnt[0][0], P.rec_cap);
+    bool failed = false;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + i;
+        if (rec->slot >= 0) continue;
+        const int slot = mlm_block_slot(P, rec->bkey);
+        if (slot >= 0) rec->slot = slot;
+        else failed = true;
+    }
+    if (__any(failed) && (threadIdx.x & 63) == 0) mlm_gp(P.ctr)->pool_short = 2u; // (2: still short after this pass)
 }
-// the same with the parameters taken from the device-resident tables (the launch sequence of a single frame is replayed as a HIP
-// graph: its kernel arguments must not change from call to call)
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_frame_tab(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot) {
-    mlm_apply_frame_body(slot_tab[slot], frame_tab[slot], 0, 0u, 0u);
+// (second launch of the pair: turns "not seen short by the pass above" into "complete")
+__global__ void k_alloc_retry_done(const MlmDev P) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) mlm_gp(P.ctr)->pool_short = mlm_gp(P.ctr)->pool_short == 2u ? 1u : 0u;
 }
+
 // First and last node of the single-frame graph: the frame's parameters come from pinned host memory (one 128-thread block
 // copies them into the device-resident table and clears the slot's counters), the counters and the map-wide flags go back
 // the same way — kernel nodes with fixed arguments instead of memcpy / memset nodes.

@@ -19,7 +19,8 @@ struct MlmCounters {
     unsigned int n_multi;     // hit cells that received more than one kind of contribution
     unsigned int n_ex_rays;   // explore mode: queued rays
     unsigned int n_ex_miss;   // explore mode: unique miss cells
-    unsigned int rsv2;        // (unused)
+    unsigned int pool_short;  // sector path: k_tile could not create a block the frame touches (the pool is full): the frame is applied
+                              // once the host has grown the pool and k_alloc_retry has filled the records' slots
     unsigned int n_big;       // multi-kind cells with more than 1024 contributions
     unsigned int n_groups;    // contribution groups kept in the blocks' own slices of `bnodes` (folded by k_collect_hits)
     unsigned int sector_overflow; // sector path: an LDS table of some column overflowed -> the frame is redone by the cell-table path
@@ -29,7 +30,7 @@ struct MlmCounters {
                                  // [k][1] = device-scope atomics the frame's kernels issued (sector path, counted by k_sector)
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // cell-table path: [k][0] = voxels touched by misses, sub-list k; sector path: [0][0] voxel records,
-                                   // [1][0] entries of vr_hit, [2][0] entries of vr_retry, [3][0] miss cells reserved in mc_list
+                                   // [1][0] entries of vr_hit, [3][0] miss cells reserved in mc_list
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
     unsigned int node_cnt[8][32];  // [k][0] = contribution nodes allocated in region k
     unsigned int mc_cnt[8][32];    // [k][0] = unique miss cells queued in sub-list k
@@ -235,14 +236,16 @@ struct MlmDev {
     MlmVoxRec *vr_rec;         // [rec_cap] one record per voxel the frame touches (count: MlmCounters::mvox_cnt[0][0])
     unsigned int rec_cap;
     MlmVoxHit *vr_hit;         // [nCells] the hits of voxels with two or more, a voxel's hits contiguous (count: mvox_cnt[1][0])
-    uint32_t *vr_retry;        // [rec_cap] records whose block did not fit the pool (count: mvox_cnt[2][0]): applied again once
-                               // the host has grown the pool
+    uint32_t *tile_dir;        // [n_tiles][4] {first record of the tile in vr_rec, count, frame sequence number, -}: written by k_tile,
+                               // valid for the frame whose sequence number it carries (never cleared)
     unsigned long long *sbkt;  // [sbkt_cap] this slot's bucket-first table of the emulated hit container: (~seq << 32 | time),
     unsigned int sbkt_cap;     // never cleared (a newer frame's entries win the min)
     MlmCounters *ctr;          // this slot's per-frame counters
     MlmGlobal *g;
 };
 
+#define MLM_FRAME_EXACT_KEYS 1 // hl_key holds the exact iteration-order keys (order_hits_exact): no speculation check, keys from hl_key
+#define MLM_FRAME_SKIP 2       // the frame has been applied by other means (redone on the cell-table path)
 struct MlmFrame {
     // T_ls = T_wa^-1 * T_wb * T_bs (map_awareness.cpp:184-186), t_wa = t_wb
     double q_ls[4]; // w,x,y,z
@@ -258,4 +261,6 @@ struct MlmFrame {
     unsigned int rehash_thr; // the emulated hit container takes this many elements without a rehash (speculative Stage B)
     int lv_o[3];           // origin of the frame-local voxel grid (MlmDev::lv_state) in voxel coordinates
     int pad2;                  // frontier mode: running frame number (test hook MLM_SEC_FAIL_EVERY; seq stays 0 there)
+    int flags;                 // sector path, k_apply_tiles: MLM_FRAME_EXACT_KEYS | MLM_FRAME_SKIP
+    int pad3;
 };

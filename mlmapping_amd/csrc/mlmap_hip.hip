@@ -52,7 +52,6 @@ struct MlmSlot {
     unsigned int ex_um = 0;   // frontier mode: unique miss cells of the frame it holds
     size_t alloc_end = 0;     // mlm_handle::allocs.size() once this slot was allocated
     bool sector = false;      // the frame it holds went through the sector path (Stage A and the frame-local voxel grid)
-    unsigned int retry_done = 0; // entries of the frame's retry list (blocks that did not fit the pool) already launched again
     bool keys_exact = false;  // hl_key of the frame it holds was written by order_hits_exact (a replay must not recompute it:
                               // the emulated container's policy state has moved on)
     uint16_t *d_img = nullptr; // staging for host images
@@ -301,8 +300,11 @@ void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb
     // origin of the frame-local voxel grid: the awareness cylinder around t_wa with a margin of four voxels
     const MlmDev &P = h->P;
     const double R = P.nRho * P.dRho;
-    F.lv_o[0] = (int)std::floor((F.t_wa[0] - R) / P.d_sub) - 4;
-    F.lv_o[1] = (int)std::floor((F.t_wa[1] - R) / P.d_sub) - 4;
+    // (x, y snapped down to a tile boundary: a frame-local tile is then a WORLD tile, which is what lets one workgroup own a
+    // tile's voxels across the frames of a batch — k_apply_tiles)
+    const int edge_mask = (1 << P.tile_sh) - 1;
+    F.lv_o[0] = ((int)std::floor((F.t_wa[0] - R) / P.d_sub) - 4) & ~edge_mask;
+    F.lv_o[1] = ((int)std::floor((F.t_wa[1] - R) / P.d_sub) - 4) & ~edge_mask;
     F.lv_o[2] = (int)std::floor((F.t_wa[2] + P.z_border_min) / P.d_sub) - 4;
 }
 
@@ -814,6 +816,59 @@ int explore_redo_overflows(mlm_handle *h, int base, int n) {
 // device flag g->fail_frame holds the first sequence number whose speculation did not hold (sticky), and every
 // Stage B/C kernel of a frame >= it is a no-op.  `pending` lists submitted-but-unconfirmed frames in order.
 
+// The map-dependent part of the frames in slots base..base+n (sector path): one launch, a workgroup per world tile of the box the
+// frames' grids span (k_apply_tiles).  Frames whose poses lie far apart are applied in several launches so that the box stays small.
+int launch_apply_tiles(mlm_handle *h, int base, int n, int f_begin = 0) {
+    const MlmDev &P = h->slots[(size_t)base].P;
+    const int sh = P.tile_sh, n_ty = P.n_tiles / P.n_tx;
+    int j0 = std::max(0, f_begin);
+    while (j0 < n) {
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, j1 = j0;
+        for (; j1 < n; ++j1) {
+            const MlmFrame &F = h->slots[(size_t)(base + j1)].F;
+            const int wx = F.lv_o[0] >> sh, wy = F.lv_o[1] >> sh;
+            const int nx0 = j1 == j0 ? wx : std::min(x0, wx), nx1 = j1 == j0 ? wx : std::max(x1, wx);
+            const int ny0 = j1 == j0 ? wy : std::min(y0, wy), ny1 = j1 == j0 ? wy : std::max(y1, wy);
+            if (j1 > j0 && (long long)(nx1 - nx0 + P.n_tx) * (ny1 - ny0 + n_ty) > (1ll << 20)) break;
+            x0 = nx0;
+            x1 = nx1;
+            y0 = ny0;
+            y1 = ny1;
+        }
+        const long long grid = (long long)(x1 - x0 + P.n_tx) * (y1 - y0 + n_ty);
+        if (grid > 0x7FFFFFFFll) {
+            h->err = "frame-local grid too large for one launch";
+            return MLM_ERR_UNSUPPORTED;
+        }
+        // (the kernel derives the box from the frames [base + j0, base + j1) itself: it gets that range as ITS slot range)
+        tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(MLM_BLOCK), 0, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0);
+        j0 = j1;
+    }
+    return MLM_OK;
+}
+// A frame whose blocks k_tile could not create (the pool was full): create them now, growing the pool as often as it takes.
+// Nothing may be in flight.  On return the frame's records carry their slots and the device's error flag is clear.
+int fix_pool_short(mlm_handle *h, MlmSlot &R) {
+    while (R.h_ctr->pool_short) {
+        if (!h->pool_grow) {
+            h->err = "block pool or block hash table full (raise mlm_limits.max_blocks)";
+            return MLM_ERR_CAPACITY;
+        }
+        HIPCHK(h, hipMemcpy(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost));
+        const size_t nb = std::min<size_t>(h->h_g->n_blocks, (size_t)h->P.max_blocks);
+        if ((h->h_g->err & 1u) || nb + h->frame_block_bound > (size_t)h->P.max_blocks) { // (else: grown since, on account of an earlier frame)
+            const int rc = grow_pool(h, (size_t)h->P.max_blocks + 2 * h->frame_block_bound);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_alloc_retry, dim3(256), dim3(MLM_BLOCK), 0, h->stream, R.P);
+        hipLaunchKernelGGL(k_alloc_retry_done, dim3(1), dim3(64), 0, h->stream, R.P);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return MLM_OK;
+}
+
 int submit_batch(mlm_handle *h, int base, int n) {
     if (h->hit_n_bkt > h->max_buckets) {
         h->err = "emulated bucket count exceeds capacity";
@@ -838,7 +893,6 @@ int submit_batch(mlm_handle *h, int base, int n) {
     for (int j = 0; j < n; ++j) {
         h->slots[(size_t)(base + j)].sector = sectors;
         h->slots[(size_t)(base + j)].keys_exact = false;
-        h->slots[(size_t)(base + j)].retry_done = 0;
     }
     if (!sectors && share_ct(h)) {
         // the cell-table path's per-frame state exists once: every frame runs alone, Stage A and the two map-dependent kernels
@@ -865,18 +919,11 @@ int submit_batch(mlm_handle *h, int base, int n) {
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
     if (sectors) {
-        // one launch per frame: Stage A has grouped the frame's hits and misses by voxel already (k_apply_frame)
+        // ONE launch for the batch: Stage A has grouped every frame's hits and misses by voxel, tile by tile (k_apply_tiles)
         Timed t(h, h->stream, "stage_bc_batch");
-        unsigned int scg = h->sc_grid * MLM_RAY_LISTS;
-        if (!h->sc_grid_fixed) { // one voxel record per thread for a frame like the last confirmed one
-            const long long items = h->last_queue > 0 ? h->last_queue * 5 / 4 : h->stats.n_hit_cells + h->stats.n_miss_cells;
-            scg = (unsigned int)std::min<long long>(8192, std::max<long long>(64, (items + MLM_BLOCK - 1) / MLM_BLOCK));
-        }
-        for (int j = 0; j < n; ++j) {
-            MlmSlot &S = h->slots[(size_t)(base + j)];
-            tlaunch(h, "k_apply_frame", k_apply_frame, dim3(scg * (MLM_BLOCK / h->sc_block)), dim3(h->sc_block), 0, h->stream, S.P, S.F, 0, 0u, 0u);
-            h->pending.push_back(&S);
-        }
+        rc = launch_apply_tiles(h, base, n);
+        if (rc) return rc;
+        for (int j = 0; j < n; ++j) h->pending.push_back(&h->slots[(size_t)(base + j)]);
     } else {
         // launch j = k_apply of frame j-1 + k_voxelize of frame j (see k_apply_voxelize): n+1 launches for n frames
         Timed t(h, h->stream, "stage_bc_batch");
@@ -926,50 +973,17 @@ int drain(mlm_handle *h, bool g_copied) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         const int f = h->h_g->fail_frame;
-        const bool pool_full = (h->h_g->err & 1u) && h->pool_grow;
-        if (pool_full) h->h_g->err &= ~1u; // (handled below: not an error of the frames confirmed here)
+        // (a full pool is no error of the frames confirmed here: k_tile flags the frame whose blocks did not fit, the batch stops in
+        // front of it and fix_pool_short below grows the pool)
+        const unsigned int err_bits = h->h_g->err;
+        if (h->pool_grow) h->h_g->err &= ~1u;
         size_t ok = 0;
         while (ok < h->pending.size() && h->pending[ok]->seq < f) ++ok;
         int rc = confirm_front(h, (int)ok);
         if (rc) return rc;
-        if (pool_full) {
-            // A frame ran out of blocks.  On the sector path it is applied voxel by voxel — the voxels whose block did not fit
-            // were left pending in the frame-local grid and the frame flagged itself, so it and the frames behind it have
-            // not touched those voxels: grow the pool and launch them again (the voxels that were applied are skipped).
-            // (Frames of the cell-table path never get here for lack of blocks: ensure_free_blocks before their submission.)
-            rc = grow_pool(h, (size_t)h->P.max_blocks + 2 * h->frame_block_bound);
-            if (rc) return rc;
-            h->h_g->fail_frame = 0x7FFFFFFF;
-            HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-            if (f == 0x7FFFFFFF) { // (no frame flagged itself: a path without replay overflowed although room was made for it)
-                h->err = "block pool overflowed on a path that cannot be replayed";
-                return MLM_ERR_CAPACITY;
-            }
-            for (MlmSlot *R : h->pending) {
-                if (R->sector) {
-                    // the frame that ran out of blocks: only the voxels it put on its retry list; the frames behind it did nothing
-                    const unsigned int n_retry = std::min(R->h_ctr->mvox_cnt[2][0], R->P.rec_cap);
-                    if (R == h->pending.front() && n_retry > R->retry_done) {
-                        tlaunch(h, "k_apply_frame", k_apply_frame, dim3(64), dim3(MLM_BLOCK), 0, h->stream, R->P, R->F, R->keys_exact ? 1 : 0, R->retry_done, n_retry);
-                        R->retry_done = n_retry;
-                    } else {
-                        tlaunch(h, "k_apply_frame", k_apply_frame, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, R->P, R->F, R->keys_exact ? 1 : 0, 0u, 0u);
-                    }
-                } else {
-                    if (share_ct(h)) { // (its Stage A outputs have been overwritten by the frames behind it)
-                        rc = launch_stage_a_batch(h, (int)(R - h->slots.data()), 1, true);
-                        if (rc) return rc;
-                        if (R->keys_exact) { // (its exact keys went with them)
-                            HIPCHK(h, hipMemcpyAsync(R->h_ctr, R->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-                            HIPCHK(h, hipStreamSynchronize(h->stream));
-                            R->keys_exact = false;
-                        }
-                    }
-                    launch_stage_bc(h, *R, R->keys_exact ? 0 : h->hit_n_bkt);
-                }
-                HIPCHK(h, hipMemcpyAsync(R->h_ctr, R->P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-            }
-            continue;
+        if (h->pending.empty() && (err_bits & 1u) && h->pool_grow) { // (nothing left to fix it for: a path without replay overflowed)
+            h->err = "block pool overflowed on a path that cannot be replayed";
+            return MLM_ERR_CAPACITY;
         }
         if (h->pending.empty()) break;
         // pending.front() does not fit the emulated container without a rehash (replay its Stage B exactly), or one of
@@ -1011,6 +1025,7 @@ int drain(mlm_handle *h, bool g_copied) {
                     HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
                     R.sector = false;
                 }
+                if (h->pool_grow) h->h_g->err &= ~1u; // (fix_pool_short below)
                 rc = check_queues(h, R);
                 if (rc) return rc;
                 if (!R.keys_exact) {
@@ -1018,28 +1033,24 @@ int drain(mlm_handle *h, bool g_copied) {
                     if (rc) return rc;
                     R.keys_exact = true;
                 }
-                if (R.sector)
-                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(1024), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1, 0u, 0u);
-                else
-                    launch_stage_bc(h, R, 0);
-                // The frame is finished before the next one starts (this is the rare path): a sector frame that ran out of blocks
-                // gets the pool grown and its retry list launched right here, so that a cell-table frame behind it — whose
-                // Stage A state may be shared with the frames behind IT — never has to be replayed once more.
-                for (;;) {
-                    HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-                    HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+                const int si = (int)(&R - h->slots.data());
+                if (R.sector) {
                     HIPCHK(h, hipStreamSynchronize(h->stream));
-                    HIPCHK(h, hipGetLastError());
-                    if (!((h->h_g->err & 1u) && h->pool_grow && R.sector)) break;
-                    const unsigned int n_retry = std::min(R.h_ctr->mvox_cnt[2][0], R.P.rec_cap);
-                    if (n_retry <= R.retry_done) break; // (nothing of this frame is waiting: reported by check_queues below)
-                    rc = grow_pool(h, (size_t)h->P.max_blocks + 2 * h->frame_block_bound);
+                    rc = fix_pool_short(h, R); // (k_tile found the pool full: the frame's blocks are created now)
                     if (rc) return rc;
-                    h->h_g->fail_frame = 0x7FFFFFFF;
-                    HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream));
-                    tlaunch(h, "k_apply_frame", k_apply_frame, dim3(64), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F, 1, R.retry_done, n_retry);
-                    R.retry_done = n_retry;
+                    R.F.flags |= MLM_FRAME_EXACT_KEYS;
+                    h->h_frame_tab[si] = R.F;
+                    HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + si, h->h_frame_tab + si, sizeof(MlmFrame), hipMemcpyHostToDevice, h->stream));
+                    rc = launch_apply_tiles(h, si, 1);
+                    if (rc) return rc;
+                } else {
+                    launch_stage_bc(h, R, 0);
                 }
+                // the frame is finished before the next one starts (this is the rare path)
+                HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                HIPCHK(h, hipGetLastError());
                 if (h->h_g->err) { // (pool full with growth off, a queue overflow)
                     rc = check_queues(h, R);
                     if (rc) return rc;
@@ -1074,6 +1085,8 @@ int drain(mlm_handle *h, bool g_copied) {
     for (int k = 0; k < MLM_SETS; ++k) h->set_pending[k] = 0;
     if (h->next_seq > 0x3FFFFFFF) { // nothing in flight: sequence numbers restart, so the bucket table must forget them
         h->next_seq = 0;
+        for (auto &S : h->slots)
+            if (S.P.tile_dir) HIPCHK(h, hipMemsetAsync(S.P.tile_dir, 0xFF, 4 * (size_t)S.P.n_tiles * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long), h->stream));
     }
     return MLM_OK;
@@ -1140,7 +1153,6 @@ int submit_single_graph(mlm_handle *h, int base) {
     S.F.rehash_thr = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
     S.sector = true;
     S.keys_exact = false;
-    S.retry_done = 0;
     const unsigned int nb = S.mode == 0 ? (unsigned int)(((S.F.width + 31) / 32) * ((S.F.height + 7) / 8)) : (unsigned int)(((size_t)S.F.n + 255) / 256);
     if (nb > P.nb_cap) {
         h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
@@ -1182,7 +1194,7 @@ int submit_single_graph(mlm_handle *h, int base) {
             hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
             hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
             hipLaunchKernelGGL(k_tile, dim3((unsigned int)P.n_tiles, 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
-            hipLaunchKernelGGL(k_apply_frame_tab, dim3(256), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            hipLaunchKernelGGL(k_apply_tiles, dim3((unsigned int)P.n_tiles), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, 1, 0);
             e = hipGetLastError();
         }
         if (h->graph_copies == 1) {
@@ -1654,7 +1666,8 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         P.rec_cap = (unsigned int)std::min<size_t>(NC, (size_t)P.lv_nx * P.lv_ny * P.lv_nz);
         if ((rc = dev_alloc(h, &P.vr_rec, (size_t)P.rec_cap))) return rc;
         if ((rc = dev_alloc(h, &P.vr_hit, NC))) return rc;
-        if ((rc = dev_alloc(h, &P.vr_retry, (size_t)P.rec_cap))) return rc;
+        if ((rc = dev_alloc(h, &P.tile_dir, 4 * (size_t)P.n_tiles))) return rc;
+        HIPCHK(h, hipMemset(P.tile_dir, 0xFF, 4 * (size_t)P.n_tiles * sizeof(uint32_t))); // (no frame carries that sequence number)
         // bucket-first table of this slot: room for the emulated container of a frame with up to 2 * max_points unique
         // hit cells (more: the handle continues on the cell-table path)
         P.sbkt_cap = (unsigned int)std::min<size_t>(h->max_buckets, std::__detail::_Prime_rehash_policy()._M_next_bkt(4 * (size_t)h->lim.max_points + 2));
@@ -1925,6 +1938,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             while (P.tile_sh > 0 && ((size_t)P.lv_nz << (2 * P.tile_sh)) > 8192) --P.tile_sh;
             if (const char *e = getenv("MLM_TILE_SH")) P.tile_sh = std::min(3, std::max(0, atoi(e)));
             const int edge = 1 << P.tile_sh;
+            P.lv_nx += edge; // (the grid's origin is snapped down to a tile boundary: frame_setup)
+            P.lv_ny += edge;
             P.n_tx = (P.lv_nx + edge - 1) / edge;
             P.n_tiles = P.n_tx * ((P.lv_ny + edge - 1) / edge);
             P.tile_desc_cap = (unsigned int)P.nPhi + 64u; // a column's ray crosses a tile once: one descriptor per (column, tile)
@@ -1939,7 +1954,9 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
                          P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
                          (P.explore ? P.nRho <= 256
                                     : (((size_t)P.lv_nz << (2 * P.tile_sh)) <= 65536 && h->tile_lds_bytes <= 96u * 1024u && cells_per_voxel < 65536.0 &&
-                                       P.n_tiles < (1 << 24) && P.lv_nz < 65536));
+                                       P.n_tiles < (1 << 24) && P.lv_nz < 65536 &&
+                                       // (blocks one tile may overlap: their pool slots live in k_tile's LDS)
+                                       (long long)((1 << P.tile_sh) / P.n + 2) * ((1 << P.tile_sh) / P.n + 2) * (P.lv_nz / P.n + 2) <= MLM_TILE_COMBOS));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         // (lean slots cost the worst-case scenes their batching — every frame overflowing its sector tables: 1.3k instead of
         // 4.4k frames/s on the "scatter" scene — so they are used on request, or when the full slots do not fit the device)
