@@ -1358,7 +1358,9 @@ __device__ __forceinline__ int mlm_floor_div(int a, int n) {
 // increment of a single hit, the pool slot of the block if it exists already — into the frame's record list; the hits of
 // voxels with several go next to each other into vr_hit with their iteration-order keys.  The kernel that applies the frame
 // then needs two round trips per voxel: record -> (log-odds, class, hits).  Global atomics: two list reservations per tile.
+#ifndef MLM_TILE_THREADS
 #define MLM_TILE_THREADS 256
+#endif
 #define MLM_TILE_DESC 256   // descriptors staged per pass
 #define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap (its pool slots are kept in LDS; the host checks the geometry)
 struct MlmTileLds {
@@ -1566,7 +1568,7 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
                 const int slot = s_slot[(bz * ngy + (gy - gy0)) * ngx + (gx - gx0)];
                 const unsigned long long key = mlm_pack_key(gx, gy, gz0 + bz);
                 MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + o_rec;
-                *(MLM_GLOBAL mlm_u32x4 *)rec = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)cid, c & 0xFFFFu};
+                *(MLM_GLOBAL mlm_u32x4 *)rec = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)cid, (c & 0xFFFFu) | (((vxy << 10) | zz) << 16)}; // (lv_nz <= 1024, at most 64 columns per tile)
                 *(MLM_GLOBAL mlm_u32x2 *)&rec->slot = mlm_u32x2{(uint32_t)slot, nh};
                 if (nh != 1u) *(MLM_GLOBAL mlm_u32x2 *)&rec->inc0 = mlm_u32x2{0u, hit_base + o_hit}; // (one hit: written by that hit's lane)
                 ++o_rec;
@@ -1597,15 +1599,30 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot_base,
                                                            int n_frames, int f_begin) {
     __builtin_amdgcn_s_setprio(3); // the serial chain of the pipeline: its few waves issue ahead of Stage A's
-    __shared__ uint32_t s_first[64], s_count[64];
-    __shared__ int s_wx0, s_wy0, s_stop, s_nwx;
+    // The tile's voxels stay in LDS for the whole batch: a voxel is fetched from the map when a frame first touches it and
+    // written back once, after the last frame — between frames only an LDS barrier stands (not a round trip to memory and
+    // the wait for the stores' acknowledgement), and the map's lines are touched once per batch instead of once per frame.
+    // The frames' grids differ in their z origin (the sensor's height): the LDS column of a tile spans 2 * lv_nz layers from
+    // the lowest origin of the range (the host cuts a batch where the origins lie farther apart).
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    // per frame of the range, gathered once (the loop over the frames touches no frame or slot parameters in memory):
+    __shared__ const MlmVoxRec *s_rec[64];           // this tile's records of the frame
+    __shared__ const MlmVoxHit *s_hit[64];           // the frame's hit pairs
+    __shared__ const unsigned long long *s_key[64];  // its exact keys (replayed frames), else null
+    __shared__ uint32_t s_count[64];
+    __shared__ int s_dz[64];                         // the frame's z origin above the range's lowest
+    __shared__ int s_wx0, s_wy0, s_stop, s_nwx, s_z0;
     const int lane = threadIdx.x & 63;
     const MlmDev &P0 = slot_tab[slot_base];
-    const int sh = P0.tile_sh;
+    const int sh = P0.tile_sh, lv_nz = P0.lv_nz;
+    const uint32_t cells = (uint32_t)P0.cells;
+    const float lo_max = P0.lo_max, lo_sh = P0.lo_sh;
+    MLM_GLOBAL float *const pool_L = mlm_gp(P0.log_odds); // (the pool is the same in every slot)
+    MLM_GLOBAL uint8_t *const pool_o = mlm_gp(P0.occ);
     // the batch's box of world tiles (every workgroup derives it from the frames' grid origins: no launch argument changes from
     // call to call, which lets a single frame's launch sequence be replayed as a graph)
     if (threadIdx.x < 64) {
-        int wx = 0x7FFFFFFF, wy = 0x7FFFFFFF, wxm = -0x7FFFFFFF;
+        int wx = 0x7FFFFFFF, wy = 0x7FFFFFFF, wxm = -0x7FFFFFFF, z0 = 0x7FFFFFFF;
         bool ok = true;
         if (lane < n_frames) {
             const MlmFrame &F = frame_tab[slot_base + lane];
@@ -1613,6 +1630,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
             wx = F.lv_o[0] >> sh;
             wy = F.lv_o[1] >> sh;
             wxm = wx;
+            z0 = F.lv_o[2];
             ok = (F.flags & MLM_FRAME_SKIP) ||
                  (c->sector_overflow == 0u && c->pool_short == 0u && ((F.flags & MLM_FRAME_EXACT_KEYS) || c->u_hit <= F.rehash_thr));
         }
@@ -1620,11 +1638,13 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
             wx = min(wx, __shfl_xor(wx, off, 64));
             wy = min(wy, __shfl_xor(wy, off, 64));
             wxm = max(wxm, __shfl_xor(wxm, off, 64));
+            z0 = min(z0, __shfl_xor(z0, off, 64));
         }
         const unsigned long long bad = __ballot(!ok && lane >= f_begin && lane < n_frames);
         if (lane == 0) {
             s_wx0 = wx;
             s_wy0 = wy;
+            s_z0 = z0;
             s_nwx = wxm - wx + P0.n_tx;
             int stop = bad ? __ffsll((long long)bad) - 1 : n_frames;
             // an EARLIER batch is to be replayed first: nothing of this one may be applied
@@ -1636,107 +1656,203 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
     }
     __syncthreads();
     const int f_stop = s_stop;
+    const uint32_t NZ = 2u * (uint32_t)lv_nz, NV = NZ << (2 * sh);
+    float *s_L = (float *)s_dyn;                         // [NV] log-odds of the tile's voxels (valid where s_at != NIL)
+    uint32_t *s_at = (uint32_t *)(s_dyn + 4u * NV);      // [NV] the voxel's address in the pool (slot * cells + cell id), MLM_NIL: not fetched
+    uint8_t *s_o = (uint8_t *)(s_dyn + 8u * NV);         // [NV] occupancy class
+    for (uint32_t v = threadIdx.x; v < NV; v += blockDim.x) s_at[v] = MLM_NIL;
     const int WX = s_wx0 + (int)(blockIdx.x % (unsigned int)s_nwx), WY = s_wy0 + (int)(blockIdx.x / (unsigned int)s_nwx);
     // this world tile's records in every frame of the range (one lane per frame: the directory entries arrive together)
     if (threadIdx.x < 64) {
-        uint32_t first = 0, count = 0;
+        uint32_t count = 0;
+        const MlmVoxRec *rec = nullptr;
+        const MlmVoxHit *hit = nullptr;
+        const unsigned long long *key = nullptr;
+        int dz = 0;
         if (lane >= f_begin && lane < f_stop) {
             const MlmFrame &F = frame_tab[slot_base + lane];
             const MlmDev &P = slot_tab[slot_base + lane];
             const int tx = WX - (F.lv_o[0] >> sh), ty = WY - (F.lv_o[1] >> sh);
-            if (!(F.flags & MLM_FRAME_SKIP) && tx >= 0 && ty >= 0 && tx < P.n_tx && ty * P.n_tx + tx < P.n_tiles) {
+            dz = F.lv_o[2] - s_z0;
+            if (!(F.flags & MLM_FRAME_SKIP) && tx >= 0 && ty >= 0 && tx < P.n_tx && ty * P.n_tx + tx < P.n_tiles && dz >= 0 && dz <= lv_nz) {
                 const mlm_u32x4 e = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_dir) + 4 * (size_t)(ty * P.n_tx + tx));
                 if (e.z == (uint32_t)F.seq) {
-                    first = e.x;
+                    rec = P.vr_rec + e.x;
                     count = e.y;
+                    hit = P.vr_hit;
+                    key = (F.flags & MLM_FRAME_EXACT_KEYS) ? (const unsigned long long *)P.hl_key : nullptr;
                 }
             }
         }
-        s_first[lane] = first;
+        s_rec[lane] = rec;
+        s_hit[lane] = hit;
+        s_key[lane] = key;
         s_count[lane] = count;
+        s_dz[lane] = dz;
     }
     __syncthreads();
-    for (int f = f_begin; f < f_stop; ++f) {
+    // The records of the next frame that has any for this tile are fetched while the current frame is applied (they do not depend
+    // on the map).  Two records per thread are held in registers; a tile with more takes the rest straight from memory.
+    constexpr int PRE = 2;
+    mlm_u32x4 n0[PRE], n1[PRE];
+    auto next_frame = [&](int f) {
+        while (f < f_stop && s_count[f] == 0u) ++f;
+        return f;
+    };
+    auto prefetch = [&](int f) {
+        if (f >= f_stop) return;
+        const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(s_rec[f]);
         const uint32_t count = s_count[f];
-        if (!count) continue; // (uniform)
-        const MlmDev &P = slot_tab[slot_base + f];
-        const int explicit_keys = frame_tab[slot_base + f].flags & MLM_FRAME_EXACT_KEYS;
-        const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.vr_rec) + s_first[f]);
-        for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) {
-            const mlm_u32x4 r0 = recs[2 * (size_t)i], r1 = recs[2 * (size_t)i + 1];
-            const uint32_t cid = r0.z, km = r0.w, nh = r1.y, first = r1.w;
-            const int slot = (int)r1.x;
-            if (slot < 0) continue; // (cannot happen: a frame whose blocks could not be created is not applied)
-            const size_t v = (size_t)slot * P.cells + cid;
-            float L = mlm_gp(P.log_odds)[v];
-            uint8_t o = mlm_gp(P.occ)[v];
-            auto hit = [&](float inc) { // map_local.cpp:157-171
-                if (L < P.lo_max) {
-                    L = L + inc;
-                    L = L > P.lo_max ? P.lo_max : L;
-                }
-                if (L > P.lo_sh && o != 'o') o = 'o';
-            };
-            if (nh == 1u) { // the common case: a single contribution
-                hit(__uint_as_float(r1.z));
-            } else if (nh) {
-                // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
-                // reference's iteration order); explicit_keys: hl_key holds the exact keys of a replayed frame
-                const MLM_GLOBAL mlm_u32x4 *hh = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.vr_hit) + first);
-                auto key_of = [&](const mlm_u32x4 &e) -> unsigned long long {
-                    return explicit_keys ? mlm_gp(P.hl_key)[e.w] : ((unsigned long long)e.x | ((unsigned long long)e.y << 32));
-                };
-                if (nh <= MLM_APPLY_REGS) {
-                    unsigned long long ks[MLM_APPLY_REGS];
-                    float vs[MLM_APPLY_REGS];
 #pragma unroll
-                    for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                        ks[q] = 0; // real keys are never 0
-                        vs[q] = 0.0f;
-                    }
-                    for (uint32_t j = 0; j < nh; ++j) {
-                        const mlm_u32x4 e = hh[j];
-                        unsigned long long k = key_of(e);
-                        float inc = __uint_as_float(e.z);
+        for (int k = 0; k < PRE; ++k) {
+            const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
+            if (i < count) {
+                n0[k] = recs[2 * (size_t)i];
+                n1[k] = recs[2 * (size_t)i + 1];
+            }
+        }
+    };
+    int f = next_frame(f_begin);
+    prefetch(f);
+    while (f < f_stop) {
+        const uint32_t count = s_count[f];
+        const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(s_rec[f]);
+        const MLM_GLOBAL MlmVoxHit *hits = mlm_gp(s_hit[f]);
+        const MLM_GLOBAL unsigned long long *xkeys = mlm_gp(s_key[f]); // exact keys of a replayed frame, else null
+        const uint32_t dz = (uint32_t)s_dz[f];
+        mlm_u32x4 c0[PRE], c1[PRE];
 #pragma unroll
-                        for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                            if (k > ks[q]) {
-                                const unsigned long long tk = ks[q];
-                                const float tv = vs[q];
-                                ks[q] = k;
-                                vs[q] = inc;
-                                k = tk;
-                                inc = tv;
-                            }
-                        }
-                    }
+        for (int k = 0; k < PRE; ++k) {
+            c0[k] = n0[k];
+            c1[k] = n1[k];
+        }
+        const int f_next = next_frame(f + 1);
+        prefetch(f_next);
+        // a thread's records in chunks of four: the records of a chunk are loaded together (the first two came with the
+        // previous frame), then the voxels that are not in LDS yet are fetched together, then the chunk is applied — the
+        // round trips of a chunk overlap instead of following each other
+        constexpr int U = 4;
+        for (uint32_t i0 = threadIdx.x, chunk = 0; i0 < count; i0 += blockDim.x * U, ++chunk) {
+            mlm_u32x4 r0[U], r1[U];
 #pragma unroll
-                    for (int q = 0; q < MLM_APPLY_REGS; ++q)
-                        if ((uint32_t)q < nh) hit(vs[q]);
-                } else {
-                    // more hits than registers: repeated selection of the next key straight from memory
-                    unsigned long long last = ~0ull;
-                    for (uint32_t done = 0; done < nh; ++done) {
-                        unsigned long long bestkey = 0;
-                        float bestinc = 0.0f;
-                        for (uint32_t j = 0; j < nh; ++j) {
-                            const mlm_u32x4 e = hh[j];
-                            const unsigned long long k = key_of(e);
-                            if (k < last && k > bestkey) {
-                                bestkey = k;
-                                bestinc = __uint_as_float(e.z);
-                            }
-                        }
-                        hit(bestinc);
-                        last = bestkey;
-                    }
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+                if (chunk == 0 && u < PRE) {
+                    r0[u] = c0[u];
+                    r1[u] = c1[u];
+                } else if (i < count) {
+                    r0[u] = recs[2 * (size_t)i];
+                    r1[u] = recs[2 * (size_t)i + 1];
                 }
             }
-            mlm_apply_misses(P, L, o, km);
-            mlm_gp(P.log_odds)[v] = L;
-            mlm_gp(P.occ)[v] = o;
+            float Lv[U];
+            uint8_t ov[U];
+            uint32_t vts[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+                vts[u] = MLM_NIL;
+                Lv[u] = 0.0f;
+                ov[u] = 'u';
+                if (i >= count) continue;
+                const uint32_t vt = (r0[u].w >> 26) * NZ + ((r0[u].w >> 16) & 1023u) + dz; // (tile column, layer above the range's lowest origin)
+                const int slot = (int)r1[u].x;
+                if (slot < 0 || vt >= NV) continue; // (cannot happen: a frame whose blocks could not be created is not applied)
+                vts[u] = vt;
+                if (s_at[vt] == MLM_NIL) { // first touch of the voxel in this batch (one record per voxel and frame: no other lane has it now)
+                    const uint32_t at = (uint32_t)slot * cells + r0[u].z; // (< 2^31: alloc_pool)
+                    Lv[u] = pool_L[at];
+                    ov[u] = pool_o[at];
+                    s_at[vt] = at;
+                } else {
+                    Lv[u] = s_L[vt];
+                    ov[u] = s_o[vt];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t vt = vts[u];
+                if (vt == MLM_NIL) continue;
+                const uint32_t km = r0[u].w & 0xFFFFu, nh = r1[u].y, first = r1[u].w;
+                float L = Lv[u];
+                uint8_t o = ov[u];
+                auto hit = [&](float inc) { // map_local.cpp:157-171
+                    if (L < lo_max) {
+                        L = L + inc;
+                        L = L > lo_max ? lo_max : L;
+                    }
+                    if (L > lo_sh && o != 'o') o = 'o';
+                };
+                if (nh == 1u) { // the common case: a single contribution
+                    hit(__uint_as_float(r1[u].z));
+                } else if (nh) {
+                    // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
+                    // reference's iteration order); a replayed frame's exact keys come from hl_key
+                    const MLM_GLOBAL mlm_u32x4 *hh = (const MLM_GLOBAL mlm_u32x4 *)(hits + first);
+                    auto key_of = [&](const mlm_u32x4 &e) -> unsigned long long {
+                        return xkeys ? xkeys[e.w] : ((unsigned long long)e.x | ((unsigned long long)e.y << 32));
+                    };
+                    if (nh <= MLM_APPLY_REGS) {
+                        unsigned long long ks[MLM_APPLY_REGS];
+                        float vs[MLM_APPLY_REGS];
+#pragma unroll
+                        for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                            ks[q] = 0; // real keys are never 0
+                            vs[q] = 0.0f;
+                        }
+                        for (uint32_t j = 0; j < nh; ++j) {
+                            const mlm_u32x4 e = hh[j];
+                            unsigned long long kk = key_of(e);
+                            float inc = __uint_as_float(e.z);
+#pragma unroll
+                            for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                                if (kk > ks[q]) {
+                                    const unsigned long long tk = ks[q];
+                                    const float tv = vs[q];
+                                    ks[q] = kk;
+                                    vs[q] = inc;
+                                    kk = tk;
+                                    inc = tv;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < MLM_APPLY_REGS; ++q)
+                            if ((uint32_t)q < nh) hit(vs[q]);
+                    } else {
+                        // more hits than registers: repeated selection of the next key straight from memory
+                        unsigned long long last = ~0ull;
+                        for (uint32_t done = 0; done < nh; ++done) {
+                            unsigned long long bestkey = 0;
+                            float bestinc = 0.0f;
+                            for (uint32_t j = 0; j < nh; ++j) {
+                                const mlm_u32x4 e = hh[j];
+                                const unsigned long long kk = key_of(e);
+                                if (kk < last && kk > bestkey) {
+                                    bestkey = kk;
+                                    bestinc = __uint_as_float(e.z);
+                                }
+                            }
+                            hit(bestinc);
+                            last = bestkey;
+                        }
+                    }
+                }
+                mlm_apply_misses(P0, L, o, km);
+                s_L[vt] = L;
+                s_o[vt] = o;
+            }
         }
-        __syncthreads(); // (this frame's stores are visible to the workgroup's loads of the next frame)
+        __syncthreads(); // (this frame's voxels are in LDS before the next frame reads them)
+        f = f_next;
+    }
+    // the voxels the batch touched go back to the map
+    for (uint32_t v = threadIdx.x; v < NV; v += blockDim.x) {
+        const uint32_t at = s_at[v];
+        if (at != MLM_NIL) {
+            pool_L[at] = s_L[v];
+            pool_o[at] = s_o[v];
+        }
     }
 }
 

@@ -160,6 +160,7 @@ struct mlm_handle {
     bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
     size_t frame_block_bound = 0; // most blocks one frame can create
     unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
+    unsigned int apply_lds_bytes = 0; // dynamic LDS of k_apply_tiles: 9 bytes per voxel of a tile
     unsigned int big_grid = 256;     // workgroups of k_sector_big per batch: one per CU (MLM_BIG_GRID)
     int big_armed = 0;               // batches (single frames) for which the pass with the large cell table stays scheduled
     int big_armed_from = 0;          // first frame (sequence number; frontier mode: frame number) submitted after it was scheduled
@@ -823,17 +824,22 @@ int launch_apply_tiles(mlm_handle *h, int base, int n, int f_begin = 0) {
     const int sh = P.tile_sh, n_ty = P.n_tiles / P.n_tx;
     int j0 = std::max(0, f_begin);
     while (j0 < n) {
-        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, j1 = j0;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0, j1 = j0;
         for (; j1 < n; ++j1) {
             const MlmFrame &F = h->slots[(size_t)(base + j1)].F;
-            const int wx = F.lv_o[0] >> sh, wy = F.lv_o[1] >> sh;
+            const int wx = F.lv_o[0] >> sh, wy = F.lv_o[1] >> sh, wz = F.lv_o[2];
             const int nx0 = j1 == j0 ? wx : std::min(x0, wx), nx1 = j1 == j0 ? wx : std::max(x1, wx);
             const int ny0 = j1 == j0 ? wy : std::min(y0, wy), ny1 = j1 == j0 ? wy : std::max(y1, wy);
-            if (j1 > j0 && (long long)(nx1 - nx0 + P.n_tx) * (ny1 - ny0 + n_ty) > (1ll << 20)) break;
+            const int nz0 = j1 == j0 ? wz : std::min(z0, wz), nz1 = j1 == j0 ? wz : std::max(z1, wz);
+            // (a launch's box of world tiles stays small, and its frames' z origins within one grid height: k_apply_tiles keeps
+            // two grid heights of a tile's layers in LDS)
+            if (j1 > j0 && ((long long)(nx1 - nx0 + P.n_tx) * (ny1 - ny0 + n_ty) > (1ll << 20) || nz1 - nz0 > P.lv_nz)) break;
             x0 = nx0;
             x1 = nx1;
             y0 = ny0;
             y1 = ny1;
+            z0 = nz0;
+            z1 = nz1;
         }
         const long long grid = (long long)(x1 - x0 + P.n_tx) * (y1 - y0 + n_ty);
         if (grid > 0x7FFFFFFFll) {
@@ -841,7 +847,7 @@ int launch_apply_tiles(mlm_handle *h, int base, int n, int f_begin = 0) {
             return MLM_ERR_UNSUPPORTED;
         }
         // (the kernel derives the box from the frames [base + j0, base + j1) itself: it gets that range as ITS slot range)
-        tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(MLM_BLOCK), 0, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0);
+        tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(MLM_BLOCK), h->apply_lds_bytes, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0);
         j0 = j1;
     }
     return MLM_OK;
@@ -1194,7 +1200,7 @@ int submit_single_graph(mlm_handle *h, int base) {
             hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
             hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
             hipLaunchKernelGGL(k_tile, dim3((unsigned int)P.n_tiles, 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
-            hipLaunchKernelGGL(k_apply_tiles, dim3((unsigned int)P.n_tiles), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, 1, 0);
+            hipLaunchKernelGGL(k_apply_tiles, dim3((unsigned int)P.n_tiles), dim3(MLM_BLOCK), h->apply_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1, 0);
             e = hipGetLastError();
         }
         if (h->graph_copies == 1) {
@@ -1944,6 +1950,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             P.n_tiles = P.n_tx * ((P.lv_ny + edge - 1) / edge);
             P.tile_desc_cap = (unsigned int)P.nPhi + 64u; // a column's ray crosses a tile once: one descriptor per (column, tile)
             h->tile_lds_bytes = mlm_tile_lds((unsigned int)(edge * edge * P.lv_nz), (unsigned int)P.lv_nz).total;
+            h->apply_lds_bytes = (unsigned int)(edge * edge * 2 * P.lv_nz) * 9u + 16u; // (two grid heights of layers: frames of a range differ in z origin)
         }
         // (frontier mode: no tiles; its insertion times hold point index * 256 + ray step in 32 bits)
         // (k_sector lists a column's miss cells in its cell table's space; k_tile counts a voxel's misses and hits in 16 bits each:
@@ -1954,7 +1961,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
                          P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
                          (P.explore ? P.nRho <= 256
                                     : (((size_t)P.lv_nz << (2 * P.tile_sh)) <= 65536 && h->tile_lds_bytes <= 96u * 1024u && cells_per_voxel < 65536.0 &&
-                                       P.n_tiles < (1 << 24) && P.lv_nz < 65536 &&
+                                       P.n_tiles < (1 << 24) && P.lv_nz <= 1024 && h->apply_lds_bytes <= 150u * 1024u &&
                                        // (blocks one tile may overlap: their pool slots live in k_tile's LDS)
                                        (long long)((1 << P.tile_sh) / P.n + 2) * ((1 << P.tile_sh) / P.n + 2) * (P.lv_nz / P.n + 2) <= MLM_TILE_COMBOS));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
@@ -1971,6 +1978,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             else
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
             if (!P.explore) HIPCHK(h, hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds_bytes));
+            if (!P.explore) HIPCHK(h, hipFuncSetAttribute((const void *)k_apply_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->apply_lds_bytes));
             if (P.sec_tab_big) {
                 if (P.explore)
                     HIPCHK(h, hipFuncSetAttribute((const void *)k_sector_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_big_lds_bytes));
