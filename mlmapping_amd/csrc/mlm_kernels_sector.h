@@ -960,6 +960,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             if (m_cnt | h_cnt) {
                 const uint32_t tile = s_run_tile[r];
                 const unsigned int k = g_atomic_add(&mlm_gp(P.tile_cnt)[tile], 1u);
+                if (k == 0u) // the tile's first descriptor of this frame: k_tile walks the list of touched tiles
+                    mlm_gp(P.tile_list)[g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[2][0], 1u)] = tile;
                 if (k < P.tile_desc_cap)
                     *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * ((size_t)tile * P.tile_desc_cap + k)) =
                         mlm_u32x4{m_base + m_first, m_cnt, s_base[0] + s_run_off[r], h_cnt};
@@ -1379,11 +1381,9 @@ __host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_n
     L.total = (o + 15u) & ~15u;
     return L;
 }
-__global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
-    MLM_SLOT_SETUP
-    const unsigned int tile = blockIdx.x;
+__device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F, const unsigned int tile) {
     const unsigned int nd_all = mlm_gp(P.tile_cnt)[tile];
-    if (nd_all == 0) return; // nothing of this frame fell into the tile (uniform)
+    if (nd_all == 0) return; // (cannot happen: the tile is on the frame's list)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t edge = 1u << P.tile_sh, NV = edge * edge * (uint32_t)P.lv_nz;
     const MlmTileLds L = mlm_tile_lds(NV, (uint32_t)P.lv_nz);
@@ -1581,6 +1581,17 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
         }
     }
     for_cells(1); // (its first barrier makes the places visible)
+}
+// blockIdx.x walks the frame's list of touched tiles (k_sector appends a tile with its first descriptor): a frame reaches a
+// fraction of its grid's tiles, and a workgroup per tile of the grid would spend most launches — each waiting for its LDS —
+// on finding its tile empty
+__global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
+    const unsigned int n_touched = min(mlm_gp(P.ctr)->mvox_cnt[2][0], (unsigned int)P.n_tiles);
+    for (unsigned int t = blockIdx.x; t < n_touched; t += gridDim.x) { // (uniform)
+        if (t != blockIdx.x) __syncthreads();                         // (the previous tile's shared state is no longer read)
+        mlm_tile_one(P, F, mlm_gp(P.tile_list)[t]);
+    }
 }
 
 // The part that needs the map (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237), sector path: ONE launch for a

@@ -30,7 +30,7 @@ struct MlmCounters {
                                  // [k][1] = device-scope atomics the frame's kernels issued (sector path, counted by k_sector)
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // cell-table path: [k][0] = voxels touched by misses, sub-list k; sector path: [0][0] voxel records,
-                                   // [1][0] entries of vr_hit, [3][0] miss cells reserved in mc_list
+                                   // [1][0] entries of vr_hit, [2][0] touched tiles (tile_list), [3][0] miss cells reserved in mc_list
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
     unsigned int node_cnt[8][32];  // [k][0] = contribution nodes allocated in region k
     unsigned int mc_cnt[8][32];    // [k][0] = unique miss cells queued in sub-list k
@@ -231,6 +231,7 @@ struct MlmDev {
     unsigned int mc_list_cap;
     uint16_t *hl_vt16;         // [nCells] vt of every unique hit (a column's hits are contiguous in hl_*, ordered by tile)
     unsigned int *tile_cnt;    // [n_tiles] descriptors handed to each tile this frame (reset by k_tile)
+    unsigned int *tile_list;   // [n_tiles] the tiles that received descriptors this frame (count: ctr->mvox_cnt[2][0])
     uint32_t *tile_desc;       // [n_tiles][tile_desc_cap][4] {first miss cell in mc_list, count, first hit in hl_*, count}
     unsigned int tile_desc_cap;
     MlmVoxRec *vr_rec;         // [rec_cap] one record per voxel the frame touches (count: MlmCounters::mvox_cnt[0][0])
