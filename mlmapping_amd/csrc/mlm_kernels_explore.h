@@ -136,6 +136,7 @@ __device__ __forceinline__ void mlm_ex_release_body(const MlmDev &P);
 // this frame's ordering depends on — the per-frame chain is two launches shorter (see also k_ex_order_keys).
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_min(const MlmDev P, unsigned int n_hit, unsigned int n_miss, unsigned long long nb_hit,
                                                             unsigned long long nb_miss, int tag, const MlmDev Pprev) {
+    __builtin_amdgcn_s_setprio(3); // (the serial chain of this mode: ahead of the next batch's Stage A)
     const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (blockIdx.y == 2) {
         mlm_ex_apply_misses_body(Pprev);
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_min(const MlmDev P, unsi
 // blockIdx.y = 2: the release scan of the PREVIOUS frame (after its miss phase, which ran with k_ex_order_min)
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_keys(const MlmDev P, unsigned int n_hit, unsigned int n_miss, unsigned long long nb_hit,
                                                              unsigned long long nb_miss, const MlmDev Pprev) {
+    __builtin_amdgcn_s_setprio(3); // (the serial chain of this mode: ahead of the next batch's Stage A)
     const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (blockIdx.y == 2) {
         mlm_ex_release_body(Pprev);
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_miss_tau(const MlmDev P, const
 // the hit push (k_voxelize's hit side, explicit keys) and the miss registration of a frame in ONE launch: they touch
 // different per-voxel words (blockIdx.y = 0 hits, 1 misses)
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_register(const MlmDev P, const MlmFrame F) {
+    __builtin_amdgcn_s_setprio(3);
     if (blockIdx.y == 0) mlm_voxelize_body(P, F, 0ull, 0u);
     else mlm_ex_miss_tau_body(P);
 }
@@ -210,6 +213,7 @@ __device__ __forceinline__ bool mlm_inside_exp_bd(double x, double y, double z) 
 // The miss cell that is first on its voxel (its key == tau) plays update_observation for that voxel if the voxel
 // is still unknown (it turns 'f' at this very miss: L <= occupied_sh for an unknown cell and the miss lowers it).
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_observe(const MlmDev P, const MlmFrame F) {
+    __builtin_amdgcn_s_setprio(3);
     const unsigned int n = P.ctr->n_ex_miss;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int v = P.ex_vox[i];

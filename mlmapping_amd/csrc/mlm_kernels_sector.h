@@ -1382,6 +1382,11 @@ __host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_n
     return L;
 }
 __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F, const unsigned int tile) {
+    // (the tile's first descriptors are requested together with their count, not after it: a single frame's latency is the
+    // number of dependent trips to memory; what lies beyond the count is not looked at)
+    const MLM_GLOBAL mlm_u32x4 *descs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * (size_t)tile * P.tile_desc_cap);
+    mlm_u32x4 dd_first = mlm_u32x4{0u, 0u, 0u, 0u};
+    if (threadIdx.x < min((unsigned int)MLM_TILE_DESC, P.tile_desc_cap)) dd_first = descs[threadIdx.x];
     const unsigned int nd_all = mlm_gp(P.tile_cnt)[tile];
     if (nd_all == 0) return; // (cannot happen: the tile is on the frame's list)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
@@ -1428,7 +1433,6 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
         for (int c = threadIdx.x + MLM_TILE_THREADS; c < n_combo; c += MLM_TILE_THREADS) s_slot[c] = combo_slot(c);
     }
     const unsigned int nd = min(nd_all, P.tile_desc_cap);
-    const MLM_GLOBAL mlm_u32x4 *descs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * (size_t)tile * P.tile_desc_cap);
     // flat item j of the staged descriptors -> (descriptor, offset inside it); pre[] = exclusive prefix of the counts
     auto locate = [&](const uint32_t *pre, uint32_t n_staged, uint32_t j, uint32_t &d, uint32_t &o) {
         uint32_t lo = 0, hi = n_staged;
@@ -1449,7 +1453,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
             uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
             mlm_u32x4 dd = mlm_u32x4{0u, 0u, 0u, 0u};
             if (threadIdx.x < n_staged) {
-                dd = descs[d0 + threadIdx.x];
+                dd = d0 == 0 ? dd_first : descs[d0 + threadIdx.x];
                 a[0] = dd.y;
                 a[1] = dd.w;
             }
@@ -1587,11 +1591,85 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
 // on finding its tile empty
 __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
+    // (the first list entry is requested together with the list's length; a stale entry is not used)
+    const unsigned int tile_first = blockIdx.x < (unsigned int)P.n_tiles ? mlm_gp(P.tile_list)[blockIdx.x] : 0u;
     const unsigned int n_touched = min(mlm_gp(P.ctr)->mvox_cnt[2][0], (unsigned int)P.n_tiles);
     for (unsigned int t = blockIdx.x; t < n_touched; t += gridDim.x) { // (uniform)
         if (t != blockIdx.x) __syncthreads();                         // (the previous tile's shared state is no longer read)
-        mlm_tile_one(P, F, mlm_gp(P.tile_list)[t]);
+        mlm_tile_one(P, F, t == blockIdx.x ? tile_first : mlm_gp(P.tile_list)[t]);
     }
+}
+
+// One voxel record applied to the voxel's state (L, o): its hits in the reference's iteration order (descending key,
+// map_local.cpp:157-171), then its misses (map_local.cpp:188-203).  hits: the frame's vr_hit; xkeys: exact keys of a replayed
+// frame (by hit-list position), else null.
+__device__ __forceinline__ void mlm_apply_record(const MlmDev &P0, const mlm_u32x4 &r0, const mlm_u32x4 &r1, const MLM_GLOBAL MlmVoxHit *hits,
+                                                 const MLM_GLOBAL unsigned long long *xkeys, float &L, uint8_t &o) {
+    const float lo_max = P0.lo_max, lo_sh = P0.lo_sh;
+    const uint32_t km = r0.w & 0xFFFFu, nh = r1.y, first = r1.w;
+    auto hit = [&](float inc) { // map_local.cpp:157-171
+        if (L < lo_max) {
+            L = L + inc;
+            L = L > lo_max ? lo_max : L;
+        }
+        if (L > lo_sh && o != 'o') o = 'o';
+    };
+    if (nh == 1u) { // the common case: a single contribution
+        hit(__uint_as_float(r1.z));
+    } else if (nh) {
+        // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
+        // reference's iteration order); a replayed frame's exact keys come from hl_key
+        const MLM_GLOBAL mlm_u32x4 *hh = (const MLM_GLOBAL mlm_u32x4 *)(hits + first);
+        auto key_of = [&](const mlm_u32x4 &e) -> unsigned long long {
+            return xkeys ? xkeys[e.w] : ((unsigned long long)e.x | ((unsigned long long)e.y << 32));
+        };
+        if (nh <= MLM_APPLY_REGS) {
+            unsigned long long ks[MLM_APPLY_REGS];
+            float vs[MLM_APPLY_REGS];
+#pragma unroll
+            for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                ks[q] = 0; // real keys are never 0
+                vs[q] = 0.0f;
+            }
+            for (uint32_t j = 0; j < nh; ++j) {
+                const mlm_u32x4 e = hh[j];
+                unsigned long long kk = key_of(e);
+                float inc = __uint_as_float(e.z);
+#pragma unroll
+                for (int q = 0; q < MLM_APPLY_REGS; ++q) {
+                    if (kk > ks[q]) {
+                        const unsigned long long tk = ks[q];
+                        const float tv = vs[q];
+                        ks[q] = kk;
+                        vs[q] = inc;
+                        kk = tk;
+                        inc = tv;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < MLM_APPLY_REGS; ++q)
+                if ((uint32_t)q < nh) hit(vs[q]);
+        } else {
+            // more hits than registers: repeated selection of the next key straight from memory
+            unsigned long long last = ~0ull;
+            for (uint32_t done = 0; done < nh; ++done) {
+                unsigned long long bestkey = 0;
+                float bestinc = 0.0f;
+                for (uint32_t j = 0; j < nh; ++j) {
+                    const mlm_u32x4 e = hh[j];
+                    const unsigned long long kk = key_of(e);
+                    if (kk < last && kk > bestkey) {
+                        bestkey = kk;
+                        bestinc = __uint_as_float(e.z);
+                    }
+                }
+                hit(bestinc);
+                last = bestkey;
+            }
+        }
+    }
+    mlm_apply_misses(P0, L, o, km);
 }
 
 // The part that needs the map (local_map_cartesian::input_pc_pose_direct, map_local.cpp:143-237), sector path: ONE launch for a
@@ -1627,7 +1705,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
     const MlmDev &P0 = slot_tab[slot_base];
     const int sh = P0.tile_sh, lv_nz = P0.lv_nz;
     const uint32_t cells = (uint32_t)P0.cells;
-    const float lo_max = P0.lo_max, lo_sh = P0.lo_sh;
     MLM_GLOBAL float *const pool_L = mlm_gp(P0.log_odds); // (the pool is the same in every slot)
     MLM_GLOBAL uint8_t *const pool_o = mlm_gp(P0.occ);
     // the batch's box of world tiles (every workgroup derives it from the frames' grid origins: no launch argument changes from
@@ -1784,72 +1861,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
             for (int u = 0; u < U; ++u) {
                 const uint32_t vt = vts[u];
                 if (vt == MLM_NIL) continue;
-                const uint32_t km = r0[u].w & 0xFFFFu, nh = r1[u].y, first = r1[u].w;
                 float L = Lv[u];
                 uint8_t o = ov[u];
-                auto hit = [&](float inc) { // map_local.cpp:157-171
-                    if (L < lo_max) {
-                        L = L + inc;
-                        L = L > lo_max ? lo_max : L;
-                    }
-                    if (L > lo_sh && o != 'o') o = 'o';
-                };
-                if (nh == 1u) { // the common case: a single contribution
-                    hit(__uint_as_float(r1[u].z));
-                } else if (nh) {
-                    // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
-                    // reference's iteration order); a replayed frame's exact keys come from hl_key
-                    const MLM_GLOBAL mlm_u32x4 *hh = (const MLM_GLOBAL mlm_u32x4 *)(hits + first);
-                    auto key_of = [&](const mlm_u32x4 &e) -> unsigned long long {
-                        return xkeys ? xkeys[e.w] : ((unsigned long long)e.x | ((unsigned long long)e.y << 32));
-                    };
-                    if (nh <= MLM_APPLY_REGS) {
-                        unsigned long long ks[MLM_APPLY_REGS];
-                        float vs[MLM_APPLY_REGS];
-#pragma unroll
-                        for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                            ks[q] = 0; // real keys are never 0
-                            vs[q] = 0.0f;
-                        }
-                        for (uint32_t j = 0; j < nh; ++j) {
-                            const mlm_u32x4 e = hh[j];
-                            unsigned long long kk = key_of(e);
-                            float inc = __uint_as_float(e.z);
-#pragma unroll
-                            for (int q = 0; q < MLM_APPLY_REGS; ++q) {
-                                if (kk > ks[q]) {
-                                    const unsigned long long tk = ks[q];
-                                    const float tv = vs[q];
-                                    ks[q] = kk;
-                                    vs[q] = inc;
-                                    kk = tk;
-                                    inc = tv;
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int q = 0; q < MLM_APPLY_REGS; ++q)
-                            if ((uint32_t)q < nh) hit(vs[q]);
-                    } else {
-                        // more hits than registers: repeated selection of the next key straight from memory
-                        unsigned long long last = ~0ull;
-                        for (uint32_t done = 0; done < nh; ++done) {
-                            unsigned long long bestkey = 0;
-                            float bestinc = 0.0f;
-                            for (uint32_t j = 0; j < nh; ++j) {
-                                const mlm_u32x4 e = hh[j];
-                                const unsigned long long kk = key_of(e);
-                                if (kk < last && kk > bestkey) {
-                                    bestkey = kk;
-                                    bestinc = __uint_as_float(e.z);
-                                }
-                            }
-                            hit(bestinc);
-                            last = bestkey;
-                        }
-                    }
-                }
-                mlm_apply_misses(P0, L, o, km);
+                mlm_apply_record(P0, r0[u], r1[u], hits, xkeys, L, o);
                 s_L[vt] = L;
                 s_o[vt] = o;
             }
@@ -1864,6 +1878,51 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
             pool_L[at] = s_L[v];
             pool_o[at] = s_o[v];
         }
+    }
+}
+
+// The same for ONE frame (a synchronous single-frame call — the reference's call pattern, src/mlmap.cpp:463-507 — and the replay
+// of one frame): nothing is carried from frame to frame, so nothing is staged in LDS, and the tiles do not matter — the frame's
+// records lie in one list.  What a single frame costs is the number of DEPENDENT trips to memory (a kernel's first touch of what
+// another kernel wrote crosses the XCDs: several microseconds each), so every thread fetches its first record together with the
+// frame's flags and counts instead of after them: parameters -> (flags, count, record) -> (log-odds, class) -> store.
+// Stops in front of the frame under the same conditions as k_apply_tiles.
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS) {
+    MLM_SLOT_SETUP
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.vr_rec);
+    mlm_u32x4 r0 = mlm_u32x4{0u, 0u, 0u, 0u}, r1 = r0;
+    if (i0 < P.rec_cap) { // (before the count is known: the list's memory is there either way)
+        r0 = recs[2 * (size_t)i0];
+        r1 = recs[2 * (size_t)i0 + 1];
+    }
+    const MLM_GLOBAL MlmCounters *c = mlm_gp(P.ctr);
+    const uint32_t total = min(c->mvox_cnt[0][0], P.rec_cap);
+    const bool ok = c->sector_overflow == 0u && c->pool_short == 0u && ((F.flags & MLM_FRAME_EXACT_KEYS) || c->u_hit <= F.rehash_thr);
+    if (F.flags & MLM_FRAME_SKIP) return;
+    if (__hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < F.seq) return; // an earlier frame is to be replayed first
+    if (!ok) { // (uniform)
+        if (i0 == 0) atomicMin(&P.g->fail_frame, F.seq);
+        return;
+    }
+    const uint32_t cells = (uint32_t)P.cells;
+    MLM_GLOBAL float *const pool_L = mlm_gp(P.log_odds);
+    MLM_GLOBAL uint8_t *const pool_o = mlm_gp(P.occ);
+    const MLM_GLOBAL MlmVoxHit *hits = mlm_gp(P.vr_hit);
+    const MLM_GLOBAL unsigned long long *xkeys = (F.flags & MLM_FRAME_EXACT_KEYS) ? (const MLM_GLOBAL unsigned long long *)mlm_gp(P.hl_key) : nullptr;
+    for (uint32_t i = i0; i < total; i += stride) {
+        if (i != i0) {
+            r0 = recs[2 * (size_t)i];
+            r1 = recs[2 * (size_t)i + 1];
+        }
+        if ((int)r1.x < 0) continue; // (no slot: cannot happen, such a frame is not applied)
+        const uint32_t at = r1.x * cells + r0.z; // (< 2^31: alloc_pool)
+        float L = pool_L[at];
+        uint8_t o = pool_o[at];
+        mlm_apply_record(P, r0, r1, hits, xkeys, L, o);
+        pool_L[at] = L;
+        pool_o[at] = o;
     }
 }
 
@@ -1895,9 +1954,15 @@ __global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_fra
     for (unsigned int i = threadIdx.x; i < sizeof(MlmFrame) / 4; i += blockDim.x) dst[i] = src[i];
     for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) c[i] = 0u;
 }
-__global__ __launch_bounds__(128) void k_frame_epilogue(const MlmCounters *ctr, MlmCounters *host_ctr, const MlmGlobal *g, MlmGlobal *host_g) {
+// The last word written is a ticket (the frame's sequence number + 1 in MlmGlobal::pad of the HOST copy): the calling thread
+// polls it instead of sleeping in hipStreamSynchronize — a synchronous call's wake-up is part of its latency.
+__global__ __launch_bounds__(128) void k_frame_epilogue(const MlmCounters *ctr, MlmCounters *host_ctr, const MlmGlobal *g, MlmGlobal *host_g,
+                                                        const MlmFrame *dev_frame) {
     const uint32_t *src = (const uint32_t *)ctr;
     uint32_t *dst = (uint32_t *)host_ctr;
     for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) dst[i] = src[i];
-    if (threadIdx.x < sizeof(MlmGlobal) / 4) ((uint32_t *)host_g)[threadIdx.x] = __hip_atomic_load((const uint32_t *)g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 3) ((uint32_t *)host_g)[threadIdx.x] = __hip_atomic_load((const uint32_t *)g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&host_g->pad, (unsigned int)dev_frame->seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

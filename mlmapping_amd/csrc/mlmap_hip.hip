@@ -16,6 +16,8 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <atomic>
+#include <chrono>
 
 #include "../../include/mlmap_hip.h"
 #include "mlm_kernels_explore.h"
@@ -160,6 +162,8 @@ struct mlm_handle {
     bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
     size_t frame_block_bound = 0; // most blocks one frame can create
     unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
+    unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
+    unsigned int single_apply_grid = 256; // workgroups of k_apply_single: a VGA frame's ~33 k voxel records, one per thread (more: in turns)
     unsigned int tile_grid = 0;      // workgroups of k_tile per frame of a batch: they walk the frame's touched tiles (MLM_TILE_GRID)
     unsigned int apply_lds_bytes = 0; // dynamic LDS of k_apply_tiles: 9 bytes per voxel of a tile
     unsigned int big_grid = 256;     // workgroups of k_sector_big per batch: one per CU (MLM_BIG_GRID)
@@ -848,7 +852,10 @@ int launch_apply_tiles(mlm_handle *h, int base, int n, int f_begin = 0) {
             return MLM_ERR_UNSUPPORTED;
         }
         // (the kernel derives the box from the frames [base + j0, base + j1) itself: it gets that range as ITS slot range)
-        tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(MLM_BLOCK), h->apply_lds_bytes, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0);
+        if (j1 - j0 == 1) // (one frame: nothing to keep in LDS between frames)
+            tlaunch(h, "k_apply_single", k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0);
+        else
+            tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(MLM_BLOCK), h->apply_lds_bytes, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0);
         j0 = j1;
     }
     return MLM_OK;
@@ -976,8 +983,19 @@ int drain(mlm_handle *h, bool g_copied) {
     if (h->P.explore) return drain_explore(h);
     for (;;) {
         if (!g_copied) HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+        bool seen = false;
+        if (g_copied && h->wait_ticket && !h->timing) {
+            // a single frame's graph: its last store is the ticket — poll it for a while (a frame takes 0.1-0.3 ms) instead of
+            // sleeping in hipStreamSynchronize, whose wake-up would be a tenth of the call
+            const volatile unsigned int *ticket = &h->h_g->pad;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned int spins = 0; !(seen = *ticket == h->wait_ticket); ++spins)
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        h->wait_ticket = 0u;
         g_copied = false;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipGetLastError());
         const int f = h->h_g->fail_frame;
         // (a full pool is no error of the frames confirmed here: k_tile flags the frame whose blocks did not fit, the batch stops in
@@ -1201,14 +1219,15 @@ int submit_single_graph(mlm_handle *h, int base) {
             hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
             hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
             hipLaunchKernelGGL(k_tile, dim3((unsigned int)std::min(P.n_tiles, 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
-            hipLaunchKernelGGL(k_apply_tiles, dim3((unsigned int)P.n_tiles), dim3(MLM_BLOCK), h->apply_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1, 0);
+            hipLaunchKernelGGL(k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
             e = hipGetLastError();
         }
         if (h->graph_copies == 1) {
             if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, sizeof(MlmCounters), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st);
         } else if (h->graph_copies == 2 && e == hipSuccess) {
-            hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(128), 0, st, (const MlmCounters *)(h->d_ctr_all + base), h->h_ctr_all + base, (const MlmGlobal *)h->P.g, h->h_g);
+            hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(128), 0, st, (const MlmCounters *)(h->d_ctr_all + base), h->h_ctr_all + base, (const MlmGlobal *)h->P.g, h->h_g,
+                               (const MlmFrame *)(h->d_frame_tab + base));
             e = hipGetLastError();
         }
         hipGraph_t graph = nullptr;
@@ -1232,6 +1251,10 @@ int submit_single_graph(mlm_handle *h, int base) {
     if (h->graph_copies == 0) {
         HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, sizeof(MlmFrame), hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, sizeof(MlmCounters), h->stream));
+    }
+    if (h->graph_copies == 2) { // (the epilogue kernel ends with a ticket in the host copy of the map-wide flags: drain polls it)
+        h->h_g->pad = 0u;
+        h->wait_ticket = (unsigned int)S.F.seq + 1u;
     }
     HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
     if (h->graph_copies == 0) {

@@ -13,6 +13,9 @@ cfg = S3 if "cfg3" in sys.argv else S1
 if os.environ.get("MLM_BENCH_NO_RAYCAST"):  # diagnostic: hits without rays
     import dataclasses
     cfg = dataclasses.replace(cfg, use_raycasting=False)
+if "frontier" in sys.argv:  # use_exploration_frontiers: true
+    import dataclasses
+    cfg = dataclasses.replace(cfg, use_exploration_frontiers=True)
 nb = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 8
 B = int(os.environ.get("MLM_KT_BATCH", "32"))
 frames, q, t = make_inputs(cfg, B, B * (nb + 2), seed=42)
