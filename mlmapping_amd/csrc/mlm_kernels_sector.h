@@ -379,6 +379,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             mlm_gp(P.ctr)->n_groups = g;
         }
     }
+    // (the column's first chunk descriptors are requested together with their count and arrive while the tables below are set
+    // up: one dependent trip to memory less in a column's life; what lies beyond the count is not looked at)
+    mlm_u32x2 chunk_first = mlm_u32x2{0u, 0u};
+    if (threadIdx.x < min((unsigned int)MLM_SEC_CHUNKS, P.chunk_cap))
+        chunk_first = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)phi * P.chunk_cap + threadIdx.x));
     const unsigned int nch_all = mlm_gp(P.col_cnt)[phi];
     if (nch_all == 0) return; // nothing fell into this column (uniform)
     const unsigned int nch = min(nch_all, P.chunk_cap);
@@ -541,7 +546,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             {
                 const uint32_t j = threadIdx.x;
                 mlm_u32x2 d = mlm_u32x2{0u, 0u};
-                if (j < n_staged) d = *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
+                if (j < n_staged) d = c0 == 0 ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
                 const uint32_t off = mlm_block_excl_scan(d.y, s_w, &total);
                 if (j < n_staged) {
                     s_chunk_first[j] = d.x;
@@ -1363,6 +1368,7 @@ __device__ __forceinline__ int mlm_floor_div(int a, int n) {
 #ifndef MLM_TILE_THREADS
 #define MLM_TILE_THREADS 256
 #endif
+#define MLM_TILE_KEEP 2     // hits per thread kept in registers between the counting and the placing pass
 #define MLM_TILE_DESC 256   // descriptors staged per pass
 #define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap (its pool slots are kept in LDS; the host checks the geometry)
 struct MlmTileLds {
@@ -1446,6 +1452,16 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     };
     // pass over the descriptors; what == 0: count the miss cells and hits per voxel; what == 1: place the hits
     uint32_t rec_base = 0, hit_base = 0;
+    uint32_t keep_pos[MLM_TILE_KEEP], keep_v[MLM_TILE_KEEP];
+    float keep_inc[MLM_TILE_KEEP];
+    unsigned long long keep_key[MLM_TILE_KEEP];
+#pragma unroll
+    for (int q = 0; q < MLM_TILE_KEEP; ++q) {
+        keep_pos[q] = 0u;
+        keep_v[q] = MLM_NIL;
+        keep_inc[q] = 0.0f;
+        keep_key[q] = 0ull;
+    }
     auto for_cells = [&](int what) {
         for (uint32_t d0 = 0; d0 < nd; d0 += MLM_TILE_DESC) {
             const uint32_t n_staged = min(nd - d0, (uint32_t)MLM_TILE_DESC);
@@ -1472,7 +1488,43 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
                     if (v < NV) atomicAdd(&s_cnt[v], 1u);
                     else s_fail = 1;
                 }
-            for (uint32_t j = threadIdx.x; j < t4[1]; j += MLM_TILE_THREADS) { // hits
+            // hits.  The first two of a thread (of the first staged pass: practically every tile) are kept in registers with their
+            // increment and key — nothing of that depends on the map or on the counts — so the placing pass reads no memory
+            auto place_hit = [&](uint32_t pos, uint32_t v, float inc, unsigned long long key) {
+                const uint32_t pl = s_place[v];
+                if ((pl >> 16) == 0xFFFFu) { // the voxel's only hit: its increment rides in the record (the last 8 bytes are this lane's)
+                    MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + (pl & 0xFFFFu);
+                    *(MLM_GLOBAL mlm_u32x2 *)&rec->inc0 = mlm_u32x2{__float_as_uint(inc), pos};
+                } else {
+                    const uint32_t k = (atomicSub(&s_cnt[v], 0x10000u) >> 16) - 1u; // (counts down: n_hit - 1 .. 0)
+                    MLM_GLOBAL MlmVoxHit *hh = mlm_gp(P.vr_hit) + hit_base + (pl >> 16) + k;
+                    *(MLM_GLOBAL mlm_u32x4 *)hh = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), __float_as_uint(inc), pos};
+                }
+            };
+            uint32_t j_tail = threadIdx.x;
+            if (d0 == 0) {
+#pragma unroll
+                for (int q = 0; q < MLM_TILE_KEEP; ++q) {
+                    const uint32_t j = threadIdx.x + (uint32_t)q * MLM_TILE_THREADS;
+                    if (j >= t4[1]) continue;
+                    if (what == 0) {
+                        uint32_t d, o;
+                        locate(s_dh, n_staged, j, d, o);
+                        const uint32_t pos = s_desc[d].z + o;
+                        const uint32_t v = mlm_gp(P.hl_vt16)[pos];
+                        keep_pos[q] = pos;
+                        keep_v[q] = v;
+                        keep_inc[q] = mlm_gp(P.hl_inc)[pos];
+                        keep_key[q] = mlm_gp(P.hl_key)[pos];
+                        if (v < NV) atomicAdd(&s_cnt[v], 0x10000u);
+                        else s_fail = 1;
+                    } else if (keep_v[q] < NV) {
+                        place_hit(keep_pos[q], keep_v[q], keep_inc[q], keep_key[q]);
+                    }
+                }
+                j_tail += MLM_TILE_KEEP * MLM_TILE_THREADS;
+            }
+            for (uint32_t j = j_tail; j < t4[1]; j += MLM_TILE_THREADS) {
                 uint32_t d, o;
                 locate(s_dh, n_staged, j, d, o);
                 const uint32_t pos = s_desc[d].z + o;
@@ -1481,20 +1533,8 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
                     s_fail = 1;
                     continue;
                 }
-                if (what == 0) {
-                    atomicAdd(&s_cnt[v], 0x10000u);
-                    continue;
-                }
-                const uint32_t pl = s_place[v];
-                if ((pl >> 16) == 0xFFFFu) { // the voxel's only hit: its increment rides in the record (the last 8 bytes are this lane's)
-                    MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + (pl & 0xFFFFu);
-                    *(MLM_GLOBAL mlm_u32x2 *)&rec->inc0 = mlm_u32x2{__float_as_uint(mlm_gp(P.hl_inc)[pos]), pos};
-                } else {
-                    const uint32_t k = (atomicSub(&s_cnt[v], 0x10000u) >> 16) - 1u; // (counts down: n_hit - 1 .. 0)
-                    MLM_GLOBAL MlmVoxHit *hh = mlm_gp(P.vr_hit) + hit_base + (pl >> 16) + k;
-                    const unsigned long long key = mlm_gp(P.hl_key)[pos];
-                    *(MLM_GLOBAL mlm_u32x4 *)hh = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), __float_as_uint(mlm_gp(P.hl_inc)[pos]), pos};
-                }
+                if (what == 0) atomicAdd(&s_cnt[v], 0x10000u);
+                else place_hit(pos, v, mlm_gp(P.hl_inc)[pos], mlm_gp(P.hl_key)[pos]);
             }
         }
     };
