@@ -8,6 +8,9 @@ timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pyt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
 timeout 300 python tools/kernel_times.py > $O/kernel_times.txt 2>&1
 timeout 300 python tools/kernel_times.py cfg3 4 > $O/kernel_times_cfg3.txt 2>&1
+MLM_KT_BATCH=1 timeout 300 python tools/kernel_times.py 64 > $O/kernel_times_single.txt 2>&1
+timeout 300 python tools/kernel_times.py frontier > $O/kernel_times_frontier.txt 2>&1
+timeout 300 python tools/kernel_times.py scatter 4 > $O/kernel_times_scatter.txt 2>&1
 timeout 900 python tools/bench_rows.py > $O/rows.json 2> $O/rows.err
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 60 > $O/kt.log 2>&1

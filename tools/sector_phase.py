@@ -26,6 +26,19 @@ t = np.stack([f[1][1] for f in frames])
 buf = (ctypes.c_ulonglong * 16)()
 m.update_map_batch(imgs, q, t)
 L.mlm_debug_phases(buf)
+if "single" in sys.argv:  # frame by frame: a phase's cycles per wave = its share of a column's latency (80 columns x 8 waves at S1)
+    m.set_async(False)
+    for k in range(n):
+        m.update_map(imgs[k], q[k], t[k])
+    L.mlm_debug_phases(buf)
+    for k in range(n):
+        m.update_map(imgs[k], q[k], t[k])
+    L.mlm_debug_phases(buf)
+    tot = sum(buf[:9])
+    print(f"single frames: {tot / n / 640 / 2.4e3:.1f} us per wave (assuming 640 waves, 2.4 GHz)")
+    for nm, v in zip(NAMES, buf[:9]):
+        print(f"  {nm:40s} {100.0 * v / tot:5.1f} %   {v / n / 640 / 2.4e3:6.2f} us per wave")
+    sys.exit(0)
 for rep in range(2):
     m.update_map_batch(imgs, q, t)
     L.mlm_debug_phases(buf)
