@@ -1,7 +1,7 @@
 // mlm_kernels.h — HIP kernels of the per-frame map update (gfx950, wave64): the CELL-TABLE path of Stage A and its
 // two-kernel Stage B+C (frontier mode, images wider than 2040 pixels, and the fall-back of frames in which an azimuth
 // sector overflows its LDS tables), the rehash-replay kernels, k_chain, queries, inflation, exports.  The default Stage A
-// (by azimuth sector) and its one-launch-per-frame apply kernel are in mlm_kernels_sector.h.
+// (by azimuth sector) and its one-launch-per-batch apply kernel are in mlm_kernels_sector.h.
 //
 // Stage A  (awareness_map_cylindrical::input_pc_pose, map_awareness.cpp:173-282)
 //   k_bin_points      point -> (rho,phi,z) bin, noise-spread hit contributions as wave groups, de-duplicated ray walk
@@ -1960,12 +1960,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_convert_f32_u16(const float *src,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         dst[i] = (uint16_t)mlm_cv_f32_to_u16(src[i]);
     }
-}
-
-// the sampled pixels of a frame (already converted on the host) into the device image at their positions
-__global__ __launch_bounds__(MLM_BLOCK) void k_scatter_u16(uint16_t *img, const int32_t *pix, const int32_t *raw, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) img[pix[i]] = (uint16_t)raw[i];
 }
 
 __global__ __launch_bounds__(MLM_BLOCK) void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {

@@ -20,11 +20,14 @@
 //                   order: rank its contributions by pixel (bitmap ranking fed with the records' 8x8 lane masks) and
 //                   store the kinds in that order.
 //   k_chain_lanes   replays the float noisy-OR chains, one cell per lane, lanes drawing cells dynamically.
-//   k_tile          one workgroup per tile of the frame-local voxel grid: counts the tile's miss cells and hits per voxel in
-//                   LDS and writes ONE 32-byte record per touched voxel (block key, cell id, counts, the increment of a
-//                   single hit, the block's pool slot if it exists); the hits of voxels with several go next to each other.
-//   k_apply_frame   the part that needs the map, ONE launch per frame: one voxel record per lane — block creation if
-//                   needed, the voxel's hits in the reference's iteration order, its misses, store.  Two round trips.
+//   k_tile          workgroups walk the frame's touched tiles of the frame-local voxel grid: count the tile's miss cells and hits
+//                   per voxel in LDS, create the blocks the frame touches there, and write ONE 32-byte record per touched voxel
+//                   (block key, cell id, counts, the increment of a single hit, the block's pool slot); the hits of voxels
+//                   with several go next to each other.
+//   k_apply_tiles   the part that needs the map, ONE launch per batch: the frame-local grids are aligned to tile boundaries, a
+//                   workgroup owns a WORLD tile, keeps its voxels in LDS and walks the batch's frames in order — per record the
+//                   voxel's hits in the reference's iteration order, then its misses.  k_apply_single: the same for one frame
+//                   (a flat loop over the frame's records; the synchronous single-frame call and replays).
 //
 // Frontier mode (use_exploration_frontiers) uses k_bin_sectors, k_sector<true>, k_rank and k_chain_lanes and continues with its
 // own map-dependent part (mlm_kernels_explore.h): there the miss container's iteration order matters as well, so the
@@ -1039,7 +1042,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     if (!P.explore) {
         // Iteration-order keys of the frame's unique hits, valid if the frame fits the emulated container without a rehash
-        // (k_apply_frame checks): (first insertion time of the hit's bucket, its own insertion time) — the bucket-first
+        // (k_apply_tiles checks): (first insertion time of the hit's bucket, its own insertion time) — the bucket-first
         // table of this slot is complete now that every column of the frame has been through k_sector
         const unsigned int n_hit = mlm_gp(P.ctr)->u_hit;
         for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hit; i += gridDim.x * blockDim.x) {

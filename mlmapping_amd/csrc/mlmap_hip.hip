@@ -116,7 +116,6 @@ struct mlm_handle {
     size_t map_bytes = 0;                    // ... of it the map, its tables and the buffers shared by all frame slots
     bool debug_alloc = getenv("MLM_DEBUG_ALLOC") != nullptr;
     size_t alloc_bytes = 0;                  // device memory the handle holds (MLM_DEBUG_CREATE prints it)
-    long long last_queue = 0;                // voxels the last confirmed sector-path frame queued (sizes k_apply_frame's grid)
     unsigned int chain_grid = 0;             // blocks per frame of k_chain_lanes (0: from the last confirmed frame's ranked cells; MLM_CHAIN_GRID)
     unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
     unsigned int sc_block = 64;              // threads per block of the per-frame apply kernels: single-wave blocks are placed as soon as any wave
@@ -576,7 +575,6 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_device_atomics = na;
     if (S.sector && !h->P.explore) {
         h->stats.n_miss_cells = c.mvox_cnt[3][0]; // (the reservation counter of the frame's miss list)
-        h->last_queue = c.mvox_cnt[0][0];         // voxel records
     }
     h->stats.n_groups = ng;
     h->stats.n_rays = nr;

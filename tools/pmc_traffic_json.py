@@ -13,8 +13,6 @@ def load(path, name):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
-            if k == "k_apply_frame_tab":  # the single-frame graph's launch of the same kernel body
-                k = "k_apply_frame"
             acc[k][0] += float(r["Counter_Value"])
             acc[k][1] += 1
     return acc
