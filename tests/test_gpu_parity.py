@@ -186,6 +186,31 @@ def test_config3_720p(mods):
             assert (st["n_hit_cells"], st["n_miss_cells"]) == (136766, 659944)
 
 
+def test_config3_stream_random_poses(mods):
+    """BASELINE config 3 as a stream: 20 jittered 1280x720 frames with a random SE(3) pose each into the 0.05 m map, through
+    the asynchronous batch entry point in batches of 5 (this map's tiles are 4x4 voxel columns of 91 layers; the batched
+    apply walks them frame after frame), from a pool of 1 024 blocks that grows on the way — against the oracle fed frame by
+    frame."""
+    MLMap, OracleMap = mods
+    cfg, n, B = S3, 20, 5
+    base = syn.room_depth(cfg)
+    frames = np.stack([syn.jitter_depth(base, k, seed=7) for k in range(B)])
+    poses = syn.random_poses(n, seed=7)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=1024, max_batch=B), OracleMap(cfg)
+    gpu.set_async(True)
+    for k0 in range(0, n, B):
+        gpu.update_map_batch(frames, q[k0:k0 + B], t[k0:k0 + B])
+        for j in range(B):
+            cpu.update_depth(frames[j], q[k0 + j], t[k0 + j])
+    gpu.sync()
+    d = compare_maps(gpu.export_blocks(), cpu.export_blocks(), "cfg3 stream, 20 frames")
+    st = gpu.frame_stats()
+    assert st["n_sector_fallbacks"] == 0 and st["n_pool_grows"] >= 1, st
+    print("cfg3 stream", d, st["block_capacity"])
+
+
 def test_single_frames_go_through_the_graph(mods, monkeypatch):
     """Synchronous single-frame calls (the reference's call pattern: one frame per depth callback, mlmap.cpp:463-507) are
     submitted as one HIP-graph replay; the result is the general submission's (MLM_GRAPH=0) bit for bit — dense frames from a
