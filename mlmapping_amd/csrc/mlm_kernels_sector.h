@@ -39,7 +39,7 @@
 #pragma once
 #include "mlm_kernels.h"
 
-#define MLM_SEC_THREADS 512
+#define MLM_SEC_THREADS 512 // threads of a column's workgroup (k_sector also exists with 256: MlmDev::sec_tab <= 1024)
 #define MLM_SEC_WAVES (MLM_SEC_THREADS / 64)
 #define MLM_SEC_COLS 256    // distinct columns one k_bin_sectors block can feed in the list modes: one per record at most (a pixel list
                             // scatters over the image); a dense 32x8 pixel strip spans a handful: 64 entries bucketed by one wave
@@ -297,9 +297,10 @@ __device__ __forceinline__ void mlm_block_excl_scan4(uint32_t (&v)[4], uint32_t 
         v[k] = off + incl[k] - v[k];
     }
 }
+template <int NW = MLM_SEC_WAVES>
 __device__ __forceinline__ uint32_t mlm_block_excl_scan(uint32_t v, uint32_t *s_w, uint32_t *total) {
     uint32_t a[4] = {v, 0u, 0u, 0u}, t[4];
-    mlm_block_excl_scan4(a, s_w, t);
+    mlm_block_excl_scan4<NW>(a, s_w, t);
     *total = t[0];
     return a[0];
 }
@@ -358,7 +359,10 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
 // One azimuth column.  BIG: the second pass over the columns whose cell table overflowed in the first (k_sector_big: a table
 // of MlmDev::sec_tab_big entries, one workgroup per CU) — the first pass leaves such a column untouched and puts it on the
 // frame's overflow list instead of sending the whole frame to the cell-table path.
-template <bool EX, bool BIG>
+// NT: threads of the workgroup (512, or 256 for columns whose cell table has at most 1 024 entries: the smaller workgroup leaves
+// wave slots and LDS of its CU to the other streams' kernels — measured +5 % frames/s in the pipeline although the kernel
+// alone is 10 % slower).
+template <bool EX, bool BIG, int NT>
 __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFrame &F, const int phi, int tile_w, int n_bin_blocks, unsigned long long rho_m,
                                                   int rho_s, unsigned long long n_bkt, int big_armed) {
     constexpr int PER_MAX = BIG ? 8 : 4; // cell-table entries per thread
@@ -409,10 +413,10 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     uint32_t *s_run_tile = (uint32_t *)(s_dyn + L.aux), *s_run_rho = s_run_tile + P.nRho, *s_run_hits = s_run_rho + P.nRho,
              *s_run_off = s_run_hits + P.nRho, *s_rho_miss = s_run_off + P.nRho, *s_rho_off = s_rho_miss + P.nRho;
     __shared__ int s_kr;
-    __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
+    __shared__ uint32_t s_w[4 * (NT / 64)];
     __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter, s_tab_full;
-    for (uint32_t e = threadIdx.x; e < TAB; e += MLM_SEC_THREADS) {
+    for (uint32_t e = threadIdx.x; e < TAB; e += NT) {
         s_tab[e].key = MLM_NIL;
         s_tab[e].tmin = MLM_EMPTY_T;
         s_tab[e].kmask = 0;
@@ -420,9 +424,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         s_tab[e].gcnt = 0;
         if (EX) s_tab[e].gpos = MLM_EMPTY_T; // (until the lists are built: first point whose centre is the cell)
     }
-    for (uint32_t e = threadIdx.x; e < NMISS; e += MLM_SEC_THREADS) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
-    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += MLM_SEC_THREADS) s_odds[e] = mlm_gp(P.odds_table)[e];
-    for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += MLM_SEC_THREADS) {
+    for (uint32_t e = threadIdx.x; e < NMISS; e += NT) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
+    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += NT) s_odds[e] = mlm_gp(P.odds_table)[e];
+    for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += NT) {
         s_sigma[e] = mlm_gp(P.sigma3)[e];
         s_run_hits[e] = 0;
         s_rho_miss[e] = 0;
@@ -441,7 +445,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     //                   (a voxel-in-tile index is vt = s_vr[rho].y * lv_nz + s_vz[z].x).  A coordinate the reference's two
     //                   independent divisions put outside [0, n) (the id-0 quirk of get_subbox_id, map_local.h:170) cannot be
     //                   expressed per axis: such a column — one in ~1e13 evaluations — sends its frame to the cell-table path.
-    for (uint32_t e = threadIdx.x; e < (uint32_t)(P.nRho + P.nZ); e += MLM_SEC_THREADS) {
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(P.nRho + P.nZ); e += NT) {
         double wx, wy, wz;
         if (e < (uint32_t)P.nRho) {
             mlm_cell_center_w(P, F.t_wa, (int)e, phi, 0, wx, wy, wz);
@@ -522,7 +526,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     };
     // pass = 0: book every record's contributions on the cells of the column (and walk the rays of points outside the
     // map); pass = 1: write a (record, kind) reference for every contribution group of a multi-kind cell.  A thread
-    // keeps the record it handled first: a column with at most MLM_SEC_THREADS records (the usual case) is not read twice.
+    // keeps the record it handled first: a column with at most NT records (the usual case) is not read twice.
     uint32_t keep_cell = MLM_NIL, keep_yx = 0, keep_total = 0xFFFFFFFFu;
     unsigned long long keep_mask = 0;
     auto refs_of = [&](uint32_t cell, uint32_t yx, unsigned long long mask) {
@@ -538,7 +542,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         });
     };
     auto for_records = [&](int pass) {
-        if (pass == 1 && nch <= MLM_SEC_CHUNKS && keep_total <= MLM_SEC_THREADS) {
+        if (pass == 1 && nch <= MLM_SEC_CHUNKS && keep_total <= NT) {
             if (keep_cell != MLM_NIL) refs_of(keep_cell, keep_yx, keep_mask);
             return;
         }
@@ -550,14 +554,14 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 const uint32_t j = threadIdx.x;
                 mlm_u32x2 d = mlm_u32x2{0u, 0u};
                 if (j < n_staged) d = c0 == 0 ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
-                const uint32_t off = mlm_block_excl_scan(d.y, s_w, &total);
+                const uint32_t off = mlm_block_excl_scan<NT / 64>(d.y, s_w, &total);
                 if (j < n_staged) {
                     s_chunk_first[j] = d.x;
                     s_chunk_start[j] = off;
                 }
             }
             __syncthreads();
-            for (uint32_t r = threadIdx.x; r < total; r += MLM_SEC_THREADS) {
+            for (uint32_t r = threadIdx.x; r < total; r += NT) {
                 if (pass == 0 && *(volatile unsigned int *)&s_tab_full) break; // (the column is given up: nothing more to book)
                 const uint32_t gi = rec_index(r, n_staged);
                 const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + gi);
@@ -645,7 +649,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     //      the column's reservations in the frame's lists (one round trip)
     //      The hit list is ordered by tile run (the hits of one tile are contiguous): rank inside the run from a returning
     //      LDS atomic, the runs' offsets from the same block scan that places the other lists.
-    const uint32_t per = TAB / MLM_SEC_THREADS; // entries e = threadIdx.x * per + q: contiguous per thread (per <= PER_MAX)
+    const uint32_t per = TAB / NT; // entries e = threadIdx.x * per + q: contiguous per thread (per <= PER_MAX)
     uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, multi, ray starts, hits of tile run `threadIdx.x`
     uint32_t w_refs = 0, w_subs = 0;  // references / ordered-kinds slots of this thread's multi-kind cells
     uint32_t hk[PER_MAX], hrun[PER_MAX]; // this thread's entries: tile run, rank among the run's hits
@@ -677,9 +681,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     }
     if (threadIdx.x < 2) s_base[4 + threadIdx.x] = 0;
     __syncthreads(); // (the runs' hit counts are complete)
-    if ((int)threadIdx.x < n_run) v[3] = s_run_hits[threadIdx.x]; // (n_run <= nRho <= MLM_SEC_THREADS)
+    if ((int)threadIdx.x < n_run) v[3] = s_run_hits[threadIdx.x]; // (n_run <= nRho <= NT)
     uint32_t tot[4];
-    mlm_block_excl_scan4(v, s_w, tot); // (its first barrier also orders the zeroing above)
+    mlm_block_excl_scan4<NT / 64>(v, s_w, tot); // (its first barrier also orders the zeroing above)
     if ((int)threadIdx.x < n_run) s_run_off[threadIdx.x] = v[3];
     if (lane == 0) {
         if (w_refs) atomicAdd(&s_base[4], w_refs);
@@ -728,7 +732,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     // ---- multi-kind cells: segments in `refs` and `subs`, descriptors for k_rank / k_chain_lanes
     {
         uint32_t carry_refs = s_base[2], carry_subs = s_base[3];
-        for (uint32_t j0 = 0; j0 < n_multi; j0 += MLM_SEC_THREADS) { // (one round unless the column holds > 512 such cells)
+        for (uint32_t j0 = 0; j0 < n_multi; j0 += NT) { // (one round unless the column holds > 512 such cells)
             const uint32_t j = j0 + threadIdx.x;
             uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
             uint32_t e = 0;
@@ -737,7 +741,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 a[0] = s_tab[e].gcnt;
                 a[1] = ((s_tab[e].cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
             }
-            mlm_block_excl_scan4(a, s_w, t4);
+            mlm_block_excl_scan4<NT / 64>(a, s_w, t4);
             if (j < n_multi) {
                 MlmSecCell &c = s_tab[e];
                 const uint32_t pos = s_base[0] + c.gpos, m = s_base[1] + j, o_refs = carry_refs + a[0], o_subs = carry_subs + a[1];
@@ -763,7 +767,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     //      z - .. rounded, round half away) says which way it goes (those steps are collected and evaluated afterwards);
     //      everywhere else that sequence is at most ~1e-12 away from the exact value, which is at least 1 / (2 rho) away
     //      from the next half-integer.  Consecutive steps that fall into one word of the mask are merged in a register.
-    for (uint32_t i0 = 0; i0 < 4u * n_rays; i0 += MLM_SEC_THREADS) {
+    for (uint32_t i0 = 0; i0 < 4u * n_rays; i0 += NT) {
         const uint32_t it = i0 + threadIdx.x;
         int rho = 0, z = 0;
         uint32_t t0 = 0; // EX: insertion time of the ray's step k is t0 + k - 1
@@ -840,7 +844,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     // ---- the column's unique hits (ordered by tile run): cell, first-touch time, voxel-in-tile index; single-kind cells get
     //      their odd and increment here (multi-kind cells: k_rank / k_chain_lanes)
     const unsigned int sl = blockIdx.x & 7;
-    for (uint32_t i = threadIdx.x; i < n_occ; i += MLM_SEC_THREADS) {
+    for (uint32_t i = threadIdx.x; i < n_occ; i += NT) {
         const MlmSecCell c = s_tab[s_occ[i]];
         int rho, z;
         key_rz(c.key, rho, z);
@@ -881,9 +885,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         // frontier mode: the unique miss list with insertion times and world voxels (what k_ex_collect_misses leaves);
         // a thread's cells take consecutive places
         uint32_t vm = 0;
-        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) vm += s_miss[w] != MLM_EMPTY_T ? 1u : 0u;
+        for (uint32_t w = threadIdx.x; w < NMISS; w += NT) vm += s_miss[w] != MLM_EMPTY_T ? 1u : 0u;
         uint32_t total;
-        const uint32_t my_off = mlm_block_excl_scan(vm, s_w, &total);
+        const uint32_t my_off = mlm_block_excl_scan<NT / 64>(vm, s_w, &total);
         if (threadIdx.x == 0) {
             s_base[5] = total ? g_atomic_add(&mlm_gp(P.ctr)->n_ex_miss, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
@@ -892,7 +896,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         }
         __syncthreads();
         uint32_t at = s_base[5] + my_off;
-        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) {
+        for (uint32_t w = threadIdx.x; w < NMISS; w += NT) {
             const uint32_t t = s_miss[w];
             if (t == MLM_EMPTY_T) continue;
             int rho, z;
@@ -912,7 +916,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         //      k_tile counts.  Miss cells per rho (LDS atomics), their offsets (one block scan), the list in LDS (the cell
         //      table's space is idle by now), one coalesced copy; then ONE descriptor per tile run — {first miss cell, count,
         //      first hit, count} — handed to the tile with a returning atomic: the only per-tile global atomic of the column.
-        for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) {
+        for (uint32_t w = threadIdx.x; w < NMISS; w += NT) {
             uint32_t bits = s_miss[w];
             const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u;
             while (bits) {
@@ -923,8 +927,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         __syncthreads();
         uint32_t total = 0;
         {
-            const uint32_t c = (int)threadIdx.x < P.nRho ? s_rho_miss[threadIdx.x] : 0u; // (nRho <= MLM_SEC_THREADS on this path)
-            const uint32_t off = mlm_block_excl_scan(c, s_w, &total);
+            const uint32_t c = (int)threadIdx.x < P.nRho ? s_rho_miss[threadIdx.x] : 0u; // (nRho <= NT on this path)
+            const uint32_t off = mlm_block_excl_scan<NT / 64>(c, s_w, &total);
             if ((int)threadIdx.x < P.nRho) {
                 s_rho_off[threadIdx.x] = off;
                 s_rho_miss[threadIdx.x] = 0; // (now the fill cursor)
@@ -946,7 +950,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         uint16_t *s_cells = (uint16_t *)s_tab; // [total] (nZ * nRho * 2 bytes <= the table's, checked by the host)
         if (total && !s_fail) {
             const uint32_t rec_base = s_base[7];
-            for (uint32_t w = threadIdx.x; w < NMISS; w += MLM_SEC_THREADS) {
+            for (uint32_t w = threadIdx.x; w < NMISS; w += NT) {
                 uint32_t bits = s_miss[w];
                 const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u;
                 const uint32_t zz = (uint32_t)s_vz[z].x;
@@ -959,7 +963,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 }
             }
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < total; i += MLM_SEC_THREADS) mlm_gp(P.mc_list)[m_base + i] = s_cells[i];
+            for (uint32_t i = threadIdx.x; i < total; i += NT) mlm_gp(P.mc_list)[m_base + i] = s_cells[i];
         }
         if ((int)threadIdx.x < n_run && !s_fail) {
             const uint32_t r = threadIdx.x, rho_a = s_run_rho[r], rho_b = (int)r + 1 < n_run ? s_run_rho[r + 1] : (uint32_t)P.nRho;
@@ -983,11 +987,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     MLM_PHASE(6);
     MLM_PHASE_END
 }
-template <bool EX>
-__global__ __launch_bounds__(MLM_SEC_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
-                                                            int rho_s, unsigned long long n_bkt, int big_armed) {
+template <bool EX, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
+                                                                                       int rho_s, unsigned long long n_bkt, int big_armed) {
     MLM_SLOT_SETUP
-    mlm_sector_column<EX, false>(P, F, (int)blockIdx.x, tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, big_armed);
+    mlm_sector_column<EX, false, NT>(P, F, (int)blockIdx.x, tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, big_armed);
 }
 // The columns on the overflow lists of a batch's frames, with the large cell table (dynamic LDS of MlmDev::sec_big_lds_bytes:
 // one workgroup per CU).  ONE launch per batch, a fixed number of workgroups that share all (frame, column) tasks.  A kernel
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector_big(const MlmDev *__
         const MlmDev &P = slot_tab[slot_base + j];
         const MlmFrame &F = frame_tab[slot_base + j];
         __syncthreads(); // (the previous column's shared state is no longer read)
-        mlm_sector_column<EX, true>(P, F, (int)mlm_gp(P.ov_list)[t - s_first[j]], tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, 0);
+        mlm_sector_column<EX, true, MLM_SEC_THREADS>(P, F, (int)mlm_gp(P.ov_list)[t - s_first[j]], tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, 0);
     }
 }
 

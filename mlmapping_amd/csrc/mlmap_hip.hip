@@ -161,6 +161,7 @@ struct mlm_handle {
     bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
     size_t frame_block_bound = 0; // most blocks one frame can create
     unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
+    int sec_threads = 512;           // threads of a column's workgroup (k_sector<.., 256 | 512>; MLM_SEC_THREADS)
     unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
     unsigned int single_apply_grid = 256; // workgroups of k_apply_single: a VGA frame's ~33 k voxel records, one per thread (more: in turns)
     unsigned int tile_grid = 0;      // workgroups of k_tile per frame of a batch: they walk the frame's touched tiles (MLM_TILE_GRID)
@@ -507,11 +508,17 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         div_magic((unsigned int)P.nRho, rm, rs);
         const int big = P.sec_tab_big && h->big_armed > 0 ? 1 : 0; // the pass with the large cell table follows (see k_sector_big)
         if (h->big_armed > 0) --h->big_armed;
-        if (P.explore)
-            tlaunch(h, "k_sector", k_sector<true>, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
+        if (P.explore && h->sec_threads == 256)
+            tlaunch(h, "k_sector", k_sector<true, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
+        else if (P.explore)
+            tlaunch(h, "k_sector", k_sector<true, 512>, dim3((unsigned int)P.nPhi, 1, n), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab,
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
+        else if (h->sec_threads == 256)
+            tlaunch(h, "k_sector", k_sector<false, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
         else
-            tlaunch(h, "k_sector", k_sector<false>, dim3((unsigned int)P.nPhi, 1, n), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab,
+            tlaunch(h, "k_sector", k_sector<false, 512>, dim3((unsigned int)P.nPhi, 1, n), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
         if (big) { // the columns whose cell table overflowed, with the large table (a few workgroups per frame walk the list)
             if (P.explore)
@@ -1209,8 +1216,13 @@ int submit_single_graph(mlm_handle *h, int base) {
             int ds, rs;
             div_magic((unsigned int)row_w, dm, ds);
             div_magic((unsigned int)P.nRho, rm, rs);
-            hipLaunchKernelGGL(k_sector<false>, dim3((unsigned int)P.nPhi, 1, 1), dim3(MLM_SEC_THREADS), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                               S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+            // (a single frame is alone on the GPU: the 512-thread workgroup finishes a column sooner; the table is the same)
+            if (h->sec_threads == 256 && P.sec_tab < 512u)
+                hipLaunchKernelGGL((k_sector<false, 256>), dim3((unsigned int)P.nPhi, 1, 1), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
+                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+            else
+                hipLaunchKernelGGL((k_sector<false, 512>), dim3((unsigned int)P.nPhi, 1, 1), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
+                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
             if (big)
                 hipLaunchKernelGGL(k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1,
                                    S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
@@ -1941,10 +1953,18 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // sector path: LDS tables of one azimuth column (k_sector).  Cell table: a column rarely holds more hit cells than a
         // few per range step; references: (record, kind) pairs of its multi-kind cells.  A column that needs more makes
         // its frame fall back to the cell-table path.
-        unsigned int tab = 1024;
-        while (tab < 12u * (unsigned int)P.nRho && tab < 2048u) tab <<= 1;
-        if (const char *e = getenv("MLM_SEC_TAB")) tab = (unsigned int)std::max(MLM_SEC_THREADS, atoi(e)); // power of two
+        // (the hit cells of a column grow faster than its range steps — finer cells also mean more distinct cells per pixel footprint:
+        // ~220 on config 2's 65 steps, ~1 000 on config 3's 130 — hence 6 entries per step for coarse maps, 12 for fine ones)
+        unsigned int tab = 512;
+        while (tab < (P.nRho > 100 ? 12u : 6u) * (unsigned int)P.nRho && tab < 2048u) tab <<= 1;
+        if (const char *e = getenv("MLM_SEC_TAB")) tab = (unsigned int)std::max(256, atoi(e)); // power of two
         P.sec_tab = tab;
+        // a column's workgroup: 256 threads where the table allows (at most 4 entries per thread, one thread per range step) — the
+        // smaller workgroup and table leave wave slots and LDS of a CU to the other streams' kernels, which is worth more in the
+        // pipeline (+5 % frames/s on config 2) than the 10 % the kernel loses alone
+        h->sec_threads = (tab <= 1024u && P.nRho <= 256) ? 256 : 512;
+        if (const char *e = getenv("MLM_SEC_THREADS")) h->sec_threads = (atoi(e) == 256 && tab <= 1024u && P.nRho <= 256) ? 256 : 512;
+        if (P.sec_tab < (unsigned int)h->sec_threads) P.sec_tab = (unsigned int)h->sec_threads;
         if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
         P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
@@ -1986,7 +2006,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // no voxel may collect 2^16 cells — at most (d_sub / dRho + 2) (d_sub / dZ + 2) nPhi cell centres fall into one)
         const double cells_per_voxel = (std::ceil(P.d_sub / P.dRho) + 2) * (std::ceil(P.d_sub / P.dZ) + 2) * P.nPhi;
         h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
-                         P.sec_tab <= 4u * MLM_SEC_THREADS && (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
+                         P.sec_tab <= 4u * (unsigned int)h->sec_threads && (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
                          P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
                          (P.explore ? P.nRho <= 256
                                     : (((size_t)P.lv_nz << (2 * P.tile_sh)) <= 65536 && h->tile_lds_bytes <= 96u * 1024u && cells_per_voxel < 65536.0 &&
@@ -2002,10 +2022,14 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries), frame-local grid %d x %d x %d in %d tiles of edge %d (%u bytes of LDS each)\n",
                     (int)h->use_sectors, P.sec_lds_bytes, P.sec_tab, P.lv_nx, P.lv_ny, P.lv_nz, P.n_tiles, 1 << P.tile_sh, h->tile_lds_bytes);
         if (h->use_sectors) {
-            if (P.explore)
-                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
-            else
-                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+            if (P.explore && h->sec_threads == 256)
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+            else if (P.explore)
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+            else { // (both: single frames take the 512-thread instantiation where the table allows)
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
+            }
             if (!P.explore) HIPCHK(h, hipFuncSetAttribute((const void *)k_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->tile_lds_bytes));
             if (!P.explore) HIPCHK(h, hipFuncSetAttribute((const void *)k_apply_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->apply_lds_bytes));
             if (P.sec_tab_big) {
