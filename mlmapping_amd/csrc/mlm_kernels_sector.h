@@ -352,6 +352,28 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
     return L;
 }
 
+// the per-block statistics of k_bin_sectors folded into the frame's counters (one wave)
+__device__ __forceinline__ void mlm_fold_bin_stats(const MlmDev &P, int n_bin_blocks) {
+    const int lane = threadIdx.x & 63;
+    unsigned int a = 0, b = 0, g = 0;
+    for (int j = lane; j < n_bin_blocks; j += 64) {
+        const mlm_u32x4 st = *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)j);
+        a += st.x;
+        b += st.y;
+        g += st.z;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+        g += __shfl_xor(g, off, 64);
+    }
+    if (lane == 0) {
+        mlm_gp(P.ctr)->n_points = a;
+        mlm_gp(P.ctr)->n_oor = b;
+        mlm_gp(P.ctr)->n_groups = g;
+    }
+}
+
 // EX: frontier mode (use_exploration_frontiers).  The miss container's iteration order matters there (mlm_kernels_explore.h),
 // so a miss cell keeps its first insertion time — point index * 256 + step of the ray, map_awareness.cpp:266-274 — instead
 // of a bit, and the map-dependent part is frontier mode's own (explore_stage_bc): the kernel ends with the unique hit list
@@ -367,29 +389,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                                                   int rho_s, unsigned long long n_bkt, int big_armed) {
     constexpr int PER_MAX = BIG ? 8 : 4; // cell-table entries per thread
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (!BIG && phi == 0 && wid == 0) { // fold the per-block statistics of k_bin_sectors
-        unsigned int a = 0, b = 0, g = 0;
-        for (int j = lane; j < n_bin_blocks; j += 64) {
-            const mlm_u32x4 st = *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)j);
-            a += st.x;
-            b += st.y;
-            g += st.z;
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            a += __shfl_xor(a, off, 64);
-            b += __shfl_xor(b, off, 64);
-            g += __shfl_xor(g, off, 64);
-        }
-        if (lane == 0) {
-            mlm_gp(P.ctr)->n_points = a;
-            mlm_gp(P.ctr)->n_oor = b;
-            mlm_gp(P.ctr)->n_groups = g;
-        }
-    }
     // (the column's first chunk descriptors are requested together with their count and arrive while the tables below are set
     // up: one dependent trip to memory less in a column's life; what lies beyond the count is not looked at)
     mlm_u32x2 chunk_first = mlm_u32x2{0u, 0u};
-    if (threadIdx.x < min((unsigned int)MLM_SEC_CHUNKS, P.chunk_cap))
+    constexpr uint32_t CH = NT < MLM_SEC_CHUNKS ? NT : MLM_SEC_CHUNKS; // chunk descriptors staged per pass: one per thread
+    if (threadIdx.x < min(CH, P.chunk_cap))
         chunk_first = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)phi * P.chunk_cap + threadIdx.x));
     const unsigned int nch_all = mlm_gp(P.col_cnt)[phi];
     if (nch_all == 0) return; // nothing fell into this column (uniform)
@@ -542,12 +546,12 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         });
     };
     auto for_records = [&](int pass) {
-        if (pass == 1 && nch <= MLM_SEC_CHUNKS && keep_total <= NT) {
+        if (pass == 1 && nch <= CH && keep_total <= NT) {
             if (keep_cell != MLM_NIL) refs_of(keep_cell, keep_yx, keep_mask);
             return;
         }
-        for (uint32_t c0 = 0; c0 < nch; c0 += MLM_SEC_CHUNKS) {
-            const uint32_t n_staged = min(nch - c0, (uint32_t)MLM_SEC_CHUNKS);
+        for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
+            const uint32_t n_staged = min(nch - c0, CH);
             __syncthreads();
             uint32_t total = 0;
             {
@@ -991,6 +995,7 @@ template <bool EX, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
                                                                                        int rho_s, unsigned long long n_bkt, int big_armed) {
     MLM_SLOT_SETUP
+    if (blockIdx.x == 0 && threadIdx.x < 64) mlm_fold_bin_stats(P, n_bin_blocks);
     mlm_sector_column<EX, false, NT>(P, F, (int)blockIdx.x, tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, big_armed);
 }
 // The columns on the overflow lists of a batch's frames, with the large cell table (dynamic LDS of MlmDev::sec_big_lds_bytes:
@@ -1377,18 +1382,18 @@ __device__ __forceinline__ int mlm_floor_div(int a, int n) {
 #endif
 #define MLM_TILE_KEEP 2     // hits per thread kept in registers between the counting and the placing pass
 #define MLM_TILE_DESC 256   // descriptors staged per pass
-#define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap (its pool slots are kept in LDS; the host checks the geometry)
+#define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap: limit of MlmDev::tile_combos (their pool slots are kept in LDS)
 struct MlmTileLds {
     uint32_t cnt, place, desc, slot, ztab, total;
 };
-__host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_nz) {
+__host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_nz, uint32_t combos) {
     MlmTileLds L;
     uint32_t o = 0;
     L.cnt = o;      o += n_vox * 4u;                 // per voxel: misses | hits << 16 (the hit half doubles as the fill cursor later)
     L.place = o;    o += n_vox * 4u;                 // per touched voxel: record index in the tile | (offset of its hits, 0xFFFF: one hit) << 16
     o = (o + 15u) & ~15u;
     L.desc = o;     o += MLM_TILE_DESC * 16u + MLM_TILE_DESC * 8u; // staged descriptors + exclusive prefixes (miss cells, hits)
-    L.slot = o;     o += MLM_TILE_COMBOS * 4u + MLM_TILE_COMBOS;  // pool slot per overlapped block + "the frame touches it" flags
+    L.slot = o;     o += combos * 4u + combos;           // pool slot per overlapped block + "the frame touches it" flags (combos: multiple of 4)
     o = (o + 3u) & ~3u;
     L.ztab = o;     o += ((lv_nz + 1u) & ~1u) * 4u;  // per grid z: block index << 8 ... (gz, cz) packed
     L.total = (o + 15u) & ~15u;
@@ -1404,12 +1409,12 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     if (nd_all == 0) return; // (cannot happen: the tile is on the frame's list)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t edge = 1u << P.tile_sh, NV = edge * edge * (uint32_t)P.lv_nz;
-    const MlmTileLds L = mlm_tile_lds(NV, (uint32_t)P.lv_nz);
+    const MlmTileLds L = mlm_tile_lds(NV, (uint32_t)P.lv_nz, P.tile_combos);
     uint32_t *s_cnt = (uint32_t *)(s_dyn + L.cnt), *s_place = (uint32_t *)(s_dyn + L.place);
     mlm_u32x4 *s_desc = (mlm_u32x4 *)(s_dyn + L.desc);
     uint32_t *s_dm = (uint32_t *)(s_desc + MLM_TILE_DESC), *s_dh = s_dm + MLM_TILE_DESC;
     int *s_slot = (int *)(s_dyn + L.slot);
-    uint8_t *s_touch = (uint8_t *)(s_slot + MLM_TILE_COMBOS);
+    uint8_t *s_touch = (uint8_t *)(s_slot + P.tile_combos);
     uint32_t *s_ztab = (uint32_t *)(s_dyn + L.ztab);
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[4];
@@ -1425,7 +1430,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     const int gx0 = mlm_floor_div(X0, P.n), gy0 = mlm_floor_div(Y0, P.n), gz0 = mlm_floor_div(Z0, P.n);
     const int ngx = mlm_floor_div(X0 + (int)edge - 1, P.n) - gx0 + 1, ngy = mlm_floor_div(Y0 + (int)edge - 1, P.n) - gy0 + 1,
               ngz = mlm_floor_div(Z0 + P.lv_nz - 1, P.n) - gz0 + 1;
-    const int n_combo = ngx * ngy * ngz; // (<= MLM_TILE_COMBOS: checked by the host for the grid's geometry)
+    const int n_combo = ngx * ngy * ngz; // (<= P.tile_combos: the host's bound for the grid's geometry)
     const bool probe = true;
     for (int c = threadIdx.x; c < n_combo; c += MLM_TILE_THREADS) s_touch[c] = 0;
     auto combo_slot = [&](int c) {

@@ -231,6 +231,7 @@ struct MlmDev {
     unsigned int mc_list_cap;
     uint16_t *hl_vt16;         // [nCells] vt of every unique hit (a column's hits are contiguous in hl_*, ordered by tile)
     unsigned int *tile_cnt;    // [n_tiles] descriptors handed to each tile this frame (reset by k_tile)
+    unsigned int tile_combos;  // most blocks a tile of the frame-local grid overlaps (k_tile keeps their pool slots in LDS), multiple of 4
     unsigned int *tile_list;   // [n_tiles] the tiles that received descriptors this frame (count: ctr->mvox_cnt[2][0])
     uint32_t *tile_desc;       // [n_tiles][tile_desc_cap][4] {first miss cell in mc_list, count, first hit in hl_*, count}
     unsigned int tile_desc_cap;

@@ -33,8 +33,11 @@ extern "C" int mlm_sort_pairs_u64_u32(void *temp, size_t temp_bytes, const unsig
 
 namespace {
 
-#define MLM_SETS 3 // slot sets: batches in flight (one being filled, one in Stage A, one draining).  Measured on config 2 with the sector
-                   // path: 44.7k frames/s with 2, 48.4k with 3, 45.3k with 4
+#ifndef MLM_SETS
+#define MLM_SETS 3
+#endif
+// MLM_SETS slot sets: batches in flight (one being filled, one in Stage A, one draining).  Measured on config 2 with the sector
+// path: round 2 44.7k frames/s with 2, 48.4k with 3, 45.3k with 4; round 3 74.0k / 80.9k / 78.7k
 
 struct KernelTime {
     const char *name;
@@ -105,7 +108,7 @@ struct mlm_handle {
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
     unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
-    unsigned int rank_grid = 512;            // blocks per frame of k_rank in a batch (config 2: 67.5k frames/s, 256: 66.9k, 1024: 65.2k; MLM_RANK_GRID)
+    unsigned int rank_grid = 256;            // blocks per frame of k_rank in a batch (config 2, r3: 80.3k frames/s, 512: 79.6k, 1024: 77.2k; MLM_RANK_GRID)
     // Lean frame slots (sector-path handles): the three large buffers only the cell-table Stage A uses — the block slices of
     // contribution nodes sized for its LDS overflow, the (block, cell) pairs and the node lists — exist ONCE per handle instead
     // of once per slot; a cell-table Stage A (a frame's fall-back, or a batch submitted while the sector path backs off) then
@@ -514,6 +517,9 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         else if (P.explore)
             tlaunch(h, "k_sector", k_sector<true, 512>, dim3((unsigned int)P.nPhi, 1, n), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
+        else if (h->sec_threads == 128)
+            tlaunch(h, "k_sector", k_sector<false, 128>, dim3((unsigned int)P.nPhi, 1, n), dim3(128), P.sec_lds_bytes, st, h->d_slot_tab,
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
         else if (h->sec_threads == 256)
             tlaunch(h, "k_sector", k_sector<false, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
@@ -1963,7 +1969,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // smaller workgroup and table leave wave slots and LDS of a CU to the other streams' kernels, which is worth more in the
         // pipeline (+5 % frames/s on config 2) than the 10 % the kernel loses alone
         h->sec_threads = (tab <= 1024u && P.nRho <= 256) ? 256 : 512;
-        if (const char *e = getenv("MLM_SEC_THREADS")) h->sec_threads = (atoi(e) == 256 && tab <= 1024u && P.nRho <= 256) ? 256 : 512;
+        if (const char *e = getenv("MLM_SEC_THREADS")) {
+            const int t = atoi(e);
+            h->sec_threads = (t == 128 && !P.explore && tab <= 512u && P.nRho <= 128) ? 128 : (t <= 256 && tab <= 1024u && P.nRho <= 256) ? 256 : 512;
+        }
         if (P.sec_tab < (unsigned int)h->sec_threads) P.sec_tab = (unsigned int)h->sec_threads;
         if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
@@ -1998,7 +2007,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             // (a camera frame reaches about a quarter of its grid's tiles; more touched tiles than workgroups are walked in turns)
             h->tile_grid = (unsigned int)std::max(32, std::min(P.n_tiles, P.n_tiles / 3 + 1));
             if (const char *e = getenv("MLM_TILE_GRID")) h->tile_grid = (unsigned int)std::max(1, std::min(P.n_tiles, atoi(e)));
-            h->tile_lds_bytes = mlm_tile_lds((unsigned int)(edge * edge * P.lv_nz), (unsigned int)P.lv_nz).total;
+            {   // blocks a tile overlaps: an extent of e voxels starting anywhere touches at most (e - 1) / n + 2 blocks of n
+                const long long cx = (edge - 1) / P.n + 2, cz = (P.lv_nz - 1) / P.n + 2;
+                P.tile_combos = (unsigned int)std::min<long long>((cx * cx * cz + 3) & ~3ll, 1ll << 20);
+            }
+            h->tile_lds_bytes = mlm_tile_lds((unsigned int)(edge * edge * P.lv_nz), (unsigned int)P.lv_nz, P.tile_combos).total;
             h->apply_lds_bytes = (unsigned int)(edge * edge * 2 * P.lv_nz) * 9u + 16u; // (two grid heights of layers: frames of a range differ in z origin)
         }
         // (frontier mode: no tiles; its insertion times hold point index * 256 + ray step in 32 bits)
@@ -2012,7 +2025,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
                                     : (((size_t)P.lv_nz << (2 * P.tile_sh)) <= 65536 && h->tile_lds_bytes <= 96u * 1024u && cells_per_voxel < 65536.0 &&
                                        P.n_tiles < (1 << 24) && P.lv_nz <= 1024 && h->apply_lds_bytes <= 150u * 1024u &&
                                        // (blocks one tile may overlap: their pool slots live in k_tile's LDS)
-                                       (long long)((1 << P.tile_sh) / P.n + 2) * ((1 << P.tile_sh) / P.n + 2) * (P.lv_nz / P.n + 2) <= MLM_TILE_COMBOS));
+                                       P.tile_combos <= MLM_TILE_COMBOS));
         if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
         // (lean slots cost the worst-case scenes their batching — every frame overflowing its sector tables: 1.3k instead of
         // 4.4k frames/s on the "scatter" scene — so they are used on request, or when the full slots do not fit the device)
@@ -2027,6 +2040,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             else if (P.explore)
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
             else { // (both: single frames take the 512-thread instantiation where the table allows)
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
             }
