@@ -1381,7 +1381,7 @@ __device__ __forceinline__ int mlm_floor_div(int a, int n) {
 #define MLM_TILE_THREADS 256
 #endif
 #define MLM_TILE_KEEP 2     // hits per thread kept in registers between the counting and the placing pass
-#define MLM_TILE_DESC 256   // descriptors staged per pass
+#define MLM_TILE_DESC 128   // descriptors staged per pass (a tile of a VGA frame has ~15; 128 instead of 256: 3 KB of LDS, a fifth workgroup per CU)
 #define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap: limit of MlmDev::tile_combos (their pool slots are kept in LDS)
 struct MlmTileLds {
     uint32_t cnt, place, desc, slot, ztab, total;
@@ -1738,13 +1738,14 @@ __device__ __forceinline__ void mlm_apply_record(const MlmDev &P0, const mlm_u32
 // exact keys: MLM_FRAME_EXACT_KEYS), or k_tile could not create its blocks (the host grows the pool).  g->fail_frame tells the
 // host which (sticky: batches behind it do nothing).  f_begin: first frame of the slot range to apply (replays).
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot_base,
-                                                           int n_frames, int f_begin) {
+                                                           int n_frames, int f_begin, int z_span) {
     __builtin_amdgcn_s_setprio(3); // the serial chain of the pipeline: its few waves issue ahead of Stage A's
     // The tile's voxels stay in LDS for the whole batch: a voxel is fetched from the map when a frame first touches it and
     // written back once, after the last frame — between frames only an LDS barrier stands (not a round trip to memory and
     // the wait for the stores' acknowledgement), and the map's lines are touched once per batch instead of once per frame.
-    // The frames' grids differ in their z origin (the sensor's height): the LDS column of a tile spans 2 * lv_nz layers from
-    // the lowest origin of the range (the host cuts a batch where the origins lie farther apart).
+    // The frames' grids differ in their z origin (the sensor's height): the LDS column of a tile spans lv_nz + z_span layers from
+    // the lowest origin of the range — z_span = the spread of the range's origins, known to the host, which cuts a batch where
+    // it would exceed a grid height (LDS left to the other streams' kernels is throughput: §5 of DESIGN.md).
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     // per frame of the range, gathered once (the loop over the frames touches no frame or slot parameters in memory):
     __shared__ const MlmVoxRec *s_rec[64];           // this tile's records of the frame
@@ -1796,7 +1797,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
     }
     __syncthreads();
     const int f_stop = s_stop;
-    const uint32_t NZ = 2u * (uint32_t)lv_nz, NV = NZ << (2 * sh);
+    const uint32_t NZ = (uint32_t)(lv_nz + z_span), NV = NZ << (2 * sh);
     float *s_L = (float *)s_dyn;                         // [NV] log-odds of the tile's voxels (valid where s_at != NIL)
     uint32_t *s_at = (uint32_t *)(s_dyn + 4u * NV);      // [NV] the voxel's address in the pool (slot * cells + cell id), MLM_NIL: not fetched
     uint8_t *s_o = (uint8_t *)(s_dyn + 8u * NV);         // [NV] occupancy class
@@ -1814,7 +1815,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
             const MlmDev &P = slot_tab[slot_base + lane];
             const int tx = WX - (F.lv_o[0] >> sh), ty = WY - (F.lv_o[1] >> sh);
             dz = F.lv_o[2] - s_z0;
-            if (!(F.flags & MLM_FRAME_SKIP) && tx >= 0 && ty >= 0 && tx < P.n_tx && ty * P.n_tx + tx < P.n_tiles && dz >= 0 && dz <= lv_nz) {
+            if (!(F.flags & MLM_FRAME_SKIP) && tx >= 0 && ty >= 0 && tx < P.n_tx && ty * P.n_tx + tx < P.n_tiles && dz >= 0 && dz <= z_span) {
                 const mlm_u32x4 e = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_dir) + 4 * (size_t)(ty * P.n_tx + tx));
                 if (e.z == (uint32_t)F.seq) {
                     rec = P.vr_rec + e.x;
