@@ -505,8 +505,8 @@ __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_PHASE_END
 }
 
-// odd of the contribution kind `sub` into a cell at rho_c (see the top of this section)
-__device__ __forceinline__ float mlm_contribution_odd(const MlmDev &P, const float *table, int rho_c, int sub) {
+// odd of the contribution kind `sub` into a cell at rho_c (see the top of this section): its place in the odds table ...
+__device__ __forceinline__ int mlm_contribution_index(const MlmDev &P, int rho_c, int sub) {
     int row = MLM_DIFF_RANGE, rho_s = rho_c;
     if (sub > 0) {
         const int d = (sub + 1) >> 1;
@@ -518,7 +518,11 @@ __device__ __forceinline__ float mlm_contribution_odd(const MlmDev &P, const flo
             rho_s = rho_c + d;
         }
     }
-    return table[row * P.nRho + rho_s];
+    return row * P.nRho + rho_s;
+}
+// ... and the value
+__device__ __forceinline__ float mlm_contribution_odd(const MlmDev &P, const float *table, int rho_c, int sub) {
+    return table[mlm_contribution_index(P, rho_c, sub)];
 }
 // logit macro, map_local.h:8, on a float: log10f(x / (1 - x)) — the HOST libm's log10f in the reference.  P.logit_exact:
 // mlm_create found that this host's log10f is glibc's table-driven one, restated bit for bit in mlm_glibc_log10f

@@ -336,7 +336,7 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
         L.chunk = o;
         o += (b + 15u) & ~15u;
     }
-    L.odds = o;     o += (2u * MLM_DIFF_RANGE + 1u) * n_rho * 4u;
+    L.odds = o;     o += ((2u * MLM_DIFF_RANGE + 1u) * n_rho + 3u) & ~3u; // a byte per entry of the odds table: its strength
     L.sigma = o;    o += ((n_rho + 3u) & ~3u) * 4u;
     L.miss = o;     o += ((n_miss + 3u) & ~3u) * 4u;
     L.rays = o;     o += TAB * 2u;                       // table entries that start a ray
@@ -403,7 +403,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, EX);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
-    float *s_odds = (float *)(s_dyn + L.odds);
+    uint8_t *s_strength = (uint8_t *)(s_dyn + L.odds); // strength (mlm_sec_strength) of every entry of the odds table: what the booking pass needs of it
     float *s_sigma = (float *)(s_dyn + L.sigma);
     uint16_t *s_rays = (uint16_t *)(s_dyn + L.rays);
     uint16_t *s_occ = (uint16_t *)(s_dyn + L.occ);
@@ -429,7 +429,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         if (EX) s_tab[e].gpos = MLM_EMPTY_T; // (until the lists are built: first point whose centre is the cell)
     }
     for (uint32_t e = threadIdx.x; e < NMISS; e += NT) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
-    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += NT) s_odds[e] = mlm_gp(P.odds_table)[e];
+    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += NT) s_strength[e] = (uint8_t)mlm_sec_strength(mlm_gp(P.odds_table)[e]);
     for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += NT) {
         s_sigma[e] = mlm_gp(P.sigma3)[e];
         s_run_hits[e] = 0;
@@ -621,7 +621,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
                         atomicOr(&s_tab[e].kmask, 1u << sub);
                         // contributions, and in the upper 12 bits (mod 4096) the sum of their strengths (mlm_sec_needs_order)
-                        const uint32_t strength = mlm_sec_strength(mlm_contribution_odd(P, s_odds, rho_t, sub));
+                        const uint32_t strength = s_strength[mlm_contribution_index(P, rho_t, sub)];
                         atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
                         atomicAdd(&s_tab[e].gcnt, 1u);
                         if (EX && sub == 0) atomicMin(&s_tab[e].gpos, i_first);
@@ -859,7 +859,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         if (!mlm_sec_needs_order(c)) {
             // one kind: cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154), 1.0f is absorbing;
             // several kinds with enough strong contributions: 1.0f in any order (mlm_sec_needs_order)
-            const float a = mlm_contribution_odd(P, s_odds, rho, __ffs((int)c.kmask) - 1);
+            const float a = mlm_gp(P.odds_table)[mlm_contribution_index(P, rho, __ffs((int)c.kmask) - 1)]; // (one value per hit cell: from memory)
             float p = __popc(c.kmask) > 1 ? 1.0f : a;
             for (uint32_t j = 1; j < (c.cnt & MLM_SEC_CNT_MASK) && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
             mlm_gp(P.hl_odd)[pos] = p;
