@@ -47,16 +47,18 @@
 #define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
 #define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
 
-// one hit cell of the column while k_sector works on it (24 bytes)
+// one hit cell of the column while k_sector works on it (20 bytes)
 struct MlmSecCell {
     uint32_t key;   // z * nRho + rho, MLM_NIL = empty
     uint32_t tmin;  // first-touch time (min over contributions)
-    uint32_t kmask; // kinds
+    uint32_t kg;    // kinds (bits 0..20) | (record, kind) references of the cell << 21 (one word: 4 bytes of LDS per entry are an
+                    // eighth workgroup per CU)
     uint32_t cnt;   // contributions
-    uint32_t gcnt;  // (record, kind) references of the cell
     uint32_t gpos;  // multi-kind cells: fill cursor into MlmDev::refs (starts at the cell's segment)
 };
 
+#define MLM_SEC_KIND_BITS 21 // MlmSecCell::kg: 2 * MLM_DIFF_RANGE + 1 kinds below the reference count
+#define MLM_SEC_KIND_MASK ((1u << MLM_SEC_KIND_BITS) - 1u)
 #define MLM_SEC_CNT_BITS 20 // MlmSecCell::cnt: contributions in the low bits (mlm_limits.max_points < 2^20 on this path)
 #define MLM_SEC_CNT_MASK ((1u << MLM_SEC_CNT_BITS) - 1u)
 // Does the float noisy-OR chain of the cell (update_odds_hashmap, map_awareness.h:147-154: p <- 1 - (1 - p)(1 - a), each
@@ -73,7 +75,7 @@ struct MlmSecCell {
 #define MLM_SEC_STRONG_ENOUGH 28u
 __device__ __forceinline__ uint32_t mlm_sec_strength(float a) { return a >= 0.875f ? 3u : (a >= 0.75f ? 2u : (a >= 0.5f ? 1u : 0u)); }
 __device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
-    return __popc(c.kmask) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH;
+    return __popc(c.kg & MLM_SEC_KIND_MASK) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH;
 }
 
 __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
@@ -423,9 +425,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     for (uint32_t e = threadIdx.x; e < TAB; e += NT) {
         s_tab[e].key = MLM_NIL;
         s_tab[e].tmin = MLM_EMPTY_T;
-        s_tab[e].kmask = 0;
+        s_tab[e].kg = 0;
         s_tab[e].cnt = 0;
-        s_tab[e].gcnt = 0;
         if (EX) s_tab[e].gpos = MLM_EMPTY_T; // (until the lists are built: first point whose centre is the cell)
     }
     for (uint32_t e = threadIdx.x; e < NMISS; e += NT) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
@@ -619,11 +620,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                             return;
                         }
                         atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
-                        atomicOr(&s_tab[e].kmask, 1u << sub);
+                        atomicOr(&s_tab[e].kg, 1u << sub);
                         // contributions, and in the upper 12 bits (mod 4096) the sum of their strengths (mlm_sec_needs_order)
                         const uint32_t strength = s_strength[mlm_contribution_index(P, rho_t, sub)];
                         atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
-                        atomicAdd(&s_tab[e].gcnt, 1u);
+                        if ((atomicAdd(&s_tab[e].kg, 1u << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) == (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) s_fail = 1; // (2 047 references of one cell: the frame takes the cell-table path)
                         if (EX && sub == 0) atomicMin(&s_tab[e].gpos, i_first);
                     });
                 }
@@ -663,10 +664,10 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         const MlmSecCell &c = s_tab[threadIdx.x * per + q];
         if (c.key == MLM_NIL) continue;
         ++v[0];
-        v[2] += c.kmask & 1u;
+        v[2] += c.kg & 1u;
         if (mlm_sec_needs_order(c)) {
             ++v[1];
-            w_refs += c.gcnt;
+            w_refs += c.kg >> MLM_SEC_KIND_BITS;
             w_subs += ((c.cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
         }
         if (EX) { // (frontier mode has no tiles: the hits keep the table's order)
@@ -702,7 +703,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             const uint32_t e = threadIdx.x * per + q;
             MlmSecCell &c = s_tab[e];
             if (c.key == MLM_NIL) continue;
-            if (c.kmask & 1u) {
+            if (c.kg & 1u) {
                 if (EX) s_ray_p0[o_rays] = c.gpos;
                 s_rays[o_rays++] = (uint16_t)e;
             }
@@ -742,7 +743,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             uint32_t e = 0;
             if (j < n_multi) {
                 e = s_multi[j];
-                a[0] = s_tab[e].gcnt;
+                a[0] = s_tab[e].kg >> MLM_SEC_KIND_BITS;
                 a[1] = ((s_tab[e].cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
             }
             mlm_block_excl_scan4<NT / 64>(a, s_w, t4);
@@ -754,7 +755,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 key_rz(c.key, c_rho, c_z);
                 // (contributions | rho << 20: what k_chain_lanes needs of the cell comes with one load)
                 *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, (c.cnt & MLM_SEC_CNT_MASK) | ((uint32_t)c_rho << MLM_SEC_CNT_BITS), c.tmin};
-                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.gcnt};
+                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.kg >> MLM_SEC_KIND_BITS};
                 mlm_gp(P.hl_base)[pos] = o_subs;
                 mlm_gp(P.hl_cnt)[pos] = c.cnt & MLM_SEC_CNT_MASK;
                 c.gpos = o_refs;
@@ -859,8 +860,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         if (!mlm_sec_needs_order(c)) {
             // one kind: cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154), 1.0f is absorbing;
             // several kinds with enough strong contributions: 1.0f in any order (mlm_sec_needs_order)
-            const float a = mlm_gp(P.odds_table)[mlm_contribution_index(P, rho, __ffs((int)c.kmask) - 1)]; // (one value per hit cell: from memory)
-            float p = __popc(c.kmask) > 1 ? 1.0f : a;
+            const float a = mlm_gp(P.odds_table)[mlm_contribution_index(P, rho, __ffs((int)(c.kg & MLM_SEC_KIND_MASK)) - 1)]; // (one value per hit cell: from memory)
+            float p = __popc(c.kg & MLM_SEC_KIND_MASK) > 1 ? 1.0f : a;
             for (uint32_t j = 1; j < (c.cnt & MLM_SEC_CNT_MASK) && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
             mlm_gp(P.hl_odd)[pos] = p;
             mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
