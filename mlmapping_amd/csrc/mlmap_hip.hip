@@ -511,16 +511,18 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         div_magic((unsigned int)P.nRho, rm, rs);
         const int big = P.sec_tab_big && h->big_armed > 0 ? 1 : 0; // the pass with the large cell table follows (see k_sector_big)
         if (h->big_armed > 0) --h->big_armed;
-        if (P.explore && h->sec_threads == 256)
+        // (a frame on its own is alone on the GPU: the 512-thread workgroup finishes a column sooner; the table is the same)
+        const int nt = (n == 1 && P.sec_tab >= 512u) ? 512 : h->sec_threads;
+        if (P.explore && nt == 256)
             tlaunch(h, "k_sector", k_sector<true, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
         else if (P.explore)
             tlaunch(h, "k_sector", k_sector<true, 512>, dim3((unsigned int)P.nPhi, 1, n), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
-        else if (h->sec_threads == 128)
+        else if (nt == 128)
             tlaunch(h, "k_sector", k_sector<false, 128>, dim3((unsigned int)P.nPhi, 1, n), dim3(128), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
-        else if (h->sec_threads == 256)
+        else if (nt == 256)
             tlaunch(h, "k_sector", k_sector<false, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
         else
@@ -2036,11 +2038,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries), frame-local grid %d x %d x %d in %d tiles of edge %d (%u bytes of LDS each)\n",
                     (int)h->use_sectors, P.sec_lds_bytes, P.sec_tab, P.lv_nx, P.lv_ny, P.lv_nz, P.n_tiles, 1 << P.tile_sh, h->tile_lds_bytes);
         if (h->use_sectors) {
-            if (P.explore && h->sec_threads == 256)
+            if (P.explore) { // (both instantiations: a frame on its own takes the 512-thread one where the table allows)
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
-            else if (P.explore)
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
-            else { // (both: single frames take the 512-thread instantiation where the table allows)
+            } else { // (both: single frames take the 512-thread instantiation where the table allows)
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
