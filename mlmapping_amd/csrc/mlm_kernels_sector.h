@@ -78,6 +78,14 @@ __device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
     return __popc(c.kg & MLM_SEC_KIND_MASK) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH;
 }
 
+// rows (bytes) of an 8x8 lane mask that hold a lane: a multi-kind cell gets one reference per such row of every contribution group
+__device__ __forceinline__ uint32_t mlm_mask_rows(unsigned long long m) {
+    m |= m >> 4;
+    m |= m >> 2;
+    m |= m >> 1;
+    return (uint32_t)__popcll(m & 0x0101010101010101ull);
+}
+
 __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
     mlm_gp(P.ctr)->sector_overflow = 1u;
     // (frontier mode does not speculate: its host reads the flag before it enqueues what depends on the map)
@@ -537,12 +545,30 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     auto refs_of = [&](uint32_t cell, uint32_t yx, unsigned long long mask) {
         const int z = (int)(cell / (uint32_t)P.nRhoPhi);
         const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
+        // the non-empty rows of the group's lane mask, once per record (three bits each): the same for every target cell
+        uint32_t rows3 = 0, n_rows = 0;
+#pragma unroll
+        for (uint32_t row = 0; row < 8u; ++row)
+            if ((uint32_t)(mask >> (8u * row)) & 0xFFu) rows3 |= row << (3u * n_rows++);
         mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int) {
             const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
             if (e >= 0 && mlm_sec_needs_order(s_tab[e])) {
-                const uint32_t at = atomicAdd(&s_tab[e].gpos, 1u);
-                if (at < P.refs_cap) // a reference carries what k_rank needs of the record: one round trip there
-                    *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.refs) + 4 * (size_t)at) = mlm_u32x4{(uint32_t)mask, (uint32_t)(mask >> 32), yx, (uint32_t)sub};
+                // one reference per non-empty ROW of the group's lane mask: {position of the row's first lane, row byte | kind << 8} —
+                // what k_rank needs, with no empty rows in its rounds (a group touches two or three of its eight rows)
+                const uint32_t at = atomicAdd(&s_tab[e].gpos, n_rows);
+                if (at + n_rows <= P.refs_cap) {
+                    auto entry = [&](uint32_t k) {
+                        const uint32_t row = (rows3 >> (3u * k)) & 7u;
+                        return mlm_u32x2{yx + (tile_w > 0 ? row << 11 : row * 8u), ((uint32_t)(mask >> (8u * row)) & 0xFFu) | ((uint32_t)sub << 8)};
+                    };
+                    MLM_GLOBAL uint32_t *dst = mlm_gp(P.refs) + 2 * (size_t)at;
+                    uint32_t k = 0;
+                    for (; k + 1 < n_rows; k += 2) { // two references per 16-byte store
+                        const mlm_u32x2 e0 = entry(k), e1 = entry(k + 1);
+                        *(MLM_GLOBAL mlm_u32x4 *)(dst + 2 * k) = mlm_u32x4{e0.x, e0.y, e1.x, e1.y};
+                    }
+                    if (k < n_rows) *(MLM_GLOBAL mlm_u32x2 *)(dst + 2 * k) = entry(k);
+                }
             }
         });
     };
@@ -612,7 +638,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                     }
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
                     const uint32_t i_first = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
-                    const uint32_t cnt = (uint32_t)__popcll(mask);
+                    const uint32_t cnt = (uint32_t)__popcll(mask), n_rows = mlm_mask_rows(mask);
                     mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int rho_t) {
                         const int e = mlm_sec_entry<true>(s_tab, tab_mask, key);
                         if (e < 0) {
@@ -624,7 +650,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         // contributions, and in the upper 12 bits (mod 4096) the sum of their strengths (mlm_sec_needs_order)
                         const uint32_t strength = s_strength[mlm_contribution_index(P, rho_t, sub)];
                         atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
-                        if ((atomicAdd(&s_tab[e].kg, 1u << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) == (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) s_fail = 1; // (2 047 references of one cell: the frame takes the cell-table path)
+                        if ((atomicAdd(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) + n_rows > (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) s_fail = 1; // (more than 2 047 references of one cell: the frame takes the cell-table path)
                         if (EX && sub == 0) atomicMin(&s_tab[e].gpos, i_first);
                     });
                 }
@@ -1067,18 +1093,17 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const MLM_GLOBAL uint32_t *refs = mlm_gp(P.refs);
-    // (record, row) pair p of a cell: the row's byte of the record's lane mask, the position (row << 11 | column) of the
-    // row's first lane, kind
+    // reference p of a cell = one non-empty row of one contribution group: the row's byte of the group's lane mask, the position
+    // (row << 11 | column) of the row's first lane, kind
     auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &yx, uint32_t &sub) {
         bits = 0;
         yx = 0;
         sub = 0;
-        if (p < rf.y * 8u) {
-            const mlm_u32x4 ref = *(const MLM_GLOBAL mlm_u32x4 *)(refs + 4 * (size_t)(rf.x + (p >> 3)));
-            const uint32_t row = p & 7u;
-            bits = ((row & 4u ? ref.y : ref.x) >> (8 * (row & 3u))) & 0xFFu;
-            yx = ref.z + (tile_w > 0 ? row << 11 : row * 8u);
-            sub = ref.w;
+        if (p < rf.y) {
+            const mlm_u32x2 ref = *(const MLM_GLOBAL mlm_u32x2 *)(refs + 2 * (size_t)(rf.x + p));
+            yx = ref.x;
+            bits = ref.y & 0xFFu;
+            sub = ref.y >> 8;
         }
     };
     auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],
@@ -1092,7 +1117,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + soff;
         volatile MLM_LDS uint8_t *SL = mlm_lp(s_kinds[wid]);
         const bool staged = n <= 1024u; // kinds are collected in LDS and leave as whole dwords
-        const int rounds = (int)min(4u, (n_refs * 8u + 63u) >> 6); // (uniform) rounds of 64 pairs held in registers
+        const int rounds = (int)min(4u, (n_refs + 63u) >> 6); // (uniform) rounds of 64 pairs held in registers
         bool bad = n > 0xFFFFu;
         auto locate = [&](uint32_t yx, uint32_t &wi, uint32_t &sh) -> bool {
             const int dx = (int)(yx & 2047u) - xlo;
@@ -1112,7 +1137,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
                     else bad = true;
                 }
             }
-            for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
+            for (uint32_t p = lane + 256u; p < n_refs; p += 64) {
                 uint32_t b, px, sb, wi, sh;
                 load_pair(rf, p, b, px, sb);
                 if (b) {
@@ -1173,7 +1198,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
                 for (int q = 0; q < 4; ++q)
                     if (q < rounds) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q], store_glb);
             }
-            for (uint32_t p = lane + 256u; p < n_refs * 8u; p += 64) {
+            for (uint32_t p = lane + 256u; p < n_refs; p += 64) {
                 uint32_t b, px, sb, wi, sh;
                 load_pair(rf, p, b, px, sb);
                 if (b) {
@@ -1193,7 +1218,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
             // position into the cell's segment of `contrib`, then rank by counting straight from memory
             MLM_GLOBAL uint32_t *K = mlm_gp(P.contrib) + soff;
             uint32_t base = 0;
-            for (uint32_t p0 = 0; p0 < n_refs * 8u; p0 += 64) {
+            for (uint32_t p0 = 0; p0 < n_refs; p0 += 64) {
                 uint32_t b, px, sb;
                 load_pair(rf, p0 + lane, b, px, sb);
                 const uint32_t item = (px >> 11) * (uint32_t)row_w + (px & 2047u); // work item of the row's first lane
