@@ -214,10 +214,10 @@ struct MlmDev {
     unsigned int sec_tab_big, sec_big_lds_bytes; // ... of k_sector_big (0 entries: no second pass)
     uint32_t *ov_list;         // [nPhi] columns whose cell table overflowed in k_sector (count: MlmCounters::n_ov)
     unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
-    uint32_t *refs;            // [refs_cap][4] {lane mask lo, hi, tile origin (row << 11 | column), kind} per contribution group of a
-                               // multi-kind cell
+    uint32_t *refs;            // [refs_cap][2] {position (row << 11 | column) of the row's first lane, row byte | kind << 8} per non-empty
+                               // row of the lane mask of every contribution group of a multi-kind cell
     unsigned int refs_cap;
-    uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count}
+    uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count of its references}
     // Frame-local voxel grid: the voxels the awareness cylinder can reach, addressed relative to MlmFrame::lv_o and cut into
     // TILES of 2^tile_sh x 2^tile_sh voxels in x,y over the grid's whole height.  Which voxel — and so which tile — a cell
     // of an azimuth column falls into is geometry (no map needed), and along a column it depends on rho only: k_sector hands

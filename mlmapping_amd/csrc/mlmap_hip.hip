@@ -1724,8 +1724,8 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         if ((rc = dev_alloc(h, &P.sbkt, (size_t)P.sbkt_cap))) return rc;
         HIPCHK(h, hipMemset(P.sbkt, 0xFF, (size_t)P.sbkt_cap * sizeof(unsigned long long)));
     }
-    P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, max_contrib); // (a (record, kind) reference stands for at least one contribution)
-    if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? 4 * (size_t)P.refs_cap : 4))) return rc;
+    P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, max_contrib); // (a reference — one row of a group's lane mask — stands for at least one contribution)
+    if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? 2 * (size_t)P.refs_cap : 4))) return rc;
     if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
     HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
     if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
