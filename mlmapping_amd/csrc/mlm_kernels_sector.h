@@ -1247,31 +1247,164 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    // one cell ahead: descriptors two cells ahead, the first four rounds of (record, row) pairs one cell ahead — a cell is
+    // ---- TWO cells per wave, one per half: a cell's work is counted in wave-instructions (about 160 with one round of
+    //      references), not in lanes, and with the empty rows gone most cells fill half a wave at best.  Each half has its own
+    //      64-row half of the bitmap, its own half of the staging buffer and its own per-cell values in vector registers; a cell
+    //      that does not fit half a wave (more than 512 contributions, taller than 64 rows, a window miss) is redone by the whole
+    //      wave with `process`.
+    const int half = lane >> 5, hl = lane & 31;
+    MLM_LDS unsigned long long *rows_h = rows + half * (MLM_SEC_RANK_WORDS / 2);
+    volatile MLM_LDS uint16_t *pref_h = pref + half * (MLM_SEC_RANK_WORDS / 2);
+    volatile MLM_LDS uint8_t *SL_h = mlm_lp(s_kinds[wid]) + half * 544; // 512 staged kinds + a spare byte per lane
+    auto half_incl_scan = [](uint32_t v) { // inclusive prefix sum inside each half of the wave (mlm_wave_incl_scan without its last step)
+        int x = (int)v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); // row_shr:1
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); // row_shr:2
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); // row_shr:4
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); // row_shr:8
+        x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+        return (uint32_t)x;
+    };
+    // returns (per lane, equal inside a half): the half's cell still has to be done by the whole wave
+    auto process_pair = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, bool valid, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],
+                            const uint32_t (&r_sub)[4]) -> bool {
+        const uint32_t soff = rec.y, n = rec.z & MLM_SEC_CNT_MASK, n_refs = rf.y;
+        const uint32_t pix0 = rec.w / MLM_TIME_SLOTS;
+        const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
+        const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64;
+        const bool act = valid && n <= 512u;
+        const int my_rounds = act ? (int)min(4u, (n_refs + 31u) >> 5) : 0;
+        const int rounds = max(mlm_readlane(my_rounds, 0), mlm_readlane(my_rounds, 32)); // (uniform)
+        bool bad = false;
+        auto locate = [&](uint32_t yx, uint32_t &wi, uint32_t &sh) -> bool {
+            const int dx = (int)(yx & 2047u) - xlo;
+            const uint32_t dy = (yx >> 11) - y0;
+            wi = 2 * dy + ((uint32_t)dx >> 6);
+            sh = (uint32_t)dx & 63u;
+            return dx >= 0 && dx <= 120 && dy < MLM_BMP_ROWS / 2;
+        };
+        uint32_t l_wi[4], l_sh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            l_wi[q] = 0;
+            l_sh[q] = 0;
+            if (q < rounds && q < my_rounds && r_bits[q]) {
+                if (locate(r_yx[q], l_wi[q], l_sh[q])) __hip_atomic_fetch_or(&rows_h[l_wi[q]], (unsigned long long)r_bits[q] << l_sh[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else bad = true;
+            }
+        }
+        if (act)
+            for (uint32_t p = (uint32_t)hl + 128u; p < n_refs; p += 32) {
+                uint32_t b, px, sb, wi, sh;
+                load_pair(rf, p, b, px, sb);
+                if (b) {
+                    if (locate(px, wi, sh)) __hip_atomic_fetch_or(&rows_h[wi], (unsigned long long)b << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else bad = true;
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long bad_lanes = __ballot(bad);
+        bool ok = act && ((uint32_t)(bad_lanes >> (32 * half)) == 0u);
+        uint32_t carry = 0, used = MLM_SEC_RANK_WORDS / 2;
+        for (uint32_t j0 = 0; j0 < MLM_SEC_RANK_WORDS / 2; j0 += 32) {
+            const bool need = ok && carry < n;
+            if (!__any(need)) break;
+            const uint32_t cw = need ? (uint32_t)__popcll(((volatile MLM_LDS unsigned long long *)rows_h)[j0 + hl]) : 0u;
+            const uint32_t incl = half_incl_scan(cw);
+            const uint32_t t0 = mlm_readlane(incl, 31), t1 = mlm_readlane(incl, 63);
+            if (need) {
+                pref_h[j0 + hl] = (uint16_t)(carry + incl - cw);
+                carry += half ? t1 : t0;
+                used = j0 + 32;
+            }
+        }
+        ok = ok && carry == n; // (a count mismatch means a window miss: the whole wave redoes the cell)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto place = [&](uint32_t bits, uint32_t wi, uint32_t sh, uint32_t sub) {
+            const unsigned long long word = ((volatile MLM_LDS unsigned long long *)rows_h)[wi];
+            const uint32_t before = pref_h[wi] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull));
+            const uint32_t seg = (uint32_t)(word >> sh) & 0xFFu;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t at = before + (uint32_t)__popc(seg & ((1u << b) - 1u));
+                SL_h[(bits >> b) & 1u ? at : 512u + (uint32_t)hl] = (uint8_t)sub;
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < rounds && ok && q < my_rounds) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q]);
+        if (ok)
+            for (uint32_t p = (uint32_t)hl + 128u; p < n_refs; p += 32) {
+                uint32_t b, px, sb, wi, sh;
+                load_pair(rf, p, b, px, sb);
+                if (b) {
+                    locate(px, wi, sh);
+                    place(b, wi, sh, sb);
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ok) {
+            MLM_GLOBAL uint32_t *S32 = (MLM_GLOBAL uint32_t *)(mlm_gp(P.subs) + soff);
+            for (uint32_t j = (uint32_t)hl; j < (n + 3u) >> 2; j += 32) S32[j] = ((volatile MLM_LDS uint32_t *)SL_h)[j]; // (segments are padded to 16 bytes)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (act)
+            for (uint32_t j = (uint32_t)hl; j < (ok ? used : (uint32_t)(MLM_SEC_RANK_WORDS / 2)); j += 32) rows_h[j] = 0ull; // clean for the next cell
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return valid && !ok;
+    };
+    // one pair of cells ahead: descriptors two pairs ahead, the first four rounds of references one pair ahead — a cell is
     // otherwise a chain of four dependent memory round trips (descriptor, references, records, store)
     mlm_u32x4 rec_cur = mlm_u32x4{0u, 0u, 0u, 0u}, rec_nxt = rec_cur;
     mlm_u32x2 rf_cur = mlm_u32x2{0u, 0u}, rf_nxt = rf_cur;
     uint32_t b_cur[4] = {0, 0, 0, 0}, p_cur[4] = {0, 0, 0, 0}, s_cur[4] = {0, 0, 0, 0}, b_nxt[4] = {0, 0, 0, 0}, p_nxt[4] = {0, 0, 0, 0},
              s_nxt[4] = {0, 0, 0, 0};
-    auto load_desc = [&](unsigned int w, mlm_u32x4 &rec, mlm_u32x2 &rf) {
-        rec = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + w);
-        rf = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)w);
+    auto load_desc = [&](unsigned int pw, mlm_u32x4 &rec, mlm_u32x2 &rf) { // the half's cell of pair pw
+        const unsigned int c = 2u * pw + (unsigned int)half;
+        rec = mlm_u32x4{0u, 0u, 0u, 0u};
+        rf = mlm_u32x2{0u, 0u};
+        if (c < n_cells) {
+            rec = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + c);
+            rf = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)c);
+        }
     };
-    if (wave < n_cells) {
+    const unsigned int n_pairs = (n_cells + 1u) >> 1;
+    if (wave < n_pairs) {
         load_desc(wave, rec_cur, rf_cur);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_pair(rf_cur, (uint32_t)lane + 64u * q, b_cur[q], p_cur[q], s_cur[q]);
+        for (int q = 0; q < 4; ++q) load_pair(rf_cur, (uint32_t)hl + 32u * q, b_cur[q], p_cur[q], s_cur[q]);
     }
-    if (wave + n_waves < n_cells) load_desc(wave + n_waves, rec_nxt, rf_nxt);
-    for (unsigned int w = wave; w < n_cells; w += n_waves) {
+    if (wave + n_waves < n_pairs) load_desc(wave + n_waves, rec_nxt, rf_nxt);
+    for (unsigned int pw = wave; pw < n_pairs; pw += n_waves) {
         mlm_u32x4 rec_nn = mlm_u32x4{0u, 0u, 0u, 0u};
         mlm_u32x2 rf_nn = mlm_u32x2{0u, 0u};
-        if (w + n_waves < n_cells) {
+        if (pw + n_waves < n_pairs) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) load_pair(rf_nxt, (uint32_t)lane + 64u * q, b_nxt[q], p_nxt[q], s_nxt[q]);
+            for (int q = 0; q < 4; ++q) load_pair(rf_nxt, (uint32_t)hl + 32u * q, b_nxt[q], p_nxt[q], s_nxt[q]);
         }
-        if (w + 2 * n_waves < n_cells) load_desc(w + 2 * n_waves, rec_nn, rf_nn);
-        process(rec_cur, rf_cur, b_cur, p_cur, s_cur);
+        if (pw + 2 * n_waves < n_pairs) load_desc(pw + 2 * n_waves, rec_nn, rf_nn);
+        const bool again = process_pair(rec_cur, rf_cur, 2u * pw + (unsigned int)half < n_cells, b_cur, p_cur, s_cur);
+        const unsigned long long again_lanes = __ballot(again);
+        for (int h = 0; h < 2; ++h) // (uniform) the whole wave on a cell that did not fit half of it
+            if ((again_lanes >> (32 * h)) & 1ull) {
+                mlm_u32x4 rec_f;
+                mlm_u32x2 rf_f;
+                rec_f.x = mlm_readlane(rec_cur.x, 32 * h);
+                rec_f.y = mlm_readlane(rec_cur.y, 32 * h);
+                rec_f.z = mlm_readlane(rec_cur.z, 32 * h);
+                rec_f.w = mlm_readlane(rec_cur.w, 32 * h);
+                rf_f.x = mlm_readlane(rf_cur.x, 32 * h);
+                rf_f.y = mlm_readlane(rf_cur.y, 32 * h);
+                uint32_t b_f[4], p_f[4], s_f[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) load_pair(rf_f, (uint32_t)lane + 64u * q, b_f[q], p_f[q], s_f[q]);
+                process(rec_f, rf_f, b_f, p_f, s_f);
+            }
         rec_cur = rec_nxt;
         rf_cur = rf_nxt;
         rec_nxt = rec_nn;
