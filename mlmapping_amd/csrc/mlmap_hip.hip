@@ -108,7 +108,8 @@ struct mlm_handle {
     unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
     unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
     unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
-    unsigned int rank_grid = 256;            // blocks per frame of k_rank in a batch (config 2, r3: 80.3k frames/s, 512: 79.6k, 1024: 77.2k; MLM_RANK_GRID)
+    unsigned int rank_grid = 128;            // blocks per frame of k_rank in a batch (config 2 with two cells per wave: 87.5k frames/s, 64: 87.7k, 256: 86.4k,
+                                             // 512: 84.7k; MLM_RANK_GRID)
     // Lean frame slots (sector-path handles): the three large buffers only the cell-table Stage A uses — the block slices of
     // contribution nodes sized for its LDS overflow, the (block, cell) pairs and the node lists — exist ONCE per handle instead
     // of once per slot; a cell-table Stage A (a frame's fall-back, or a batch submitted while the sector path backs off) then
