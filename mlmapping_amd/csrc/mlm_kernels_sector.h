@@ -1896,6 +1896,9 @@ __device__ __forceinline__ void mlm_apply_record(const MlmDev &P0, const mlm_u32
 // (redone on the cell-table path by the host), it does not fit the emulated hit container without a rehash (the host computes
 // exact keys: MLM_FRAME_EXACT_KEYS), or k_tile could not create its blocks (the host grows the pool).  g->fail_frame tells the
 // host which (sticky: batches behind it do nothing).  f_begin: first frame of the slot range to apply (replays).
+#ifndef MLM_APPLY_U
+#define MLM_APPLY_U 2 // records of a thread loaded together (4: 170 VGPRs and 1 % fewer frames/s in the pipeline — the kernel is hidden behind Stage A, its footprint is not)
+#endif
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot_base,
                                                            int n_frames, int f_begin, int z_span) {
     __builtin_amdgcn_s_setprio(3); // the serial chain of the pipeline: its few waves issue ahead of Stage A's
@@ -2031,7 +2034,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
         // a thread's records in chunks of four: the records of a chunk are loaded together (the first two came with the
         // previous frame), then the voxels that are not in LDS yet are fetched together, then the chunk is applied — the
         // round trips of a chunk overlap instead of following each other
-        constexpr int U = 4;
+        constexpr int U = MLM_APPLY_U;
         for (uint32_t i0 = threadIdx.x, chunk = 0; i0 < count; i0 += blockDim.x * U, ++chunk) {
             mlm_u32x4 r0[U], r1[U];
 #pragma unroll
