@@ -430,6 +430,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     __shared__ uint32_t s_w[4 * (NT / 64)];
     __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter, s_tab_full;
+    __shared__ uint32_t s_ref_ov[8], s_ref_ov_n; // table entries whose reference count wrapped
     for (uint32_t e = threadIdx.x; e < TAB; e += NT) {
         s_tab[e].key = MLM_NIL;
         s_tab[e].tmin = MLM_EMPTY_T;
@@ -448,6 +449,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
         s_nouter = 0;
         s_tab_full = 0;
+        s_ref_ov_n = 0;
     }
     __syncthreads();
     // Which world voxel a cell of this column falls into (get_global_idx / get_subbox_id of its centre moved by T_wa,
@@ -650,7 +652,13 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         // contributions, and in the upper 12 bits (mod 4096) the sum of their strengths (mlm_sec_needs_order)
                         const uint32_t strength = s_strength[mlm_contribution_index(P, rho_t, sub)];
                         atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
-                        if ((atomicAdd(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) + n_rows > (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) s_fail = 1; // (more than 2 047 references of one cell: the frame takes the cell-table path)
+                        if ((atomicAdd(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) + n_rows > (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) {
+                            // more than 2 047 references: the count has wrapped.  That happens to cells a few decimetres in front of
+                            // the sensor (thousands of pixels), which have one kind or saturate and need no references at all: the entry
+                            // is remembered and the frame only gives up if such a cell does need its order (checked below)
+                            const uint32_t k = atomicAdd(&s_ref_ov_n, 1u);
+                            if (k < 8u) s_ref_ov[k] = (uint32_t)e;
+                        }
                         if (EX && sub == 0) atomicMin(&s_tab[e].gpos, i_first);
                     });
                 }
@@ -674,6 +682,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             }
         }
         return;
+    }
+    if (threadIdx.x == 0 && s_ref_ov_n) { // (see the booking pass: a wrapped reference count only matters for a cell that needs its order)
+        if (s_ref_ov_n > 8u) s_fail = 1;
+        for (uint32_t k = 0; k < min(s_ref_ov_n, 8u); ++k)
+            if (mlm_sec_needs_order(s_tab[s_ref_ov[k]])) s_fail = 1;
     }
     MLM_PHASE(1);
     // ---- lists of the occupied entries (= the column's unique hits), of those with several kinds, of the ray starts;

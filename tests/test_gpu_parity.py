@@ -211,6 +211,26 @@ def test_config3_stream_random_poses(mods):
     print("cfg3 stream", d, st["block_capacity"])
 
 
+def test_near_wall_thousands_of_pixels_per_cell(mods):
+    """A surface a quarter of a metre in front of the sensor: single cells collect tens of thousands of pixels, and the column
+    kernel's 11-bit count of a cell's references wraps.  Such cells have one kind of contribution or saturate — they need no
+    references — so the frame must stay on the sector path (no fall-back) and match the oracle; the right half of the image
+    is an ordinary room."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    img = syn.room_depth(cfg).copy()
+    img[:, : cfg.width // 2] = 250
+    rng = np.random.default_rng(5)
+    img[:, : cfg.width // 2] += rng.integers(0, 30, size=(cfg.height, cfg.width // 2)).astype(np.uint16)
+    gpu, cpu = MLMap(cfg, max_blocks=4096, record_awareness=True), OracleMap(cfg)
+    for k, (q, t) in enumerate(syn.random_poses(3, seed=11)):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"near wall frame {k}")
+    assert gpu.frame_stats()["n_sector_fallbacks"] == 0, gpu.frame_stats()
+
+
 def test_single_frames_go_through_the_graph(mods, monkeypatch):
     """Synchronous single-frame calls (the reference's call pattern: one frame per depth callback, mlmap.cpp:463-507) are
     submitted as one HIP-graph replay; the result is the general submission's (MLM_GRAPH=0) bit for bit — dense frames from a
