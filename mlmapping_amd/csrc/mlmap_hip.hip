@@ -520,9 +520,6 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         else if (P.explore)
             tlaunch(h, "k_sector", k_sector<true, 512>, dim3((unsigned int)P.nPhi, 1, n), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
-        else if (nt == 128)
-            tlaunch(h, "k_sector", k_sector<false, 128>, dim3((unsigned int)P.nPhi, 1, n), dim3(128), P.sec_lds_bytes, st, h->d_slot_tab,
-                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
         else if (nt == 256)
             tlaunch(h, "k_sector", k_sector<false, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
                     h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
@@ -1973,10 +1970,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // smaller workgroup and table leave wave slots and LDS of a CU to the other streams' kernels, which is worth more in the
         // pipeline (+5 % frames/s on config 2) than the 10 % the kernel loses alone
         h->sec_threads = (tab <= 1024u && P.nRho <= 256) ? 256 : 512;
-        if (const char *e = getenv("MLM_SEC_THREADS")) {
-            const int t = atoi(e);
-            h->sec_threads = (t == 128 && !P.explore && tab <= 512u && P.nRho <= 128) ? 128 : (t <= 256 && tab <= 1024u && P.nRho <= 256) ? 256 : 512;
-        }
+        if (const char *e = getenv("MLM_SEC_THREADS")) h->sec_threads = (atoi(e) <= 256 && tab <= 1024u && P.nRho <= 256) ? 256 : 512;
         if (P.sec_tab < (unsigned int)h->sec_threads) P.sec_tab = (unsigned int)h->sec_threads;
         if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
         if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
@@ -2043,7 +2037,6 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
             } else { // (both: single frames take the 512-thread instantiation where the table allows)
-                HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.sec_lds_bytes));
             }
