@@ -165,6 +165,8 @@ struct mlm_handle {
     bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
     size_t frame_block_bound = 0; // most blocks one frame can create
     unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
+    int ov_heavy = 0;                // confirmed batches in a row whose last frame had many overflowed columns
+    bool want_widen = false;         // ... the cell table is doubled before the next submission (widen_sec_tab)
     int sec_threads = 512;           // threads of a column's workgroup (k_sector<.., 256 | 512>; MLM_SEC_THREADS)
     unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
     unsigned int single_apply_grid = 256; // workgroups of k_apply_single: a VGA frame's ~33 k voxel records, one per thread (more: in turns)
@@ -301,6 +303,7 @@ inline bool share_ct(const mlm_handle *h) { return h->lean && !h->P.explore; }
 int drain(mlm_handle *h, bool g_copied = false);
 int grow_pool(mlm_handle *h, size_t want);
 int ensure_free_blocks(mlm_handle *h, size_t need);
+int widen_sec_tab(mlm_handle *h);
 int ensure_free_blocks_idle(mlm_handle *h, size_t need);
 
 // T_ls and t_wa of one frame (map_awareness.cpp:184-186)
@@ -594,6 +597,9 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.n_spec_replays = h->n_spec_miss;
     h->stats.n_sector_fallbacks = h->n_sector_fallbacks;
     if (c.n_ov > 0) h->big_armed = h->big_arm_len; // the scene still overflows the small cell table: keep the second pass scheduled
+    // (eight or more overflowed columns in the last frame of two confirmed batches in a row: the table is too small for the scene)
+    h->ov_heavy = c.n_ov >= 8u ? h->ov_heavy + 1 : 0;
+    if (h->ov_heavy >= 2) h->want_widen = true;
     h->stats.logit_bit_exact = h->P.logit_exact;
     h->stats.n_pool_grows = h->n_pool_grows;
     h->stats.n_graph_launches = h->n_graph_launches;
@@ -1287,6 +1293,12 @@ int submit_single_graph(mlm_handle *h, int base) {
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
 int run_slots(mlm_handle *h, int n) {
     (void)hipGetLastError(); // a stale error of unrelated HIP calls in this thread is not ours
+    if (h->want_widen) {
+        h->want_widen = false;
+        h->ov_heavy = 0;
+        const int rc = widen_sec_tab(h);
+        if (rc) return rc;
+    }
     if (h->timing == 1) { // per-call mode: the list describes the last call only
         h->ktimes.clear();
         h->kpool_used = 0;
@@ -1549,6 +1561,57 @@ void free_pool(mlm_handle *h, const MlmDev &P) {
 // The reference's observed_group_map grows without bound (allocate_ram, map_local.h:215-231).  Here: a new table + pool of at
 // least `want` blocks, the blocks copied over, the table rebuilt on the device, every parameter block re-pointed.  Nothing
 // may be in flight (callers drain first).  MLM_ERR_CAPACITY only if the device cannot hold the larger pool.
+// the slots' parameter blocks as the kernels see them (device-resident tables), after the host copies changed
+int upload_slot_tab(mlm_handle *h) {
+    std::vector<MlmDev> tab(h->slots.size());
+    for (size_t i = 0; i < h->slots.size(); ++i) tab[i] = h->slots[i].P;
+    HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
+    if (h->lean && h->d_slot_tab_fb) {
+        for (size_t i = 0; i < tab.size(); ++i) {
+            tab[i].bnodes = h->fb_bnodes;
+            tab[i].pairs = h->fb_pairs;
+            tab[i].nodes = h->fb_nodes;
+        }
+        HIPCHK(h, hipMemcpy(h->d_slot_tab_fb, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
+    }
+    return MLM_OK;
+}
+
+// The scene keeps overflowing the columns' cell table (fill_stats counts the overflowed columns of each batch's last frame; every
+// one of them is redone by the pass that has a CU to itself): double the table.  The table only exists in LDS, so this is a
+// change of parameters — at a point where nothing is in flight.  The smaller table is the default because its footprint is
+// worth 5 % of throughput on scenes that fit it.
+int widen_sec_tab(mlm_handle *h) {
+    MlmDev &P = h->P;
+    const unsigned int tab = P.sec_tab * 2u, n_miss = (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW));
+    const unsigned int lds = mlm_sec_lds(tab, n_miss, (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
+    const int nt = h->sec_threads == 256 && tab <= 1024u ? 256 : 512;
+    if (!h->use_sectors || tab > 2048u || tab > 4u * (unsigned int)nt || lds > 159u * 1024u || (P.sec_tab_big && tab >= P.sec_tab_big)) return MLM_OK;
+    {
+        const int rc = drain(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipDeviceSynchronize());
+    P.sec_tab = tab;
+    P.sec_lds_bytes = lds;
+    h->sec_threads = nt;
+    for (auto &S : h->slots) {
+        S.P.sec_tab = tab;
+        S.P.sec_lds_bytes = lds;
+    }
+    if (P.explore) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_sector<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    for (auto &g : h->graphs) hipGraphExecDestroy(g.exec); // (the single-frame graphs hold the old launch geometry)
+    h->graphs.clear();
+    if (getenv("MLM_DEBUG_CREATE")) fprintf(stderr, "[sector] cell table widened to %u entries (%u bytes of LDS per column, %d threads)\n", tab, lds, nt);
+    return upload_slot_tab(h);
+}
+
 int grow_pool(mlm_handle *h, size_t want) {
     MlmGlobal g{};
     HIPCHK(h, hipMemcpy(&g, h->P.g, sizeof(g), hipMemcpyDeviceToHost));
@@ -1594,19 +1657,10 @@ int grow_pool(mlm_handle *h, size_t want) {
     copy_pool_fields(h->P, N);
     *h->h_g = g;
     for (int k = 0; k < MLM_SETS; ++k) *h->h_gb[k] = g;
-    std::vector<MlmDev> tab(h->slots.size());
-    for (size_t i = 0; i < h->slots.size(); ++i) {
-        copy_pool_fields(h->slots[i].P, N);
-        tab[i] = h->slots[i].P;
-    }
-    HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
-    if (h->lean && h->d_slot_tab_fb) {
-        for (size_t i = 0; i < tab.size(); ++i) {
-            tab[i].bnodes = h->fb_bnodes;
-            tab[i].pairs = h->fb_pairs;
-            tab[i].nodes = h->fb_nodes;
-        }
-        HIPCHK(h, hipMemcpy(h->d_slot_tab_fb, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
+    for (size_t i = 0; i < h->slots.size(); ++i) copy_pool_fields(h->slots[i].P, N);
+    {
+        const int rc = upload_slot_tab(h);
+        if (rc) return rc;
     }
     h->n_pool_grows++;
     if (getenv("MLM_DEBUG_CREATE")) fprintf(stderr, "[pool] grown to %d blocks (%u in use)\n", h->P.max_blocks, nb);

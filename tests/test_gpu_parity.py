@@ -231,6 +231,35 @@ def test_near_wall_thousands_of_pixels_per_cell(mods):
     assert gpu.frame_stats()["n_sector_fallbacks"] == 0, gpu.frame_stats()
 
 
+def test_column_table_widens_with_the_scene(mods, monkeypatch, capfd):
+    """Depth noise of metres spreads a column's hits over several hundred cells: they overflow the 512-entry LDS table the handle
+    starts with on this map.  The first such frame falls back once, the overflowed columns of the next frames are redone by the
+    large-table pass, and after two batches like that the handle doubles the table (widen_sec_tab) — the map equals the oracle's
+    throughout, in single frames and in batches."""
+    MLMap, OracleMap = mods
+    monkeypatch.setenv("MLM_DEBUG_CREATE", "1")
+    cfg = S1
+    base = syn.room_depth(cfg)
+    frames = np.stack([syn.jitter_depth(base, k, amp_mm=3000, seed=3) for k in range(4)])
+    poses = syn.random_poses(12, seed=3)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=4096, max_batch=4), OracleMap(cfg)
+    for k in range(4):  # single frames
+        gpu.update_map(frames[k], q[k], t[k])
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "noisy scene, single frames")
+    for k0 in (4, 8):  # batches
+        gpu.update_map_batch(frames, q[k0:k0 + 4], t[k0:k0 + 4])
+        for j in range(4):
+            cpu.update_depth(frames[j], q[k0 + j], t[k0 + j])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "noisy scene, batches")
+    st = gpu.frame_stats()
+    err = capfd.readouterr().err
+    assert "cell table widened" in err, err[-2000:]
+    assert st["n_sector_fallbacks"] <= 2, st
+
+
 def test_single_frames_go_through_the_graph(mods, monkeypatch):
     """Synchronous single-frame calls (the reference's call pattern: one frame per depth callback, mlmap.cpp:463-507) are
     submitted as one HIP-graph replay; the result is the general submission's (MLM_GRAPH=0) bit for bit — dense frames from a
