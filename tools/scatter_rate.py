@@ -1,22 +1,31 @@
-"""Worst-case scene (every pixel its own cell: the sector tables overflow, the handle backs off to the cell-table path):
-throughput of asynchronous 32-frame batches of HBM-resident frames."""
-import gc, os, sys, time
+"""Frames/s on the worst-case "scatter" scene (every pixel in a cell of its own): asynchronous 32-frame batches from HBM."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from mlmapping_amd import synthetic as syn
-from mlmapping_amd.config import S1
-from mlmapping_amd.mlmap import MLMap
-gc.disable()
-cfg = S1
-frames = list(syn.stream(cfg, "scatter", "smooth", 32))
-gpu = MLMap(cfg, max_blocks=65536, max_batch=32)
-f32 = np.stack([f[0] for f in frames]); q32 = np.stack([f[1][0] for f in frames]); t32 = np.stack([f[1][1] for f in frames])
-d = torch.from_numpy(f32.view(np.int16)).cuda(); torch.cuda.synchronize()
-gpu.set_async(True)
-for _ in range(4): gpu.update_map_batch_dev(d.data_ptr(), 32, cfg.width, cfg.height, q32, t32)
-gpu.sync()
-t0 = time.perf_counter()
-for _ in range(10): gpu.update_map_batch_dev(d.data_ptr(), 32, cfg.width, cfg.height, q32, t32)
-gpu.sync()
-st = gpu.frame_stats()
-print("scatter scene, async batch 32:", round(10 * 32 / (time.perf_counter() - t0)), "frames/s; fall-backs", st["n_sector_fallbacks"], "hit cells", st["n_hit_cells"])
+from mlmapping_amd import synthetic as syn  # noqa: E402
+from mlmapping_amd.config import S1  # noqa: E402
+from mlmapping_amd.mlmap import MLMap  # noqa: E402
+
+cfg, B = S1, 32
+frames = np.stack([f for f, _ in syn.stream(cfg, "scatter", "smooth", B)])
+poses = [p for _, p in syn.stream(cfg, "scatter", "smooth", B)]
+q = np.stack([p[0] for p in poses])
+t = np.stack([p[1] for p in poses])
+d = torch.from_numpy(frames.view(np.int16)).cuda()
+torch.cuda.synchronize()
+m = MLMap(cfg, max_blocks=32768, max_points=cfg.width * cfg.height, max_batch=B)
+m.set_async(True)
+for _ in range(6):
+    m.update_map_batch_dev(d.data_ptr(), B, cfg.width, cfg.height, q, t)
+m.sync()
+for rep in range(3):
+    t0 = time.perf_counter()
+    for _ in range(12):
+        m.update_map_batch_dev(d.data_ptr(), B, cfg.width, cfg.height, q, t)
+    m.sync()
+    print(f"scatter scene: {12 * B / (time.perf_counter() - t0):.0f} frames/s", {k: m.frame_stats()[k] for k in ("n_hit_cells", "n_sector_fallbacks")})
