@@ -260,6 +260,31 @@ def test_column_table_widens_with_the_scene(mods, monkeypatch, capfd):
     assert st["n_sector_fallbacks"] <= 2, st
 
 
+@pytest.mark.parametrize("threads,tab", [("256", "512"), ("256", "1024"), ("512", "512"), ("512", "2048")])
+def test_column_kernel_instantiations(mods, monkeypatch, threads, tab):
+    """The column kernel exists with 256- and 512-thread workgroups and takes tables of 512 to 2 048 entries (1 to 4 entries per
+    thread); the handle picks one pair per map.  Every pair must give the oracle's map — batches (where the choice applies) and
+    single frames (which always take the 512-thread instantiation) alike."""
+    MLMap, OracleMap = mods
+    monkeypatch.setenv("MLM_SEC_THREADS", threads)
+    monkeypatch.setenv("MLM_SEC_TAB", tab)
+    cfg = S1
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", 4)])
+    poses = syn.random_poses(10, seed=21)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=4096, max_batch=4), OracleMap(cfg)
+    for k0 in (0, 4):
+        gpu.update_map_batch(frames, q[k0:k0 + 4], t[k0:k0 + 4])
+        for j in range(4):
+            cpu.update_depth(frames[j], q[k0 + j], t[k0 + j])
+    for k in (8, 9):
+        gpu.update_map(frames[k - 8], q[k], t[k])
+        cpu.update_depth(frames[k - 8], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"column kernel {threads} threads, table {tab}")
+    assert gpu.frame_stats()["n_sector_fallbacks"] == 0
+
+
 def test_single_frames_go_through_the_graph(mods, monkeypatch):
     """Synchronous single-frame calls (the reference's call pattern: one frame per depth callback, mlmap.cpp:463-507) are
     submitted as one HIP-graph replay; the result is the general submission's (MLM_GRAPH=0) bit for bit — dense frames from a
