@@ -1578,7 +1578,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     mlm_u32x4 dd_first = mlm_u32x4{0u, 0u, 0u, 0u};
     if (threadIdx.x < min((unsigned int)MLM_TILE_DESC, P.tile_desc_cap)) dd_first = descs[threadIdx.x];
     const unsigned int nd_all = mlm_gp(P.tile_cnt)[tile];
-    if (nd_all == 0) return; // (cannot happen: the tile is on the frame's list)
+    if (nd_all == 0) return; // (a tile without descriptors: only when every tile has a workgroup)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t edge = 1u << P.tile_sh, NV = edge * edge * (uint32_t)P.lv_nz;
     const MlmTileLds L = mlm_tile_lds(NV, (uint32_t)P.lv_nz, P.tile_combos);
@@ -1815,6 +1815,10 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
 // on finding its tile empty
 __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
+    if (gridDim.x >= (unsigned int)P.n_tiles) { // a frame on its own is launched with a workgroup per tile: one dependent trip to memory
+        if (blockIdx.x < (unsigned int)P.n_tiles) mlm_tile_one(P, F, blockIdx.x); // (the list) less; empty tiles' workgroups cost a lone frame nothing
+        return;
+    }
     // (the first list entry is requested together with the list's length; a stale entry is not used)
     const unsigned int tile_first = blockIdx.x < (unsigned int)P.n_tiles ? mlm_gp(P.tile_list)[blockIdx.x] : 0u;
     const unsigned int n_touched = min(mlm_gp(P.ctr)->mvox_cnt[2][0], (unsigned int)P.n_tiles);
