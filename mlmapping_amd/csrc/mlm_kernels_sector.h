@@ -1665,12 +1665,24 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
             }
             __syncthreads();
             if (what == 0)
-                for (uint32_t j = threadIdx.x; j < t4[0]; j += MLM_TILE_THREADS) { // miss cells
-                    uint32_t d, o;
-                    locate(s_dm, n_staged, j, d, o);
-                    const uint32_t v = mlm_gp(P.mc_list)[s_desc[d].x + o];
-                    if (v < NV) atomicAdd(&s_cnt[v], 1u);
-                    else s_fail = 1;
+                for (uint32_t j0 = threadIdx.x; j0 < t4[0]; j0 += 4u * MLM_TILE_THREADS) { // miss cells, four of a thread's loads in flight
+                    uint32_t vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t j = j0 + (uint32_t)u * MLM_TILE_THREADS;
+                        vv[u] = MLM_NIL;
+                        if (j < t4[0]) {
+                            uint32_t d, o;
+                            locate(s_dm, n_staged, j, d, o);
+                            vv[u] = mlm_gp(P.mc_list)[s_desc[d].x + o]; // (16-bit entries: never MLM_NIL)
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (vv[u] == MLM_NIL) continue;
+                        if (vv[u] < NV) atomicAdd(&s_cnt[vv[u]], 1u);
+                        else s_fail = 1;
+                    }
                 }
             // hits.  The first two of a thread (of the first staged pass: practically every tile) are kept in registers with their
             // increment and key — nothing of that depends on the map or on the counts — so the placing pass reads no memory
