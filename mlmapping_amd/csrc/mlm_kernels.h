@@ -238,6 +238,28 @@ __device__ unsigned long long g_mlm_phase[MLM_PHASE_BLOCKS * 16]; // per block: 
 #define MLM_PHASE_BEGIN
 #define MLM_PHASE_END
 #endif
+// ... and of k_tile (tools/tile_phase.py), in an array of its own, accumulated over the launches
+#ifdef MLM_PHASE_PROF
+__device__ unsigned long long g_mlm_tphase[4096 * 8];
+#define MLM_TPHASE(n)                                                                                                  \
+    do {                                                                                                               \
+        const long long now_ = clock64();                                                                              \
+        if (threadIdx.x == 0) s_tphase[n] += (unsigned long long)(now_ - tph_t_);                                      \
+        tph_t_ = now_;                                                                                                 \
+    } while (0)
+#define MLM_TPHASE_BEGIN                                                                                               \
+    __shared__ unsigned long long s_tphase[8];                                                                         \
+    if (threadIdx.x < 8) s_tphase[threadIdx.x] = 0;                                                                    \
+    __syncthreads();                                                                                                   \
+    long long tph_t_ = clock64();
+#define MLM_TPHASE_END                                                                                                 \
+    if (threadIdx.x == 0)                                                                                              \
+        for (int i_ = 0; i_ < 8; ++i_) g_mlm_tphase[(tile & 4095u) * 8 + i_] += s_tphase[i_];
+#else
+#define MLM_TPHASE(n)
+#define MLM_TPHASE_BEGIN
+#define MLM_TPHASE_END
+#endif
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_bin_points(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP

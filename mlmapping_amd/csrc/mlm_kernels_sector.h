@@ -1579,6 +1579,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     if (threadIdx.x < min((unsigned int)MLM_TILE_DESC, P.tile_desc_cap)) dd_first = descs[threadIdx.x];
     const unsigned int nd_all = mlm_gp(P.tile_cnt)[tile];
     if (nd_all == 0) return; // (a tile without descriptors: only when every tile has a workgroup)
+    MLM_TPHASE_BEGIN
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t edge = 1u << P.tile_sh, NV = edge * edge * (uint32_t)P.lv_nz;
     const MlmTileLds L = mlm_tile_lds(NV, (uint32_t)P.lv_nz, P.tile_combos);
@@ -1591,6 +1592,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     __shared__ uint32_t s_w[4 * MLM_SEC_WAVES];
     __shared__ uint32_t s_base[4];
     __shared__ unsigned int s_fail, s_dead;
+    __shared__ uint32_t s_xytab[16]; // per x (first `edge` entries) and per y: block index relative to the tile's first | cell coordinate << 16
     if (threadIdx.x == 0) {
         s_dead = mlm_gp(P.ctr)->sector_overflow; // set by Stage A: the frame is redone on the cell-table path — only clean up
         s_fail = nd_all > P.tile_desc_cap ? 1u : 0u;
@@ -1613,7 +1615,13 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
         const int Z = Z0 + z, gz = mlm_floor_div(Z, P.n);
         s_ztab[z] = (uint32_t)(gz - gz0) | ((uint32_t)(Z - gz * P.n) << 16);
     }
+    if (threadIdx.x < 2u * edge) { // the same per x and per y of the tile: the loops over the voxels below divide nothing
+        const bool is_y = threadIdx.x >= edge;
+        const int C = (is_y ? Y0 : X0) + (int)(threadIdx.x & (edge - 1u)), g = mlm_floor_div(C, P.n);
+        s_xytab[threadIdx.x] = (uint32_t)(g - (is_y ? gy0 : gx0)) | ((uint32_t)(C - g * P.n) << 16);
+    }
     __syncthreads();
+    MLM_TPHASE(0); // parameters, tile_cnt / first descriptors, LDS clear
     if (threadIdx.x == 0) mlm_gp(P.tile_cnt)[tile] = 0u; // consumed: clean for the slot's next frame (every thread has read it)
     if (s_dead) return;
     // the pool slots of the tile's blocks (in flight while the cells are counted; a tile overlaps a few dozen blocks)
@@ -1735,13 +1743,14 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
         }
     };
     for_cells(0);
+    MLM_TPHASE(1); // counting pass (descriptor scan, miss cells, hits)
     if (probe && (int)threadIdx.x < n_combo) s_slot[threadIdx.x] = slot0;
     __syncthreads();
+    MLM_TPHASE(2); // block lookups arrive
     const uint32_t per = (NV + MLM_TILE_THREADS - 1) / MLM_TILE_THREADS, v_lo = min(NV, threadIdx.x * per), v_hi = min(NV, v_lo + per);
     const uint32_t lvz = (uint32_t)P.lv_nz;
     auto combo_of = [&](uint32_t vxy, uint32_t zz) { // index of the block of tile voxel (vxy, zz) among the blocks the tile overlaps
-        const int X = X0 + (int)(vxy & (edge - 1u)), Y = Y0 + (int)(vxy >> P.tile_sh);
-        return ((int)(s_ztab[zz] & 0xFFFFu) * ngy + (mlm_floor_div(Y, P.n) - gy0)) * ngx + (mlm_floor_div(X, P.n) - gx0);
+        return ((int)(s_ztab[zz] & 0xFFFFu) * ngy + (int)(s_xytab[edge + (vxy >> P.tile_sh)] & 0xFFFFu)) * ngx + (int)(s_xytab[vxy & (edge - 1u)] & 0xFFFFu);
     };
     // ---- the blocks the frame touches in this tile exist before the frame is applied (allocate_ram, map_local.h:215-231: any
     //      hit or miss cell creates its block; creating it earlier than the reference would is invisible — it stays 0 / 'u' until
@@ -1766,6 +1775,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
             if (sl < 0) mlm_gp(P.ctr)->pool_short = 1u;
         }
     __syncthreads();
+    MLM_TPHASE(3); // touched blocks, creation of the missing ones
     // ---- compaction: a thread's voxels are contiguous; touched voxels get consecutive records, voxels with several hits
     //      consecutive room in vr_hit
     uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
@@ -1788,6 +1798,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
         if (threadIdx.x == 0) mlm_sector_fail(P, F);
         return;
     }
+    MLM_TPHASE(4); // compaction scan, reservations
     rec_base = s_base[0];
     hit_base = s_base[1];
     if (threadIdx.x == 0) // the tile's records of this frame, for the workgroup that applies the world tile (k_apply_tiles)
@@ -1800,13 +1811,11 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
             if (c) {
                 const uint32_t nh = c >> 16;
                 s_place[v] = o_rec | ((nh >= 2u ? o_hit : 0xFFFFu) << 16);
-                const int X = X0 + (int)(vxy & (edge - 1u)), Y = Y0 + (int)(vxy >> P.tile_sh);
-                const int gx = mlm_floor_div(X, P.n), gy = mlm_floor_div(Y, P.n);
-                const uint32_t zt = s_ztab[zz];
-                const int bz = (int)(zt & 0xFFFFu), cz = (int)(zt >> 16);
-                const int cid = (cz * P.n + (Y - gy * P.n)) * P.n + (X - gx * P.n);
-                const int slot = s_slot[(bz * ngy + (gy - gy0)) * ngx + (gx - gx0)];
-                const unsigned long long key = mlm_pack_key(gx, gy, gz0 + bz);
+                const uint32_t xt = s_xytab[vxy & (edge - 1u)], yt = s_xytab[edge + (vxy >> P.tile_sh)], zt = s_ztab[zz];
+                const int bx = (int)(xt & 0xFFFFu), by = (int)(yt & 0xFFFFu), bz = (int)(zt & 0xFFFFu);
+                const int cid = ((int)(zt >> 16) * P.n + (int)(yt >> 16)) * P.n + (int)(xt >> 16);
+                const int slot = s_slot[(bz * ngy + by) * ngx + bx];
+                const unsigned long long key = mlm_pack_key(gx0 + bx, gy0 + by, gz0 + bz);
                 MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + o_rec;
                 *(MLM_GLOBAL mlm_u32x4 *)rec = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)cid, (c & 0xFFFFu) | (((vxy << 10) | zz) << 16)}; // (lv_nz <= 1024, at most 64 columns per tile)
                 *(MLM_GLOBAL mlm_u32x2 *)&rec->slot = mlm_u32x2{(uint32_t)slot, nh};
@@ -1820,7 +1829,10 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
             }
         }
     }
+    MLM_TPHASE(5); // records
     for_cells(1); // (its first barrier makes the places visible)
+    MLM_TPHASE(6); // placing pass
+    MLM_TPHASE_END
 }
 // blockIdx.x walks the frame's list of touched tiles (k_sector appends a tile with its first descriptor): a frame reaches a
 // fraction of its grid's tiles, and a workgroup per tile of the grid would spend most launches — each waiting for its LDS —

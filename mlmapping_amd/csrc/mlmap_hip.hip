@@ -3007,6 +3007,16 @@ int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, 
 } // extern "C"
 
 #ifdef MLM_PHASE_PROF
+// diagnostic build only: the same for k_tile (thread 0's clock per phase, summed over tiles and launches; cleared)
+extern "C" int mlm_debug_tile_phases(unsigned long long *out8) {
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> v((size_t)4096 * 8);
+    if (hipMemcpyFromSymbol(v.data(), HIP_SYMBOL(g_mlm_tphase), v.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    for (size_t i = 0; i < v.size(); ++i) out8[i & 7] += v[i];
+    std::fill(v.begin(), v.end(), 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mlm_tphase), v.data(), v.size() * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 // diagnostic build only: sum over blocks and clear the per-phase cycle counts of k_bin_points
 extern "C" int mlm_debug_phases(unsigned long long *out16) {
     hipDeviceSynchronize();
