@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — depth frames/s integrated into the map on MI355X (BASELINE.json metric).
 
-A *step* is one batch of `--batch` synthetic depth frames of ONE stream pushed through the hot path
-(awareness raycast + log-odds block-map update) in order.  Inputs (uint16 depth frames + poses) are resident in
+A *step* is `--batches-per-step` (8) batches of `--batch` (64) synthetic depth frames of ONE stream pushed through the hot
+path (awareness raycast + log-odds block-map update) in order: 512 frames, ~5 ms — one 64-frame batch (0.7 ms) is too small
+a unit to be robust to a single hiccup of the host.  `value` = frames / total time of the K steps; `value_p50` = the same
+from the median step.  Inputs (uint16 depth frames + poses) are resident in
 HBM before the timed region starts.  Workload at N=1 = BASELINE config 2 (640x480 stream, 0.1 m local map,
 S1 parameters); `--workload cfg3` selects config 3 (1280x720, 0.05 m).  At N=1 the same run also times a short
-config-3 stream (`extra.cfg3`), the per-call latency of single frames (`extra.single_frame_us`) and compares the map of
-the first frames of the stream with the CPU oracle's (`parity_check`).
+config-3 stream (`extra.cfg3`, with its own `roofline` and one-core `cpu_baseline`), the per-call latency of single frames
+(`extra.single_frame_us`, the reference's own call pattern, with the CPU oracle's rate beside it) and compares the map of
+the first >= 128 frames of the stream — submitted exactly like the timed loop: asynchronous 64-frame device batches on a
+handle with three slot sets — with the CPU oracle's (`parity_check`).
 
 Multi-GPU = BASELINE config 4: N independent config-2 streams, pose seeds 42 + rank, one rank per GPU, no data-path
 collective (the path shards by stream: SURVEY.md §8e); the barrier and the max-over-ranks reduction of the elapsed time go
@@ -101,7 +105,7 @@ def cpu_worker(argv):
     print(n, time.perf_counter() - t0)
 
 
-def cpu_baseline(cfg, workload, frames, q, t, budget_s: float, gpu_check=None):
+def cpu_baseline(cfg, workload, frames, q, t, budget_s: float, gpu_check=None, min_frames: int = 3, per_core: bool = True):
     """The CPU oracle (a port of the reference's map_awareness + map_local path: std::unordered_map/set, one thread per
     map — the reference is single-threaded per map) timed on the same stream, bounded to ~budget_s seconds per leg:
     (i) one stream on one core — its map is then compared with the GPU path's map of the same frames (`gpu_check`);
@@ -112,12 +116,15 @@ def cpu_baseline(cfg, workload, frames, q, t, budget_s: float, gpu_check=None):
     m = OracleMap(cfg)
     t0 = time.perf_counter()
     n1 = 0
-    while n1 < q.shape[0] and (time.perf_counter() - t0 < budget_s or n1 < 3):
+    while n1 < q.shape[0] and (time.perf_counter() - t0 < budget_s or n1 < min_frames):
         m.update_depth(frames[n1 % frames.shape[0]], q[n1], t[n1])
         n1 += 1
     dt1 = time.perf_counter() - t0
     parity = gpu_check(m, n1) if gpu_check is not None else None
     m.close()
+    if not per_core:
+        return {"one_core": n1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": f"first {n1} frames of the same stream on 1 thread in {dt1:.1f} s; oracle/libmlmap_oracle.so"}, parity
     cpus = physical_core_cpus()
     t_start = time.time() + 2.0 + 0.02 * len(cpus)
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(c), workload, str(1000 + i), repr(t_start),
@@ -138,12 +145,15 @@ def cpu_baseline(cfg, workload, frames, q, t, budget_s: float, gpu_check=None):
 
 
 # ---- helpers of the GPU legs --------------------------------------------------------------------------------------
-def time_stream(m, cfg, d_frames, q, t, B, K, W, distinct, sync, collect=None, settle=0):
-    """W untimed (+ `settle` more untimed repeats of them) + K timed steps of B frames; returns seconds for the K steps."""
+def measure_stream(m, cfg, d_frames, q, t, B, BPS, K, W, distinct, barrier, kernel_timing=True, n_settle=24, n_instr=6):
+    """The measurement protocol of one stream on handle `m` (asynchronous mode): W untimed steps, a few fully instrumented
+    batches to find the kernel with the largest summed device time, `n_settle` untimed batches back in the pipelined regime,
+    then K timed steps of BPS batches of B frames between barriers (only the dominant kernel's launches are bracketed there),
+    then two synchronous batches with every launch bracketed (each kernel alone on the GPU).  Returns a dict."""
     fsz = cfg.width * cfg.height
 
-    def run_step(s, timed):
-        k0 = s * B
+    def run_batch(j):
+        k0 = j * B
         f0 = k0 % distinct
         if f0 + B <= distinct:
             m.update_map_batch_dev(d_frames.data_ptr() + f0 * fsz * 2, B, cfg.width, cfg.height, q[k0:k0 + B], t[k0:k0 + B])
@@ -151,23 +161,117 @@ def time_stream(m, cfg, d_frames, q, t, B, K, W, distinct, sync, collect=None, s
             for b in range(B):
                 k = k0 + b
                 m.update_map_dev(d_frames.data_ptr() + (k % distinct) * fsz * 2, cfg.width, cfg.height, q[k], t[k])
-        if timed and collect is not None:
-            collect(m.frame_stats())
 
-    for s in range(W):
-        run_step(s, False)
-    for s in range(settle):
-        run_step(s % max(1, W), False)
-    sync()
+    def acc_times(into):
+        for name, ms in m.kernel_times():
+            a = into.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += 1
+
+    for j in range(W * BPS):
+        run_batch(j)
+    barrier()
+    # which kernel dominates?  A few fully instrumented batches (start/stop events of every launch, on the streams the kernels
+    # run on) BEFORE the timed region.  Bracketing every kernel costs throughput (the chain is latency bound), so in the timed
+    # region only that kernel's launches are bracketed (timing mode 3), every 8th of them when it is launched per frame.
+    ktime_c, ktime, iso = {}, {}, {}
+    timed_kernel, timed_every = None, 1
+    if kernel_timing:
+        m.enable_kernel_timing(2)
+        for j in range(n_instr):
+            run_batch(j)
+        m.sync()
+        acc_times(ktime_c)
+        timed_kernel = max(ktime_c.items(), key=lambda kv: kv[1][0])[0]
+        timed_every = 8 if ktime_c[timed_kernel][1] >= n_instr * B else 1
+        m.set_timed_kernel(timed_kernel, timed_every)
+        m.enable_kernel_timing(3)
+    # settle back into the pipelined regime (their launches are bracketed as well).  Two dozen batches: the HIP runtime grows
+    # its pools of signals / kernel-argument buffers while the first few dozen asynchronous batches are in flight (several
+    # ms each time, seen at the 3rd, 5th, 9th and ~18th submission of a process)
+    for j in range(n_settle):
+        run_batch(j % max(1, W * BPS))
+    barrier()
+    stats, step_end = [], []
+    # (the interpreter's cyclic garbage collector stays out of the timed region: a generation-2 pass over the modules loaded
+    # here takes ~40 ms — more than many a timed region — at a point that depends on the allocation count)
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
     for s in range(W, W + K):
-        run_step(s, True)
-    sync()
+        for b in range(BPS):
+            run_batch(s * BPS + b)
+        stats.append(m.frame_stats())
+        step_end.append(time.perf_counter())
+    barrier()
     dt = time.perf_counter() - t0
     gc.enable()
-    return dt, run_step
+    # per-step durations: a step's submissions return once the batch three sets back is confirmed, so in steady state the host
+    # clock after a step trails the GPU by a constant two batches; the last step also takes the final drain
+    step_dt = np.diff(np.array([t0] + step_end[:-1] + [t0 + dt]))
+    if kernel_timing:
+        acc_times(ktime)
+        # the same kernels alone on the GPU: synchronous batches (a batch's Stage A is complete before its apply launch starts,
+        # nothing else is in flight), every launch bracketed
+        m.set_async(False)
+        m.enable_kernel_timing(2)
+        for j in range(2):
+            run_batch(j)
+        m.sync()
+        acc_times(iso)
+        m.enable_kernel_timing(0)
+        m.set_async(True)
+    return {"dt": dt, "step_dt": step_dt, "stats": stats, "ktime_c": ktime_c, "ktime": ktime, "iso": iso, "timed_kernel": timed_kernel,
+            "timed_every": timed_every, "n_settle": n_settle, "n_instr": n_instr, "run_batch": run_batch}
+
+
+def roofline_of(res, cfg, B, BPS, K, fps_one_gpu, pmc, pmc_file, pmc_batch, pmc_batch_file):
+    """The `roofline` object from a measure_stream result: HBM roofline of the kernel with the largest summed device time."""
+    fsz = cfg.width * cfg.height
+    stats, ktime, ktime_c, iso = res["stats"], res["ktime"], res["ktime_c"], res["iso"]
+    timed_every, n_settle, n_c = res["timed_every"], res["n_settle"], res["n_instr"]
+    mean_bytes = float(np.mean([2 * fsz + 10 * (st["n_hit_cells"] + st["n_miss_cells"]) for st in stats])) if stats else 0.0
+    mean_atomics = float(np.mean([st["n_device_atomics"] for st in stats])) if stats else 0.0
+    if not ktime:
+        return None, mean_bytes
+    dom = max(ktime.items(), key=lambda kv: kv[1][0])
+    avg_ms = dom[1][0] / dom[1][1]              # average duration of one launch of the dominant kernel
+    n_inst = (K * BPS + n_settle) * B           # frames whose launches of that kernel were candidates for bracketing
+    frames_per_launch = n_inst / (dom[1][1] * timed_every)  # Stage A kernels: one launch per batch of B frames
+    ach = mean_bytes * frames_per_launch / (avg_ms * 1e-3) / 1e9
+    a_ach = mean_atomics * fps_one_gpu          # device-scope atomics per second of one GPU's stream
+    iso_ms = iso[dom[0]][0] / iso[dom[0]][1] if dom[0] in iso else None
+    # HBM-side bytes from the PMC passes committed under profiles/ (rocprofv3 cannot be driven from inside this process;
+    # tools/prof_round.sh regenerates them): per launch of the dominant kernel and for the whole path, both from passes over
+    # the SAME 64-frame batched submissions that are timed here (pmc_traffic_batch); the older single-frame passes beside them
+    traffic, traffic_src, whole, ratio = None, None, None, None
+    if pmc_batch and dom[0] in pmc_batch.get("kernels", {}):
+        traffic = pmc_batch["kernels"][dom[0]]["total_bytes"] * frames_per_launch
+        traffic_src = pmc_batch_file
+    elif pmc and dom[0] in pmc.get("kernels", {}):
+        traffic = pmc["kernels"][dom[0]]["total_bytes"] * frames_per_launch
+        traffic_src = pmc_file
+    if pmc_batch:
+        whole = pmc_batch.get("total_bytes_per_frame")
+        ratio = whole / mean_bytes if whole and mean_bytes else None
+    roof = {"bound": "hbm", "kernel": dom[0], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "frames_per_launch": frames_per_launch, "launches_bracketed": f"1 of {timed_every}",
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_whole_path": whole, "traffic_whole_path_unit": "HBM-side bytes per frame, all kernels of the batched path (PMC)",
+            "traffic_over_algorithmic": ratio, "traffic_whole_path_source": pmc_batch_file,
+            "avg_launch_us": avg_ms * 1e3, "avg_launch_us_pipelined": avg_ms * 1e3,
+            "avg_launch_us_isolated": iso_ms * 1e3 if iso_ms else None,
+            "frac_isolated": (mean_bytes * frames_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms else None,
+            "algorithmic_bytes_per_frame": mean_bytes,
+            "atomics": {"bound": "device_atomics", "achieved": a_ach, "peak": ATOMICS_PEAK_PER_S, "unit": "atomics/s",
+                        "frac": a_ach / ATOMICS_PEAK_PER_S, "atomics_per_frame": mean_atomics,
+                        "counted_by": "the Stage A kernels themselves (chunk descriptors, list reservations, per-voxel counts)",
+                        "peak_source": "tools/probes/atomic_probe.hip, measured on MI355X"},
+            "kernels_us_per_frame": {**{k + " (timed region)": v[0] * 1e3 * timed_every / max(1, n_inst) for k, v in ktime.items()},
+                                     **{k + " (instrumented batches before the region)": v[0] * 1e3 / max(1, n_c * B)
+                                        for k, v in ktime_c.items()},
+                                     **{k + " (alone on the GPU)": v[0] * 1e3 / max(1, 2 * B) for k, v in iso.items()}}}
+    return roof, mean_bytes
 
 
 def newest_profile(pattern: str):
@@ -201,10 +305,11 @@ def launch_ranks(args) -> int:
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
-def single_frame_latency(MLMap, cfg, frames, q, t, d_frames, n_calls=120):
+def single_frame_latency(MLMap, cfg, frames, q, t, d_frames, n_calls=120, cpu=True):
     """Per-call latency of the reference's own call pattern (ONE frame per depth_odom_input_callback, mlmap.cpp:463-507) in
     synchronous mode: median microseconds of mlm_integrate_depth_u16 (host buffer), mlm_integrate_depth_u16_dev (HBM
-    resident) and mlm_integrate_callback with the default 500-pixel sampler."""
+    resident) and mlm_integrate_callback with the default 500-pixel sampler — and, beside the latter, the CPU oracle's
+    callback on one core (`cpu_baseline_sampled500`, a bounded sample of the same calls)."""
     m = MLMap(cfg, max_blocks=32768, max_points=cfg.width * cfg.height, max_batch=2)
     fsz = cfg.width * cfg.height
     out = {}
@@ -228,6 +333,23 @@ def single_frame_latency(MLMap, cfg, frames, q, t, d_frames, n_calls=120):
     out["callback_sampled500"] = med(lambda k: m.depth_odom_callback(frames[k % frames.shape[0]], 0.0, t[k], q[k], zero3, 0.0, zero3, 0.0, 0.0, sampled=True))
     gc.enable()
     m.close()
+    if cpu:
+        from oracle.binding import OracleMap
+
+        o = OracleMap(cfg)
+        for k in range(8):
+            o.depth_odom_callback(frames[k % frames.shape[0]], 0.0, t[k], q[k], zero3, 0.0, zero3, 0.0, 0.0, sampled=True)
+        ts = []
+        t_end = time.perf_counter() + 3.0
+        k = 8
+        while k < q.shape[0] and (time.perf_counter() < t_end or len(ts) < 50):
+            a = time.perf_counter()
+            o.depth_odom_callback(frames[k % frames.shape[0]], 0.0, t[k], q[k], zero3, 0.0, zero3, 0.0, 0.0, sampled=True)
+            ts.append(time.perf_counter() - a)
+            k += 1
+        o.close()
+        out["cpu_baseline_sampled500"] = {"value": float(np.median(ts) * 1e6), "unit": "us per call (median)", "cores": 1, "kind": "port",
+                                          "sample": f"{len(ts)} sampled-500 callbacks of the same stream on 1 thread; oracle/libmlmap_oracle.so"}
     return out
 
 
@@ -236,9 +358,10 @@ def main():
         return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (one batched Stage A launch sequence)")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per batched submission (one batched Stage A launch sequence)")
+    ap.add_argument("--batches-per-step", type=int, default=8, help="batched submissions per step (a step = this x --batch frames)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--distinct", type=int, default=64, help="distinct depth frames kept in HBM (cycled; rounded up to a multiple of --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -287,9 +410,9 @@ def main():
     if os.environ.get("MLM_BENCH_NO_RAYCAST"):  # diagnostic only (not the BASELINE workload): hits without rays
         import dataclasses
         cfg = dataclasses.replace(cfg, use_raycasting=False)
-    B, K, W = args.batch, args.steps, args.warmup
-    args.distinct = max(B, (args.distinct + B - 1) // B * B)  # whole batches: a step is always ONE batched submission
-    n_total = (K + W) * B
+    B, BPS, K, W = args.batch, max(1, args.batches_per_step), args.steps, args.warmup
+    args.distinct = max(B, (args.distinct + B - 1) // B * B)  # whole batches: a batch is always ONE batched submission
+    n_total = max((K + W) * BPS * B, 8 * B, 256)
     frames, q, t = make_inputs(cfg, args.distinct, n_total, seed=42 + rank)  # config 4: pose seeds 42 .. 42 + N - 1
     # inputs resident in HBM: torch owns the buffer (uint16 payload viewed as int16 storage)
     d_frames = torch.from_numpy(frames.view(np.int16)).cuda(local_rank)
@@ -304,81 +427,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warm-up (untimed), then: which kernel dominates?  A few fully instrumented batches (start/stop events of every
-    # launch, on the streams the kernels run on) BEFORE the timed region: the kernel with the largest summed device time is
-    # the one the roofline is about.  Bracketing every kernel costs throughput (the per-frame chain is latency bound), so
-    # in the timed region only that kernel's launches are bracketed (timing mode 3), every 8th of them when it is
-    # launched per frame.
-    _, run_step = time_stream(m, cfg, d_frames, q, t, B, 0, W, args.distinct, barrier)
-    ktime_c, ktime = {}, {}
-    n_c = min(K, 6)
-    n_settle = 24  # untimed batches between the instrumented ones and the timed region (see below)
-    timed_kernel, timed_every = None, 1
-    if not args.no_kernel_timing:
-        m.enable_kernel_timing(2)
-        for s in range(n_c):
-            run_step(s, False)
-        m.sync()
-        for name, ms in m.kernel_times():
-            a = ktime_c.setdefault(name, [0.0, 0])
-            a[0] += ms
-            a[1] += 1
-        timed_kernel = max(ktime_c.items(), key=lambda kv: kv[1][0])[0]
-        per_frame = ktime_c[timed_kernel][1] >= n_c * B
-        timed_every = 8 if per_frame else 1
-        m.set_timed_kernel(timed_kernel, timed_every)
-        m.enable_kernel_timing(3)
-    # settle back into the pipelined regime (their launches are bracketed as well).  Two dozen batches: the HIP runtime
-    # grows its pools of signals / kernel-argument buffers while the first few dozen asynchronous batches are in flight
-    # (several ms each time, seen at the 3rd, 5th, 9th and ~18th submission of a process)
-    for s in range(n_settle):
-        run_step(s % max(1, W), False)
-    barrier()
-    stats = []
-    step_t = []
-    # (the interpreter's cyclic garbage collector stays out of the timed region: a generation-2 pass over the modules
-    # loaded here takes ~40 ms — more than many a timed region — at a point that depends on the allocation count)
-    gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    for s in range(W, W + K):
-        run_step(s, True)
-        stats.append(m.frame_stats())
-        step_t.append(time.perf_counter())
-    barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    if os.environ.get("MLM_BENCH_STEP_TIMES"):  # diagnostic: host time of every submission call of the timed region
-        d = np.diff(np.array([t0] + step_t)) * 1e3
-        print("step ms:", [(i, round(float(x), 2)) for i, x in enumerate(d) if x > 1.5], "final barrier", round((t0 + dt - step_t[-1]) * 1e3, 2),
-              file=sys.stderr)
+    res = measure_stream(m, cfg, d_frames, q, t, B, BPS, K, W, args.distinct, barrier, kernel_timing=not args.no_kernel_timing)
+    dt, stats = res["dt"], res["stats"]
+    if os.environ.get("MLM_BENCH_STEP_TIMES"):  # diagnostic: host time of every step of the timed region
+        print("step ms:", [round(float(x) * 1e3, 2) for x in res["step_dt"]], file=sys.stderr)
     coll_dev = f"cuda:{local_rank}" if backend == "nccl" else "cpu"
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    iso = {}
-    if not args.no_kernel_timing:
-        for name, ms in m.kernel_times():
-            a = ktime.setdefault(name, [0.0, 0])
-            a[0] += ms
-            a[1] += 1
-        # the same kernels alone on the GPU: synchronous batches (a batch's Stage A is complete before its per-frame launches
-        # start, nothing else is in flight), every launch bracketed
-        m.set_async(False)
-        m.enable_kernel_timing(2)
-        for s in range(2):
-            run_step(s, False)
-        m.sync()
-        for name, ms in m.kernel_times():
-            a = iso.setdefault(name, [0.0, 0])
-            a[0] += ms
-            a[1] += 1
-        m.enable_kernel_timing(0)
-        m.set_async(True)
     fsz = cfg.width * cfg.height
-    algo_bytes = [2 * fsz + 10 * (st["n_hit_cells"] + st["n_miss_cells"]) for st in stats]
-    atomics = [st["n_device_atomics"] for st in stats]
 
     # ---- config 4's exchange step: ONE global-map merge over the communicator after the streams (no reference counterpart)
     merge = None
@@ -408,14 +466,14 @@ def main():
 
     # PCIe-inclusive rate: the same batches handed over as HOST buffers (uploads overlap with compute); reported, never
     # `value`
-    n_host = min(K, 8)
+    n_host = 16
     host_batch = np.ascontiguousarray(frames[[b % args.distinct for b in range(B)]])
     for s in range(4):  # the first host-buffer submission of every slot set allocates its image buffers
         m.update_map_batch(host_batch, q[s * B:s * B + B], t[s * B:s * B + B])
     m.sync()
     th = time.perf_counter()
     for s in range(n_host):
-        k0 = s * B
+        k0 = (s * B) % (n_total - B + 1)
         m.update_map_batch(host_batch, q[k0:k0 + B], t[k0:k0 + B])
     m.sync()
     pcie_fps = n_host * B / (time.perf_counter() - th)
@@ -423,46 +481,20 @@ def main():
     m.close()
 
     if rank == 0:
-        fps = world * K * B / dt
-        mean_bytes = float(np.mean(algo_bytes)) if algo_bytes else 0.0
-        mean_atomics = float(np.mean(atomics)) if atomics else 0.0
-        roof = None
-        # HBM-side bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3
-        # cannot be driven from inside this process; tools/pmc_workload.py + tools/pmc_traffic_json.py regenerate it)
-        pmc, pmc_file = None, None
+        F_STEP = B * BPS
+        fps = world * K * F_STEP / dt
+        step_p50 = float(np.median(res["step_dt"]))
+        pmc, pmc_file, pmc_b, pmc_b_file = None, None, None, None
         try:
             f = newest_profile("pmc_traffic.json")
             if f and args.workload == "cfg2":
-                pmc_file = os.path.basename(f)
-                pmc = json.load(open(f))
+                pmc_file, pmc = os.path.basename(f), json.load(open(f))
+            f = newest_profile("pmc_traffic_batch.json" if args.workload == "cfg2" else "pmc_traffic_batch_cfg3.json")
+            if f:
+                pmc_b_file, pmc_b = os.path.basename(f), json.load(open(f))
         except Exception:
-            pmc = None
-        if ktime:
-            dom = max(ktime.items(), key=lambda kv: kv[1][0])
-            avg_ms = dom[1][0] / dom[1][1]          # average duration of one launch of the dominant kernel
-            n_inst = (K + n_settle) * B             # frames whose launches of that kernel were candidates for bracketing
-            frames_per_launch = n_inst / (dom[1][1] * timed_every)  # Stage A kernels: one launch per batch of B frames
-            ach = mean_bytes * frames_per_launch / (avg_ms * 1e-3) / 1e9
-            a_ach = mean_atomics * fps / world      # device-scope atomics per second of one GPU's stream
-            iso_ms = iso[dom[0]][0] / iso[dom[0]][1] if dom[0] in iso else None
-            roof = {"bound": "hbm", "kernel": dom[0], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS,
-                    "frames_per_launch": frames_per_launch, "launches_bracketed": f"1 of {timed_every}",
-                    "traffic": (pmc["kernels"][dom[0]]["total_bytes"] * frames_per_launch
-                                if pmc and dom[0] in pmc.get("kernels", {}) else None),
-                    "traffic_source": pmc_file, "avg_launch_us": avg_ms * 1e3,
-                    "avg_launch_us_pipelined": avg_ms * 1e3,
-                    "avg_launch_us_isolated": iso_ms * 1e3 if iso_ms else None,
-                    "frac_isolated": (mean_bytes * frames_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms else None,
-                    "algorithmic_bytes_per_frame": mean_bytes,
-                    "atomics": {"bound": "device_atomics", "achieved": a_ach, "peak": ATOMICS_PEAK_PER_S, "unit": "atomics/s",
-                                "frac": a_ach / ATOMICS_PEAK_PER_S, "atomics_per_frame": mean_atomics,
-                                "counted_by": "the Stage A kernels themselves (chunk descriptors, list reservations, per-voxel counts)",
-                                "peak_source": "tools/probes/atomic_probe.hip, measured on MI355X"},
-                    "kernels_us_per_frame": {**{k + " (timed region)": v[0] * 1e3 * timed_every / max(1, n_inst) for k, v in ktime.items()},
-                                             **{k + " (instrumented batches before the region)": v[0] * 1e3 / max(1, n_c * B)
-                                                for k, v in ktime_c.items()},
-                                             **{k + " (alone on the GPU)": v[0] * 1e3 / max(1, 2 * B) for k, v in iso.items()}}}
+            pass
+        roof, mean_bytes = roofline_of(res, cfg, B, BPS, K, fps / world, pmc, pmc_file, pmc_b, pmc_b_file)
         out = {
             "metric": "depth frames/s into local map", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -471,7 +503,10 @@ def main():
                                     if world == 1 else f"BASELINE cfg4: {world} independent cfg2 streams (pose seeds 42..{41 + world}), one per GPU, "
                                                        "then one RCCL global-map merge (timed separately: merge)")
                        if args.workload == "cfg2" else "BASELINE cfg3: 1280x720 room+jitter stream, S3 0.05 m map",
-                       "frames_per_step": B, "streams": world, "parallelism": f"{world} independent streams"},
+                       "frames_per_step": F_STEP, "batch": B, "batches_per_step": BPS, "streams": world,
+                       "parallelism": f"{world} independent streams"},
+            "value_p50": world * F_STEP / step_p50, "ms_per_step_p50": step_p50 * 1e3,
+            "ms_per_step_min_max": [float(res["step_dt"].min() * 1e3), float(res["step_dt"].max() * 1e3)],
             "achieved_hbm_gbs_whole_path": fps * mean_bytes / 1e9,
             "pcie_inclusive_frames_per_s": pcie_fps * world,
             "path": {"sector_fallbacks": last_stats["n_sector_fallbacks"], "spec_replays": last_stats["n_spec_replays"],
@@ -481,9 +516,10 @@ def main():
         if merge is not None:
             out["merge"] = merge
         if world == 1 and args.workload == "cfg2" and not args.no_extra:
-            # config 3 (1280x720, 0.05 m) in the same invocation: a short stream, same protocol
-            B3, K3, W3, D3 = 16, 12, 2, 16
-            f3, q3, t3 = make_inputs(S3, D3, (K3 + W3) * B3, seed=42)
+            # config 3 (1280x720, 0.05 m) in the same invocation: a short stream, same protocol (its own roofline; its CPU
+            # baseline below)
+            B3, BPS3, K3, W3, D3 = 16, 2, 6, 1, 16
+            f3, q3, t3 = make_inputs(S3, D3, (K3 + W3) * B3 * BPS3, seed=42)
             d3 = torch.from_numpy(f3.view(np.int16)).cuda(local_rank)
             m3 = MLMap(S3, device=local_rank, max_blocks=65536, max_points=S3.width * S3.height, max_batch=B3)
             m3.set_async(True)
@@ -492,36 +528,59 @@ def main():
                 m3.sync()
                 torch.cuda.synchronize()
 
-            st3 = []
-            dt3, _ = time_stream(m3, S3, d3, q3, t3, B3, K3, W3, D3, sync3, st3.append, settle=10)
-            b3 = float(np.mean([2 * S3.width * S3.height + 10 * (s["n_hit_cells"] + s["n_miss_cells"]) for s in st3]))
-            out["extra"] = {"cfg3": {"workload": "BASELINE cfg3: 1280x720 room+jitter stream, S3 0.05 m map", "value": K3 * B3 / dt3,
-                                     "unit": "frames/s", "steps": K3, "frames_per_step": B3,
-                                     "achieved_hbm_gbs_whole_path": K3 * B3 / dt3 * b3 / 1e9,
-                                     "sector_fallbacks": st3[-1]["n_sector_fallbacks"]}}
+            r3 = measure_stream(m3, S3, d3, q3, t3, B3, BPS3, K3, W3, D3, sync3, kernel_timing=not args.no_kernel_timing, n_settle=10, n_instr=2)
+            fps3 = K3 * B3 * BPS3 / r3["dt"]
+            pmc3, pmc3_file = None, None
+            try:
+                f = newest_profile("pmc_traffic_batch_cfg3.json")
+                if f:
+                    pmc3_file, pmc3 = os.path.basename(f), json.load(open(f))
+            except Exception:
+                pass
+            roof3, b3 = roofline_of(r3, S3, B3, BPS3, K3, fps3, None, None, pmc3, pmc3_file)
+            out["extra"] = {"cfg3": {"workload": "BASELINE cfg3: 1280x720 room+jitter stream, S3 0.05 m map", "value": fps3,
+                                     "unit": "frames/s", "steps": K3, "frames_per_step": B3 * BPS3, "batch": B3,
+                                     "value_p50": B3 * BPS3 / float(np.median(r3["step_dt"])),
+                                     "achieved_hbm_gbs_whole_path": fps3 * b3 / 1e9,
+                                     "sector_fallbacks": r3["stats"][-1]["n_sector_fallbacks"], "roofline": roof3}}
             m3.close()
             del d3
-            out["extra"]["single_frame_us"] = single_frame_latency(MLMap, cfg, frames, q, t, d_frames)
+            out["extra"]["single_frame_us"] = single_frame_latency(MLMap, cfg, frames, q, t, d_frames, cpu=not args.no_cpu_baseline)
+            if not args.no_cpu_baseline:
+                out["extra"]["cfg3"]["cpu_baseline"], _ = cpu_baseline(S3, "cfg3", f3, q3, t3, args.cpu_budget, None, min_frames=3, per_core=False)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             def gpu_check(oracle_map, n):
-                """A fresh GPU handle fed the frames leg (i) integrated, compared with the oracle's map (outside every timed
-                region): block keys, occupancy classes and the float bits of every voxel's log-odds."""
+                """A fresh GPU handle fed the frames leg (i) integrated — submitted EXACTLY like the timed loop: asynchronous
+                B-frame contiguous device batches (mlm_integrate_depth_batch_dev) on a handle with max_batch = B and three slot
+                sets — compared with the oracle's map (outside every timed region): block keys, occupancy classes and the
+                float bits of every voxel's log-odds."""
                 from tests.util import compare_maps
 
-                g = MLMap(cfg, device=local_rank, max_blocks=32768, max_points=cfg.width * cfg.height, max_batch=16)
+                g = MLMap(cfg, device=local_rank, max_blocks=32768, max_points=cfg.width * cfg.height, max_batch=B)
                 g.set_async(True)
-                for k in range(n):
+                nb = n // B
+                for j in range(nb):
+                    k0 = j * B
+                    f0 = k0 % args.distinct
+                    g.update_map_batch_dev(d_frames.data_ptr() + f0 * fsz * 2, B, cfg.width, cfg.height, q[k0:k0 + B], t[k0:k0 + B])
+                for k in range(nb * B, n):  # (a remainder shorter than a batch: frame by frame)
                     g.update_map_dev(d_frames.data_ptr() + (k % args.distinct) * fsz * 2, cfg.width, cfg.height, q[k], t[k])
                 gb, cb = g.export_blocks(), oracle_map.export_blocks()
+                gs = g.frame_stats()
                 g.close()
+                info = {"frames": n, "batch": B, "batches": nb, "submission": "async mlm_integrate_depth_batch_dev, max_batch = batch, 3 slot sets (as timed)",
+                        "spec_replays": gs["n_spec_replays"], "sector_fallbacks": gs["n_sector_fallbacks"], "pool_grows": gs["n_pool_grows"]}
                 try:
                     d = compare_maps(gb, cb, "bench parity check", exact=False)
-                    return {"frames": n, "blocks": d["blocks"], "voxels": d["cells"], "classes_equal": True, "max_dodd": d["max_dodd"],
+                    return {**info, "blocks": d["blocks"], "voxels": d["cells"], "classes_equal": True, "max_dodd": d["max_dodd"],
                             "bit_mismatch": d["bit_mismatch"]}
                 except AssertionError as e:
-                    return {"frames": n, "classes_equal": False, "error": str(e)[:300]}
+                    return {**info, "classes_equal": False, "error": str(e)[:300]}
 
-            out["cpu_baseline"], out["parity_check"] = cpu_baseline(cfg, args.workload, frames, q, t, args.cpu_budget, gpu_check)
+            # (leg (i) runs at least two whole batches of the stream — 128 frames, ~20 s of one core — so that the parity check
+            # covers the 64-frame k_apply_tiles chain at its real size)
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(cfg, args.workload, frames, q, t, args.cpu_budget, gpu_check,
+                                                                    min_frames=2 * B if B <= 64 else B)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

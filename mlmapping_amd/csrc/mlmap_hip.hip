@@ -181,7 +181,7 @@ struct mlm_handle {
     // read-back) instead of a dozen launches and copies spread over two streams: the call's cost is launch latency, not work.
     struct SingleGraph {
         int mode, width, height, base, big;
-        unsigned int nb;
+        unsigned int nb, sec_tab; // (sec_tab stands for the column kernel's launch geometry: threads and LDS follow from it)
         size_t n_bkt;
         hipGraphExec_t exec;
     };
@@ -194,6 +194,7 @@ struct mlm_handle {
     int32_t *h_stage = nullptr;  // pinned staging of the callback's sampled pixels (indices, then raw depths)
     size_t stage_cap = 0;
     long long n_pool_grows = 0;
+    size_t grow_failed_at = 0;   // a pool of this many blocks did not fit the device (grow_pool does not retry it)
     MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
     MlmPair *fb_pairs = nullptr;
 };
@@ -1175,18 +1176,21 @@ void wipe_frame_grids(mlm_handle *h) {
     hipStreamSynchronize(h->stream);
 }
 
-// Can the frame described in slot `base` go through the single-frame graph?  (sector path, the handle's own stream, synchronous
-// mode, no per-kernel timing, nothing in flight)
+// The handle-level half of "this call goes through the single-frame graph" (sector path, the handle's own stream, synchronous
+// mode, no per-kernel timing, nothing in flight): ONE predicate for the stream a call's inputs are uploaded on and for the
+// submission itself — the frame-level half (geometry, bucket table) is added by single_fast_ok once the frame is described.
+inline bool fast_handle_ok(const mlm_handle *h) {
+    return h->use_graph && !h->P.explore && !h->async_mode && h->own_stream && h->timing == 0 && h->use_sectors && h->sector_backoff == 0 &&
+           h->hit_n_bkt > 1 && h->pending.empty();
+}
 bool single_fast_ok(const mlm_handle *h, int n) {
-    if (n != 1 || !h->use_graph || h->P.explore || h->async_mode || !h->own_stream || h->timing != 0 || !h->pending.empty()) return false;
+    if (n != 1 || !fast_handle_ok(h)) return false;
     const MlmSlot &S = h->slots[(size_t)(h->cur_set * h->lim.max_batch)];
-    return h->use_sectors && h->sector_backoff == 0 && S.F.width <= 2040 && h->hit_n_bkt <= S.P.sbkt_cap && h->hit_n_bkt > 1 && S.F.n > 0;
+    return S.F.width <= 2040 && h->hit_n_bkt <= S.P.sbkt_cap && S.F.n > 0;
 }
-// the stream uploads of a call's inputs go to: the one its Stage A will run on
-inline hipStream_t upload_stream(const mlm_handle *h) {
-    const bool fast = h->use_graph && !h->P.explore && !h->async_mode && h->own_stream && h->timing == 0 && h->use_sectors && h->sector_backoff == 0 && h->hit_n_bkt > 1;
-    return fast ? h->stream : h->stream_as[h->cur_set];
-}
+// the stream uploads of a call's inputs go to: the one its Stage A will run on (a frame-level veto of the graph path is
+// repaired by run_slots with an event between the two streams)
+inline hipStream_t upload_stream(const mlm_handle *h) { return fast_handle_ok(h) ? h->stream : h->stream_as[h->cur_set]; }
 int submit_single_graph(mlm_handle *h, int base) {
     MlmSlot &S = h->slots[(size_t)base];
     const MlmDev &P = S.P;
@@ -1205,7 +1209,7 @@ int submit_single_graph(mlm_handle *h, int base) {
     if (h->big_armed > 0) --h->big_armed;
     mlm_handle::SingleGraph *G = nullptr;
     for (auto &g : h->graphs)
-        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
+        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.sec_tab == P.sec_tab && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
     if (!G) {
         if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
             for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
@@ -1267,7 +1271,7 @@ int submit_single_graph(mlm_handle *h, int base) {
             h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
             return MLM_ERR_HIP;
         }
-        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, h->hit_n_bkt, exec});
+        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, exec});
         G = &h->graphs.back();
     }
     h->h_frame_tab[base] = S.F;
@@ -1623,11 +1627,18 @@ int grow_pool(mlm_handle *h, size_t want) {
         h->err = "block pool cannot grow further (2^31 voxels)";
         return MLM_ERR_CAPACITY;
     }
+    if (h->grow_failed_at && target >= h->grow_failed_at) { // (the device could not hold this much before: do not allocate-and-fail every frame)
+        h->err = "device memory exhausted while growing the block pool (a pool of " + std::to_string(h->grow_failed_at) + " blocks did not fit)";
+        return MLM_ERR_CAPACITY;
+    }
     MlmDev N = h->P;
+    N.ht_keys = nullptr, N.ht_slot = nullptr, N.block_keys = nullptr, N.log_odds = nullptr, N.occ = nullptr, N.infl = nullptr, N.vox_head = nullptr,
+    N.vox_miss = nullptr, N.frnt = nullptr, N.vox_tau = nullptr, N.blk_collapsed = nullptr, N.blk_observed = nullptr;
     int rc = alloc_pool(h, N, (int)target);
     if (rc) {
         (void)hipGetLastError();
-        // (arrays allocated before the failure stay in `allocs` and are released by mlm_destroy)
+        free_pool(h, N); // (what was allocated before the failure; dev_free skips the null fields)
+        h->grow_failed_at = target;
         h->err = "device memory exhausted while growing the block pool: " + h->err;
         return MLM_ERR_CAPACITY;
     }
@@ -2489,7 +2500,6 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         const size_t want = (size_t)h->cfg.sample_cnt;
         if (h->stage_cap < 2 * want) {
             if (h->h_stage) hipHostFree(h->h_stage);
-    if (h->upload_ev) hipEventDestroy(h->upload_ev);
             h->h_stage = nullptr;
             h->stage_cap = 0;
             HIPCHK(h, hipHostMalloc((void **)&h->h_stage, 2 * want * sizeof(int32_t), hipHostMallocDefault));
@@ -2548,8 +2558,9 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
             return MLM_ERR_HIP;
         }
     } else {
-        HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
-        h->last_upload = h->stream_as[h->cur_set];
+        hipStream_t up = sampled ? h->stream_as[h->cur_set] : upload_stream(h); // (the sampled general path synchronises that stream below)
+        HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, up));
+        h->last_upload = up;
     }
     if (sampled) { // (sample count larger than half the point capacity: the general path)
         const uint16_t *img = is_f32 ? host_u16.data() : (const uint16_t *)depth;

@@ -129,16 +129,32 @@ def _baseline_ops(base: Optional[Dict[str, torch.Tensor]], union: torch.Tensor, 
     if not base or base["packed"].numel() == 0:
         return None, None
     b_lo = base["log_odds"].to(dev)
-    pos = torch.searchsorted(union, base["packed"].to(dev))
+    b_keys = base["packed"].to(dev)
+    pos = torch.searchsorted(union, b_keys)
+    # every baseline block must still be in the union (blocks never disappear): a missing key would silently shift rows
+    if bool((pos >= union.shape[0]).any()) or not bool((union[pos.clamp(max=union.shape[0] - 1)] == b_keys).all()):
+        raise RuntimeError("merge baseline holds blocks the maps no longer have: the handle's content changed outside the merge "
+                           "(recreated handle / foreign import) — drop the baseline (m._merge_base = None) on every rank")
 
+    # (increment and re-add in FP64, rounded once each: a voxel nobody touched since the baseline gets back exactly M)
     def subtract(dense: torch.Tensor) -> None:
-        dense[pos] -= b_lo
+        dense[pos] = (dense[pos].double() - b_lo.double()).float()
 
     def add_base(my_lo: torch.Tensor, first_row: int) -> None:
         sel = (pos >= first_row) & (pos < first_row + my_lo.shape[0])
-        my_lo[pos[sel] - first_row] += b_lo[sel]
+        rows = pos[sel] - first_row
+        my_lo[rows] = (my_lo[rows].double() + b_lo[sel].double()).float()
 
     return subtract, add_base
+
+
+def _baseline_tag(base: Optional[Dict[str, torch.Tensor]]) -> int:
+    """A cheap fingerprint of a baseline (0: none) that the ranks compare before they exchange increments."""
+    if not base or base["packed"].numel() == 0:
+        return 0
+    p = base["packed"]
+    bits = base["log_odds"].contiguous().view(torch.int32).sum(dtype=torch.int64)  # (integer sum: exact, order-free)
+    return int((int(p.sum().item()) ^ (int(p.numel()) << 40) ^ int(bits.item())) & 0x7FFFFFFFFFFFFFFF) or 1
 
 
 def _finish_torch(cfg: MapConfig) -> Callable[[torch.Tensor, torch.Tensor], torch.Tensor]:
@@ -212,7 +228,17 @@ def merge_device_maps(m, group=None, load_back: bool = True) -> Dict[str, torch.
     torch.cuda.synchronize()
     if n_u:
         m.merge_pack(ukeys.data_ptr(), n_u, dense.data_ptr(), seen.data_ptr())
-    subtract, add_base = _baseline_ops(getattr(m, "_merge_base", None), union, dev)
+    base = getattr(m, "_merge_base", None)
+    # every rank must merge against the SAME baseline (or none): a rank whose handle was re-imported / cleared / recreated since
+    # the last merge has dropped it (MLMap.import_blocks, setFree_map_in_bound), and M would be miscounted
+    tag = torch.tensor([_baseline_tag(base)], dtype=torch.int64, device=dev)
+    tags = torch.empty(world, dtype=torch.int64, device=dev)
+    _all_gather(tags, tag, group)
+    if not bool((tags == tags[0]).all()):
+        raise RuntimeError("merge_device_maps: the ranks hold different merge baselines (a handle changed outside the merge); "
+                           "set m._merge_base = None on every rank and merge maps that do not share a loaded-back past")
+    # (one rank: the sum of one map is the map — no increments, so that a periodic merge leaves its log-odds bits alone)
+    subtract, add_base = _baseline_ops(base if world > 1 else None, union, dev)
     if subtract is not None:
         subtract(dense)
 

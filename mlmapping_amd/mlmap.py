@@ -295,6 +295,7 @@ class MLMap:
         return out
 
     def setFree_map_in_bound(self, box_min, box_max):
+        self._merge_base = None  # (the map no longer is "merged map + own observations": see merge.merge_device_maps)
         self._chk(self._L.mlm_set_free_in_bound(self._h, _p(_f64(box_min)), _p(_f64(box_max))),
                   "mlm_set_free_in_bound")
 
@@ -360,6 +361,7 @@ class MLMap:
         else:
             keep = np.ascontiguousarray(keys, dtype=np.int32).reshape(-1, 3)
             kp, n = _p(keep), keep.shape[0]
+        self._merge_base = None  # (a foreign import invalidates the baseline of periodic merges; merge_device_maps sets its own afterwards)
         holds = [ptr(log_odds, np.float32), ptr(occ, np.uint8), ptr(infl, np.uint8), ptr(collapsed, np.uint8)]
         self._chk(self._L.mlm_import_blocks(self._h, n, kp, holds[0][0], holds[1][0], holds[2][0], holds[3][0]),
                   "mlm_import_blocks")

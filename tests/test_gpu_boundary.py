@@ -353,7 +353,7 @@ def test_bench_launcher_contract_two_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-extra"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--batches-per-step", "2", "--no-cpu-baseline", "--no-extra"]
     if torch.cuda.device_count() < 2:
         r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "one rank per GPU" in r.stderr, (r.returncode, r.stderr[-500:])
@@ -364,9 +364,9 @@ def test_bench_launcher_contract_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["streams"] == 2 and d["config"]["frames_per_step"] == 8 and "cfg4" in d["config"]["workload"]
+    assert d["config"]["streams"] == 2 and d["config"]["frames_per_step"] == 16 and d["config"]["batch"] == 8 and "cfg4" in d["config"]["workload"]
     # whole-job aggregate: frames of BOTH ranks over the slower rank's time
-    assert abs(d["value"] - 2 * 3 * 8 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 2 * 3 * 16 / (d["ms_per_step"] * 3 / 1e3)) < 1e-6 * d["value"] and d["value_p50"] > 0
     assert d["roofline"]["frac"] > 0 and d["roofline"]["atomics"]["atomics_per_frame"] > 0
     mg = d["merge"]  # the two streams have different poses: the union is larger than either map
     assert mg["merge_ms"] > 0 and mg["union_blocks"] > mg["own_blocks"] > 0 and mg["merge_bytes_per_rank"] > 0

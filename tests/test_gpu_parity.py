@@ -514,6 +514,55 @@ def test_ros_free_callback(mods):
         assert gpu.frame_stats()["n_points"] == (500 if sampled else gpu.frame_stats()["n_points"])
 
 
+def test_callback_mixed_upload_streams_on_one_handle(mods):
+    """One handle, every entry point that uploads host inputs, interleaved — dense 16UC1 callback (graph path), sampled callback
+    (pinned staging buffer allocated on first use), 32FC1 dense callback, a wide host image through mlm_integrate_depth_u16
+    with a pixel list, explicit points — then mlm_destroy.  The uploads go to the stream the call's Stage A runs on
+    (upload_stream); where a frame-level veto moves Stage A to another stream an event orders it behind the upload, and that
+    event must survive the (re)allocation of the sampler's staging buffer (round-3 advisor finding: it was destroyed there and
+    used again by the next cross-stream upload)."""
+    MLMap, OracleMap = mods
+    libc = ctypes.CDLL("libc.so.6")
+    cfg = SDEF
+    base_u16 = syn.room_depth(cfg)
+    base_f32 = base_u16.astype(np.float32) / 1000.0
+    gpu, cpu = MLMap(cfg, max_blocks=4096, record_awareness=True), OracleMap(cfg)
+    rng = np.random.default_rng(5)
+    poses = syn.smooth_trajectory(12, 3)
+    for k in range(12):
+        q, t = poses[k]
+        args = dict(t_img=1.0 + k / 30.0, odom_p=t, odom_q=q, odom_v=[0.2, 0.0, 0.0], t_odom=1.0 + k / 30.0, imu_w=[0.0, 0.0, 0.2],
+                    t_imu=1.0 + k / 30.0, latency=0.01)
+        kind = k % 6
+        libc.srand(40 + k)
+        if kind == 0:    # dense 16UC1 callback: uploads on the main stream (graph path)
+            gpu.depth_odom_callback(base_u16, sampled=False, **args)
+            libc.srand(40 + k)
+            cpu.depth_odom_callback(base_u16, sampled=False, **args)
+        elif kind == 1:  # sampled callback: allocates the pinned staging buffer on its first use
+            gpu.depth_odom_callback(base_u16, sampled=True, **args)
+            libc.srand(40 + k)
+            cpu.depth_odom_callback(base_u16, sampled=True, **args)
+        elif kind == 2:  # 32FC1 dense: converted on a side stream
+            gpu.depth_odom_callback(base_f32, sampled=False, **args)
+            libc.srand(40 + k)
+            cpu.depth_odom_callback(base_f32, sampled=False, **args)
+        elif kind == 3:  # host image + pixel list
+            pix = rng.choice(cfg.width * cfg.height, 700, replace=False).astype(np.int32)
+            gpu.update_map(base_u16, q, t, pixel_idx=pix)
+            cpu.update_depth_indexed(base_u16, pix, q, t)
+        elif kind == 4:  # explicit points
+            pts = cpu.project_dense(base_u16)[::97]
+            gpu.update_map_points(pts, q, t)
+            cpu.update_points(pts, q, t)
+        else:            # 32FC1 sampled
+            gpu.depth_odom_callback(base_f32, sampled=True, **args)
+            libc.srand(40 + k)
+            cpu.depth_odom_callback(base_f32, sampled=True, **args)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"mixed entry points, call {k} (kind {kind})")
+    gpu.close()  # mlm_destroy: every event is destroyed exactly once
+
+
 def test_gpu_against_golden_digests(mods):
     """The HIP path against the committed golden fixtures (tests/golden/oracle_digests.json): every integer/byte output
     must hash to the recorded digest (log-odds are float and compared by tolerance elsewhere)."""
@@ -671,18 +720,17 @@ def test_random_configurations(mods):
 
 
 def test_long_stream_cfg2(mods):
-    """BASELINE config 2 as the bench runs it: 300 frames of the jittered room with a random SE(3) pose per frame through
-    mlm_integrate_depth_batch_dev in asynchronous mode (two batches in flight, speculative Stage B), against the oracle
-    fed frame by frame — full map comparison every 50 frames.  (SURVEY cfg 2 asks for >= 1000 frames; 300 keeps the
-    oracle's share of the GPU box's test time under a minute — MLM_LONG_STREAM_FRAMES=1000 runs the full length, about
-    three minutes of oracle time; DESIGN.md §2 records the last such run.)"""
+    """BASELINE config 2 at the length SURVEY §8d asks for: 1000 frames of the jittered room with a random SE(3) pose per frame
+    in asynchronous mode (three slot sets in flight, speculative Stage B), against the oracle fed frame by frame — full map
+    comparison (keys, classes, log-odds bits) every 50 frames; the pool starts at 64 blocks and grows on the way.  About
+    three minutes, most of it the oracle.  (MLM_LONG_STREAM_FRAMES overrides the length.)"""
     import os
 
     import torch
 
     MLMap, OracleMap = mods
     cfg = S1
-    n, B, distinct = int(os.environ.get("MLM_LONG_STREAM_FRAMES", "300")) // 50 * 50, 25, 32
+    n, B, distinct = int(os.environ.get("MLM_LONG_STREAM_FRAMES", "1000")) // 50 * 50, 25, 32
     base = syn.room_depth(cfg)
     frames = np.stack([syn.jitter_depth(base, k, seed=42) for k in range(distinct)])
     poses = syn.random_poses(n, seed=42)
@@ -713,6 +761,41 @@ def test_long_stream_cfg2(mods):
     st = gpu.frame_stats()
     assert st["n_spec_replays"] + st["n_sector_fallbacks"] >= 1  # the emulated container did rehash on the way
     assert st["n_pool_grows"] >= 1 and st["block_capacity"] >= cpu.block_count() > 64, st
+
+
+def test_bench_batch64_parity(mods):
+    """The configuration bench.py TIMES, compared with the oracle at its real size: 192 frames of the bench stream (64 distinct
+    jittered room frames resident in HBM, random SE(3) poses) submitted as three asynchronous 64-frame contiguous
+    mlm_integrate_depth_batch_dev calls on a handle with max_batch = 64 (three slot sets: all three batches in flight), from a
+    pool of 64 blocks.  The 64-frame k_apply_tiles chain — one lane per frame bookkeeping, LDS sized by the batch's spread of
+    z origins, voxels LDS-resident across 64 frames — is what no smaller batch exercises; the update is order dependent
+    (map_local.cpp:147-207), so any slip in the frame order inside a batch shows up in the log-odds bits."""
+    import torch
+
+    from bench import make_inputs
+
+    MLMap, OracleMap = mods
+    cfg, B, nb = S1, 64, 3
+    frames, q, t = make_inputs(cfg, B, B * nb, seed=42)
+    d_frames = torch.from_numpy(frames.view(np.int16)).cuda()
+    torch.cuda.synchronize()
+    gpu, cpu = MLMap(cfg, max_blocks=64, max_points=cfg.width * cfg.height, max_batch=B), OracleMap(cfg)
+    gpu.set_async(True)
+    for j in range(nb):
+        gpu.update_map_batch_dev(d_frames.data_ptr(), B, cfg.width, cfg.height, q[j * B:(j + 1) * B], t[j * B:(j + 1) * B])
+    for k in range(B * nb):
+        cpu.update_depth(frames[k % B], q[k], t[k])
+    d = compare_maps(gpu.export_blocks(), cpu.export_blocks(), "bench configuration: 3 x 64-frame async batches")
+    st = gpu.frame_stats()
+    print("batch64 parity", d, {k: st[k] for k in ("n_spec_replays", "n_sector_fallbacks", "n_pool_grows", "block_capacity")})
+    assert d["bit_mismatch"] == 0 and st["n_pool_grows"] >= 1
+    # the batches after the container has settled run speculatively (no host round trip inside a batch): one more batch on
+    # the grown map, still bit-equal
+    gpu.update_map_batch_dev(d_frames.data_ptr(), B, cfg.width, cfg.height, q[:B], t[:B])
+    for k in range(B):
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "bench configuration: fourth batch")
+    gpu.close()
 
 
 def test_corridor_substitute(mods):

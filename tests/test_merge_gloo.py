@@ -117,3 +117,68 @@ def test_merge_two_ranks(tmp_path):
     m30 = np.load(tmp_path / "merged3_0.npz")
     assert np.array_equal(m30["keys"], m20["keys"]) and np.array_equal(m30["occ"], m20["occ"])
     assert np.allclose(m30["log_odds"], m20["log_odds"], atol=1e-6)
+
+
+# ---- world size 4, uneven block counts per rank (one rank with an empty map): the union does not split into equal shards of
+#      whole blocks, so it is padded (merge._key_union) and the padding rows travel through the all-to-all / all-gather
+def _uneven_blocks(rank, variant):
+    b = _rank_blocks(rank % 2 if rank < 3 else 0)
+    n = [7, 4, 9, 0][rank]
+    o = np.lexsort((b["keys"][:, 2], b["keys"][:, 1], b["keys"][:, 0]))
+    sel = o[rank::2][:n] if rank < 3 else o[:0]  # (ranks 0 and 2 share a scene: overlapping and disjoint blocks)
+    if variant == 1 and rank == 0:
+        sel = sel[1:]  # (its first block is the one only rank 0 holds: the union shrinks by one)
+    return {k: b[k][sel] for k in ("keys", "log_odds", "occ")}
+
+
+def _worker4(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from mlmapping_amd.config import SDEF
+    from mlmapping_amd.merge import merge_global_map
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for variant in (0, 1):
+        merged = merge_global_map(_uneven_blocks(rank, variant), SDEF)
+        np.savez(os.path.join(out_dir, f"m4_{variant}_{rank}.npz"), **{k: v.cpu().numpy() for k, v in merged.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_merge_four_ranks_uneven(tmp_path):
+    import torch.multiprocessing as mp
+
+    from mlmapping_amd.config import SDEF
+
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    padded = 0
+    for variant in (0, 1):
+        res = [np.load(tmp_path / f"m4_{variant}_{r}.npz") for r in range(4)]
+        for r in range(1, 4):
+            for k in ("keys", "log_odds", "occ"):
+                assert np.array_equal(res[0][k], res[r][k]), f"variant {variant}: rank {r} disagrees on {k}"
+        own = [_uneven_blocks(r, variant) for r in range(4)]
+        assert own[3]["keys"].shape[0] == 0 and len({b["keys"].shape[0] for b in own}) == 4  # uneven, one empty
+        allk = np.unique(np.concatenate([b["keys"] for b in own]), axis=0)
+        allk = allk[np.lexsort((allk[:, 2], allk[:, 1], allk[:, 0]))]
+        assert np.array_equal(res[0]["keys"], allk)
+        padded += int(allk.shape[0] % 4 != 0)
+        C = SDEF.cells_per_block
+        lo = np.zeros((allk.shape[0], C), np.float32)
+        seen = np.zeros((allk.shape[0], C), bool)
+        idx = {tuple(k): i for i, k in enumerate(allk)}
+        for b in own:  # (rank order = the order the shards are summed in)
+            for j, k in enumerate(b["keys"]):
+                lo[idx[tuple(k)]] += b["log_odds"][j]
+                seen[idx[tuple(k)]] |= b["occ"][j] != ord("u")
+        lo = np.clip(lo, np.float32(SDEF.lm_log_odds_min), np.float32(SDEF.lm_log_odds_max))
+        cls = np.full(lo.shape, ord("u"), np.uint8)
+        cls[seen] = ord("f")
+        cls[lo > np.float32(SDEF.lm_occupied_sh)] = ord("o")
+        assert np.allclose(res[0]["log_odds"], lo, atol=1e-6)
+        assert np.array_equal(res[0]["occ"], cls)
+    assert padded >= 1  # (the two variants' unions differ by one block: at least one is not a multiple of the world size)

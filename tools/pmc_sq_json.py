@@ -10,7 +10,9 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(lambda: defaultdict(int))
 seen_in, dup = {}, set()
-for path in sys.argv[1:-1]:
+args = [a for a in sys.argv[1:] if not a.startswith("frames=")]
+frames_arg = [a for a in sys.argv[1:] if a.startswith("frames=")]
+for path in args[:-1]:
     for c, p0 in list(seen_in.items()):
         if p0 != path:
             dup.add((path, c))
@@ -23,12 +25,12 @@ for path in sys.argv[1:-1]:
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[k][r["Counter_Name"]] += 1
         seen_in[r["Counter_Name"]] = path
-n_frames = 48.0  # tools/pmc_batch.py: three 16-frame batches
-out = {"source": "two rocprofv3 --pmc passes over python3 tools/pmc_batch.py (--kernel-trace only): SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS "
+n_frames = float(frames_arg[0].split("=")[1]) if frames_arg else 48.0  # tools/pmc_batch.py: three 16-frame batches; frames=N: tools/pmc_batch64.py
+out = {"source": "two rocprofv3 --pmc passes over python3 tools/pmc_batch.py or tools/pmc_batch64.py (--kernel-trace only): SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS "
                  "SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY; SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
                  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES.  WAIT_ANY (parked on s_waitcnt / barrier) + WAIT_INST_ANY (issue stall) + "
                  "ACTIVE_INST_ANY (issuing) ~ WAVE_CYCLES (MI355X_MICROARCH.md, rocprofv3 PMC slots)",
-       "unit": "per frame (48 frames of the bench workload in three batches)", "kernels": {}}
+       "unit": "per frame (%d frames of the bench workload%s)" % (n_frames, ": asynchronous 64-frame device batches as bench.py submits them" if frames_arg else " in three batches"), "kernels": {}}
 for k, cs in acc.items():
     d = {c: v / n_frames for c, v in sorted(cs.items())}
     if d.get("SQ_WAVE_CYCLES"):
@@ -39,6 +41,6 @@ for k, cs in acc.items():
                 d[name] = d[c] / d["SQ_WAVE_CYCLES"]
     d["launches"] = max(launches[k].values())
     out["kernels"][k] = d
-json.dump(out, open(sys.argv[-1], "w"), indent=1)
+json.dump(out, open(args[-1], "w"), indent=1)
 for k, d in out["kernels"].items():
     print(k, {c: (round(v, 3) if isinstance(v, float) else v) for c, v in d.items()})
