@@ -468,6 +468,7 @@ def main():
     # `value`
     n_host = 16
     host_batch = np.ascontiguousarray(frames[[b % args.distinct for b in range(B)]])
+    m.host_register(host_batch)  # (a replay tool pins its frame buffer once: DMA straight from it, mlm_host_register)
     for s in range(4):  # the first host-buffer submission of every slot set allocates its image buffers
         m.update_map_batch(host_batch, q[s * B:s * B + B], t[s * B:s * B + B])
     m.sync()
@@ -478,6 +479,7 @@ def main():
     m.sync()
     pcie_fps = n_host * B / (time.perf_counter() - th)
     last_stats = m.frame_stats()
+    m.host_unregister(host_batch)
     m.close()
 
     if rank == 0:

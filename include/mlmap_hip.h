@@ -20,9 +20,13 @@
  *    that returned (in async mode they first wait for everything submitted).  mlm_last_error is per handle: read it
  *    on the thread that got the failure before that thread issues another call.  mlm_destroy must not race with
  *    other calls;
- *  - the block pool grows on demand; after MLM_ERR_CAPACITY (device memory exhausted, a frame with more points than
- *    mlm_limits.max_points, or a fixed pool: MLM_POOL_GROW=0) the handle stays usable: the map keeps what the failing call
- *    applied before it ran out of room, later frames integrate normally;
+ *  - the block pool grows on demand (while it grows, the old and the new pool are resident together: about three times the old
+ *    pool for a moment); after MLM_ERR_CAPACITY (device memory exhausted, a frame with more points than mlm_limits.max_points, or
+ *    a pool fixed by the test knob "pool_grow" = 0) the handle stays usable: the map keeps what the failing call applied before it
+ *    ran out of room, later frames integrate normally.  Blocks are created by the map-independent stage, up to three batches
+ *    ahead of the stage that applies a frame: after a failed call the map may hold blocks of frames that were never applied —
+ *    all 'u' / 0.0f, i.e. what the reference's allocate_ram leaves for a block nothing was integrated into — and
+ *    mlm_frame_stats.n_blocks counts them;
  *  - poses are q_wb = (w,x,y,z) and t_wb of T_wb (body in world), exactly what mlmap.cpp:494 builds;
  *  - positions are world-frame doubles (Vec3 of include/common.h:22), n x 3 row-major.
  */
@@ -36,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MLM_ABI_VERSION 3
+#define MLM_ABI_VERSION 4
 
 typedef enum mlm_status {
     MLM_OK = 0,
@@ -81,7 +85,7 @@ typedef struct mlm_limits {
     int32_t max_blocks;      /* INITIAL capacity of the hashed block pool (n^3 cells each); 0 = default 65536.  The pool
                               * grows on demand (table and pool re-allocated at twice the size, blocks copied, table rebuilt
                               * on the device) like the reference's observed_group_map; MLM_ERR_CAPACITY only when the
-                              * device cannot hold the larger pool (or with the environment's MLM_POOL_GROW=0) */
+                              * device cannot hold the larger pool (or with the test knob "pool_grow" = 0) */
     int32_t max_points;      /* largest point count of one frame; 0 = 1280*720 */
     int32_t max_batch;       /* frames integrated per launch sequence (batch entry points); 0 = 8, at most 64;
                               * every frame in flight owns ~0.35 GB (S1) .. 2.2 GB (S3) of scratch, three sets of them
@@ -210,6 +214,13 @@ int mlm_import_blocks(mlm_handle *h, int n, const int32_t *keys, const float *lo
 int mlm_merge_pack(mlm_handle *h, const int32_t *keys_dev, int n, float *log_odds_dev, uint8_t *seen_dev);
 int mlm_merge_finish(mlm_handle *h, float *log_odds_dev, const uint8_t *seen_dev, size_t n_cells, uint8_t *occ_dev);
 
+/* Pin a caller-owned host buffer (hipHostRegister) so that the host-buffer entry points (mlm_integrate_depth_batch,
+ * mlm_integrate_depth_u16, mlm_integrate_callback, mlm_integrate_points) DMA straight from it: from pageable memory a copy is
+ * staged by the HIP runtime at a third of the link's rate.  A replay tool registers its frame buffer once; the ROS callback
+ * pattern (one frame per call) does not need it.  Unregister before freeing the buffer (waits for everything submitted). */
+int mlm_host_register(mlm_handle *h, const void *ptr, size_t bytes);
+int mlm_host_unregister(mlm_handle *h, const void *ptr);
+
 int mlm_sync(mlm_handle *h);
 /* async = 1: integrate calls return once the work is SUBMITTED (two batches may be in flight); errors of a batch and
  * mlm_get_frame_stats lag by one call; mlm_sync, queries and exports wait for everything.  Default 0: integrate calls
@@ -235,6 +246,14 @@ int mlm_get_odds_table(mlm_handle *h, float *out);
 int mlm_get_kernel_times(mlm_handle *h, int cap, const char **names, float *ms, int *n_out);
 int mlm_enable_kernel_timing(mlm_handle *h, int on);
 int mlm_set_timed_kernel(mlm_handle *h, const char *name, int every);
+
+/* Test and experiment knobs — NOT part of the drop-in contract.  Named integers read by the NEXT mlm_create of this process:
+ * forced fall-backs ("sec_fail_every", "sec_backoff", "sectors"), simulated allocation failures ("debug_fail_slot"), a fixed pool
+ * ("pool_grow"), slot layout ("lean_slots", "slot_sets"), launch geometries ("sec_tab", "sec_threads", "rank_grid", ...; the full
+ * list is kKnobNames in mlmap_hip.hip).  Unknown names: MLM_ERR_INVALID.  mlm_debug_reset forgets them all.  The library reads
+ * no environment variable for behaviour; MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN only print diagnostics. */
+int mlm_debug_set(const char *name, long long value);
+int mlm_debug_reset(void);
 
 #ifdef __cplusplus
 }

@@ -86,174 +86,243 @@ __device__ __forceinline__ uint32_t mlm_mask_rows(unsigned long long m) {
     return (uint32_t)__popcll(m & 0x0101010101010101ull);
 }
 
+// A reference of a multi-kind cell = one non-empty row of the 8x8 lane mask of one contribution group, 4 bytes:
+//   bits 0-7 the row's byte of the mask, 8-12 the kind, 13-31 where the row's first lane lies relative to the cell's FIRST pixel
+//   (its earliest contribution, MlmSecCell::tmin: no contribution lies in a row above it):
+//     dense images   (rows below the first pixel's) << 8 | column >> 3          11 + 8 bits (images up to 2040 wide)
+//     lists          (64-item rows below the first item's) << 3 | mask row      16 + 3 bits (2^20 items)
+#define MLM_REF_DY_DENSE 2047u
+#define MLM_REF_DY_LIST 65535u
+__device__ __forceinline__ uint32_t mlm_ref_pack(uint32_t bits, uint32_t kind, bool dense, uint32_t dy0, uint32_t row, uint32_t x0) {
+    const uint32_t pos = dense ? ((dy0 + row) << 8) | (x0 >> 3) : (dy0 << 3) | row;
+    return bits | (kind << 8) | (pos << 13);
+}
+// -> row byte, kind, rows below the cell's first pixel, column of the row's first lane
+__device__ __forceinline__ void mlm_ref_unpack(uint32_t ref, bool dense, uint32_t &bits, uint32_t &kind, uint32_t &dy, uint32_t &x) {
+    bits = ref & 0xFFu;
+    kind = (ref >> 8) & 31u;
+    const uint32_t pos = ref >> 13;
+    dy = dense ? pos >> 8 : pos >> 3;
+    x = dense ? (pos & 255u) << 3 : (pos & 7u) << 3;
+}
+
 __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
     mlm_gp(P.ctr)->sector_overflow = 1u;
     // (frontier mode does not speculate: its host reads the flag before it enqueues what depends on the map)
     if (!P.explore) g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS) {
+// work item of thread `threadIdx.x` in strip `strip` of the frame (mlm_tile_item with the strip index instead of blockIdx.x):
+// dense images are cut into strips of 32 x 8 pixels (a wave = an 8x8 tile), lists into runs of 256 items
+template <int MODE> __device__ __forceinline__ MlmTile mlm_strip_item(const MlmFrame &F, unsigned int strip) {
+    MlmTile t;
+    if (MODE == 0) {
+        const int tiles_x = (F.width + 31) >> 5;
+        const int by = (int)strip / tiles_x;
+        const int bx = (int)strip - by * tiles_x;
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        const int px = bx * 32 + (w & 3) * 8 + (l & 7);
+        const int py = by * 8 + (l >> 3);
+        t.valid = px < F.width && py < F.height;
+        t.i = py * F.width + px;
+    } else {
+        t.i = (int)(strip * 256u + threadIdx.x);
+        t.valid = t.i < F.n;
+    }
+    return t;
+}
+
+// S strips per workgroup, worked on TOGETHER (every phase runs for all S before the next starts): a strip on its own is a chain
+// pixel load -> ~150 dependent FP64 instructions -> peel loops -> column table -> barrier -> scan -> barrier -> record stores ->
+// returning atomic -> descriptor store, and a wave spends most of its life waiting for one of them; with two strips the loads,
+// the FP64 division sequences and the atomics of the two overlap (S = 2 for dense images).  A record never touches LDS: the lane
+// that leads a group of pixels keeps it in registers until its place in the strip's slice is known (a lane leads at most one
+// record) — what is staged per strip is the column table (phi, count, offset: 768 bytes for a dense strip).
+template <int MODE, int S>
+__global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int n_strips) {
     MLM_SLOT_SETUP
-    constexpr uint32_t COLS = MODE == 0 ? 64u : (uint32_t)MLM_SEC_COLS; // entries of the block's column table
-    __shared__ MlmNode s_node[256];
-    __shared__ uint32_t s_col_phi[COLS], s_col_cnt[COLS], s_col_off[COLS];
-    __shared__ uint16_t s_rec_col[256], s_rec_pos[256];
-    __shared__ unsigned int s_cnt[4], s_wsum[4];
-    __shared__ unsigned int s_nnode, s_over;
-    if (threadIdx.x < COLS) {
-        s_col_phi[threadIdx.x] = MLM_NIL;
-        s_col_cnt[threadIdx.x] = 0;
+    constexpr uint32_t COLS = MODE == 0 ? 64u : (uint32_t)MLM_SEC_COLS; // entries of a strip's column table
+    static_assert(MODE == 0 || S == 1, "list modes: one strip per workgroup (one column entry per thread)");
+    __shared__ uint32_t s_col_phi[S][COLS], s_col_cnt[S][COLS], s_col_off[S][COLS];
+    __shared__ unsigned int s_cnt[S][4], s_wsum[4];
+    __shared__ unsigned int s_over;
+    for (uint32_t e = threadIdx.x; e < S * COLS; e += 256u) {
+        (&s_col_phi[0][0])[e] = MLM_NIL;
+        (&s_col_cnt[0][0])[e] = 0;
     }
-    if (threadIdx.x == 0) {
-        s_nnode = 0;
-        s_over = 0;
-    }
-    __syncthreads();
-    const MlmTile T = mlm_tile_item<MODE>(F);
-    const int i = T.i;
+    if (threadIdx.x == 0) s_over = 0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    bool have = T.valid;
-    double xs = 0, ys = 0, zs = 0;
-    if (have) {
-        if (MODE == 2) {
-            xs = mlm_gp(F.pts)[3 * (size_t)i + 0];
-            ys = mlm_gp(F.pts)[3 * (size_t)i + 1];
-            zs = mlm_gp(F.pts)[3 * (size_t)i + 2];
-        } else {
-            const int pix = (MODE == 1) ? mlm_gp(F.pix)[i] : i;
-            const int v = pix / F.width;
-            const int u = pix - v * F.width;
-            const uint16_t raw = (MODE == 1 && F.raw) ? (uint16_t)mlm_gp(F.raw)[i] : mlm_gp(F.img)[(size_t)v * F.row_stride + u];
-            if (raw == 0) { // mlmap.cpp:338-341
-                have = false;
+    const unsigned int strip0 = blockIdx.x * (unsigned int)S;
+    // ---- the strips' inputs (all loads in flight together)
+    int item[S];
+    bool have[S];
+    double xs[S], ys[S], zs[S];
+    uint16_t raw[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        MlmTile T = mlm_strip_item<MODE>(F, strip0 + (unsigned int)j);
+        if (strip0 + (unsigned int)j >= n_strips) T.valid = false;
+        item[j] = T.i;
+        have[j] = T.valid;
+        xs[j] = ys[j] = zs[j] = 0;
+        raw[j] = 0;
+        if (have[j]) {
+            if (MODE == 2) {
+                xs[j] = mlm_gp(F.pts)[3 * (size_t)T.i + 0];
+                ys[j] = mlm_gp(F.pts)[3 * (size_t)T.i + 1];
+                zs[j] = mlm_gp(F.pts)[3 * (size_t)T.i + 2];
             } else {
-                // mlmap.cpp:329,344-346: (size_t u - float cx_) is a float subtraction, the rest is double
-                const double depth = raw * P.inv_factor;
-                xs = ((float)u - P.cx) * depth / P.fx;
-                ys = ((float)v - P.cy) * depth / P.fy;
-                zs = depth;
+                const int pix = (MODE == 1) ? mlm_gp(F.pix)[T.i] : T.i;
+                const int v = pix / F.width;
+                const int u = pix - v * F.width;
+                raw[j] = (MODE == 1 && F.raw) ? (uint16_t)mlm_gp(F.raw)[T.i] : mlm_gp(F.img)[(size_t)v * F.row_stride + u];
+                // mlmap.cpp:329,344-346: (size_t u - float cx_) is a float subtraction, the rest is double (the depth factor below)
+                xs[j] = (double)((float)u - P.cx);
+                ys[j] = (double)((float)v - P.cy);
             }
         }
     }
-    int rho = 0, phi = 0, zi = 0, c0 = -1;
-    bool can_do_cast = false, inside = false;
-    if (have) {
-        // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
-        double x, y, z;
-        mlm_quat_rot(F.q_ls, xs, ys, zs, x, y, z);
-        x = x + F.t_ls[0];
-        y = y + F.t_ls[1];
-        z = z + F.t_ls[2];
-        inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
-        if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
-    }
-    const uint32_t i00 = (uint32_t)mlm_readlane(i, 0); // work item of lane 0 of this wave (see MlmNode)
-    // lanes of one centre cell -> one record, held by their lowest lane (= earliest insertion time)
-    unsigned long long my_mask = 0;
-    bool leader = false;
-    mlm_wave_groups(c0, inside, [&](int, unsigned long long m) {
-        leader = true;
-        my_mask = m;
-    });
-    // points outside the map that can still cast (map_awareness.cpp:241,249-265): identical starts merged per wave
-    const bool outer = have && !inside && can_do_cast && P.visibility;
-    bool ray_leader = false;
-    {
-        unsigned long long todo = __ballot(outer);
-        while (todo) {
-            const int ld = __ffsll((long long)todo) - 1;
-            const int kr = mlm_readlane(rho, ld), kp = mlm_readlane(phi, ld), kz = mlm_readlane(zi, ld);
-            const unsigned long long m = __ballot(outer && rho == kr && phi == kp && zi == kz);
-            if (lane == ld) {
-                ray_leader = true;
-                my_mask = m;
+    __syncthreads(); // (the column tables are clear)
+    // ---- bins, records (in registers), column buckets
+    uint32_t rec_cell[S], rec_pos[S], rec_i00[S], rec_phi[S], rec_place[S]; // rec_place: column entry | position in its run << 16, MLM_NIL: no record
+    unsigned long long rec_mask[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        if (MODE != 2 && have[j]) {
+            if (raw[j] == 0) { // mlmap.cpp:338-341
+                have[j] = false;
+            } else {
+                const double depth = raw[j] * P.inv_factor;
+                xs[j] = xs[j] * depth / P.fx;
+                ys[j] = ys[j] * depth / P.fy;
+                zs[j] = depth;
             }
-            todo &= ~m;
         }
     }
-    if (leader || ray_leader) {
-        const unsigned int k = atomicAdd(&s_nnode, 1u); // <= 256: a lane belongs to exactly one record
-        MlmNode nd;
-        nd.cell = leader ? (uint32_t)c0 : (uint32_t)rho;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        int rho = 0, phi = 0, zi = 0, c0 = -1;
+        bool can_do_cast = false, inside = false;
+        if (have[j]) {
+            // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
+            double x, y, z;
+            mlm_quat_rot(F.q_ls, xs[j], ys[j], zs[j], x, y, z);
+            x = x + F.t_ls[0];
+            y = y + F.t_ls[1];
+            z = z + F.t_ls[2];
+            inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
+            if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
+        }
+        const uint32_t i00 = (uint32_t)mlm_readlane(item[j], 0); // work item of lane 0 of this wave (see MlmNode)
+        // lanes of one centre cell -> one record, held by their lowest lane (= earliest insertion time)
+        unsigned long long my_mask = 0;
+        bool leader = false;
+        mlm_wave_groups(c0, inside, [&](int, unsigned long long m) {
+            leader = true;
+            my_mask = m;
+        });
+        // points outside the map that can still cast (map_awareness.cpp:241,249-265): identical starts merged per wave
+        const bool outer = have[j] && !inside && can_do_cast && P.visibility;
+        bool ray_leader = false;
+        {
+            unsigned long long todo = __ballot(outer);
+            while (todo) {
+                const int ld = __ffsll((long long)todo) - 1;
+                const int kr = mlm_readlane(rho, ld), kp = mlm_readlane(phi, ld), kz = mlm_readlane(zi, ld);
+                const unsigned long long m = __ballot(outer && rho == kr && phi == kp && zi == kz);
+                if (lane == ld) {
+                    ray_leader = true;
+                    my_mask = m;
+                }
+                todo &= ~m;
+            }
+        }
+        rec_place[j] = MLM_NIL;
+        rec_cell[j] = leader ? (uint32_t)c0 : (uint32_t)rho;
         // hit records carry their tile's origin (row << 11 | column of lane 0; list modes: 64 items = one row) for k_rank
         uint32_t yx = i00 >> 6 << 11;
         if (MODE == 0) {
             const uint32_t y0 = i00 / (uint32_t)F.width;
             yx = (y0 << 11) | (i00 - y0 * (uint32_t)F.width);
         }
-        nd.pos = leader ? yx : (uint32_t)zi;
-        nd.i00_sub = i00 | (leader ? 0u : (MLM_SEC_OUTER << 27));
-        nd.pad = (uint32_t)phi;
-        nd.mask = my_mask;
-        s_node[k] = nd;
-    }
-    const unsigned int n_pts = (unsigned int)__popcll(__ballot(have));
-    const unsigned int n_oor = (unsigned int)__popcll(__ballot(have && !(can_do_cast && P.visibility)));
-    if (lane == 0) s_cnt[wid] = n_pts | (n_oor << 10);
-    __syncthreads();
-    // ---- bucket the block's records by column
-    const unsigned int nn = s_nnode;
-    if (threadIdx.x < nn) {
-        const uint32_t ph = s_node[threadIdx.x].pad;
-        uint32_t e = (ph * 2654435761u) >> (MODE == 0 ? 26 : 24);
-        bool placed = false;
-        for (uint32_t probe = 0; probe < COLS; ++probe) {
-            const uint32_t prev = atomicCAS(&s_col_phi[e], MLM_NIL, ph);
-            if (prev == MLM_NIL || prev == ph) {
-                placed = true;
-                break;
+        rec_pos[j] = leader ? yx : (uint32_t)zi;
+        rec_i00[j] = i00 | (leader ? 0u : (MLM_SEC_OUTER << 27));
+        rec_phi[j] = (uint32_t)phi;
+        rec_mask[j] = my_mask;
+        if (leader || ray_leader) { // bucket the record by column
+            const uint32_t ph = (uint32_t)phi;
+            uint32_t e = (ph * 2654435761u) >> (MODE == 0 ? 26 : 24);
+            bool placed = false;
+            for (uint32_t probe = 0; probe < COLS; ++probe) {
+                const uint32_t prev = atomicCAS(&s_col_phi[j][e], MLM_NIL, ph);
+                if (prev == MLM_NIL || prev == ph) {
+                    placed = true;
+                    break;
+                }
+                e = (e + 1) & (COLS - 1);
             }
-            e = (e + 1) & (COLS - 1);
+            if (placed) rec_place[j] = e | (atomicAdd(&s_col_cnt[j][e], 1u) << 16);
+            else s_over = 1; // (dense tiles only: more than 64 columns in one 32x8 pixel strip)
         }
-        if (placed) {
-            s_rec_col[threadIdx.x] = (uint16_t)e;
-            s_rec_pos[threadIdx.x] = (uint16_t)atomicAdd(&s_col_cnt[e], 1u);
-        } else { // (dense tiles only: more than 64 columns in one 32x8 pixel strip)
-            s_rec_col[threadIdx.x] = 0xFFFFu;
-            s_over = 1;
-        }
+        const unsigned int n_pts = (unsigned int)__popcll(__ballot(have[j]));
+        const unsigned int n_oor = (unsigned int)__popcll(__ballot(have[j] && !(can_do_cast && P.visibility)));
+        if (lane == 0) s_cnt[j][wid] = n_pts | (n_oor << 10);
     }
     __syncthreads();
-    // offsets of the columns' runs inside the block's slice; after the records are stored, one chunk descriptor per run, its
-    // place in the column's list from a returning atomic.  Dense tiles: one wave does it (the other waves are done once the
-    // records are stored and do not wait for the atomic); list modes: one table entry per thread.
-    uint32_t run_cnt = 0, run_off = 0;
+    // ---- offsets of the columns' runs inside the strips' slices.  Dense strips: wave j does strip j (the other waves are done
+    //      once their records are stored and do not wait for the atomic); list modes: one table entry per thread.
+    uint32_t run_cnt = 0, run_off = 0, run_tot = 0;
     if (MODE == 0) {
-        if (wid == 0) {
-            run_cnt = s_col_cnt[lane];
-            run_off = mlm_wave_incl_scan(run_cnt) - run_cnt;
-            s_col_off[lane] = run_off;
+        if (wid < S) {
+            run_cnt = s_col_cnt[wid][lane];
+            const uint32_t incl = mlm_wave_incl_scan(run_cnt);
+            run_off = incl - run_cnt;
+            run_tot = mlm_readlane(incl, 63);
+            s_col_off[wid][lane] = run_off;
         }
     } else {
-        run_cnt = s_col_cnt[threadIdx.x];
+        run_cnt = s_col_cnt[0][threadIdx.x];
         run_off = mlm_wave_incl_scan(run_cnt);
         if (lane == 63) s_wsum[wid] = run_off;
         __syncthreads();
         for (int w = 0; w < wid; ++w) run_off += s_wsum[w];
+        run_tot = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         run_off -= run_cnt;
-        s_col_off[threadIdx.x] = run_off;
+        s_col_off[0][threadIdx.x] = run_off;
     }
     __syncthreads();
-    if (threadIdx.x < nn && s_rec_col[threadIdx.x] != 0xFFFFu) {
-        const unsigned int e = s_rec_col[threadIdx.x];
-        mlm_store_node(mlm_gp(P.bnodes) + ((size_t)blockIdx.x * 256u + s_col_off[e] + s_rec_pos[threadIdx.x]), s_node[threadIdx.x]);
-    }
-    if (threadIdx.x == 0) {
-        unsigned int pts = 0, oor = 0;
-        for (unsigned int w = 0; w < 4; ++w) {
-            pts += s_cnt[w] & 1023u;
-            oor += s_cnt[w] >> 10;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        if (rec_place[j] != MLM_NIL) {
+            MlmNode nd;
+            nd.cell = rec_cell[j];
+            nd.pos = rec_pos[j];
+            nd.i00_sub = rec_i00[j];
+            nd.pad = rec_phi[j];
+            nd.mask = rec_mask[j];
+            mlm_store_node(mlm_gp(P.bnodes) + ((size_t)(strip0 + (unsigned int)j) * 256u + s_col_off[j][rec_place[j] & 0xFFFFu] + (rec_place[j] >> 16)), nd);
         }
-        *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)blockIdx.x) = mlm_u32x4{pts, oor, nn, 0u};
-        if (s_over) mlm_sector_fail(P, F);
     }
-    if (MODE == 0 && wid != 0) return;
-    if (run_cnt) {
-        const uint32_t ph = s_col_phi[MODE == 0 ? lane : (int)threadIdx.x];
+    const bool owner = MODE == 0 ? (wid < S && lane == 0) : threadIdx.x == 0; // the thread that knows strip `wid`'s record count
+    if (owner) {
+        const int j = MODE == 0 ? wid : 0;
+        if (strip0 + (unsigned int)j < n_strips) {
+            unsigned int pts = 0, oor = 0;
+            for (unsigned int w = 0; w < 4; ++w) {
+                pts += s_cnt[j][w] & 1023u;
+                oor += s_cnt[j][w] >> 10;
+            }
+            *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.blk_stats) + 4 * (size_t)(strip0 + (unsigned int)j)) = mlm_u32x4{pts, oor, run_tot, 0u};
+        }
+        if (threadIdx.x == 0 && s_over) mlm_sector_fail(P, F);
+    }
+    if (MODE == 0 && wid >= S) return;
+    if (run_cnt) { // one chunk descriptor per run, its place in the column's list from a returning atomic
+        const int j = MODE == 0 ? wid : 0;
+        const uint32_t ph = s_col_phi[j][MODE == 0 ? lane : (int)threadIdx.x];
         const unsigned int k = g_atomic_add(&mlm_gp(P.col_cnt)[ph], 1u);
         if (k < P.chunk_cap)
-            *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)ph * P.chunk_cap + k)) = mlm_u32x2{blockIdx.x * 256u + run_off, run_cnt};
+            *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)ph * P.chunk_cap + k)) = mlm_u32x2{(strip0 + (unsigned int)j) * 256u + run_off, run_cnt};
         else
             mlm_sector_fail(P, F);
     }
@@ -396,7 +465,7 @@ __device__ __forceinline__ void mlm_fold_bin_stats(const MlmDev &P, int n_bin_bl
 // alone is 10 % slower).
 template <bool EX, bool BIG, int NT>
 __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFrame &F, const int phi, int tile_w, int n_bin_blocks, unsigned long long rho_m,
-                                                  int rho_s, unsigned long long n_bkt, int big_armed) {
+                                                  int rho_s, unsigned long long n_bkt, int big_armed, unsigned long long row_m, int row_s) {
     constexpr int PER_MAX = BIG ? 8 : 4; // cell-table entries per thread
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // (the column's first chunk descriptors are requested together with their count and arrive while the tables below are set
@@ -555,21 +624,21 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int) {
             const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
             if (e >= 0 && mlm_sec_needs_order(s_tab[e])) {
-                // one reference per non-empty ROW of the group's lane mask: {position of the row's first lane, row byte | kind << 8} —
-                // what k_rank needs, with no empty rows in its rounds (a group touches two or three of its eight rows)
+                // one 4-byte reference per non-empty ROW of the group's lane mask (mlm_ref_pack): row byte, kind, and the row's
+                // position relative to the cell's first pixel — what k_rank needs, with no empty rows in its rounds (a group
+                // touches two or three of its eight rows)
                 const uint32_t at = atomicAdd(&s_tab[e].gpos, n_rows);
-                if (at + n_rows <= P.refs_cap) {
-                    auto entry = [&](uint32_t k) {
+                const uint32_t pix0 = s_tab[e].tmin / MLM_TIME_SLOTS;
+                const uint32_t y0c = tile_w > 0 ? (uint32_t)(((unsigned long long)pix0 * row_m) >> row_s) : pix0 >> 6;
+                const uint32_t dy0 = (yx >> 11) - y0c; // (>= 0: the cell's first pixel is its contributions' smallest)
+                if (dy0 + 7u > (tile_w > 0 ? MLM_REF_DY_DENSE : MLM_REF_DY_LIST)) {
+                    s_fail = 1; // (an image more than 2 047 rows tall below the cell's first pixel: not expressible — the frame falls back)
+                } else if (at + n_rows <= P.refs_cap) {
+                    MLM_GLOBAL uint32_t *dst = mlm_gp(P.refs) + at;
+                    for (uint32_t k = 0; k < n_rows; ++k) {
                         const uint32_t row = (rows3 >> (3u * k)) & 7u;
-                        return mlm_u32x2{yx + (tile_w > 0 ? row << 11 : row * 8u), ((uint32_t)(mask >> (8u * row)) & 0xFFu) | ((uint32_t)sub << 8)};
-                    };
-                    MLM_GLOBAL uint32_t *dst = mlm_gp(P.refs) + 2 * (size_t)at;
-                    uint32_t k = 0;
-                    for (; k + 1 < n_rows; k += 2) { // two references per 16-byte store
-                        const mlm_u32x2 e0 = entry(k), e1 = entry(k + 1);
-                        *(MLM_GLOBAL mlm_u32x4 *)(dst + 2 * k) = mlm_u32x4{e0.x, e0.y, e1.x, e1.y};
+                        dst[k] = mlm_ref_pack((uint32_t)(mask >> (8u * row)) & 0xFFu, (uint32_t)sub, tile_w > 0, dy0, row, yx & 2047u);
                     }
-                    if (k < n_rows) *(MLM_GLOBAL mlm_u32x2 *)(dst + 2 * k) = entry(k);
                 }
             }
         });
@@ -917,6 +986,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         // its voxel (k_tile groups the frame's hits and misses by voxel, tile by tile) and the bucket-first time of the
         // emulated container (iteration order, see Stage B in mlm_kernels.h) for the bucket count the frame was submitted with
         mlm_gp(P.hl_vt16)[pos] = (uint16_t)(s_vr[rho].y * P.lv_nz + s_vz[z].x);
+        // (a fire-and-forget atomic: measured 32-byte transactions, 1.2 MB per VGA frame with k_rank's read-back — walking the hit
+        // list once per class of buckets with the minima in LDS instead, profiles/r4c, cost 4.6 MB of re-reads and 2.5 us per frame)
         const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
         mlm_gp(P.hl_bkt)[pos] = (uint32_t)b;
         if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
@@ -958,8 +1029,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         // ---- the column's unique miss cells (its bit mask) leave as voxel-in-tile indices, ordered by rho and therefore by
         //      tile run: every miss adds the same constant (map_local.cpp:188-192), only the count per voxel matters, and
         //      k_tile counts.  Miss cells per rho (LDS atomics), their offsets (one block scan), the list in LDS (the cell
-        //      table's space is idle by now), one coalesced copy; then ONE descriptor per tile run — {first miss cell, count,
-        //      first hit, count} — handed to the tile with a returning atomic: the only per-tile global atomic of the column.
+        //      table's space is idle by now), one coalesced copy into the column's own stretch of the frame's miss list; then the
+        //      descriptors of its tile runs (below).
         for (uint32_t w = threadIdx.x; w < NMISS; w += NT) {
             uint32_t bits = s_miss[w];
             const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u;
@@ -979,18 +1050,17 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             }
         }
         if (threadIdx.x == 0) {
-            // (the returned base is the column's place in the frame's miss list; the counter's final value = unique miss cells)
-            s_base[6] = total ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[3][0], total) : 0u;
+            // (the column's place in the frame's miss list is its own: room for every cell of a column; the counter only counts)
+            if (total) __hip_atomic_fetch_add(&mlm_gp(P.ctr)->mvox_cnt[3][0], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base[7] = (total && P.record_awareness) ? g_atomic_add(&mlm_gp(P.ctr)->n_miss_list, total) : 0u;
             if (n_rays + s_nouter) g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][0], n_rays + s_nouter); // statistic only
-            // device-scope atomics on account of this column: its chunk descriptors (k_bin_sectors), the list reservations
-            // above and here (up to 8, this one included), a bucket-min per hit, a descriptor per tile run
+            // device-scope atomics on account of this column: its chunk descriptors (k_bin_sectors) and the four list reservations
+            // (the ones something waits for), and fire-and-forget: a bucket-min per hit, a mask bit per tile run, four counters
             g_atomic_add(&mlm_gp(P.ctr)->ray_cnt[sl][1], nch_all + 8u + n_occ + (uint32_t)n_run);
             mlm_gp(P.col_cnt)[phi] = 0; // consumed: clean for the slot's next frame
         }
         __syncthreads();
-        const uint32_t m_base = s_base[6];
-        if (m_base + total > P.mc_list_cap) s_fail = 1; // (cannot happen: the list holds every cell of the map)
+        const uint32_t m_base = (uint32_t)phi * (uint32_t)(P.nRho * P.nZ);
         uint16_t *s_cells = (uint16_t *)s_tab; // [total] (nZ * nRho * 2 bytes <= the table's, checked by the host)
         if (total && !s_fail) {
             const uint32_t rec_base = s_base[7];
@@ -1009,20 +1079,19 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < total; i += NT) mlm_gp(P.mc_list)[m_base + i] = s_cells[i];
         }
+        // ONE descriptor per tile run — {first miss cell, count, first hit, count} — in the column's OWN slot of the tile's
+        // descriptor table, announced by the column's bit in the tile's column mask (a fire-and-forget atomic): nothing here waits
+        // for memory.  k_tile reads the mask, takes the descriptors of the columns it names and clears it.
         if ((int)threadIdx.x < n_run && !s_fail) {
             const uint32_t r = threadIdx.x, rho_a = s_run_rho[r], rho_b = (int)r + 1 < n_run ? s_run_rho[r + 1] : (uint32_t)P.nRho;
             const uint32_t m_first = s_rho_off[rho_a], m_cnt = (rho_b < (uint32_t)P.nRho ? s_rho_off[rho_b] : total) - m_first;
             const uint32_t h_cnt = s_run_hits[r];
             if (m_cnt | h_cnt) {
                 const uint32_t tile = s_run_tile[r];
-                const unsigned int k = g_atomic_add(&mlm_gp(P.tile_cnt)[tile], 1u);
-                if (k == 0u) // the tile's first descriptor of this frame: k_tile walks the list of touched tiles
-                    mlm_gp(P.tile_list)[g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[2][0], 1u)] = tile;
-                if (k < P.tile_desc_cap)
-                    *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * ((size_t)tile * P.tile_desc_cap + k)) =
-                        mlm_u32x4{m_base + m_first, m_cnt, s_base[0] + s_run_off[r], h_cnt};
-                else
-                    s_fail = 1;
+                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * ((size_t)tile * (size_t)P.nPhi + (size_t)phi)) =
+                    mlm_u32x4{m_base + m_first, m_cnt, s_base[0] + s_run_off[r], h_cnt};
+                __hip_atomic_fetch_or(mlm_gp(P.tile_cols) + (size_t)tile * P.tile_words + ((uint32_t)phi >> 5), 1u << ((uint32_t)phi & 31u), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -1033,10 +1102,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
 }
 template <bool EX, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
-                                                                                       int rho_s, unsigned long long n_bkt, int big_armed) {
+                                                                                       int rho_s, unsigned long long n_bkt, int big_armed, unsigned long long row_m, int row_s) {
+    // (row_m, row_s: exact division of a pixel index by the image width — the row of a cell's first pixel, mlm_ref_pack)
     MLM_SLOT_SETUP
     if (blockIdx.x == 0 && threadIdx.x < 64) mlm_fold_bin_stats(P, n_bin_blocks);
-    mlm_sector_column<EX, false, NT>(P, F, (int)blockIdx.x, tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, big_armed);
+    mlm_sector_column<EX, false, NT>(P, F, (int)blockIdx.x, tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, big_armed, row_m, row_s);
 }
 // The columns on the overflow lists of a batch's frames, with the large cell table (dynamic LDS of MlmDev::sec_big_lds_bytes:
 // one workgroup per CU).  ONE launch per batch, a fixed number of workgroups that share all (frame, column) tasks.  A kernel
@@ -1048,7 +1118,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_
 template <bool EX>
 __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector_big(const MlmDev *__restrict__ slot_tab, const MlmFrame *__restrict__ frame_tab, int slot_base,
                                                                 int n_frames, int tile_w, int n_bin_blocks, unsigned long long rho_m, int rho_s,
-                                                                unsigned long long n_bkt) {
+                                                                unsigned long long n_bkt, unsigned long long row_m, int row_s) {
     __shared__ unsigned int s_first[65]; // exclusive prefix of the frames' overflow counts (n_frames <= 64)
     if (threadIdx.x < 64) {
         const int j = (int)threadIdx.x;
@@ -1066,7 +1136,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector_big(const MlmDev *__
         const MlmDev &P = slot_tab[slot_base + j];
         const MlmFrame &F = frame_tab[slot_base + j];
         __syncthreads(); // (the previous column's shared state is no longer read)
-        mlm_sector_column<EX, true, MLM_SEC_THREADS>(P, F, (int)mlm_gp(P.ov_list)[t - s_first[j]], tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, 0);
+        mlm_sector_column<EX, true, MLM_SEC_THREADS>(P, F, (int)mlm_gp(P.ov_list)[t - s_first[j]], tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, 0, row_m, row_s);
     }
 }
 
@@ -1107,20 +1177,21 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     __builtin_amdgcn_wave_barrier();
     const MLM_GLOBAL uint32_t *refs = mlm_gp(P.refs);
     // reference p of a cell = one non-empty row of one contribution group: the row's byte of the group's lane mask, the position
-    // (row << 11 | column) of the row's first lane, kind
-    auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &yx, uint32_t &sub) {
-        bits = 0;
-        yx = 0;
-        sub = 0;
-        if (p < rf.y) {
-            const mlm_u32x2 ref = *(const MLM_GLOBAL mlm_u32x2 *)(refs + 2 * (size_t)(rf.x + p));
-            yx = ref.x;
-            bits = ref.y & 0xFFu;
-            sub = ref.y >> 8;
-        }
+    // of the row's first lane relative to the cell's first pixel, kind (mlm_ref_pack)
+    // (a reference travels as its one packed word — the rounds held in registers one pair of cells ahead cost a register each —
+    // and is taken apart where it is used; 0 = none: a real reference has a non-empty row byte)
+    auto load_ref = [&](const mlm_u32x2 &rf, uint32_t p) -> uint32_t { return p < rf.y ? refs[(size_t)(rf.x + p)] : 0u; };
+    // (yx: rows below the cell's first pixel << 11 | column of the row's first lane)
+    auto unpack = [&](uint32_t ref, uint32_t &bits, uint32_t &yx, uint32_t &sub) {
+        uint32_t dy, x;
+        mlm_ref_unpack(ref, tile_w > 0, bits, sub, dy, x);
+        yx = (dy << 11) | x;
     };
-    auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],
-                       const uint32_t (&r_sub)[4]) {
+    auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &yx, uint32_t &sub) { unpack(load_ref(rf, p), bits, yx, sub); };
+    auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_ref)[4]) {
+        uint32_t r_bits[4], r_yx[4], r_sub[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) unpack(r_ref[q], r_bits[q], r_yx[q], r_sub[q]);
         // (the descriptor is the same in every lane: scalar registers, uniform branches)
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z) & MLM_SEC_CNT_MASK,
                        n_refs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rf.y);
@@ -1134,7 +1205,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         bool bad = n > 0xFFFFu;
         auto locate = [&](uint32_t yx, uint32_t &wi, uint32_t &sh) -> bool {
             const int dx = (int)(yx & 2047u) - xlo;
-            const uint32_t dy = (yx >> 11) - y0;
+            const uint32_t dy = yx >> 11;
             wi = 2 * dy + ((uint32_t)dx >> 6);
             sh = (uint32_t)dx & 63u;
             return dx >= 0 && dx <= 120 && dy < MLM_BMP_ROWS;
@@ -1234,7 +1305,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
             for (uint32_t p0 = 0; p0 < n_refs; p0 += 64) {
                 uint32_t b, px, sb;
                 load_pair(rf, p0 + lane, b, px, sb);
-                const uint32_t item = (px >> 11) * (uint32_t)row_w + (px & 2047u); // work item of the row's first lane
+                const uint32_t item = (px >> 11) * (uint32_t)row_w + (px & 2047u); // work item of the row's first lane, counted from the first row of the cell
                 const uint32_t cb = (uint32_t)__popc(b);
                 const uint32_t incl = mlm_wave_incl_scan(cb);
                 uint32_t at = base + incl - cb;
@@ -1279,8 +1350,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         return (uint32_t)x;
     };
     // returns (per lane, equal inside a half): the half's cell still has to be done by the whole wave
-    auto process_pair = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, bool valid, const uint32_t (&r_bits)[4], const uint32_t (&r_yx)[4],
-                            const uint32_t (&r_sub)[4]) -> bool {
+    auto process_pair = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, bool valid, const uint32_t (&r_ref)[4]) -> bool {
         const uint32_t soff = rec.y, n = rec.z & MLM_SEC_CNT_MASK, n_refs = rf.y;
         const uint32_t pix0 = rec.w / MLM_TIME_SLOTS;
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
@@ -1291,19 +1361,24 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         bool bad = false;
         auto locate = [&](uint32_t yx, uint32_t &wi, uint32_t &sh) -> bool {
             const int dx = (int)(yx & 2047u) - xlo;
-            const uint32_t dy = (yx >> 11) - y0;
+            const uint32_t dy = yx >> 11;
             wi = 2 * dy + ((uint32_t)dx >> 6);
             sh = (uint32_t)dx & 63u;
             return dx >= 0 && dx <= 120 && dy < MLM_BMP_ROWS / 2;
         };
-        uint32_t l_wi[4], l_sh[4];
+        uint32_t l_ws[4]; // bitmap word << 6 | shift of each held reference (the packed reference itself is taken apart where it is used)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            l_wi[q] = 0;
-            l_sh[q] = 0;
-            if (q < rounds && q < my_rounds && r_bits[q]) {
-                if (locate(r_yx[q], l_wi[q], l_sh[q])) __hip_atomic_fetch_or(&rows_h[l_wi[q]], (unsigned long long)r_bits[q] << l_sh[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else bad = true;
+            l_ws[q] = 0;
+            if (q < rounds && q < my_rounds && (r_ref[q] & 0xFFu)) {
+                uint32_t bits, yx, sub, wi, sh;
+                unpack(r_ref[q], bits, yx, sub);
+                if (locate(yx, wi, sh)) {
+                    __hip_atomic_fetch_or(&rows_h[wi], (unsigned long long)bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    l_ws[q] = (wi << 6) | sh;
+                } else {
+                    bad = true;
+                }
             }
         }
         if (act)
@@ -1347,7 +1422,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         };
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (q < rounds && ok && q < my_rounds) place(r_bits[q], l_wi[q], l_sh[q], r_sub[q]);
+            if (q < rounds && ok && q < my_rounds) place(r_ref[q] & 0xFFu, l_ws[q] >> 6, l_ws[q] & 63u, (r_ref[q] >> 8) & 31u);
         if (ok)
             for (uint32_t p = (uint32_t)hl + 128u; p < n_refs; p += 32) {
                 uint32_t b, px, sb, wi, sh;
@@ -1375,8 +1450,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     // otherwise a chain of four dependent memory round trips (descriptor, references, records, store)
     mlm_u32x4 rec_cur = mlm_u32x4{0u, 0u, 0u, 0u}, rec_nxt = rec_cur;
     mlm_u32x2 rf_cur = mlm_u32x2{0u, 0u}, rf_nxt = rf_cur;
-    uint32_t b_cur[4] = {0, 0, 0, 0}, p_cur[4] = {0, 0, 0, 0}, s_cur[4] = {0, 0, 0, 0}, b_nxt[4] = {0, 0, 0, 0}, p_nxt[4] = {0, 0, 0, 0},
-             s_nxt[4] = {0, 0, 0, 0};
+    uint32_t r_cur[4] = {0, 0, 0, 0}, r_nxt[4] = {0, 0, 0, 0};
     auto load_desc = [&](unsigned int pw, mlm_u32x4 &rec, mlm_u32x2 &rf) { // the half's cell of pair pw
         const unsigned int c = 2u * pw + (unsigned int)half;
         rec = mlm_u32x4{0u, 0u, 0u, 0u};
@@ -1390,7 +1464,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     if (wave < n_pairs) {
         load_desc(wave, rec_cur, rf_cur);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) load_pair(rf_cur, (uint32_t)hl + 32u * q, b_cur[q], p_cur[q], s_cur[q]);
+        for (int q = 0; q < 4; ++q) r_cur[q] = load_ref(rf_cur, (uint32_t)hl + 32u * q);
     }
     if (wave + n_waves < n_pairs) load_desc(wave + n_waves, rec_nxt, rf_nxt);
     for (unsigned int pw = wave; pw < n_pairs; pw += n_waves) {
@@ -1398,10 +1472,10 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         mlm_u32x2 rf_nn = mlm_u32x2{0u, 0u};
         if (pw + n_waves < n_pairs) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) load_pair(rf_nxt, (uint32_t)hl + 32u * q, b_nxt[q], p_nxt[q], s_nxt[q]);
+            for (int q = 0; q < 4; ++q) r_nxt[q] = load_ref(rf_nxt, (uint32_t)hl + 32u * q);
         }
         if (pw + 2 * n_waves < n_pairs) load_desc(pw + 2 * n_waves, rec_nn, rf_nn);
-        const bool again = process_pair(rec_cur, rf_cur, 2u * pw + (unsigned int)half < n_cells, b_cur, p_cur, s_cur);
+        const bool again = process_pair(rec_cur, rf_cur, 2u * pw + (unsigned int)half < n_cells, r_cur);
         const unsigned long long again_lanes = __ballot(again);
         for (int h = 0; h < 2; ++h) // (uniform) the whole wave on a cell that did not fit half of it
             if ((again_lanes >> (32 * h)) & 1ull) {
@@ -1413,10 +1487,10 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
                 rec_f.w = mlm_readlane(rec_cur.w, 32 * h);
                 rf_f.x = mlm_readlane(rf_cur.x, 32 * h);
                 rf_f.y = mlm_readlane(rf_cur.y, 32 * h);
-                uint32_t b_f[4], p_f[4], s_f[4];
+                uint32_t r_f[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) load_pair(rf_f, (uint32_t)lane + 64u * q, b_f[q], p_f[q], s_f[q]);
-                process(rec_f, rf_f, b_f, p_f, s_f);
+                for (int q = 0; q < 4; ++q) r_f[q] = load_ref(rf_f, (uint32_t)lane + 64u * q);
+                process(rec_f, rf_f, r_f);
             }
         rec_cur = rec_nxt;
         rf_cur = rf_nxt;
@@ -1424,9 +1498,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         rf_nxt = rf_nn;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            b_cur[q] = b_nxt[q];
-            p_cur[q] = p_nxt[q];
-            s_cur[q] = s_nxt[q];
+            r_cur[q] = r_nxt[q];
         }
     }
 }
@@ -1554,6 +1626,7 @@ __device__ __forceinline__ int mlm_floor_div(int a, int n) {
 #endif
 #define MLM_TILE_KEEP 2     // hits per thread kept in registers between the counting and the placing pass
 #define MLM_TILE_DESC 128   // descriptors staged per pass (a tile of a VGA frame has ~15; 128 instead of 256: 3 KB of LDS, a fifth workgroup per CU)
+#define MLM_TILE_WORDS 64    // most words of a tile's column mask: MlmDev::tile_words = ceil(nPhi / 32) (sector path: nPhi <= 2048)
 #define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap: limit of MlmDev::tile_combos (their pool slots are kept in LDS)
 struct MlmTileLds {
     uint32_t cnt, place, desc, slot, ztab, total;
@@ -1571,14 +1644,34 @@ __host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_n
     L.total = (o + 15u) & ~15u;
     return L;
 }
-__device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F, const unsigned int tile) {
-    // (the tile's first descriptors are requested together with their count, not after it: a single frame's latency is the
-    // number of dependent trips to memory; what lies beyond the count is not looked at)
-    const MLM_GLOBAL mlm_u32x4 *descs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * (size_t)tile * P.tile_desc_cap);
+// colw: the tile's column mask (MlmDev::tile_words words, in LDS): bit phi = column phi left a descriptor in its slot
+__device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F, const unsigned int tile, const uint32_t *colw) {
+    const MLM_GLOBAL mlm_u32x4 *descs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * (size_t)tile * (size_t)P.nPhi);
+    __shared__ uint32_t s_cpre[MLM_TILE_WORDS + 1]; // exclusive prefix of the mask words' popcounts
+    if (threadIdx.x < 64) { // (one wave: MlmDev::tile_words <= 64)
+        const uint32_t w = threadIdx.x < P.tile_words ? colw[threadIdx.x] : 0u;
+        const uint32_t c = (uint32_t)__popc(w), incl = mlm_wave_incl_scan(c);
+        if (threadIdx.x < P.tile_words) s_cpre[threadIdx.x] = incl - c;
+        if (threadIdx.x == 63) s_cpre[P.tile_words] = incl;
+        // consumed: clean for the slot's next frame (the words were read into LDS by the caller)
+        if (threadIdx.x < P.tile_words && w) mlm_gp(P.tile_cols)[(size_t)tile * P.tile_words + threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    const unsigned int nd_all = s_cpre[P.tile_words];
+    // the j-th column (in ascending phi) that left a descriptor
+    auto nth_column = [&](uint32_t j) -> uint32_t {
+        uint32_t lo = 0, hi = P.tile_words; // largest w with s_cpre[w] <= j
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_cpre[mid] <= j) lo = mid;
+            else hi = mid;
+        }
+        uint32_t bits = colw[lo];
+        for (uint32_t k = j - s_cpre[lo]; k; --k) bits &= bits - 1;
+        return lo * 32u + (uint32_t)__ffs((int)bits) - 1u;
+    };
     mlm_u32x4 dd_first = mlm_u32x4{0u, 0u, 0u, 0u};
-    if (threadIdx.x < min((unsigned int)MLM_TILE_DESC, P.tile_desc_cap)) dd_first = descs[threadIdx.x];
-    const unsigned int nd_all = mlm_gp(P.tile_cnt)[tile];
-    if (nd_all == 0) return; // (a tile without descriptors: only when every tile has a workgroup)
+    if (threadIdx.x < min((unsigned int)MLM_TILE_DESC, nd_all)) dd_first = descs[nth_column(threadIdx.x)];
     MLM_TPHASE_BEGIN
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t edge = 1u << P.tile_sh, NV = edge * edge * (uint32_t)P.lv_nz;
@@ -1595,7 +1688,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     __shared__ uint32_t s_xytab[16]; // per x (first `edge` entries) and per y: block index relative to the tile's first | cell coordinate << 16
     if (threadIdx.x == 0) {
         s_dead = mlm_gp(P.ctr)->sector_overflow; // set by Stage A: the frame is redone on the cell-table path — only clean up
-        s_fail = nd_all > P.tile_desc_cap ? 1u : 0u;
+        s_fail = 0u;
     }
     for (uint32_t v = threadIdx.x; v < NV; v += MLM_TILE_THREADS) s_cnt[v] = 0u;
     // the tile's place in the world: grid coordinates of its corner, the blocks it overlaps
@@ -1621,8 +1714,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
         s_xytab[threadIdx.x] = (uint32_t)(g - (is_y ? gy0 : gx0)) | ((uint32_t)(C - g * P.n) << 16);
     }
     __syncthreads();
-    MLM_TPHASE(0); // parameters, tile_cnt / first descriptors, LDS clear
-    if (threadIdx.x == 0) mlm_gp(P.tile_cnt)[tile] = 0u; // consumed: clean for the slot's next frame (every thread has read it)
+    MLM_TPHASE(0); // parameters, column mask / first descriptors, LDS clear
     if (s_dead) return;
     // the pool slots of the tile's blocks (in flight while the cells are counted; a tile overlaps a few dozen blocks)
     int slot0 = -1;
@@ -1630,7 +1722,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
         if ((int)threadIdx.x < n_combo) slot0 = combo_slot((int)threadIdx.x);
         for (int c = threadIdx.x + MLM_TILE_THREADS; c < n_combo; c += MLM_TILE_THREADS) s_slot[c] = combo_slot(c);
     }
-    const unsigned int nd = min(nd_all, P.tile_desc_cap);
+    const unsigned int nd = nd_all;
     // flat item j of the staged descriptors -> (descriptor, offset inside it); pre[] = exclusive prefix of the counts
     auto locate = [&](const uint32_t *pre, uint32_t n_staged, uint32_t j, uint32_t &d, uint32_t &o) {
         uint32_t lo = 0, hi = n_staged;
@@ -1661,7 +1753,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
             uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
             mlm_u32x4 dd = mlm_u32x4{0u, 0u, 0u, 0u};
             if (threadIdx.x < n_staged) {
-                dd = d0 == 0 ? dd_first : descs[d0 + threadIdx.x];
+                dd = d0 == 0 ? dd_first : descs[nth_column(d0 + threadIdx.x)];
                 a[0] = dd.y;
                 a[1] = dd.w;
             }
@@ -1696,9 +1788,9 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
             // increment and key — nothing of that depends on the map or on the counts — so the placing pass reads no memory
             auto place_hit = [&](uint32_t pos, uint32_t v, float inc, unsigned long long key) {
                 const uint32_t pl = s_place[v];
-                if ((pl >> 16) == 0xFFFFu) { // the voxel's only hit: its increment rides in the record (the last 8 bytes are this lane's)
+                if ((pl >> 16) == 0xFFFFu) { // the voxel's only hit: its increment rides in the record (that word is this lane's)
                     MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + (pl & 0xFFFFu);
-                    *(MLM_GLOBAL mlm_u32x2 *)&rec->inc0 = mlm_u32x2{__float_as_uint(inc), pos};
+                    rec->inc_first = __float_as_uint(inc);
                 } else {
                     const uint32_t k = (atomicSub(&s_cnt[v], 0x10000u) >> 16) - 1u; // (counts down: n_hit - 1 .. 0)
                     MLM_GLOBAL MlmVoxHit *hh = mlm_gp(P.vr_hit) + hit_base + (pl >> 16) + k;
@@ -1815,11 +1907,10 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
                 const int bx = (int)(xt & 0xFFFFu), by = (int)(yt & 0xFFFFu), bz = (int)(zt & 0xFFFFu);
                 const int cid = ((int)(zt >> 16) * P.n + (int)(yt >> 16)) * P.n + (int)(xt >> 16);
                 const int slot = s_slot[(bz * ngy + by) * ngx + bx];
-                const unsigned long long key = mlm_pack_key(gx0 + bx, gy0 + by, gz0 + bz);
+                const int at = slot >= 0 ? slot * P.cells + cid : -1; // (< 2^31: alloc_pool; -1: k_alloc_retry once the pool has grown)
                 MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + rec_base + o_rec;
-                *(MLM_GLOBAL mlm_u32x4 *)rec = mlm_u32x4{(uint32_t)key, (uint32_t)(key >> 32), (uint32_t)cid, (c & 0xFFFFu) | (((vxy << 10) | zz) << 16)}; // (lv_nz <= 1024, at most 64 columns per tile)
-                *(MLM_GLOBAL mlm_u32x2 *)&rec->slot = mlm_u32x2{(uint32_t)slot, nh};
-                if (nh != 1u) *(MLM_GLOBAL mlm_u32x2 *)&rec->inc0 = mlm_u32x2{0u, hit_base + o_hit}; // (one hit: written by that hit's lane)
+                // (lv_nz <= 1024, at most 64 columns per tile; one hit: its increment is written by that hit's lane in the placing pass)
+                *(MLM_GLOBAL mlm_u32x4 *)rec = mlm_u32x4{(uint32_t)at, (c & 0xFFFFu) | (((vxy << 10) | zz) << 16), nh != 1u ? hit_base + o_hit : 0u, nh};
                 ++o_rec;
                 if (nh >= 2u) o_hit += nh;
             }
@@ -1834,31 +1925,41 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     MLM_TPHASE(6); // placing pass
     MLM_TPHASE_END
 }
-// blockIdx.x walks the frame's list of touched tiles (k_sector appends a tile with its first descriptor): a frame reaches a
-// fraction of its grid's tiles, and a workgroup per tile of the grid would spend most launches — each waiting for its LDS —
-// on finding its tile empty
+// A workgroup takes the tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the frame-local grid: it reads the column masks of ALL its
+// candidates in one go (a frame reaches a fraction of its grid's tiles: most masks are empty) and works on the tiles that some
+// column announced itself to.  No list of touched tiles, no per-tile counter: the columns hand over with plain stores and one
+// fire-and-forget atomic each (k_sector).
 __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
-    if (gridDim.x >= (unsigned int)P.n_tiles) { // a frame on its own is launched with a workgroup per tile: one dependent trip to memory
-        if (blockIdx.x < (unsigned int)P.n_tiles) mlm_tile_one(P, F, blockIdx.x); // (the list) less; empty tiles' workgroups cost a lone frame nothing
-        return;
-    }
-    // (the first list entry is requested together with the list's length; a stale entry is not used)
-    const unsigned int tile_first = blockIdx.x < (unsigned int)P.n_tiles ? mlm_gp(P.tile_list)[blockIdx.x] : 0u;
-    const unsigned int n_touched = min(mlm_gp(P.ctr)->mvox_cnt[2][0], (unsigned int)P.n_tiles);
-    for (unsigned int t = blockIdx.x; t < n_touched; t += gridDim.x) { // (uniform)
-        if (t != blockIdx.x) __syncthreads();                         // (the previous tile's shared state is no longer read)
-        mlm_tile_one(P, F, t == blockIdx.x ? tile_first : mlm_gp(P.tile_list)[t]);
+    __shared__ uint32_t s_cand[MLM_TILE_THREADS];
+    const uint32_t TW = P.tile_words, KC = (uint32_t)MLM_TILE_THREADS / TW, nt = (uint32_t)P.n_tiles; // candidates per round
+    for (uint32_t k0 = 0; blockIdx.x + k0 * gridDim.x < nt; k0 += KC) { // (uniform)
+        if (k0) __syncthreads(); // (the previous round's masks are no longer read)
+        {
+            const uint32_t k = threadIdx.x / TW, w = threadIdx.x - k * TW;
+            const unsigned long long tile = blockIdx.x + (unsigned long long)(k0 + k) * gridDim.x;
+            s_cand[threadIdx.x] = (k < KC && tile < nt) ? mlm_gp(P.tile_cols)[(size_t)tile * TW + w] : 0u;
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < KC; ++k) {
+            const unsigned long long tile = blockIdx.x + (unsigned long long)(k0 + k) * gridDim.x;
+            if (tile >= nt) break;
+            uint32_t any = 0;
+            for (uint32_t w = 0; w < TW; ++w) any |= s_cand[k * TW + w];
+            if (!any) continue; // (uniform: every thread reads the same words)
+            mlm_tile_one(P, F, (unsigned int)tile, s_cand + k * TW);
+            __syncthreads(); // (the tile's shared state is no longer read)
+        }
     }
 }
 
 // One voxel record applied to the voxel's state (L, o): its hits in the reference's iteration order (descending key,
 // map_local.cpp:157-171), then its misses (map_local.cpp:188-203).  hits: the frame's vr_hit; xkeys: exact keys of a replayed
 // frame (by hit-list position), else null.
-__device__ __forceinline__ void mlm_apply_record(const MlmDev &P0, const mlm_u32x4 &r0, const mlm_u32x4 &r1, const MLM_GLOBAL MlmVoxHit *hits,
+__device__ __forceinline__ void mlm_apply_record(const MlmDev &P0, const mlm_u32x4 &r, const MLM_GLOBAL MlmVoxHit *hits,
                                                  const MLM_GLOBAL unsigned long long *xkeys, float &L, uint8_t &o) {
     const float lo_max = P0.lo_max, lo_sh = P0.lo_sh;
-    const uint32_t km = r0.w & 0xFFFFu, nh = r1.y, first = r1.w;
+    const uint32_t km = r.y & 0xFFFFu, nh = r.w, first = r.z;
     auto hit = [&](float inc) { // map_local.cpp:157-171
         if (L < lo_max) {
             L = L + inc;
@@ -1867,7 +1968,7 @@ __device__ __forceinline__ void mlm_apply_record(const MlmDev &P0, const mlm_u32
         if (L > lo_sh && o != 'o') o = 'o';
     };
     if (nh == 1u) { // the common case: a single contribution
-        hit(__uint_as_float(r1.z));
+        hit(__uint_as_float(r.z));
     } else if (nh) {
         // (key, increment) of all its hits, next to each other in vr_hit, ordered in registers by descending key (the
         // reference's iteration order); a replayed frame's exact keys come from hl_key
@@ -1960,7 +2061,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
     const int lane = threadIdx.x & 63;
     const MlmDev &P0 = slot_tab[slot_base];
     const int sh = P0.tile_sh, lv_nz = P0.lv_nz;
-    const uint32_t cells = (uint32_t)P0.cells;
     MLM_GLOBAL float *const pool_L = mlm_gp(P0.log_odds); // (the pool is the same in every slot)
     MLM_GLOBAL uint8_t *const pool_o = mlm_gp(P0.occ);
     // the batch's box of world tiles (every workgroup derives it from the frames' grid origins: no launch argument changes from
@@ -2038,7 +2138,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
     // The records of the next frame that has any for this tile are fetched while the current frame is applied (they do not depend
     // on the map).  Two records per thread are held in registers; a tile with more takes the rest straight from memory.
     constexpr int PRE = 2;
-    mlm_u32x4 n0[PRE], n1[PRE];
+    mlm_u32x4 nx[PRE];
     auto next_frame = [&](int f) {
         while (f < f_stop && s_count[f] == 0u) ++f;
         return f;
@@ -2050,10 +2150,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
             const uint32_t i = threadIdx.x + (uint32_t)k * blockDim.x;
-            if (i < count) {
-                n0[k] = recs[2 * (size_t)i];
-                n1[k] = recs[2 * (size_t)i + 1];
-            }
+            if (i < count) nx[k] = recs[i];
         }
     };
     int f = next_frame(f_begin);
@@ -2064,30 +2161,22 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
         const MLM_GLOBAL MlmVoxHit *hits = mlm_gp(s_hit[f]);
         const MLM_GLOBAL unsigned long long *xkeys = mlm_gp(s_key[f]); // exact keys of a replayed frame, else null
         const uint32_t dz = (uint32_t)s_dz[f];
-        mlm_u32x4 c0[PRE], c1[PRE];
+        mlm_u32x4 cur[PRE];
 #pragma unroll
-        for (int k = 0; k < PRE; ++k) {
-            c0[k] = n0[k];
-            c1[k] = n1[k];
-        }
+        for (int k = 0; k < PRE; ++k) cur[k] = nx[k];
         const int f_next = next_frame(f + 1);
         prefetch(f_next);
-        // a thread's records in chunks of four: the records of a chunk are loaded together (the first two came with the
-        // previous frame), then the voxels that are not in LDS yet are fetched together, then the chunk is applied — the
-        // round trips of a chunk overlap instead of following each other
+        // a thread's records in chunks of U: the records of a chunk are loaded together (the first two came with the previous
+        // frame), then the voxels that are not in LDS yet are fetched together, then the chunk is applied — the round trips of
+        // a chunk overlap instead of following each other
         constexpr int U = MLM_APPLY_U;
         for (uint32_t i0 = threadIdx.x, chunk = 0; i0 < count; i0 += blockDim.x * U, ++chunk) {
-            mlm_u32x4 r0[U], r1[U];
+            mlm_u32x4 r[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t i = i0 + (uint32_t)u * blockDim.x;
-                if (chunk == 0 && u < PRE) {
-                    r0[u] = c0[u];
-                    r1[u] = c1[u];
-                } else if (i < count) {
-                    r0[u] = recs[2 * (size_t)i];
-                    r1[u] = recs[2 * (size_t)i + 1];
-                }
+                if (chunk == 0 && u < PRE) r[u] = cur[u];
+                else if (i < count) r[u] = recs[i];
             }
             float Lv[U];
             uint8_t ov[U];
@@ -2099,12 +2188,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
                 Lv[u] = 0.0f;
                 ov[u] = 'u';
                 if (i >= count) continue;
-                const uint32_t vt = (r0[u].w >> 26) * NZ + ((r0[u].w >> 16) & 1023u) + dz; // (tile column, layer above the range's lowest origin)
-                const int slot = (int)r1[u].x;
-                if (slot < 0 || vt >= NV) continue; // (cannot happen: a frame whose blocks could not be created is not applied)
+                const uint32_t vt = (r[u].y >> 26) * NZ + ((r[u].y >> 16) & 1023u) + dz; // (tile column, layer above the range's lowest origin)
+                if ((int)r[u].x < 0 || vt >= NV) continue; // (cannot happen: a frame whose blocks could not be created is not applied)
                 vts[u] = vt;
                 if (s_at[vt] == MLM_NIL) { // first touch of the voxel in this batch (one record per voxel and frame: no other lane has it now)
-                    const uint32_t at = (uint32_t)slot * cells + r0[u].z; // (< 2^31: alloc_pool)
+                    const uint32_t at = r[u].x;
                     Lv[u] = pool_L[at];
                     ov[u] = pool_o[at];
                     s_at[vt] = at;
@@ -2119,7 +2207,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
                 if (vt == MLM_NIL) continue;
                 float L = Lv[u];
                 uint8_t o = ov[u];
-                mlm_apply_record(P0, r0[u], r1[u], hits, xkeys, L, o);
+                mlm_apply_record(P0, r[u], hits, xkeys, L, o);
                 s_L[vt] = L;
                 s_o[vt] = o;
             }
@@ -2148,11 +2236,8 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.vr_rec);
-    mlm_u32x4 r0 = mlm_u32x4{0u, 0u, 0u, 0u}, r1 = r0;
-    if (i0 < P.rec_cap) { // (before the count is known: the list's memory is there either way)
-        r0 = recs[2 * (size_t)i0];
-        r1 = recs[2 * (size_t)i0 + 1];
-    }
+    mlm_u32x4 r = mlm_u32x4{0u, 0u, 0u, 0u};
+    if (i0 < P.rec_cap) r = recs[i0]; // (before the count is known: the list's memory is there either way)
     const MLM_GLOBAL MlmCounters *c = mlm_gp(P.ctr);
     const uint32_t total = min(c->mvox_cnt[0][0], P.rec_cap);
     const bool ok = c->sector_overflow == 0u && c->pool_short == 0u && ((F.flags & MLM_FRAME_EXACT_KEYS) || c->u_hit <= F.rehash_thr);
@@ -2162,37 +2247,44 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS) {
         if (i0 == 0) atomicMin(&P.g->fail_frame, F.seq);
         return;
     }
-    const uint32_t cells = (uint32_t)P.cells;
     MLM_GLOBAL float *const pool_L = mlm_gp(P.log_odds);
     MLM_GLOBAL uint8_t *const pool_o = mlm_gp(P.occ);
     const MLM_GLOBAL MlmVoxHit *hits = mlm_gp(P.vr_hit);
     const MLM_GLOBAL unsigned long long *xkeys = (F.flags & MLM_FRAME_EXACT_KEYS) ? (const MLM_GLOBAL unsigned long long *)mlm_gp(P.hl_key) : nullptr;
     for (uint32_t i = i0; i < total; i += stride) {
-        if (i != i0) {
-            r0 = recs[2 * (size_t)i];
-            r1 = recs[2 * (size_t)i + 1];
-        }
-        if ((int)r1.x < 0) continue; // (no slot: cannot happen, such a frame is not applied)
-        const uint32_t at = r1.x * cells + r0.z; // (< 2^31: alloc_pool)
+        if (i != i0) r = recs[i];
+        if ((int)r.x < 0) continue; // (no block: cannot happen, such a frame is not applied)
+        const uint32_t at = r.x;
         float L = pool_L[at];
         uint8_t o = pool_o[at];
-        mlm_apply_record(P, r0, r1, hits, xkeys, L, o);
+        mlm_apply_record(P, r, hits, xkeys, L, o);
         pool_L[at] = L;
         pool_o[at] = o;
     }
 }
 
 // After the host has grown the block pool: the blocks a frame's voxel records still lack (k_tile found the pool full) are created
-// and their slots filled in; pool_short is cleared if every one fitted.
-__global__ __launch_bounds__(MLM_BLOCK) void k_alloc_retry(const MlmDev P) {
-    const unsigned int n = min(mlm_gp(P.ctr)->mvox_cnt[0][0], P.rec_cap);
+// and the records' pool addresses filled in; pool_short is cleared if every one fitted.  A record carries no block key: its
+// block and cell follow from its tile and voxel-in-tile index exactly as in k_tile (one workgroup walks the tiles in turns).
+__global__ __launch_bounds__(MLM_BLOCK) void k_alloc_retry(const MlmDev P, const MlmFrame F) {
     bool failed = false;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + i;
-        if (rec->slot >= 0) continue;
-        const int slot = mlm_block_slot(P, rec->bkey);
-        if (slot >= 0) rec->slot = slot;
-        else failed = true;
+    const uint32_t edge = 1u << P.tile_sh;
+    for (unsigned int tile = blockIdx.x; tile < (unsigned int)P.n_tiles; tile += gridDim.x) {
+        const mlm_u32x4 dir = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_dir) + 4 * (size_t)tile);
+        if (dir.z != (uint32_t)F.seq) continue; // (the tile has no records of this frame)
+        const int ty = (int)(tile / (unsigned int)P.n_tx), tx = (int)tile - ty * P.n_tx;
+        const int X0 = (tx << P.tile_sh) + F.lv_o[0], Y0 = (ty << P.tile_sh) + F.lv_o[1], Z0 = F.lv_o[2];
+        for (unsigned int i = threadIdx.x; i < dir.y; i += blockDim.x) {
+            MLM_GLOBAL MlmVoxRec *rec = mlm_gp(P.vr_rec) + dir.x + i;
+            if (rec->at >= 0) continue;
+            const uint32_t vt = rec->km_vt >> 16, vxy = vt >> 10, zz = vt & 1023u;
+            const int X = X0 + (int)(vxy & (edge - 1u)), Y = Y0 + (int)(vxy >> P.tile_sh), Z = Z0 + (int)zz;
+            const int gx = mlm_floor_div(X, P.n), gy = mlm_floor_div(Y, P.n), gz = mlm_floor_div(Z, P.n);
+            const int cid = ((Z - gz * P.n) * P.n + (Y - gy * P.n)) * P.n + (X - gx * P.n);
+            const int slot = mlm_block_slot(P, mlm_pack_key(gx, gy, gz));
+            if (slot >= 0) rec->at = slot * P.cells + cid;
+            else failed = true;
+        }
     }
     if (__any(failed) && (threadIdx.x & 63) == 0) mlm_gp(P.ctr)->pool_short = 2u; // (2: still short after this pass)
 }

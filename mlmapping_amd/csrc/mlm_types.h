@@ -30,7 +30,7 @@ struct MlmCounters {
                                  // [k][1] = device-scope atomics the frame's kernels issued (sector path, counted by k_sector)
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
     unsigned int mvox_cnt[8][32];  // cell-table path: [k][0] = voxels touched by misses, sub-list k; sector path: [0][0] voxel records,
-                                   // [1][0] entries of vr_hit, [2][0] touched tiles (tile_list), [3][0] miss cells reserved in mc_list
+                                   // [1][0] entries of vr_hit, [3][0] unique miss cells of the frame
     unsigned int umiss_part[8][32];// [k][0] = partial count of unique miss cells
     unsigned int node_cnt[8][32];  // [k][0] = contribution nodes allocated in region k
     unsigned int mc_cnt[8][32];    // [k][0] = unique miss cells queued in sub-list k
@@ -82,15 +82,15 @@ struct MlmCell {
 };
 
 // One voxel a frame touches (sector path, written by k_tile): everything the kernel that applies the frame needs comes with
-// one 32-byte load.  (map_local.cpp:147-207: the voxel's hits in container order, then its misses.)
+// one 16-byte load.  (map_local.cpp:147-207: the voxel's hits in container order, then its misses.)  The voxel's block key and
+// cell id are not stored: k_tile has created the block, so the record carries the voxel's ADDRESS in the pool; where the pool was
+// full (at = -1) k_alloc_retry recomputes block and cell from the tile and `vt` after the host has grown the pool.
 struct MlmVoxRec {
-    unsigned long long bkey; // packed block key of the voxel's block
-    uint32_t cid;            // cell id inside the block
-    uint32_t n_miss;         // unique miss cells of the frame that fall into the voxel
-    int32_t slot;            // the block's pool slot if it existed when k_tile looked, else -1
+    int32_t at;              // slot * cells + cell id of the voxel in the block pool; -1: its block could not be created yet
+    uint32_t km_vt;          // unique miss cells of the frame that fall into the voxel (low 16 bits) | voxel in its tile (column << 10 | layer) << 16
+    uint32_t inc_first;      // n_hit == 1: float bits of that hit's log-odds increment (its order is irrelevant);
+                             // n_hit >= 2: first of its n_hit entries in MlmDev::vr_hit
     uint32_t n_hit;          // unique hit cells that fall into it
-    float inc0;              // n_hit == 1: that hit's log-odds increment (its order is irrelevant)
-    uint32_t first;          // n_hit == 1: the hit's index in hl_*; n_hit >= 2: first of its n_hit entries in MlmDev::vr_hit
 };
 // One hit of a voxel with several: increment, iteration-order key (k_rank's speculative one; on a replayed frame hl_key[pos]
 // holds the exact key instead)
@@ -214,8 +214,8 @@ struct MlmDev {
     unsigned int sec_tab_big, sec_big_lds_bytes; // ... of k_sector_big (0 entries: no second pass)
     uint32_t *ov_list;         // [nPhi] columns whose cell table overflowed in k_sector (count: MlmCounters::n_ov)
     unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
-    uint32_t *refs;            // [refs_cap][2] {position (row << 11 | column) of the row's first lane, row byte | kind << 8} per non-empty
-                               // row of the lane mask of every contribution group of a multi-kind cell
+    uint32_t *refs;            // [refs_cap] one 4-byte reference (mlm_ref_pack: row byte, kind, position relative to the cell's first pixel) per
+                               // non-empty row of the lane mask of every contribution group of a multi-kind cell
     unsigned int refs_cap;
     uint32_t *mt_ref;          // [nCells][2] per multi-kind cell: {start in `refs`, count of its references}
     // Frame-local voxel grid: the voxels the awareness cylinder can reach, addressed relative to MlmFrame::lv_o and cut into
@@ -226,15 +226,16 @@ struct MlmDev {
     // touched voxel, and the kernel that applies the frame reads those records.  No per-cell global atomic anywhere.
     int lv_nx, lv_ny, lv_nz;
     int tile_sh, n_tx, n_tiles;        // tile edge 2^tile_sh voxels; tiles per grid row; tiles per frame
-    uint16_t *mc_list;         // [mc_list_cap] the frame's unique miss cells as voxel-in-tile indices
+    uint16_t *mc_list;         // [nPhi][nRho * nZ] the frame's unique miss cells as voxel-in-tile indices, every column in a stretch of its own;
                                // vt = ((y & m) << tile_sh | (x & m)) * lv_nz + z; a column's cells are contiguous, ordered by tile
     unsigned int mc_list_cap;
     uint16_t *hl_vt16;         // [nCells] vt of every unique hit (a column's hits are contiguous in hl_*, ordered by tile)
-    unsigned int *tile_cnt;    // [n_tiles] descriptors handed to each tile this frame (reset by k_tile)
     unsigned int tile_combos;  // most blocks a tile of the frame-local grid overlaps (k_tile keeps their pool slots in LDS), multiple of 4
-    unsigned int *tile_list;   // [n_tiles] the tiles that received descriptors this frame (count: ctr->mvox_cnt[2][0])
-    uint32_t *tile_desc;       // [n_tiles][tile_desc_cap][4] {first miss cell in mc_list, count, first hit in hl_*, count}
-    unsigned int tile_desc_cap;
+    uint32_t *tile_cols;       // [n_tiles][tile_words] column mask of each tile: bit phi = column phi left a descriptor this frame (set by
+                               // k_sector with a fire-and-forget atomic, read and cleared by k_tile)
+    unsigned int tile_words;   // ceil(nPhi / 32)
+    uint32_t *tile_desc;       // [n_tiles][nPhi][4] slot [tile][phi] = {first miss cell in mc_list, count, first hit in hl_*, count} of
+                               // column phi's run through the tile (a column's ray crosses a tile once)
     MlmVoxRec *vr_rec;         // [rec_cap] one record per voxel the frame touches (count: MlmCounters::mvox_cnt[0][0])
     unsigned int rec_cap;
     MlmVoxHit *vr_hit;         // [nCells] the hits of voxels with two or more, a voxel's hits contiguous (count: mvox_cnt[1][0])

@@ -44,6 +44,30 @@ struct KernelTime {
     hipEvent_t a, b;
 };
 
+// Test and experiment knobs (mlm_debug_set): named integers that mlm_create reads — launch geometries, forced fall-backs,
+// simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
+// for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
+const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "bin_strips", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
+                                  "debug_fail_slot", "expand_block", "graph", "graph_copies", "lean_slots", "logit_exact", "node_lds", "pool_grow",
+                                  "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
+                                  "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
+struct KnobStore {
+    std::mutex mu;
+    std::unordered_map<std::string, long long> v;
+};
+KnobStore &knob_store() {
+    static KnobStore k;
+    return k;
+}
+bool knob(const char *name, long long &out) {
+    KnobStore &k = knob_store();
+    std::lock_guard<std::mutex> lock(k.mu);
+    auto it = k.v.find(name);
+    if (it == k.v.end()) return false;
+    out = it->second;
+    return true;
+}
+
 } // namespace
 
 // One frame in flight: private awareness scratch + unique-hit list, its own stream for Stage A.
@@ -194,6 +218,7 @@ struct mlm_handle {
     int32_t *h_stage = nullptr;  // pinned staging of the callback's sampled pixels (indices, then raw depths)
     size_t stage_cap = 0;
     long long n_pool_grows = 0;
+    int bin_strips = 1;          // strips per k_bin_sectors workgroup for the dense frames of a batch (MLM_BIN_STRIPS=2|4: experiments)
     size_t grow_failed_at = 0;   // a pool of this many blocks did not fit the device (grow_pool does not retry it)
     MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
     MlmPair *fb_pairs = nullptr;
@@ -499,12 +524,18 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
             h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
             return MLM_ERR_CAPACITY;
         }
-        if (mode == 0)
-            tlaunch(h, "k_bin_sectors", k_bin_sectors<0>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+        // (one strip per workgroup: two or four strips worked on together are 5 % quicker with nothing else on the GPU — 3.22 -> 3.06
+        // us per frame — and cost the pipeline 6 %: 91.0 -> 85.3 k frames/s, profiles/r4b; MLM_BIN_STRIPS selects them for experiments)
+        if (mode == 0 && n > 1 && h->bin_strips == 4)
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<0, 4>, dim3((nb + 3) / 4, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+        else if (mode == 0 && n > 1 && h->bin_strips == 2)
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<0, 2>, dim3((nb + 1) / 2, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+        else if (mode == 0)
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<0, 1>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
         else if (mode == 1)
-            tlaunch(h, "k_bin_sectors", k_bin_sectors<1>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<1, 1>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
         else
-            tlaunch(h, "k_bin_sectors", k_bin_sectors<2>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            tlaunch(h, "k_bin_sectors", k_bin_sectors<2, 1>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
     }
     {
         const int row_w = mode == 0 ? F.width : 64; // rows of the ranking bitmap
@@ -520,23 +551,23 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         const int nt = (n == 1 && P.sec_tab >= 512u) ? 512 : h->sec_threads;
         if (P.explore && nt == 256)
             tlaunch(h, "k_sector", k_sector<true, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
-                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big, dm, ds);
         else if (P.explore)
             tlaunch(h, "k_sector", k_sector<true, 512>, dim3((unsigned int)P.nPhi, 1, n), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab,
-                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big);
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, big, dm, ds);
         else if (nt == 256)
             tlaunch(h, "k_sector", k_sector<false, 256>, dim3((unsigned int)P.nPhi, 1, n), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab,
-                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
         else
             tlaunch(h, "k_sector", k_sector<false, 512>, dim3((unsigned int)P.nPhi, 1, n), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab,
-                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+                    h->d_frame_tab, base, mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
         if (big) { // the columns whose cell table overflowed, with the large table (a few workgroups per frame walk the list)
             if (P.explore)
                 tlaunch(h, "k_sector_big", k_sector_big<true>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, n,
-                        mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull);
+                        mode == 0 ? F.width : 0, (int)nb, rm, rs, 1ull, dm, ds);
             else
                 tlaunch(h, "k_sector_big", k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, n,
-                        mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
+                        mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
         }
         tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->rank_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
                 mode == 0 ? F.width : 0, row_w, dm, ds);
@@ -893,7 +924,7 @@ int fix_pool_short(mlm_handle *h, MlmSlot &R) {
             const int rc = grow_pool(h, (size_t)h->P.max_blocks + 2 * h->frame_block_bound);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(k_alloc_retry, dim3(256), dim3(MLM_BLOCK), 0, h->stream, R.P);
+        hipLaunchKernelGGL(k_alloc_retry, dim3(256), dim3(MLM_BLOCK), 0, h->stream, R.P, R.F);
         hipLaunchKernelGGL(k_alloc_retry_done, dim3(1), dim3(64), 0, h->stream, R.P);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
@@ -909,7 +940,8 @@ int submit_batch(mlm_handle *h, int base, int n) {
     }
     const int set = base / (h->lim.max_batch);
     int rc;
-    // (the sector path packs a tile's image column into 11 bits; its bucket-first tables hold sbkt_cap buckets)
+    // (the sector path packs a tile's image column into 8 bits of a reference: images up to 2040 pixels wide; its bucket-first
+    // tables hold sbkt_cap buckets)
     const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040 &&
                          h->hit_n_bkt <= h->slots[(size_t)base].P.sbkt_cap;
     if (h->sector_backoff > 0) --h->sector_backoff;
@@ -1170,7 +1202,7 @@ void clear_device_error(mlm_handle *h) {
 void wipe_frame_grids(mlm_handle *h) {
     if (!h->use_sectors) return;
     for (auto &S : h->slots) {
-        if (S.P.tile_cnt) hipMemsetAsync(S.P.tile_cnt, 0, (size_t)S.P.n_tiles * sizeof(unsigned int), h->stream);
+        if (S.P.tile_cols) hipMemsetAsync(S.P.tile_cols, 0, (size_t)S.P.n_tiles * S.P.tile_words * sizeof(uint32_t), h->stream);
         if (S.P.col_cnt) hipMemsetAsync(S.P.col_cnt, 0, (size_t)S.P.nPhi * sizeof(unsigned int), h->stream);
     }
     hipStreamSynchronize(h->stream);
@@ -1225,9 +1257,9 @@ int submit_single_graph(mlm_handle *h, int base) {
             hipLaunchKernelGGL(k_frame_prologue, dim3(1), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
         }
         if (e == hipSuccess) {
-            if (S.mode == 0) hipLaunchKernelGGL(k_bin_sectors<0>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
-            else if (S.mode == 1) hipLaunchKernelGGL(k_bin_sectors<1>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
-            else hipLaunchKernelGGL(k_bin_sectors<2>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+            if (S.mode == 0) hipLaunchKernelGGL((k_bin_sectors<0, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+            else if (S.mode == 1) hipLaunchKernelGGL((k_bin_sectors<1, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+            else hipLaunchKernelGGL((k_bin_sectors<2, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
             const int row_w = S.mode == 0 ? S.F.width : 64;
             unsigned long long dm, rm;
             int ds, rs;
@@ -1236,13 +1268,13 @@ int submit_single_graph(mlm_handle *h, int base) {
             // (a single frame is alone on the GPU: the 512-thread workgroup finishes a column sooner; the table is the same)
             if (h->sec_threads == 256 && P.sec_tab < 512u)
                 hipLaunchKernelGGL((k_sector<false, 256>), dim3((unsigned int)P.nPhi, 1, 1), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
             else
                 hipLaunchKernelGGL((k_sector<false, 512>), dim3((unsigned int)P.nPhi, 1, 1), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big);
+                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
             if (big)
                 hipLaunchKernelGGL(k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1,
-                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt);
+                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
             hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
             hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
             hipLaunchKernelGGL(k_tile, dim3((unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
@@ -1702,8 +1734,8 @@ int ensure_free_blocks(mlm_handle *h, size_t need) {
 
 int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float> &sigma3) {
     if (!h->lean) // (test hook: the full slots "do not fit" from slot k on, so that the lean retry of mlm_create runs)
-        if (const char *e = getenv("MLM_DEBUG_FAIL_SLOT"))
-            if ((long long)index >= atoll(e)) {
+        if (long long kv; knob("debug_fail_slot", kv))
+            if ((long long)index >= kv) {
                 h->err = "simulated allocation failure (MLM_DEBUG_FAIL_SLOT)";
                 return MLM_ERR_HIP;
             }
@@ -1771,10 +1803,9 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         P.mc_list_cap = (unsigned int)NC; // unique miss cells of a frame
         if ((rc = dev_alloc(h, &P.mc_list, (size_t)P.mc_list_cap + 8))) return rc;
         if ((rc = dev_alloc(h, &P.hl_vt16, NC + 8))) return rc;
-        if ((rc = dev_alloc(h, &P.tile_cnt, (size_t)P.n_tiles))) return rc;
-        HIPCHK(h, hipMemset(P.tile_cnt, 0, (size_t)P.n_tiles * sizeof(unsigned int)));
-        if ((rc = dev_alloc(h, &P.tile_list, (size_t)P.n_tiles))) return rc;
-        if ((rc = dev_alloc(h, &P.tile_desc, 4 * (size_t)P.n_tiles * P.tile_desc_cap))) return rc;
+        if ((rc = dev_alloc(h, &P.tile_cols, (size_t)P.n_tiles * P.tile_words))) return rc;
+        HIPCHK(h, hipMemset(P.tile_cols, 0, (size_t)P.n_tiles * P.tile_words * sizeof(uint32_t)));
+        if ((rc = dev_alloc(h, &P.tile_desc, 4 * (size_t)P.n_tiles * (size_t)P.nPhi))) return rc;
         // a frame touches at most one voxel per awareness cell, and no more voxels than its grid has
         P.rec_cap = (unsigned int)std::min<size_t>(NC, (size_t)P.lv_nx * P.lv_ny * P.lv_nz);
         if ((rc = dev_alloc(h, &P.vr_rec, (size_t)P.rec_cap))) return rc;
@@ -1788,7 +1819,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         HIPCHK(h, hipMemset(P.sbkt, 0xFF, (size_t)P.sbkt_cap * sizeof(unsigned long long)));
     }
     P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, max_contrib); // (a reference — one row of a group's lane mask — stands for at least one contribution)
-    if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? 2 * (size_t)P.refs_cap : 4))) return rc;
+    if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? (size_t)P.refs_cap : 4))) return rc;
     if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
     HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
     if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
@@ -1846,6 +1877,41 @@ extern "C" {
 
 int mlm_abi_version(void) { return MLM_ABI_VERSION; }
 
+int mlm_debug_set(const char *name, long long value) {
+    if (!name) return MLM_ERR_INVALID;
+    bool known = false;
+    for (const char *k : kKnobNames) known = known || strcmp(k, name) == 0;
+    if (!known) return MLM_ERR_INVALID;
+    KnobStore &k = knob_store();
+    std::lock_guard<std::mutex> lock(k.mu);
+    k.v[name] = value;
+    return MLM_OK;
+}
+int mlm_debug_reset(void) {
+    KnobStore &k = knob_store();
+    std::lock_guard<std::mutex> lock(k.mu);
+    k.v.clear();
+    return MLM_OK;
+}
+
+int mlm_host_register(mlm_handle *h, const void *ptr, size_t bytes) {
+    if (!h || !ptr || bytes == 0) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault));
+    return MLM_OK;
+}
+int mlm_host_unregister(mlm_handle *h, const void *ptr) {
+    if (!h || !ptr) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = drain(h); // (nothing may still be reading from it)
+    if (rc) return rc;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipHostUnregister(const_cast<void *>(ptr)));
+    return MLM_OK;
+}
+
 const char *mlm_last_error(mlm_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_handle **out) {
@@ -1856,6 +1922,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         return MLM_ERR_INVALID;
     mlm_handle *h = new mlm_handle();
     *out = h; // returned even on failure so that mlm_last_error can be read; caller must mlm_destroy it
+    long long kv = 0; // (value of a test / experiment knob, see mlm_debug_set)
     h->device = device;
     h->cfg = *cfg;
     if (lim_in) h->lim = *lim_in;
@@ -1881,21 +1948,20 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // leaves the rest to Stage A, so that the chain is not stretched by queueing behind Stage A's waves.
         int lo = 0, hi = 0; // numerically lower = higher priority
         HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        if (const char *e = getenv("MLM_EXPAND_BLOCK")) h->expand_block = (unsigned int)std::max(64, atoi(e));
-        if (const char *e = getenv("MLM_SORT_BLOCK")) h->sort_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
-        if (const char *e = getenv("MLM_SORT_GRID")) h->sort_grid = (unsigned int)std::max(1, atoi(e));
-        if (const char *e = getenv("MLM_CHAIN_GRID")) h->chain_grid = (unsigned int)std::max(1, atoi(e));
-        if (const char *e = getenv("MLM_RANK_GRID")) h->rank_grid = (unsigned int)std::max(1, atoi(e));
-        if (const char *e = getenv("MLM_COLLECT_GRID")) h->collect_grid = (unsigned int)std::max(1, atoi(e));
-        if (const char *e = getenv("MLM_SC_BLOCK")) h->sc_block = (unsigned int)std::min(256, std::max(64, atoi(e)));
-        if (const char *e = getenv("MLM_SC_GRID")) {
-            h->sc_grid = (unsigned int)std::max(1, atoi(e));
+        if (knob("expand_block", kv)) h->expand_block = (unsigned int)std::max(64, (int)kv);
+        if (knob("sort_block", kv)) h->sort_block = (unsigned int)std::min(256, std::max(64, (int)kv));
+        if (knob("sort_grid", kv)) h->sort_grid = (unsigned int)std::max(1, (int)kv);
+        if (knob("chain_grid", kv)) h->chain_grid = (unsigned int)std::max(1, (int)kv);
+        if (knob("rank_grid", kv)) h->rank_grid = (unsigned int)std::max(1, (int)kv);
+        if (knob("collect_grid", kv)) h->collect_grid = (unsigned int)std::max(1, (int)kv);
+        if (knob("sc_block", kv)) h->sc_block = (unsigned int)std::min(256, std::max(64, (int)kv));
+        if (knob("sc_grid", kv)) {
+            h->sc_grid = (unsigned int)std::max(1, (int)kv);
             h->sc_grid_fixed = true;
         }
-        const char *env = getenv("MLM_CU_SPLIT");
-        h->cu_split = env ? atoi(env) : 0;
+        h->cu_split = knob("cu_split", kv) ? (int)kv : 0;
         // MLM_CU_RESERVE=k: Stage A stays off the first k CUs, the main stream may use all of them
-        if (const char *e = getenv("MLM_CU_RESERVE")) h->cu_reserve = std::max(0, atoi(e));
+        if (knob("cu_reserve", kv)) h->cu_reserve = std::max(0, (int)kv);
         hipDeviceProp_t prop;
         HIPCHK(h, hipGetDeviceProperties(&prop, device));
         const int ncu = prop.multiProcessorCount;
@@ -1985,7 +2051,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         std::vector<float> ratios(h->odds_table.size());
         for (size_t i = 0; i < ratios.size(); ++i) ratios[i] = h->odds_table[i] / (1 - h->odds_table[i]);
         P.logit_exact = host_log10f_matches(ratios.data(), ratios.size()) ? 1 : 0;
-        if (const char *e = getenv("MLM_LOGIT_EXACT")) P.logit_exact = P.logit_exact && atoi(e) != 0;
+        if (knob("logit_exact", kv)) P.logit_exact = P.logit_exact && (int)kv != 0;
     }
     {
         // a point spreads into 1 + 2*dmax cells; the wider the spread, the more groups and distinct cells a block produces
@@ -2001,11 +2067,11 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         }
         // block size of k_bin_points and its LDS buffers (the sizes above are per 256 threads); experiment knobs
         P.bin_block = 256; // measured on config 2: 34.4k frames/s vs 33.6k with 512 and 31.9k with 1024
-        if (const char *e = getenv("MLM_BIN_BLOCK")) P.bin_block = (atoi(e) >= 1024) ? 1024u : (atoi(e) >= 512 ? 512u : 256u);
+        if (knob("bin_block", kv)) P.bin_block = ((int)kv >= 1024) ? 1024u : ((int)kv >= 512 ? 512u : 256u);
         P.node_lds = P.node_lds * (P.bin_block / 256);
         P.agg_lds = P.agg_lds * (P.bin_block / 256);
-        if (const char *e = getenv("MLM_NODE_LDS")) P.node_lds = (unsigned int)atoi(e);
-        if (const char *e = getenv("MLM_AGG_LDS")) P.agg_lds = (unsigned int)atoi(e); // power of two >= bin_block
+        if (knob("node_lds", kv)) P.node_lds = (unsigned int)(int)kv;
+        if (knob("agg_lds", kv)) P.agg_lds = (unsigned int)(int)kv; // power of two >= bin_block
         unsigned int lg = 0;
         while ((1u << lg) < P.agg_lds) ++lg;
         P.agg_shift = 32 - lg;
@@ -2029,23 +2095,23 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         // ~220 on config 2's 65 steps, ~1 000 on config 3's 130 — hence 6 entries per step for coarse maps, 12 for fine ones)
         unsigned int tab = 512;
         while (tab < (P.nRho > 100 ? 12u : 6u) * (unsigned int)P.nRho && tab < 2048u) tab <<= 1;
-        if (const char *e = getenv("MLM_SEC_TAB")) tab = (unsigned int)std::max(256, atoi(e)); // power of two
+        if (knob("sec_tab", kv)) tab = (unsigned int)std::max(256, (int)kv); // power of two
         P.sec_tab = tab;
         // a column's workgroup: 256 threads where the table allows (at most 4 entries per thread, one thread per range step) — the
         // smaller workgroup and table leave wave slots and LDS of a CU to the other streams' kernels, which is worth more in the
         // pipeline (+5 % frames/s on config 2) than the 10 % the kernel loses alone
         h->sec_threads = (tab <= 1024u && P.nRho <= 256) ? 256 : 512;
-        if (const char *e = getenv("MLM_SEC_THREADS")) h->sec_threads = (atoi(e) <= 256 && tab <= 1024u && P.nRho <= 256) ? 256 : 512;
+        if (knob("sec_threads", kv)) h->sec_threads = ((int)kv <= 256 && tab <= 1024u && P.nRho <= 256) ? 256 : 512;
         if (P.sec_tab < (unsigned int)h->sec_threads) P.sec_tab = (unsigned int)h->sec_threads;
-        if (const char *e = getenv("MLM_SEC_BACKOFF")) h->sector_backoff_len = std::max(0, atoi(e));
-        if (const char *e = getenv("MLM_SEC_FAIL_EVERY")) P.sec_fail_every = (unsigned int)std::max(0, atoi(e));
+        if (knob("sec_backoff", kv)) h->sector_backoff_len = std::max(0, (int)kv);
+        if (knob("sec_fail_every", kv)) P.sec_fail_every = (unsigned int)std::max(0, (int)kv);
         P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
         {
             // second pass for the columns that overflow that table: the largest table (up to 4096 entries = 8 per thread) that
             // fits a CU's LDS — an S1 column has 2 665 cells in all, so no scene overflows it there
             unsigned int big = 4096;
             while (big > P.sec_tab && mlm_sec_lds(big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total > 159u * 1024u) big >>= 1;
-            if (const char *e = getenv("MLM_SEC_TAB_BIG")) big = (unsigned int)atoi(e); // (0 or <= MLM_SEC_TAB: no second pass)
+            if (knob("sec_tab_big", kv)) big = (unsigned int)(int)kv; // (0 or <= MLM_SEC_TAB: no second pass)
             P.sec_tab_big = big > P.sec_tab && big <= 8u * MLM_SEC_THREADS ? big : 0u;
             P.sec_big_lds_bytes = P.sec_tab_big ? mlm_sec_lds(P.sec_tab_big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total : 0u;
         }
@@ -2060,16 +2126,16 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             P.lv_nz = (int)std::ceil(P.nZ * P.dZ / P.d_sub) + 10;
             P.tile_sh = 3;
             while (P.tile_sh > 0 && ((size_t)P.lv_nz << (2 * P.tile_sh)) > 4096) --P.tile_sh;
-            if (const char *e = getenv("MLM_TILE_SH")) P.tile_sh = std::min(3, std::max(0, atoi(e)));
+            if (knob("tile_sh", kv)) P.tile_sh = std::min(3, std::max(0, (int)kv));
             const int edge = 1 << P.tile_sh;
             P.lv_nx += edge; // (the grid's origin is snapped down to a tile boundary: frame_setup)
             P.lv_ny += edge;
             P.n_tx = (P.lv_nx + edge - 1) / edge;
             P.n_tiles = P.n_tx * ((P.lv_ny + edge - 1) / edge);
-            P.tile_desc_cap = (unsigned int)P.nPhi + 64u; // a column's ray crosses a tile once: one descriptor per (column, tile)
-            // (a camera frame reaches about a quarter of its grid's tiles; more touched tiles than workgroups are walked in turns)
+            P.tile_words = (unsigned int)(P.nPhi + 31) / 32u; // a column's ray crosses a tile once: one descriptor slot per (tile, column)
+            // (a camera frame reaches about a quarter of its grid's tiles: a workgroup takes three candidate tiles, most of them empty)
             h->tile_grid = (unsigned int)std::max(32, std::min(P.n_tiles, P.n_tiles / 3 + 1));
-            if (const char *e = getenv("MLM_TILE_GRID")) h->tile_grid = (unsigned int)std::max(1, std::min(P.n_tiles, atoi(e)));
+            if (knob("tile_grid", kv)) h->tile_grid = (unsigned int)std::max(1, std::min(P.n_tiles, (int)kv));
             {   // blocks a tile overlaps: an extent of e voxels starting anywhere touches at most (e - 1) / n + 2 blocks of n
                 const long long cx = (edge - 1) / P.n + 2, cz = (P.lv_nz - 1) / P.n + 2;
                 P.tile_combos = (unsigned int)std::min<long long>((cx * cx * cz + 3) & ~3ll, 1ll << 20);
@@ -2084,16 +2150,17 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
                          P.sec_tab <= 4u * (unsigned int)h->sec_threads && (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
                          P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
+                         P.nPhi <= 32 * MLM_TILE_WORDS /* k_tile: a tile's column mask */ &&
                          (P.explore ? P.nRho <= 256
                                     : (((size_t)P.lv_nz << (2 * P.tile_sh)) <= 65536 && h->tile_lds_bytes <= 96u * 1024u && cells_per_voxel < 65536.0 &&
                                        P.n_tiles < (1 << 24) && P.lv_nz <= 1024 && h->apply_lds_bytes <= 150u * 1024u &&
                                        // (blocks one tile may overlap: their pool slots live in k_tile's LDS)
                                        P.tile_combos <= MLM_TILE_COMBOS));
-        if (const char *e = getenv("MLM_SECTORS")) h->use_sectors = h->use_sectors && atoi(e) != 0;
+        if (knob("sectors", kv)) h->use_sectors = h->use_sectors && (int)kv != 0;
         // (lean slots cost the worst-case scenes their batching — every frame overflowing its sector tables: 1.3k instead of
         // 4.4k frames/s on the "scatter" scene — so they are used on request, or when the full slots do not fit the device)
         h->lean = h->use_sectors;
-        if (const char *e = getenv("MLM_LEAN_SLOTS")) h->lean = h->use_sectors && atoi(e) != 0;
+        if (knob("lean_slots", kv)) h->lean = h->use_sectors && (int)kv != 0;
         if (getenv("MLM_DEBUG_CREATE"))
             fprintf(stderr, "[create] sector path %d: LDS %u bytes per column (table %u entries), frame-local grid %d x %d x %d in %d tiles of edge %d (%u bytes of LDS each)\n",
                     (int)h->use_sectors, P.sec_lds_bytes, P.sec_tab, P.lv_nx, P.lv_ny, P.lv_nz, P.n_tiles, 1 << P.tile_sh, h->tile_lds_bytes);
@@ -2165,11 +2232,12 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         auto nb = [&](int nv) { return (long long)(nv + P.n - 1) / P.n + 1; };
         const long long b = nb(P.lv_nx) * nb(P.lv_ny) * nb(P.lv_nz);
         h->frame_block_bound = (size_t)std::min<long long>(b, 1ll << 30);
-        if (const char *e = getenv("MLM_POOL_GROW")) h->pool_grow = atoi(e) != 0;
-        if (const char *e = getenv("MLM_GRAPH")) h->use_graph = atoi(e) != 0;
-        if (const char *e = getenv("MLM_BIG_GRID")) h->big_grid = (unsigned int)std::max(1, atoi(e));
-        if (const char *e = getenv("MLM_BIG_ARM")) h->big_arm_len = std::max(0, atoi(e));
-        if (const char *e = getenv("MLM_GRAPH_COPIES")) h->graph_copies = atoi(e);
+        if (knob("pool_grow", kv)) h->pool_grow = (int)kv != 0;
+        if (knob("graph", kv)) h->use_graph = (int)kv != 0;
+        if (knob("big_grid", kv)) h->big_grid = (unsigned int)std::max(1, (int)kv);
+        if (knob("big_arm", kv)) h->big_arm_len = std::max(0, (int)kv);
+        if (knob("graph_copies", kv)) h->graph_copies = (int)kv;
+        if (knob("bin_strips", kv)) h->bin_strips = (int)kv == 2 ? 2 : ((int)kv == 4 ? 4 : 1);
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
     std::memset(h->h_g, 0, sizeof(MlmGlobal));
@@ -2183,7 +2251,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     if ((rc = dev_alloc(h, (char **)&h->sort_tmp, h->sort_tmp_bytes))) return rc;
 
     // frame slots
-    if (const char *e = getenv("MLM_SLOT_SETS")) h->n_sets = std::min(MLM_SETS, std::max(2, atoi(e)));
+    if (knob("slot_sets", kv)) h->n_sets = std::min(MLM_SETS, std::max(2, (int)kv));
     size_t NS = (size_t)h->lim.max_batch * h->n_sets; // one set being filled while the others are in flight
     h->slots.resize(NS);
     if ((rc = dev_alloc(h, &h->d_ctr_all, NS))) return rc;

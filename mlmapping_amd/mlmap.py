@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
     "mlm_export_blocks", "mlm_export_block_flags", "mlm_export_frontier", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
     "mlm_get_awareness_hits",
     "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
-    "mlm_enable_kernel_timing", "mlm_set_timed_kernel",
+    "mlm_enable_kernel_timing", "mlm_set_timed_kernel", "mlm_host_register", "mlm_host_unregister", "mlm_debug_set", "mlm_debug_reset",
 ]
 
 
@@ -138,6 +138,16 @@ def load_library(path: Optional[str] = None):
     L.mlm_get_kernel_times.argtypes = [vp, i32, vp, vp, vp]
     L.mlm_enable_kernel_timing.argtypes = [vp, i32]
     L.mlm_set_timed_kernel.argtypes = [vp, ctypes.c_char_p, i32]
+    L.mlm_host_register.argtypes = [vp, vp, ctypes.c_size_t]
+    L.mlm_host_unregister.argtypes = [vp, vp]
+    L.mlm_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+    L.mlm_debug_reset.argtypes = []
+    if path is None and os.environ.get("MLM_KNOBS"):
+        # tooling convenience (tools/*.py, experiments): MLM_KNOBS="rank_grid=64,sec_tab=1024" -> mlm_debug_set before the first create
+        for kv in os.environ["MLM_KNOBS"].split(","):
+            k, _, v = kv.partition("=")
+            if k.strip() and L.mlm_debug_set(k.strip().encode(), int(v)) != MLM_OK:
+                raise MlmError(f"MLM_KNOBS: unknown knob {k.strip()!r}")
     if path is None:
         _lib = L
     return L
@@ -149,6 +159,16 @@ def _p(a: np.ndarray):
 
 def _f64(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def debug_set(name: str, value: int):
+    """Test / experiment knob read by the next mlm_create of this process (mlm_debug_set; not part of the drop-in contract)."""
+    if load_library().mlm_debug_set(name.encode(), int(value)) != MLM_OK:
+        raise MlmError(f"mlm_debug_set: unknown knob {name!r}")
+
+
+def debug_reset():
+    load_library().mlm_debug_reset()
 
 
 class MLMap:
@@ -193,6 +213,13 @@ class MLMap:
 
     def sync(self):
         self._chk(self._L.mlm_sync(self._h), "mlm_sync")
+
+    def host_register(self, arr: np.ndarray):
+        """Pin a host array the host-buffer entry points will be fed from (mlm_host_register)."""
+        self._chk(self._L.mlm_host_register(self._h, _p(arr), arr.nbytes), "mlm_host_register")
+
+    def host_unregister(self, arr: np.ndarray):
+        self._chk(self._L.mlm_host_unregister(self._h, _p(arr)), "mlm_host_unregister")
 
     def set_async(self, on: bool = True):
         """Integrate calls return after submission (two batches in flight); sync()/queries wait for everything."""

@@ -18,3 +18,16 @@ def oracle_lib():
 
     binding.build()
     return binding.lib()
+
+
+@pytest.fixture
+def knobs():
+    """Test / experiment knobs of the library (mlm_debug_set): read by the next mlm_create, forgotten again after the test."""
+    from mlmapping_amd import mlmap
+
+    class Knobs:
+        def set(self, name, value):
+            mlmap.debug_set(name, int(value))
+
+    yield Knobs()
+    mlmap.debug_reset()

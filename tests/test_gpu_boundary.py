@@ -159,7 +159,7 @@ def test_caller_stream_orders_device_inputs(mods):
 
 
 @pytest.mark.parametrize("explore", [False, True])
-def test_handle_survives_capacity_error(mods, explore, monkeypatch):
+def test_handle_survives_capacity_error(mods, explore, monkeypatch, knobs):
     """After MLM_ERR_CAPACITY (block pool full and not allowed to grow: MLM_POOL_GROW=0, which stands in for a device out of
     memory) the handle stays usable: the blocks that exist keep accepting updates and answering queries (the device error
     flag used to stay set, failing every later call) — also in frontier mode, whose synchronous path has its own error
@@ -167,7 +167,7 @@ def test_handle_survives_capacity_error(mods, explore, monkeypatch):
     from mlmapping_amd.mlmap import MlmError
 
     MLMap, OracleMap = mods
-    monkeypatch.setenv("MLM_POOL_GROW", "0")
+    knobs.set("pool_grow", "0")
     cfg = S1.with_(use_exploration_frontiers=explore)
     gpu = MLMap(cfg, max_blocks=40)
     img = syn.room_depth(cfg)      # 116 blocks of 1 m
@@ -318,11 +318,11 @@ def test_merge_device_maps_two_ranks_periodic(tmp_path):
         assert np.allclose(m2["log_odds"], m3["log_odds"], atol=1e-6)
 
 
-def test_two_slot_sets(mods, monkeypatch):
+def test_two_slot_sets(mods, monkeypatch, knobs):
     """The handle falls back to two slot sets when three do not fit the device memory; forced here (MLM_SLOT_SETS=2): the
     asynchronous batch pipeline must give the same map."""
     MLMap, OracleMap = mods
-    monkeypatch.setenv("MLM_SLOT_SETS", "2")
+    knobs.set("slot_sets", "2")
     cfg = S1
     n = 20
     frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
@@ -372,16 +372,16 @@ def test_bench_launcher_contract_two_ranks():
     assert mg["merge_ms"] > 0 and mg["union_blocks"] > mg["own_blocks"] > 0 and mg["merge_bytes_per_rank"] > 0
 
 
-def test_lean_slots_when_the_full_ones_do_not_fit(mods, monkeypatch):
+def test_lean_slots_when_the_full_ones_do_not_fit(mods, monkeypatch, knobs):
     """Full slots (MLM_LEAN_SLOTS=0: every frame slot with cell-table state of its own) are the exception now; mlm_create
     falls back to lean slots (that state once per handle) when the full ones do not fit the device — simulated here: the first
     attempt fails at the third slot.  The handle then works as usual, fall-backs to the cell-table path (forced on every
     second frame) included."""
     MLMap, OracleMap = mods
-    monkeypatch.setenv("MLM_LEAN_SLOTS", "0")
-    monkeypatch.setenv("MLM_DEBUG_FAIL_SLOT", "2")
-    monkeypatch.setenv("MLM_SEC_FAIL_EVERY", "2")
-    monkeypatch.setenv("MLM_SEC_BACKOFF", "0")
+    knobs.set("lean_slots", "0")
+    knobs.set("debug_fail_slot", "2")
+    knobs.set("sec_fail_every", "2")
+    knobs.set("sec_backoff", "0")
     cfg = S1
     gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=2), OracleMap(cfg)
     frames = list(syn.stream(cfg, "room_jitter", "random", 6))

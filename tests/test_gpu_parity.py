@@ -91,12 +91,12 @@ def test_stream_parity(mods, scene, poses, cfg, frames):
 
 
 @pytest.mark.parametrize("node_lds,agg_lds", [(32, 256), (448, 16), (48, 16)])
-def test_forced_buffer_overflows(mods, monkeypatch, node_lds, agg_lds):
+def test_forced_buffer_overflows(mods, monkeypatch, knobs, node_lds, agg_lds):
     """The rare paths of k_bin_points / k_book_cells (a block's LDS group buffer or cell table overflows: groups booked one
     by one by k_assign_nodes, rays walked lane by lane) forced by shrinking the buffers; results must not change."""
     MLMap, OracleMap = mods
-    monkeypatch.setenv("MLM_NODE_LDS", str(node_lds))
-    monkeypatch.setenv("MLM_AGG_LDS", str(agg_lds))
+    knobs.set("node_lds", str(node_lds))
+    knobs.set("agg_lds", str(agg_lds))
     for scene, poses, cfg, frames in (("room_jitter", "random", S1, 3), ("scatter", "static", S1, 2)):
         gpu, cpu = MLMap(cfg, max_blocks=8192, record_awareness=True), OracleMap(cfg)
         for k, (img, (q, t)) in enumerate(syn.stream(cfg, scene, poses, frames)):
@@ -261,13 +261,13 @@ def test_column_table_widens_with_the_scene(mods, monkeypatch, capfd):
 
 
 @pytest.mark.parametrize("threads,tab", [("256", "512"), ("256", "1024"), ("512", "512"), ("512", "2048")])
-def test_column_kernel_instantiations(mods, monkeypatch, threads, tab):
+def test_column_kernel_instantiations(mods, monkeypatch, knobs, threads, tab):
     """The column kernel exists with 256- and 512-thread workgroups and takes tables of 512 to 2 048 entries (1 to 4 entries per
     thread); the handle picks one pair per map.  Every pair must give the oracle's map — batches (where the choice applies) and
     single frames (which always take the 512-thread instantiation) alike."""
     MLMap, OracleMap = mods
-    monkeypatch.setenv("MLM_SEC_THREADS", threads)
-    monkeypatch.setenv("MLM_SEC_TAB", tab)
+    knobs.set("sec_threads", threads)
+    knobs.set("sec_tab", tab)
     cfg = S1
     frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", 4)])
     poses = syn.random_poses(10, seed=21)
@@ -285,16 +285,16 @@ def test_column_kernel_instantiations(mods, monkeypatch, threads, tab):
     assert gpu.frame_stats()["n_sector_fallbacks"] == 0
 
 
-def test_single_frames_go_through_the_graph(mods, monkeypatch):
+def test_single_frames_go_through_the_graph(mods, monkeypatch, knobs):
     """Synchronous single-frame calls (the reference's call pattern: one frame per depth callback, mlmap.cpp:463-507) are
-    submitted as one HIP-graph replay; the result is the general submission's (MLM_GRAPH=0) bit for bit — dense frames from a
+    submitted as one HIP-graph replay; the result is the general submission's (knob graph = 0) bit for bit — dense frames from a
     host buffer, pixel lists, the callback's sampler — and the oracle's."""
     MLMap, OracleMap = mods
     cfg = SDEF
     frames = list(syn.stream(cfg, "room_jitter", "random", 8))
     maps = []
     for graph in ("1", "0"):
-        monkeypatch.setenv("MLM_GRAPH", graph)
+        knobs.set("graph", graph)
         gpu = MLMap(cfg, max_blocks=2048, max_batch=2)
         for k, (img, (q, t)) in enumerate(frames):
             if k % 3 == 2:
@@ -649,7 +649,7 @@ def test_heavy_cell_beyond_lds_window(mods):
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "heavy cell")
 
 
-def test_argument_and_capacity_errors(mods, monkeypatch):
+def test_argument_and_capacity_errors(mods, monkeypatch, knobs):
     """Error behaviour of the boundary: statuses, never exceptions or silent corruption."""
     import ctypes as C
 
@@ -665,11 +665,11 @@ def test_argument_and_capacity_errors(mods, monkeypatch):
         MLMap(S1, device=99)
     with pytest.raises(MlmError, match="UNSUPPORTED"):  # outside the supported envelope: said at creation, not at the first frame
         MLMap(S1.with_(am_n_Rho=1000, depth_noise_coe=1e-6), max_blocks=64, max_points=1000)
-    monkeypatch.setenv("MLM_POOL_GROW", "0")
+    knobs.set("pool_grow", "0")
     m = MLMap(S1, max_blocks=8, max_points=640 * 480)  # block pool far too small and not allowed to grow
     with pytest.raises(MlmError, match="CAPACITY"):
         m.update_map(syn.room_depth(S1), *syn.static_pose())
-    monkeypatch.delenv("MLM_POOL_GROW")
+    knobs.set("pool_grow", "1")
     m2 = MLMap(SDEF, max_blocks=1024, max_points=1000)
     with pytest.raises(MlmError, match="CAPACITY"):
         m2.update_map(syn.room_depth(SDEF), *syn.static_pose())  # 230 400 pixels > max_points
@@ -946,12 +946,12 @@ def test_callback_query_interleaving(mods):
                                  {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "2"}, {"MLM_SECTORS": "0"},
                                  {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_BACKOFF": "1", "MLM_LEAN_SLOTS": "0"},
                                  {"MLM_SEC_TAB": "512", "MLM_SEC_TAB_BIG": "1024", "MLM_SEC_BACKOFF": "0"}])
-def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
+def test_sector_fallback_and_cell_table_path(mods, monkeypatch, knobs, env):
     """Stage A by azimuth sector falls back to the cell-table path frame by frame when a column overflows its LDS tables
     (forced here by shrinking them); MLM_SECTORS=0 runs the cell-table path alone.  Results must not change."""
     MLMap, OracleMap = mods
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knobs.set(k[4:].lower(), v)
     cfg = S1
     n = 10
     frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
@@ -985,13 +985,13 @@ def test_sector_fallback_and_cell_table_path(mods, monkeypatch, env):
 @pytest.mark.parametrize("env", [{}, {"MLM_SEC_FAIL_EVERY": "1", "MLM_SEC_BACKOFF": "0"}, {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_BACKOFF": "0"},
                                  {"MLM_SEC_FAIL_EVERY": "4", "MLM_SEC_BACKOFF": "1"}, {"MLM_SECTORS": "0"},
                                  {"MLM_SEC_FAIL_EVERY": "3", "MLM_SEC_BACKOFF": "0", "MLM_LEAN_SLOTS": "0"}])
-def test_frontier_mode_sector_path(mods, monkeypatch, env):
+def test_frontier_mode_sector_path(mods, monkeypatch, knobs, env):
     """Frontier mode runs Stage A by azimuth sector too (insertion times of the miss cells kept in LDS); a frame whose sector
     tables overflow redoes Stage A on the cell-table path before anything that depends on the map is enqueued.  Single
     frames, batches and asynchronous batches against the oracle: map, frontier set, awareness lists."""
     MLMap, OracleMap = mods
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knobs.set(k[4:].lower(), v)
     cfg = S1.with_(use_exploration_frontiers=True)
     n = 11
     frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
@@ -1029,16 +1029,16 @@ def test_frontier_mode_sector_path(mods, monkeypatch, env):
     gpu.close()
 
 
-def test_async_replay_with_mixed_stage_a_paths(mods, monkeypatch):
+def test_async_replay_with_mixed_stage_a_paths(mods, monkeypatch, knobs):
     """Asynchronous submission keeps up to three batches in flight.  Here a cell-table batch (submitted while the sector path
     backs off after a forced overflow) is followed by sector batches, and a frame of the OLDER, cell-table batch turns out to
     need a rehash of the emulated hit container (its hit count jumps from ~3 k to ~14 k): the replay must finish every
     pending frame on the path its Stage A took (round-2 advisor finding: the sector frames were resubmitted through
     k_voxelize, which reads per-hit fields k_sector never writes)."""
     MLMap, OracleMap = mods
-    monkeypatch.setenv("MLM_SEC_FAIL_EVERY", "7")
-    monkeypatch.setenv("MLM_SEC_BACKOFF", "1")
-    monkeypatch.setenv("MLM_BIG_ARM", "0")  # (a fall-back backs the sector path off right away instead of scheduling the large-table pass)
+    knobs.set("sec_fail_every", "7")
+    knobs.set("sec_backoff", "1")
+    knobs.set("big_arm", "0")  # (a fall-back backs the sector path off right away instead of scheduling the large-table pass)
     cfg = S1
     n = 14
     frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "random", n)])
