@@ -47,15 +47,18 @@
 #define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
 #define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
 
-// one hit cell of the column while k_sector works on it (20 bytes)
+// one hit cell of the column while k_sector works on it (16 bytes: a 2 048-entry table is 32 KB of LDS)
 struct MlmSecCell {
-    uint32_t key;   // z * nRho + rho, MLM_NIL = empty
+    uint32_t key;   // low 16 bits: z * nRho + rho (nZ * nRho < 65 536), MLM_NIL = empty; high 16 bits, set once the column's lists are
+                    // built (cells that need their order): where the cell's references start, in units of MLM_SEC_REF_ALIGN references
+                    // from the column's first
     uint32_t tmin;  // first-touch time (min over contributions)
-    uint32_t kg;    // kinds (bits 0..20) | (record, kind) references of the cell << 21 (one word: 4 bytes of LDS per entry are an
-                    // eighth workgroup per CU)
+    uint32_t kg;    // kinds (bits 0..20) | (record, kind) references of the cell << 21: counted up while the contributions are booked,
+                    // counted down while the references are written (the count hands every writer its own stretch of the cell's segment)
     uint32_t cnt;   // contributions
-    uint32_t gpos;  // multi-kind cells: fill cursor into MlmDev::refs (starts at the cell's segment)
 };
+#define MLM_SEC_REF_ALIGN 4u // a cell's references start at a multiple of this many (16 bytes) from the column's first
+#define MLM_SEC_KEY_MASK 0xFFFFu
 
 #define MLM_SEC_KIND_BITS 21 // MlmSecCell::kg: 2 * MLM_DIFF_RANGE + 1 kinds below the reference count
 #define MLM_SEC_KIND_MASK ((1u << MLM_SEC_KIND_BITS) - 1u)
@@ -341,8 +344,8 @@ __device__ __forceinline__ int mlm_sec_entry(MlmSecCell *tab, uint32_t tab_mask,
             if (prev == MLM_NIL || prev == key) return (int)e;
         } else {
             const uint32_t k = tab[e].key;
-            if (k == key) return (int)e;
             if (k == MLM_NIL) return -1;
+            if ((k & MLM_SEC_KEY_MASK) == key) return (int)e;
         }
         e = (e + 1) & tab_mask;
     }
@@ -421,7 +424,7 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
     L.rays = o;     o += TAB * 2u;                       // table entries that start a ray
     L.occ = L.chunk;                                     // occupied table entries (= the column's unique hits): in the chunk
                                                          // staging, idle between the first record pass and the second
-    L.multi = o;    o += TAB * 2u;                       // ... those that received several kinds
+    L.multi = o;    if (explore) o += TAB * 4u;          // frontier mode: per table entry, the first point whose hit centre is the cell
     L.ray_p0 = o;   if (explore) o += TAB * 4u;          // frontier mode: first point of every ray start
     o = (o + 15u) & ~15u;
     L.vox = o;      o += (n_rho + n_z) * 16u;            // world voxel per axis: x, y by rho; z by z (see k_sector)
@@ -472,7 +475,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     // up: one dependent trip to memory less in a column's life; what lies beyond the count is not looked at)
     mlm_u32x2 chunk_first = mlm_u32x2{0u, 0u};
     constexpr uint32_t CH = NT < MLM_SEC_CHUNKS ? NT : MLM_SEC_CHUNKS; // chunk descriptors staged per pass: one per thread
-    if (threadIdx.x < min(CH, P.chunk_cap))
+    // (one wave's worth: a column of a VGA frame has ~50, and every column — also the four in five that hold nothing — asks)
+    if (threadIdx.x < min(64u, P.chunk_cap))
         chunk_first = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)phi * P.chunk_cap + threadIdx.x));
     const unsigned int nch_all = mlm_gp(P.col_cnt)[phi];
     if (nch_all == 0) return; // nothing fell into this column (uniform)
@@ -486,7 +490,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     float *s_sigma = (float *)(s_dyn + L.sigma);
     uint16_t *s_rays = (uint16_t *)(s_dyn + L.rays);
     uint16_t *s_occ = (uint16_t *)(s_dyn + L.occ);
-    uint16_t *s_multi = (uint16_t *)(s_dyn + L.multi);
+    uint32_t *s_p0 = (uint32_t *)(s_dyn + L.multi); // (EX only) first point whose hit centre is the cell, per table entry
     uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.chunk);
     uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
     uint32_t *s_ray_p0 = (uint32_t *)(s_dyn + L.ray_p0); // (EX only)
@@ -505,7 +509,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         s_tab[e].tmin = MLM_EMPTY_T;
         s_tab[e].kg = 0;
         s_tab[e].cnt = 0;
-        if (EX) s_tab[e].gpos = MLM_EMPTY_T; // (until the lists are built: first point whose centre is the cell)
+        if (EX) s_p0[e] = MLM_EMPTY_T;
     }
     for (uint32_t e = threadIdx.x; e < NMISS; e += NT) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
     for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += NT) s_strength[e] = (uint8_t)mlm_sec_strength(mlm_gp(P.odds_table)[e]);
@@ -627,7 +631,10 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 // one 4-byte reference per non-empty ROW of the group's lane mask (mlm_ref_pack): row byte, kind, and the row's
                 // position relative to the cell's first pixel — what k_rank needs, with no empty rows in its rounds (a group
                 // touches two or three of its eight rows)
-                const uint32_t at = atomicAdd(&s_tab[e].gpos, n_rows);
+                // (the count of the cell's references, counted up by the booking pass, is counted down here: every group gets its own
+                // stretch of the cell's segment; the order of the references inside a segment does not matter)
+                const uint32_t left = atomicSub(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS;
+                const uint32_t at = s_base[2] + (s_tab[e].key >> 16) * MLM_SEC_REF_ALIGN + (left - n_rows);
                 const uint32_t pix0 = s_tab[e].tmin / MLM_TIME_SLOTS;
                 const uint32_t y0c = tile_w > 0 ? (uint32_t)(((unsigned long long)pix0 * row_m) >> row_s) : pix0 >> 6;
                 const uint32_t dy0 = (yx >> 11) - y0c; // (>= 0: the cell's first pixel is its contributions' smallest)
@@ -655,7 +662,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             {
                 const uint32_t j = threadIdx.x;
                 mlm_u32x2 d = mlm_u32x2{0u, 0u};
-                if (j < n_staged) d = c0 == 0 ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
+                if (j < n_staged) d = (c0 == 0 && j < 64u) ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
                 const uint32_t off = mlm_block_excl_scan<NT / 64>(d.y, s_w, &total);
                 if (j < n_staged) {
                     s_chunk_first[j] = d.x;
@@ -728,7 +735,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                             const uint32_t k = atomicAdd(&s_ref_ov_n, 1u);
                             if (k < 8u) s_ref_ov[k] = (uint32_t)e;
                         }
-                        if (EX && sub == 0) atomicMin(&s_tab[e].gpos, i_first);
+                        if (EX && sub == 0) atomicMin(&s_p0[e], i_first);
                     });
                 }
             }
@@ -764,76 +771,48 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     //      LDS atomic, the runs' offsets from the same block scan that places the other lists.
     const uint32_t per = TAB / NT; // entries e = threadIdx.x * per + q: contiguous per thread (per <= PER_MAX)
     uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, multi, ray starts, hits of tile run `threadIdx.x`
-    uint32_t w_refs = 0, w_subs = 0;  // references / ordered-kinds slots of this thread's multi-kind cells
-    uint32_t hk[PER_MAX], hrun[PER_MAX]; // this thread's entries: tile run, rank among the run's hits
+    uint32_t w[4] = {0u, 0u, 0u, 0u}; // reference slots (a cell's count rounded up to MLM_SEC_REF_ALIGN) / ordered-kinds slots of this thread's multi-kind cells
+    uint32_t hk[PER_MAX];           // this thread's entries: rank among their tile run's hits
+    uint32_t p0r[EX ? PER_MAX : 1]; // (EX) first point whose centre is the cell
 #pragma unroll
     for (uint32_t q = 0; q < (uint32_t)PER_MAX; ++q) {
         if (q >= per) break;
         const MlmSecCell &c = s_tab[threadIdx.x * per + q];
+        if (EX) p0r[EX ? q : 0] = 0;
         if (c.key == MLM_NIL) continue;
         ++v[0];
         v[2] += c.kg & 1u;
         if (mlm_sec_needs_order(c)) {
             ++v[1];
-            w_refs += c.kg >> MLM_SEC_KIND_BITS;
-            w_subs += ((c.cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
+            w[0] += ((c.kg >> MLM_SEC_KIND_BITS) + MLM_SEC_REF_ALIGN - 1u) & ~(MLM_SEC_REF_ALIGN - 1u);
+            w[1] += ((c.cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
         }
         if (EX) { // (frontier mode has no tiles: the hits keep the table's order)
-            hrun[q] = 0u;
             hk[q] = v[0] - 1u;
+            p0r[EX ? q : 0] = s_p0[threadIdx.x * per + q];
         } else {
             int rho, z;
             key_rz(c.key, rho, z);
-            hrun[q] = (uint32_t)s_vr[rho].w;
-            hk[q] = atomicAdd(&s_run_hits[hrun[q]], 1u);
+            hk[q] = atomicAdd(&s_run_hits[s_vr[rho].w], 1u);
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        w_refs += __shfl_xor(w_refs, off, 64);
-        w_subs += __shfl_xor(w_subs, off, 64);
-    }
-    if (threadIdx.x < 2) s_base[4 + threadIdx.x] = 0;
     __syncthreads(); // (the runs' hit counts are complete)
     if ((int)threadIdx.x < n_run) v[3] = s_run_hits[threadIdx.x]; // (n_run <= nRho <= NT)
-    uint32_t tot[4];
-    mlm_block_excl_scan4<NT / 64>(v, s_w, tot); // (its first barrier also orders the zeroing above)
+    uint32_t tot[4], wtot[4];
+    mlm_block_excl_scan4<NT / 64>(v, s_w, tot);
+    mlm_block_excl_scan4<NT / 64>(w, s_w, wtot);
     if ((int)threadIdx.x < n_run) s_run_off[threadIdx.x] = v[3];
-    if (lane == 0) {
-        if (w_refs) atomicAdd(&s_base[4], w_refs);
-        if (w_subs) atomicAdd(&s_base[5], w_subs);
-    }
-    __syncthreads(); // (the runs' offsets are visible)
-    {
-        uint32_t o_multi = v[1], o_rays = v[2];
-#pragma unroll
-        for (uint32_t q = 0; q < (uint32_t)PER_MAX; ++q) {
-            if (q >= per) break;
-            const uint32_t e = threadIdx.x * per + q;
-            MlmSecCell &c = s_tab[e];
-            if (c.key == MLM_NIL) continue;
-            if (c.kg & 1u) {
-                if (EX) s_ray_p0[o_rays] = c.gpos;
-                s_rays[o_rays++] = (uint16_t)e;
-            }
-            const uint32_t place = (EX ? v[0] : s_run_off[hrun[q]]) + hk[q];
-            if (mlm_sec_needs_order(c)) {
-                s_multi[o_multi++] = (uint16_t)e;
-                c.gpos = place; // (its place in the hit list, until the reference cursor replaces it below)
-            }
-            s_occ[place] = (uint16_t)e;
-        }
-    }
-    __syncthreads();
     const uint32_t n_occ = tot[0], n_multi = tot[1], n_rays = P.visibility ? tot[2] : 0u;
-    const uint32_t tot_refs = s_base[4], tot_subs = s_base[5];
+    const uint32_t tot_refs = wtot[0], tot_subs = wtot[1];
     if (threadIdx.x == 0) {
         s_base[0] = n_occ ? g_atomic_add(&mlm_gp(P.ctr)->u_hit, n_occ) : 0u;
         s_base[1] = n_multi ? g_atomic_add(&mlm_gp(P.ctr)->n_multi, n_multi) : 0u;
         s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
         s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
-        if (s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap) s_fail = 1;
+        // (a cell's segment start is kept in 16 bits, in units of MLM_SEC_REF_ALIGN references from the column's first)
+        if (s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap || tot_refs >= 65536u * MLM_SEC_REF_ALIGN) s_fail = 1;
     }
-    __syncthreads();
+    __syncthreads(); // (the runs' offsets and the column's places in the frame's lists are visible)
     MLM_PHASE(2);
     if (s_fail) { // a table of this column overflowed: the frame is redone by the cell-table path (uniform branch)
         if (threadIdx.x == 0) {
@@ -842,36 +821,42 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         }
         return;
     }
-    // ---- multi-kind cells: segments in `refs` and `subs`, descriptors for k_rank / k_chain_lanes
+    // ---- lists of the occupied entries (= the column's unique hits, ordered by tile run: the hits of one tile are contiguous;
+    //      rank inside the run from the returning LDS atomic above, the runs' offsets from the block scan) and of the ray starts;
+    //      multi-kind cells that need their order: segments in `refs` and `subs`, descriptors for k_rank / k_chain_lanes — the
+    //      thread that owns a table entry knows all of it (places from the scans above)
     {
-        uint32_t carry_refs = s_base[2], carry_subs = s_base[3];
-        for (uint32_t j0 = 0; j0 < n_multi; j0 += NT) { // (one round unless the column holds > 512 such cells)
-            const uint32_t j = j0 + threadIdx.x;
-            uint32_t a[4] = {0u, 0u, 0u, 0u}, t4[4];
-            uint32_t e = 0;
-            if (j < n_multi) {
-                e = s_multi[j];
-                a[0] = s_tab[e].kg >> MLM_SEC_KIND_BITS;
-                a[1] = ((s_tab[e].cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
+        uint32_t o_multi = v[1], o_rays = v[2], o_refs = w[0], o_subs = w[1];
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)PER_MAX; ++q) {
+            if (q >= per) break;
+            const uint32_t e = threadIdx.x * per + q;
+            MlmSecCell &c = s_tab[e];
+            if (c.key == MLM_NIL) continue;
+            if (c.kg & 1u) {
+                if (EX) s_ray_p0[o_rays] = p0r[EX ? q : 0];
+                s_rays[o_rays++] = (uint16_t)e;
             }
-            mlm_block_excl_scan4<NT / 64>(a, s_w, t4);
-            if (j < n_multi) {
-                MlmSecCell &c = s_tab[e];
-                const uint32_t pos = s_base[0] + c.gpos, m = s_base[1] + j, o_refs = carry_refs + a[0], o_subs = carry_subs + a[1];
-                mlm_gp(P.mt_list)[m] = pos;
-                int c_rho, c_z;
-                key_rz(c.key, c_rho, c_z);
+            int c_rho, c_z;
+            key_rz(c.key, c_rho, c_z);
+            const uint32_t place = (EX ? v[0] : s_run_off[s_vr[c_rho].w]) + hk[q];
+            s_occ[place] = (uint16_t)e;
+            if (mlm_sec_needs_order(c)) {
+                const uint32_t n_ref = c.kg >> MLM_SEC_KIND_BITS, n_con = c.cnt & MLM_SEC_CNT_MASK;
+                const uint32_t pos = s_base[0] + place, m = s_base[1] + o_multi, g_refs = s_base[2] + o_refs, g_subs = s_base[3] + o_subs;
                 // (contributions | rho << 20: what k_chain_lanes needs of the cell comes with one load)
-                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, o_subs, (c.cnt & MLM_SEC_CNT_MASK) | ((uint32_t)c_rho << MLM_SEC_CNT_BITS), c.tmin};
-                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{o_refs, c.kg >> MLM_SEC_KIND_BITS};
-                mlm_gp(P.hl_base)[pos] = o_subs;
-                mlm_gp(P.hl_cnt)[pos] = c.cnt & MLM_SEC_CNT_MASK;
-                c.gpos = o_refs;
+                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, g_subs, n_con | ((uint32_t)c_rho << MLM_SEC_CNT_BITS), c.tmin};
+                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{g_refs, n_ref};
+                mlm_gp(P.hl_base)[pos] = g_subs;
+                mlm_gp(P.hl_cnt)[pos] = n_con;
+                c.key = (c.key & MLM_SEC_KEY_MASK) | ((o_refs / MLM_SEC_REF_ALIGN) << 16);
+                ++o_multi;
+                o_refs += (n_ref + MLM_SEC_REF_ALIGN - 1u) & ~(MLM_SEC_REF_ALIGN - 1u);
+                o_subs += (n_con + 15u) & ~15u;
             }
-            carry_refs += t4[0];
-            carry_subs += t4[1];
         }
     }
+    __syncthreads();
     // ---- rays of the cells that hold a hit centre (every point of one (rho,phi,z) cell casts the identical ray,
     //      map_awareness.cpp:243-274: once per cell), FOUR LANES per ray, each a quarter of its steps.
     //      z' = round(z - k (z - zc) / rho) for k = 1 .. rho-1 is followed by an integer DDA on
@@ -885,7 +870,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         int rho = 0, z = 0;
         uint32_t t0 = 0; // EX: insertion time of the ray's step k is t0 + k - 1
         if (it < 4u * n_rays) {
-            key_rz(s_tab[s_rays[it >> 2]].key, rho, z);
+            key_rz(s_tab[s_rays[it >> 2]].key & MLM_SEC_KEY_MASK, rho, z);
             if (EX) t0 = s_ray_p0[it >> 2] * 256u;
         }
         const int seg = (rho + 2) >> 2; // steps k = 1 .. rho-1 in four segments of `seg`
@@ -960,7 +945,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     for (uint32_t i = threadIdx.x; i < n_occ; i += NT) {
         const MlmSecCell c = s_tab[s_occ[i]];
         int rho, z;
-        key_rz(c.key, rho, z);
+        key_rz(c.key & MLM_SEC_KEY_MASK, rho, z);
         const uint32_t pos = s_base[0] + i;
         mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
         mlm_gp(P.hl_t)[pos] = c.tmin;
@@ -1101,7 +1086,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     MLM_PHASE_END
 }
 template <bool EX, int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
+// (256 threads: eight workgroups per CU = eight waves per SIMD, 64 VGPRs; 512 threads — tables above 1 024 entries: at most three
+// workgroups per CU by LDS, or a frame on its own — six waves per SIMD, 80 VGPRs)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 8 : 6))) void k_sector(MLM_SLOT_ARGS, int tile_w, int n_bin_blocks, unsigned long long rho_m,
                                                                                        int rho_s, unsigned long long n_bkt, int big_armed, unsigned long long row_m, int row_s) {
     // (row_m, row_s: exact division of a pixel index by the image width — the row of a cell's first pixel, mlm_ref_pack)
     MLM_SLOT_SETUP

@@ -1818,7 +1818,9 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
         if ((rc = dev_alloc(h, &P.sbkt, (size_t)P.sbkt_cap))) return rc;
         HIPCHK(h, hipMemset(P.sbkt, 0xFF, (size_t)P.sbkt_cap * sizeof(unsigned long long)));
     }
-    P.refs_cap = (unsigned int)std::min<size_t>(P.contrib_cap, max_contrib); // (a reference — one row of a group's lane mask — stands for at least one contribution)
+    // (a reference — one row of a group's lane mask — stands for at least one contribution; a cell's references start at a multiple
+    // of MLM_SEC_REF_ALIGN, and a cell that needs references has at least two contributions)
+    P.refs_cap = (unsigned int)std::min<size_t>(0xFFFFFFF0ull, max_contrib + (MLM_SEC_REF_ALIGN - 1) * std::min<size_t>(NC, max_contrib / 2) + 64);
     if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? (size_t)P.refs_cap : 4))) return rc;
     if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
     HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
