@@ -250,7 +250,7 @@ int mlm_set_timed_kernel(mlm_handle *h, const char *name, int every);
 /* Test and experiment knobs — NOT part of the drop-in contract.  Named integers read by the NEXT mlm_create of this process:
  * forced fall-backs ("sec_fail_every", "sec_backoff", "sectors"), simulated allocation failures ("debug_fail_slot"), a fixed pool
  * ("pool_grow"), slot layout ("lean_slots", "slot_sets"), launch geometries ("sec_tab", "sec_threads", "rank_grid", ...; the full
- * list is kKnobNames in mlmap_hip.hip).  Unknown names: MLM_ERR_INVALID.  mlm_debug_reset forgets them all.  The library reads
+ * list is kKnobNames in mlmapping_amd/csrc/mlm_handle.h).  Unknown names: MLM_ERR_INVALID.  mlm_debug_reset forgets them all.  The library reads
  * no environment variable for behaviour; MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN only print diagnostics. */
 int mlm_debug_set(const char *name, long long value);
 int mlm_debug_reset(void);

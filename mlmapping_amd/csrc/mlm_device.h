@@ -29,6 +29,9 @@ template <class T> __device__ __forceinline__ T g_atomic_or(MLM_GLOBAL T *p, T v
 template <class T> __device__ __forceinline__ T g_atomic_add(MLM_GLOBAL T *p, T v) {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+template <class T> __device__ __forceinline__ T g_atomic_max(MLM_GLOBAL T *p, T v) {
+    return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <class T> __device__ __forceinline__ T g_atomic_min(MLM_GLOBAL T *p, T v) {
     return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

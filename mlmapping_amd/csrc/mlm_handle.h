@@ -1,0 +1,313 @@
+// mlm_handle.h — the handle behind the C ABI (struct mlm_handle, one frame slot, the test knobs) and the small helpers every part of
+// the host driver uses: error macro, lock, device allocation, timed kernel launches.  Part of the single device TU mlmap_hip.hip.
+#pragma once
+using namespace mlm_host;
+
+extern "C" size_t mlm_sort_temp_bytes(size_t n);
+extern "C" int mlm_sort_pairs_u64_u32(void *temp, size_t temp_bytes, const unsigned long long *kin,
+                                      unsigned long long *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+                                      hipStream_t stream);
+
+namespace {
+
+#ifndef MLM_SETS
+#define MLM_SETS 3
+#endif
+// MLM_SETS slot sets: batches in flight (one being filled, one in Stage A, one draining).  Measured on config 2 with the sector
+// path: round 2 44.7k frames/s with 2, 48.4k with 3, 45.3k with 4; round 3 74.0k / 80.9k / 78.7k
+
+struct KernelTime {
+    const char *name;
+    hipEvent_t a, b;
+};
+
+// Test and experiment knobs (mlm_debug_set): named integers that mlm_create reads — launch geometries, forced fall-backs,
+// simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
+// for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
+const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "bin_strips", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
+                                  "debug_fail_slot", "expand_block", "graph", "graph_copies", "lean_slots", "logit_exact", "node_lds", "pool_grow",
+                                  "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
+                                  "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
+struct KnobStore {
+    std::mutex mu;
+    std::unordered_map<std::string, long long> v;
+};
+KnobStore &knob_store() {
+    static KnobStore k;
+    return k;
+}
+bool knob(const char *name, long long &out) {
+    KnobStore &k = knob_store();
+    std::lock_guard<std::mutex> lock(k.mu);
+    auto it = k.v.find(name);
+    if (it == k.v.end()) return false;
+    out = it->second;
+    return true;
+}
+
+} // namespace
+
+// One frame in flight: private awareness scratch + unique-hit list, its own stream for Stage A.
+struct MlmSlot {
+    MlmDev P{};               // shared map pointers + this slot's scratch pointers
+    MlmCounters *h_ctr = nullptr; // pinned mirror of P.ctr (points into mlm_handle::h_ctr_all)
+    MlmFrame F{};
+    int mode = 0;
+    int seq = 0;              // sequence number of the frame it currently holds
+    unsigned int nb = 0;      // k_bin_points blocks
+    unsigned int ex_um = 0;   // frontier mode: unique miss cells of the frame it holds
+    size_t alloc_end = 0;     // mlm_handle::allocs.size() once this slot was allocated
+    bool sector = false;      // the frame it holds went through the sector path (Stage A and the frame-local voxel grid)
+    bool keys_exact = false;  // hl_key of the frame it holds was written by order_hits_exact (a replay must not recompute it:
+                              // the emulated container's policy state has moved on)
+    uint16_t *d_img = nullptr; // staging for host images
+    size_t img_cap = 0;
+    int32_t *d_pix = nullptr;
+    double *d_pts = nullptr;
+};
+
+struct mlm_handle {
+    int device = 0;
+    hipStream_t stream = nullptr; // main stream: Stage B/C (ordered across frames), queries
+    bool own_stream = true;
+    mlm_config cfg{};
+    mlm_limits lim{};
+    MlmDev P{};                   // template: constants + shared pointers
+    std::vector<MlmSlot> slots;
+    int last_slot = 0;
+    Q4 q_bs{};
+    D3 t_bs{};
+    std::vector<float> odds_table;
+    std::vector<void *> allocs;
+    double *d_qpos = nullptr; // query positions
+    void *d_qout = nullptr;
+    size_t q_cap = 0;
+    // sort buffers (rehash frames only)
+    unsigned long long *sk_in = nullptr, *sk_out = nullptr;
+    uint32_t *sv_in = nullptr, *sv_out = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    MlmGlobal *h_g = nullptr; // pinned mirror of P.g
+    // emulated libstdc++ state of awareness_map->hit_idx_odds_hashmap: bucket count + rehash policy.
+    // clear() (map_awareness.cpp:178) keeps both, so they persist across frames.
+    size_t hit_n_bkt = 1;
+    std::__detail::_Prime_rehash_policy hit_pol;
+    size_t max_buckets = 0;
+    // the same for awareness_map->miss_idx_set (only tracked in frontier mode, where its iteration order matters)
+    size_t miss_n_bkt = 1;
+    std::__detail::_Prime_rehash_policy miss_pol;
+    mlm_frame_stats stats{};
+    std::string err;
+    int timing = 0;
+    std::vector<KernelTime> ktimes;
+    std::vector<KernelTime> kpool;
+    size_t kpool_used = 0;
+    // submission state (see submit_batch / drain)
+    std::vector<MlmSlot *> pending;
+    int next_seq = 0;
+    int cur_set = 0;
+    unsigned int expand_block = 256;         // threads per k_expand_nodes block (128 and 64 measured slower)
+    unsigned int sort_block = 256;           // threads per k_sort_contribs<1024> block
+    unsigned int sort_grid = 256;            // blocks per frame of k_sort_contribs<1024> in a batch
+    unsigned int rank_grid = 128;            // blocks per frame of k_rank in a batch (config 2 with two cells per wave: 87.5k frames/s, 64: 87.7k, 256: 86.4k,
+                                             // 512: 84.7k; MLM_RANK_GRID)
+    // Lean frame slots (sector-path handles): the three large buffers only the cell-table Stage A uses — the block slices of
+    // contribution nodes sized for its LDS overflow, the (block, cell) pairs and the node lists — exist ONCE per handle instead
+    // of once per slot; a cell-table Stage A (a frame's fall-back, or a batch submitted while the sector path backs off) then
+    // runs one frame at a time, ordered by fb_done across the sets' streams.
+    bool lean = false;
+    MlmDev *d_slot_tab_fb = nullptr;         // the slots' constants with those three buffers pointing at the shared ones
+    hipEvent_t fb_done = nullptr;
+    size_t map_bytes = 0;                    // ... of it the map, its tables and the buffers shared by all frame slots
+    bool debug_alloc = getenv("MLM_DEBUG_ALLOC") != nullptr;
+    size_t alloc_bytes = 0;                  // device memory the handle holds (MLM_DEBUG_CREATE prints it)
+    unsigned int chain_grid = 0;             // blocks per frame of k_chain_lanes (0: from the last confirmed frame's ranked cells; MLM_CHAIN_GRID)
+    unsigned int collect_grid = 16;          // blocks per sub-list of k_collect_hits (grid-stride loop)
+    unsigned int sc_block = 64;              // threads per block of the per-frame apply kernels: single-wave blocks are placed as soon as any wave
+                                             // slot frees between Stage A's workgroups (config 2: 66.5k frames/s, 128: 64.1k, 256: 57.2k)
+    bool sc_grid_fixed = false;              // MLM_SC_GRID given: do not adapt
+    unsigned int sc_grid = 80;               // blocks per list of k_apply_voxelize (grid-stride loops; 40..120 measured equal, 160 3 % slower)
+    std::string timed_kernel = "k_bin_points"; // the kernel bracketed in timing mode 3 ...
+    unsigned int timed_every = 1, timed_count = 0; // ... on every timed_every-th launch
+    int n_sets = MLM_SETS;     // slot sets in use (2 when three do not fit the device memory)
+    int set_pending[MLM_SETS] = {};
+    bool async_mode = false;
+    int cu_split = 0;
+    int cu_reserve = 0;
+    float *d_f32 = nullptr;                  // staging of a 32FC1 frame (mlm_integrate_callback)
+    size_t f32_cap = 0;
+    hipStream_t stream_as[MLM_SETS] = {};    // Stage A of whole batches, one stream per slot set (overlaps Stage B/C of the
+                                             // previous batch and the tails of the other set's Stage A kernels)
+    hipEvent_t stage_a_done[MLM_SETS] = {};
+    hipEvent_t set_free[MLM_SETS] = {}; // main stream finished reading the set's Stage A outputs
+    MlmDev *d_slot_tab = nullptr;            // [2K] device copies of the slots' MlmDev
+    MlmFrame *d_frame_tab = nullptr;         // [2K] per-frame parameters of the frames in flight
+    MlmFrame *h_frame_tab = nullptr;         // pinned staging of d_frame_tab
+    MlmCounters *d_ctr_all = nullptr;        // [2K] contiguous per-slot counters
+    MlmCounters *h_ctr_all = nullptr;        // pinned mirror
+    hipEvent_t batch_done[MLM_SETS] = {};
+    hipEvent_t inputs_ready = nullptr;       // caller-supplied stream only: orders Stage A after the caller's work on it
+    MlmGlobal *h_gb[MLM_SETS] = {}; // pinned snapshots of P.g taken at the end of each batch
+    bool use_sectors = true;   // Stage A by azimuth sector (mlm_kernels_sector.h); MLM_SECTORS=0: the cell-table path
+    struct ExBatch {
+        int set, n;
+        bool bc_enqueued;
+    };
+    std::deque<ExBatch> ex_q;   // frontier mode, asynchronous submission: batches in flight, oldest first
+    hipEvent_t ex_counts[MLM_SETS] = {}, ex_bc_done[MLM_SETS] = {};
+    MlmSlot *ex_tail = nullptr; // frontier mode: the frame whose miss phase + release scan ride with the next frame's ordering launches
+    int ex_tag = 0;            // frontier mode: per-frame tag of the bucket-first tables (k_ex_order_min)
+    unsigned int ex_frame_no = 0; // frontier mode: frames submitted (MlmFrame::pad2)
+    int sector_backoff_len = 16; // (MLM_SEC_BACKOFF)
+    int sector_backoff = 0;    // batches that go straight to the cell-table path after a sector overflow (the scene does not fit the sectors' LDS tables: do not pay for both paths)
+    long long n_sector_fallbacks = 0; // frames redone by the cell-table path because a sector's LDS tables overflowed
+    std::recursive_mutex mu;   // serialises the entry points of this handle (see MLM_LOCK)
+    long long n_spec_miss = 0; // frames replayed because the speculative "no rehash" plan did not hold
+    bool pool_grow = true;     // the block pool grows on demand (MLM_POOL_GROW=0: fixed at mlm_limits.max_blocks, MLM_ERR_CAPACITY when full)
+    size_t frame_block_bound = 0; // most blocks one frame can create
+    unsigned int tile_lds_bytes = 0; // dynamic LDS of k_tile
+    int ov_heavy = 0;                // confirmed batches in a row whose last frame had many overflowed columns
+    bool want_widen = false;         // ... the cell table is doubled before the next submission (widen_sec_tab)
+    int sec_threads = 512;           // threads of a column's workgroup (k_sector<.., 256 | 512>; MLM_SEC_THREADS)
+    unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
+    unsigned int single_apply_grid = 256; // workgroups of k_apply_single: a VGA frame's ~33 k voxel records, one per thread (more: in turns)
+    unsigned int tile_grid = 0;      // workgroups of k_tile per frame of a batch: they walk the frame's touched tiles (MLM_TILE_GRID)
+    unsigned int apply_lds_bytes = 0; // dynamic LDS of k_apply_tiles: 9 bytes per voxel of a tile
+    unsigned int big_grid = 256;     // workgroups of k_sector_big per batch: one per CU (MLM_BIG_GRID)
+    int big_armed = 0;               // batches (single frames) for which the pass with the large cell table stays scheduled
+    int big_armed_from = 0;          // first frame (sequence number; frontier mode: frame number) submitted after it was scheduled
+    int big_arm_len = 64;            // (MLM_BIG_ARM: 0 never schedules it)
+    // Single frames in synchronous mode — the reference's own call pattern, one frame per depth callback (mlmap.cpp:463-507) — are
+    // submitted as ONE replay of a HIP graph on the main stream (parameter upload, counter reset, six kernels, counter
+    // read-back) instead of a dozen launches and copies spread over two streams: the call's cost is launch latency, not work.
+    struct SingleGraph {
+        int mode, width, height, base, big;
+        unsigned int nb, sec_tab; // (sec_tab stands for the column kernel's launch geometry: threads and LDS follow from it)
+        size_t n_bkt;
+        hipGraphExec_t exec;
+    };
+    std::vector<SingleGraph> graphs;
+    bool use_graph = true;       // (MLM_GRAPH=0: always the general submission)
+    int graph_copies = 2;        // 0: issued eagerly around the graph, 2: as kernels of the graph reading / writing the pinned buffers; 1: the graph holds the parameter upload / counter reset / read-back as memcpy and memset nodes (MLM_GRAPH_COPIES=0: issued eagerly around it)
+    hipStream_t last_upload = nullptr; // the stream the current call's inputs were uploaded on (run_slots orders Stage A behind it)
+    hipEvent_t upload_ev = nullptr;
+    long long n_graph_launches = 0;
+    int32_t *h_stage = nullptr;  // pinned staging of the callback's sampled pixels (indices, then raw depths)
+    size_t stage_cap = 0;
+    long long n_pool_grows = 0;
+    long long n_big_redos = 0;   // frames whose overflowed columns were redone with the large table at drain time (redo_overflow_columns)
+    int bin_strips = 1;          // strips per k_bin_sectors workgroup for the dense frames of a batch (MLM_BIN_STRIPS=2|4: experiments)
+    size_t grow_failed_at = 0;   // a pool of this many blocks did not fit the device (grow_pool does not retry it)
+    MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
+    MlmPair *fb_pairs = nullptr;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                                               \
+    do {                                                                                                              \
+        hipError_t e__ = (expr);                                                                                      \
+        if (e__ != hipSuccess) {                                                                                      \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                            \
+            return MLM_ERR_HIP;                                                                                       \
+        }                                                                                                             \
+    } while (0)
+
+// Every entry point takes the handle's lock: integrate calls, queries and exports may come from different threads (the
+// reference runs planner queries and the depth callback on an MT nodelet, nodelet_map.cpp:21); a query then observes the
+// map of the last integrate call that returned.  Recursive because entry points call each other.
+#define MLM_LOCK(h) std::lock_guard<std::recursive_mutex> lock__((h)->mu)
+
+template <class T> int dev_alloc(mlm_handle *h, T **p, size_t n) {
+    void *v = nullptr;
+    HIPCHK(h, hipMalloc(&v, std::max<size_t>(n, 1) * sizeof(T)));
+    h->alloc_bytes += std::max<size_t>(n, 1) * sizeof(T);
+    if (h->debug_alloc && n * sizeof(T) > (8u << 20)) fprintf(stderr, "[alloc] #%zu %.1f MB\n", h->allocs.size(), n * sizeof(T) / 1e6);
+    h->allocs.push_back(v);
+    *p = (T *)v;
+    return MLM_OK;
+}
+inline unsigned int grid_for(size_t n) { return (unsigned int)((n + MLM_BLOCK - 1) / MLM_BLOCK); }
+// blocks of k_bin_points for one frame (tile geometry: mlm_tile_item)
+inline unsigned int bin_grid(const MlmDev &P, const MlmFrame &F, int mode) {
+    const int tile_h = (int)(P.bin_block / 256) * 8;
+    if (mode == 0) return (unsigned int)(((F.width + 31) / 32) * ((F.height + tile_h - 1) / tile_h));
+    return (unsigned int)(((size_t)F.n + P.bin_block - 1) / P.bin_block);
+}
+constexpr unsigned int kListGrid = 256; // blocks of the grid-stride kernels that walk a device-sized list
+
+struct Timed {
+    mlm_handle *h;
+    hipStream_t s;
+    KernelTime *kt = nullptr;
+    Timed(mlm_handle *hh, hipStream_t st, const char *name) : h(hh), s(st) {
+        if (h->timing != 4) return; // mode 4: the two stage spans of a batch (plain event pairs on the stream)
+        if (h->kpool_used == h->kpool.size()) {
+            KernelTime k{name, nullptr, nullptr};
+            hipEventCreate(&k.a);
+            hipEventCreate(&k.b);
+            h->kpool.push_back(k);
+        }
+        kt = &h->kpool[h->kpool_used++];
+        kt->name = name;
+        hipEventRecord(kt->a, s);
+    }
+    ~Timed() {
+        if (kt) {
+            hipEventRecord(kt->b, s);
+            h->ktimes.push_back(*kt);
+        }
+    }
+};
+
+// Launch a kernel; when its launches are being timed, through hipExtLaunchKernelGGL with a start/stop event pair: the
+// pair reports the kernel's own begin/end on the device (what rocprofv3 reports as its duration), not the time the
+// stream waited for compute units behind the other streams' waves.
+inline KernelTime *timing_slot(mlm_handle *h, const char *name) {
+    if (!h->timing || h->timing == 4) return nullptr;
+    if (h->timing == 3) { // one kernel only (bench: the dominant one), every `timed_every`-th launch of it
+        if (strcmp(name, h->timed_kernel.c_str()) != 0) return nullptr;
+        if (h->timed_count++ % h->timed_every != 0) return nullptr;
+    }
+    if (h->kpool_used == h->kpool.size()) {
+        KernelTime k{name, nullptr, nullptr};
+        hipEventCreate(&k.a);
+        hipEventCreate(&k.b);
+        h->kpool.push_back(k);
+    }
+    KernelTime *kt = &h->kpool[h->kpool_used++];
+    kt->name = name;
+    return kt;
+}
+template <class K, class... A>
+inline void tlaunch(mlm_handle *h, const char *name, K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t st, A... args) {
+    if (KernelTime *kt = timing_slot(h, name)) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, st, kt->a, kt->b, 0, args...);
+        h->ktimes.push_back(*kt);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
+    }
+}
+
+// A frame's Stage A gave up on the sector path.  First answer: schedule the pass with the large cell table for the batches to come
+// (the usual reason is a column that overflowed the small table); if that pass was scheduled already, the scene does not fit
+// the sector path at all: the next batches go straight to the cell-table path for a while.
+inline void note_fallback(mlm_handle *h, int frame_no) {
+    if (!(h->P.sec_tab_big && h->big_arm_len > 0)) {
+        h->sector_backoff = h->sector_backoff_len;
+    } else if (h->big_armed <= 0) {
+        h->big_armed = h->big_arm_len;
+        h->big_armed_from = h->P.explore ? (int)(h->ex_frame_no & 0x3FFFFFFF) : h->next_seq; // (frames submitted from now on have the pass behind them)
+    } else if (frame_no >= h->big_armed_from) {
+        h->sector_backoff = h->sector_backoff_len; // (it had the pass and gave up all the same)
+    }
+}
+// lean slots of a sector-path handle outside frontier mode: the cell-table path's per-frame state exists once (alloc_slot)
+inline bool share_ct(const mlm_handle *h) { return h->lean && !h->P.explore; }
+int drain(mlm_handle *h, bool g_copied = false);
+int grow_pool(mlm_handle *h, size_t want);
+int ensure_free_blocks(mlm_handle *h, size_t need);
+int widen_sec_tab(mlm_handle *h);
+int ensure_free_blocks_idle(mlm_handle *h, size_t need);
+
+} // namespace

@@ -110,7 +110,7 @@ __device__ __forceinline__ void mlm_ref_unpack(uint32_t ref, bool dense, uint32_
 }
 
 __device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
-    mlm_gp(P.ctr)->sector_overflow = 1u;
+    g_atomic_max(&mlm_gp(P.ctr)->sector_overflow, 2u); // (2: the frame takes the cell-table path; 1: see the column kernel's full-table branch)
     // (frontier mode does not speculate: its host reads the flag before it enqueues what depends on the map)
     if (!P.explore) g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
 }
@@ -748,10 +748,17 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     __syncthreads();
     if (s_tab_full) { // (uniform) nothing has left the workgroup yet
         if (threadIdx.x == 0) {
-            if (!BIG && big_armed && !s_fail) { // (big_armed: k_sector_big follows this launch)
-                // the column keeps its chunk descriptors and waits for the pass with the large table
+            if (!BIG && P.sec_tab_big && !s_fail && (big_armed || !EX)) {
+                // the column keeps its chunk descriptors and waits for the pass with the large table.  big_armed: k_sector_big follows
+                // this launch; else the frame is flagged (sector_overflow = 1): nothing of it is applied, the host runs the large-table
+                // pass and the rest of Stage A for it when it drains (redo_overflow_columns) and schedules the pass for the batches to
+                // come — no frame goes to the cell-table path because a scene's first crowded column surprised the small table
                 const unsigned int k = g_atomic_add(&mlm_gp(P.ctr)->n_ov, 1u);
                 mlm_gp(P.ov_list)[k] = (uint32_t)phi; // (k < nPhi: a column is listed once)
+                if (!big_armed) {
+                    g_atomic_max(&mlm_gp(P.ctr)->sector_overflow, 1u);
+                    g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
+                }
             } else {
                 mlm_sector_fail(P, F);
                 mlm_gp(P.col_cnt)[phi] = 0;
@@ -1674,7 +1681,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
     __shared__ unsigned int s_fail, s_dead;
     __shared__ uint32_t s_xytab[16]; // per x (first `edge` entries) and per y: block index relative to the tile's first | cell coordinate << 16
     if (threadIdx.x == 0) {
-        s_dead = mlm_gp(P.ctr)->sector_overflow; // set by Stage A: the frame is redone on the cell-table path — only clean up
+        s_dead = mlm_gp(P.ctr)->sector_overflow >= 2u; // set by Stage A: the frame is redone on the cell-table path — only clean up
         s_fail = 0u;
     }
     for (uint32_t v = threadIdx.x; v < NV; v += MLM_TILE_THREADS) s_cnt[v] = 0u;
@@ -1919,6 +1926,10 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
 __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
     __shared__ uint32_t s_cand[MLM_TILE_THREADS];
+    __shared__ unsigned int s_state;
+    if (threadIdx.x == 0) s_state = mlm_gp(P.ctr)->sector_overflow;
+    __syncthreads();
+    if (s_state == 1u) return; // columns of the frame still wait for the large-table pass: the tiles are grouped when the host has run it
     const uint32_t TW = P.tile_words, KC = (uint32_t)MLM_TILE_THREADS / TW, nt = (uint32_t)P.n_tiles; // candidates per round
     for (uint32_t k0 = 0; blockIdx.x + k0 * gridDim.x < nt; k0 += KC) { // (uniform)
         if (k0) __syncthreads(); // (the previous round's masks are no longer read)

@@ -23,7 +23,8 @@ struct MlmCounters {
                               // once the host has grown the pool and k_alloc_retry has filled the records' slots
     unsigned int n_big;       // multi-kind cells with more than 1024 contributions
     unsigned int n_groups;    // contribution groups kept in the blocks' own slices of `bnodes` (folded by k_collect_hits)
-    unsigned int sector_overflow; // sector path: an LDS table of some column overflowed -> the frame is redone by the cell-table path
+    unsigned int sector_overflow; // sector path: 2 = Stage A gave up, the frame is redone by the cell-table path; 1 = columns whose cell table
+                                  // overflowed wait on ov_list for a large-table pass that was not scheduled: the host runs it when it drains
     unsigned int n_refs;      // sector path: (record, kind) references of the multi-kind cells
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart;

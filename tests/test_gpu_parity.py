@@ -82,8 +82,9 @@ def test_stream_parity(mods, scene, poses, cfg, frames):
         d = compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{scene}/{poses} frame {k}")
         worst["max_dodd"] = max(worst["max_dodd"], d["max_dodd"])
         worst["bit_mismatch"] = max(worst["bit_mismatch"], d["bit_mismatch"])
-    if scene == "scatter":  # every pixel in a cell of its own: the columns overflow the small cell table — the first frame falls back
-        assert gpu.frame_stats()["n_sector_fallbacks"] == 1, gpu.frame_stats()  # and schedules the pass with the large table for the rest
+    if scene == "scatter":  # every pixel in a cell of its own: the columns overflow the small cell table — the first frame's columns are
+        # redone with the large table when the call drains (no frame takes the cell-table path), which also schedules that pass for the rest
+        assert gpu.frame_stats()["n_sector_fallbacks"] == 0, gpu.frame_stats()
     if scene == "room" and poses == "static" and cfg is S1:
         c = gpu.class_counts()
         assert (c["o"], c["f"]) == (9435, 32462)  # SURVEY §8d frame-19 KAT (iteration-order dependent)
