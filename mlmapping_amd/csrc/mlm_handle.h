@@ -24,7 +24,7 @@ struct KernelTime {
 // Test and experiment knobs (mlm_debug_set): named integers that mlm_create reads — launch geometries, forced fall-backs,
 // simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
-const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "bin_strips", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
+const char *const kKnobNames[] = {"agg_lds", "apply_block", "big_arm", "big_grid", "bin_block", "bin_strips", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
                                   "debug_fail_slot", "expand_block", "graph", "graph_copies", "lean_slots", "logit_exact", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
                                   "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
@@ -134,6 +134,8 @@ struct mlm_handle {
     bool async_mode = false;
     int cu_split = 0;
     int cu_reserve = 0;
+    uint16_t *d_img_set[MLM_SETS] = {};      // per slot set: device buffer of a whole batch of host frames that arrive back to back
+    size_t img_set_cap[MLM_SETS] = {};       // (mlm_integrate_depth_batch: one upload per batch)
     float *d_f32 = nullptr;                  // staging of a 32FC1 frame (mlm_integrate_callback)
     size_t f32_cap = 0;
     hipStream_t stream_as[MLM_SETS] = {};    // Stage A of whole batches, one stream per slot set (overlaps Stage B/C of the
@@ -196,6 +198,7 @@ struct mlm_handle {
     size_t stage_cap = 0;
     long long n_pool_grows = 0;
     long long n_big_redos = 0;   // frames whose overflowed columns were redone with the large table at drain time (redo_overflow_columns)
+    unsigned int apply_block = MLM_BLOCK; // threads of a k_apply_tiles workgroup (knob apply_block: 128 | 256)
     int bin_strips = 1;          // strips per k_bin_sectors workgroup for the dense frames of a batch (MLM_BIN_STRIPS=2|4: experiments)
     size_t grow_failed_at = 0;   // a pool of this many blocks did not fit the device (grow_pool does not retry it)
     MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers

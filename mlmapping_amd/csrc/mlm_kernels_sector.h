@@ -1619,7 +1619,10 @@ __device__ __forceinline__ int mlm_floor_div(int a, int n) {
 #define MLM_TILE_THREADS 256
 #endif
 #define MLM_TILE_KEEP 2     // hits per thread kept in registers between the counting and the placing pass
-#define MLM_TILE_DESC 128   // descriptors staged per pass (a tile of a VGA frame has ~15; 128 instead of 256: 3 KB of LDS, a fifth workgroup per CU)
+#ifndef MLM_TILE_DESC
+#define MLM_TILE_DESC 128
+#endif
+// ^ descriptors staged per pass (a tile of a VGA frame has ~15; 128 instead of 256: 3 KB of LDS, a fifth workgroup per CU)
 #define MLM_TILE_WORDS 64    // most words of a tile's column mask: MlmDev::tile_words = ceil(nPhi / 32) (sector path: nPhi <= 2048)
 #define MLM_TILE_COMBOS 2048 // most blocks a tile may overlap: limit of MlmDev::tile_combos (their pool slots are kept in LDS)
 struct MlmTileLds {

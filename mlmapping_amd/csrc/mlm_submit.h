@@ -41,7 +41,7 @@ int launch_apply_tiles(mlm_handle *h, int base, int n, int f_begin = 0) {
         if (j1 - j0 == 1) // (one frame: nothing to keep in LDS between frames)
             tlaunch(h, "k_apply_single", k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0);
         else
-            tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(MLM_BLOCK),
+            tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(h->apply_block),
                     (size_t)(P.lv_nz + (z1 - z0)) * 9u * (1u << (2 * sh)) + 16u, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0, z1 - z0);
         j0 = j1;
     }

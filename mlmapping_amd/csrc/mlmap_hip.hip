@@ -401,6 +401,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (knob("big_grid", kv)) h->big_grid = (unsigned int)std::max(1, (int)kv);
         if (knob("big_arm", kv)) h->big_arm_len = std::max(0, (int)kv);
         if (knob("graph_copies", kv)) h->graph_copies = (int)kv;
+        if (knob("apply_block", kv)) h->apply_block = (int)kv == 128 ? 128u : (unsigned int)MLM_BLOCK;
         if (knob("bin_strips", kv)) h->bin_strips = (int)kv == 2 ? 2 : ((int)kv == 4 ? 4 : 1);
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
@@ -552,6 +553,8 @@ int mlm_destroy(mlm_handle *h) {
     if (h->inputs_ready) hipEventDestroy(h->inputs_ready);
     if (h->fb_done) hipEventDestroy(h->fb_done);
     if (h->d_f32) hipFree(h->d_f32);
+    for (int k = 0; k < MLM_SETS; ++k)
+        if (h->d_img_set[k]) hipFree(h->d_img_set[k]);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     if (h->h_g) hipHostFree(h->h_g);
@@ -626,15 +629,35 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
     const size_t n_px = (size_t)row_stride * height;
     for (int k0 = 0; k0 < n_frames; k0 += K) {
         const int n = std::min(K, n_frames - k0);
+        // frames that lie back to back in host memory go up in ONE copy into the slot set's batch buffer (64 copies of 0.6 MB each
+        // reach a third of the link's rate); others frame by frame into the slots' own buffers
+        const bool packed = frame_stride == n_px && n > 1;
+        const int set = h->cur_set;
+        if (packed) {
+            if (h->img_set_cap[set] < (size_t)K * n_px) {
+                if (h->d_img_set[set]) {
+                    HIPCHK(h, hipStreamSynchronize(h->stream_as[set])); // (its last user is long done: the set is being refilled)
+                    hipFree(h->d_img_set[set]);
+                }
+                h->d_img_set[set] = nullptr;
+                h->img_set_cap[set] = 0;
+                HIPCHK(h, hipMalloc((void **)&h->d_img_set[set], (size_t)K * n_px * sizeof(uint16_t)));
+                h->img_set_cap[set] = (size_t)K * n_px;
+            }
+            HIPCHK(h, hipMemcpyAsync(h->d_img_set[set], img_host + (size_t)k0 * frame_stride, (size_t)n * n_px * sizeof(uint16_t), hipMemcpyHostToDevice,
+                                     h->stream_as[set]));
+        }
         for (int j = 0; j < n; ++j) {
             MlmSlot &S = cur_slot(h, j);
-            int rc = ensure_img(h, S, n_px);
-            if (rc) return rc;
-            HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t),
-                                     hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
+            if (!packed) {
+                int rc = ensure_img(h, S, n_px);
+                if (rc) return rc;
+                HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t),
+                                         hipMemcpyHostToDevice, h->stream_as[set]));
+            }
             S.F = MlmFrame{};
             frame_setup(h, q_wb + 4 * (size_t)(k0 + j), t_wb + 3 * (size_t)(k0 + j), S.F);
-            S.F.img = S.d_img;
+            S.F.img = packed ? h->d_img_set[set] + (size_t)j * n_px : S.d_img;
             S.F.width = width;
             S.F.height = height;
             S.F.row_stride = row_stride;
@@ -772,6 +795,8 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         // the converted frame stays in a buffer owned by the handle (no allocation per call)
         if (h->f32_cap < n_px) {
             if (h->d_f32) hipFree(h->d_f32);
+    for (int k = 0; k < MLM_SETS; ++k)
+        if (h->d_img_set[k]) hipFree(h->d_img_set[k]);
             h->d_f32 = nullptr;
             h->f32_cap = 0;
             HIPCHK(h, hipMalloc((void **)&h->d_f32, n_px * sizeof(float)));
