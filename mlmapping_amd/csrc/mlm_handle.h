@@ -25,9 +25,9 @@ struct KernelTime {
 // simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
 const char *const kKnobNames[] = {"agg_lds", "apply_block", "big_arm", "big_grid", "bin_block", "bin_strips", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
-                                  "debug_fail_slot", "expand_block", "graph", "graph_copies", "lean_slots", "logit_exact", "node_lds", "pool_grow",
+                                  "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
-                                  "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
+                                  "sectors", "single_eager", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
     std::mutex mu;
     std::unordered_map<std::string, long long> v;
@@ -190,7 +190,7 @@ struct mlm_handle {
     };
     std::vector<SingleGraph> graphs;
     bool use_graph = true;       // (MLM_GRAPH=0: always the general submission)
-    int graph_copies = 2;        // 0: issued eagerly around the graph, 2: as kernels of the graph reading / writing the pinned buffers; 1: the graph holds the parameter upload / counter reset / read-back as memcpy and memset nodes (MLM_GRAPH_COPIES=0: issued eagerly around it)
+    int single_eager = 0;        // 1: the single-frame launch sequence is issued launch by launch instead of as a graph replay (knob single_eager)
     hipStream_t last_upload = nullptr; // the stream the current call's inputs were uploaded on (run_slots orders Stage A behind it)
     hipEvent_t upload_ev = nullptr;
     long long n_graph_launches = 0;
