@@ -396,6 +396,43 @@ bool single_fast_ok(const mlm_handle *h, int n) {
 // the stream uploads of a call's inputs go to: the one its Stage A will run on (a frame-level veto of the graph path is
 // repaired by run_slots with an event between the two streams)
 inline hipStream_t upload_stream(const mlm_handle *h) { return fast_handle_ok(h) ? h->stream : h->stream_as[h->cur_set]; }
+// The launch sequence of ONE frame on stream `st` (the sector path, everything on one stream): a prologue kernel takes the frame's
+// parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, an epilogue kernel writes the
+// counters, the map-wide flags and — last — the completion ticket back to pinned memory.  Issued directly, or captured into a graph.
+hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int big, hipStream_t st) {
+    const MlmSlot &S = h->slots[(size_t)base];
+    const MlmDev &P = S.P;
+    hipLaunchKernelGGL(k_frame_prologue, dim3(1), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
+    if (S.mode == 0) hipLaunchKernelGGL((k_bin_sectors<0, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+    else if (S.mode == 1) hipLaunchKernelGGL((k_bin_sectors<1, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+    else hipLaunchKernelGGL((k_bin_sectors<2, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+    const int row_w = S.mode == 0 ? S.F.width : 64;
+    unsigned long long dm, rm;
+    int ds, rs;
+    div_magic((unsigned int)row_w, dm, ds);
+    div_magic((unsigned int)P.nRho, rm, rs);
+    // (a single frame is alone on the GPU: the 512-thread workgroup finishes a column sooner; the table is the same)
+    if (h->sec_threads == 256 && P.sec_tab < 512u)
+        hipLaunchKernelGGL((k_sector<false, 256>), dim3((unsigned int)P.nPhi, 1, 1), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
+                           S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
+    else
+        hipLaunchKernelGGL((k_sector<false, 512>), dim3((unsigned int)P.nPhi, 1, 1), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
+                           S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
+    if (big)
+        hipLaunchKernelGGL(k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1,
+                           S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
+    hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
+    hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
+    hipLaunchKernelGGL(k_tile, dim3((unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
+    hipLaunchKernelGGL(k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
+    hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(128), 0, st, (const MlmCounters *)(h->d_ctr_all + base), h->h_ctr_all + base, (const MlmGlobal *)h->P.g, h->h_g,
+                       (const MlmFrame *)(h->d_frame_tab + base));
+    return hipGetLastError();
+}
+
+// A single frame in synchronous mode: that sequence as ONE replay of a HIP graph, or (knob single_eager) issued launch by launch —
+// measured 8 us slower per call than the replay (profiles/r4o README entry).  Either way the calling thread then polls the ticket
+// the epilogue kernel writes (drain).
 int submit_single_graph(mlm_handle *h, int base) {
     MlmSlot &S = h->slots[(size_t)base];
     const MlmDev &P = S.P;
@@ -412,86 +449,45 @@ int submit_single_graph(mlm_handle *h, int base) {
     }
     const int big = P.sec_tab_big && h->big_armed > 0 ? 1 : 0;
     if (h->big_armed > 0) --h->big_armed;
-    mlm_handle::SingleGraph *G = nullptr;
-    for (auto &g : h->graphs)
-        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.sec_tab == P.sec_tab && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
-    if (!G) {
-        if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
-            for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
-            h->graphs.clear();
-        }
-        hipStream_t st = h->stream;
-        HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipSuccess;
-        if (h->graph_copies == 1) {
-            e = hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, sizeof(MlmFrame), hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemsetAsync(h->d_ctr_all + base, 0, sizeof(MlmCounters), st);
-        } else if (h->graph_copies == 2) {
-            hipLaunchKernelGGL(k_frame_prologue, dim3(1), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
-        }
-        if (e == hipSuccess) {
-            if (S.mode == 0) hipLaunchKernelGGL((k_bin_sectors<0, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
-            else if (S.mode == 1) hipLaunchKernelGGL((k_bin_sectors<1, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
-            else hipLaunchKernelGGL((k_bin_sectors<2, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
-            const int row_w = S.mode == 0 ? S.F.width : 64;
-            unsigned long long dm, rm;
-            int ds, rs;
-            div_magic((unsigned int)row_w, dm, ds);
-            div_magic((unsigned int)P.nRho, rm, rs);
-            // (a single frame is alone on the GPU: the 512-thread workgroup finishes a column sooner; the table is the same)
-            if (h->sec_threads == 256 && P.sec_tab < 512u)
-                hipLaunchKernelGGL((k_sector<false, 256>), dim3((unsigned int)P.nPhi, 1, 1), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
-            else
-                hipLaunchKernelGGL((k_sector<false, 512>), dim3((unsigned int)P.nPhi, 1, 1), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
-            if (big)
-                hipLaunchKernelGGL(k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1,
-                                   S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
-            hipLaunchKernelGGL(k_rank, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
-            hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
-            hipLaunchKernelGGL(k_tile, dim3((unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
-            hipLaunchKernelGGL(k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
-            e = hipGetLastError();
-        }
-        if (h->graph_copies == 1) {
-            if (e == hipSuccess) e = hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, sizeof(MlmCounters), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st);
-        } else if (h->graph_copies == 2 && e == hipSuccess) {
-            hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(128), 0, st, (const MlmCounters *)(h->d_ctr_all + base), h->h_ctr_all + base, (const MlmGlobal *)h->P.g, h->h_g,
-                               (const MlmFrame *)(h->d_frame_tab + base));
-            e = hipGetLastError();
-        }
-        hipGraph_t graph = nullptr;
-        const hipError_t e2 = hipStreamEndCapture(st, &graph);
-        if (e != hipSuccess || e2 != hipSuccess || !graph) {
-            if (graph) hipGraphDestroy(graph);
-            h->err = std::string("single-frame graph capture: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-            return MLM_ERR_HIP;
-        }
-        hipGraphExec_t exec = nullptr;
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-            h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
-            return MLM_ERR_HIP;
-        }
-        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, exec});
-        G = &h->graphs.back();
-    }
     h->h_frame_tab[base] = S.F;
-    if (h->graph_copies == 0) {
-        HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, sizeof(MlmFrame), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, sizeof(MlmCounters), h->stream));
-    }
-    if (h->graph_copies == 2) { // (the epilogue kernel ends with a ticket in the host copy of the map-wide flags: drain polls it)
-        h->h_g->pad = 0u;
-        h->wait_ticket = (unsigned int)S.F.seq + 1u;
-    }
-    HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
-    if (h->graph_copies == 0) {
-        HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
+    h->h_g->pad = 0u; // (the epilogue kernel ends with a ticket in the host copy of the map-wide flags: drain polls it)
+    h->wait_ticket = (unsigned int)S.F.seq + 1u;
+    if (h->single_eager) {
+        const hipError_t e = enqueue_single_frame(h, base, nb, big, h->stream);
+        if (e != hipSuccess) {
+            h->err = std::string("single-frame launch sequence: ") + hipGetErrorString(e);
+            return MLM_ERR_HIP;
+        }
+    } else {
+        mlm_handle::SingleGraph *G = nullptr;
+        for (auto &g : h->graphs)
+            if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.sec_tab == P.sec_tab && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
+        if (!G) {
+            if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
+                for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
+                h->graphs.clear();
+            }
+            hipStream_t st = h->stream;
+            HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const hipError_t e = enqueue_single_frame(h, base, nb, big, st);
+            hipGraph_t graph = nullptr;
+            const hipError_t e2 = hipStreamEndCapture(st, &graph);
+            if (e != hipSuccess || e2 != hipSuccess || !graph) {
+                if (graph) hipGraphDestroy(graph);
+                h->err = std::string("single-frame graph capture: ") + hipGetErrorString(e != hipSuccess ? e : e2);
+                return MLM_ERR_HIP;
+            }
+            hipGraphExec_t exec = nullptr;
+            const hipError_t e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e3 != hipSuccess) {
+                h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3);
+                return MLM_ERR_HIP;
+            }
+            h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, exec});
+            G = &h->graphs.back();
+        }
+        HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
     }
     h->n_graph_launches++;
     h->pending.push_back(&S);
