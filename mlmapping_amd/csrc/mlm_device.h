@@ -41,6 +41,7 @@ __device__ __forceinline__ int mlm_readlane(int v, int src) { return __builtin_a
 __device__ __forceinline__ uint32_t mlm_readlane(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
 typedef unsigned int mlm_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int mlm_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int mlm_u32x3 __attribute__((ext_vector_type(3)));
 
 __device__ __forceinline__ int mlm_cvt_int(double v) {
     if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;

@@ -190,6 +190,8 @@ struct mlm_handle {
     };
     std::vector<SingleGraph> graphs;
     bool use_graph = true;       // (MLM_GRAPH=0: always the general submission)
+    bool no_spread = false;      // the noise model never spreads a hit beyond its own cell (3 sigma < 1 cell everywhere, e.g. the reference's default
+                                 // depth_noise_coe 1e-6): k_chain_lanes has nothing to do and is not launched
     int single_eager = 0;        // 1: the single-frame launch sequence is issued launch by launch instead of as a graph replay (knob single_eager)
     hipStream_t last_upload = nullptr; // the stream the current call's inputs were uploaded on (run_slots orders Stage A behind it)
     hipEvent_t upload_ev = nullptr;

@@ -1175,6 +1175,11 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     // (a reference travels as its one packed word — the rounds held in registers one pair of cells ahead cost a register each —
     // and is taken apart where it is used; 0 = none: a real reference has a non-empty row byte)
     auto load_ref = [&](const mlm_u32x2 &rf, uint32_t p) -> uint32_t { return p < rf.y ? refs[(size_t)(rf.x + p)] : 0u; };
+    // The same for the rounds held in registers one pair ahead: issued UNCONDITIONALLY from a clamped index, the range check is made
+    // where the word is used (ref_of).  The compiler counts outstanding loads (s_waitcnt vmcnt(N)) only through straight-line code:
+    // behind a per-lane branch it has to wait for everything, i.e. for the prefetches it has just issued.
+    auto load_ref_ahead = [&](const mlm_u32x2 &rf, uint32_t p) -> uint32_t { return refs[(size_t)rf.x + (p < rf.y ? p : 0u)]; };
+    auto ref_of = [&](uint32_t word, uint32_t p, uint32_t n_refs) -> uint32_t { return p < n_refs ? word : 0u; };
     // (yx: rows below the cell's first pixel << 11 | column of the row's first lane)
     auto unpack = [&](uint32_t ref, uint32_t &bits, uint32_t &yx, uint32_t &sub) {
         uint32_t dy, x;
@@ -1182,10 +1187,10 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         yx = (dy << 11) | x;
     };
     auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &yx, uint32_t &sub) { unpack(load_ref(rf, p), bits, yx, sub); };
-    auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_ref)[4]) {
+    auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_raw)[4]) {
         uint32_t r_bits[4], r_yx[4], r_sub[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) unpack(r_ref[q], r_bits[q], r_yx[q], r_sub[q]);
+        for (int q = 0; q < 4; ++q) unpack(ref_of(r_raw[q], (uint32_t)lane + 64u * q, rf.y), r_bits[q], r_yx[q], r_sub[q]);
         // (the descriptor is the same in every lane: scalar registers, uniform branches)
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y), n = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z) & MLM_SEC_CNT_MASK,
                        n_refs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rf.y);
@@ -1344,7 +1349,10 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         return (uint32_t)x;
     };
     // returns (per lane, equal inside a half): the half's cell still has to be done by the whole wave
-    auto process_pair = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, bool valid, const uint32_t (&r_ref)[4]) -> bool {
+    auto process_pair = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, bool valid, const uint32_t (&r_raw)[4]) -> bool {
+        uint32_t r_ref[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r_ref[q] = ref_of(r_raw[q], (uint32_t)hl + 32u * q, valid ? rf.y : 0u);
         const uint32_t soff = rec.y, n = rec.z & MLM_SEC_CNT_MASK, n_refs = rf.y;
         const uint32_t pix0 = rec.w / MLM_TIME_SLOTS;
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
@@ -1441,35 +1449,35 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         return valid && !ok;
     };
     // one pair of cells ahead: descriptors two pairs ahead, the first four rounds of references one pair ahead — a cell is
-    // otherwise a chain of four dependent memory round trips (descriptor, references, records, store)
-    mlm_u32x4 rec_cur = mlm_u32x4{0u, 0u, 0u, 0u}, rec_nxt = rec_cur;
-    mlm_u32x2 rf_cur = mlm_u32x2{0u, 0u}, rf_nxt = rf_cur;
-    uint32_t r_cur[4] = {0, 0, 0, 0}, r_nxt[4] = {0, 0, 0, 0};
-    auto load_desc = [&](unsigned int pw, mlm_u32x4 &rec, mlm_u32x2 &rf) { // the half's cell of pair pw
-        const unsigned int c = 2u * pw + (unsigned int)half;
-        rec = mlm_u32x4{0u, 0u, 0u, 0u};
-        rf = mlm_u32x2{0u, 0u};
-        if (c < n_cells) {
-            rec = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + c);
-            rf = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)c);
-        }
-    };
+    // otherwise a chain of four dependent memory round trips (descriptor, references, records, store).  Every load of the loop is
+    // issued unconditionally (clamped indices; validity travels beside the data): what was requested while the previous pair was
+    // worked on is waited for ONCE at the top of the loop, nothing is waited for in the middle of a pair.
     const unsigned int n_pairs = (n_cells + 1u) >> 1;
-    if (wave < n_pairs) {
-        load_desc(wave, rec_cur, rf_cur);
+    if (wave >= n_pairs) return; // (uniform; n_cells >= 1 from here on)
+    auto load_desc = [&](unsigned int pw, mlm_u32x4 &rec, mlm_u32x2 &rf) { // the half's cell of pair pw (clamped to the last cell)
+        const unsigned int c = min(2u * min(pw, n_pairs - 1u) + (unsigned int)half, n_cells - 1u);
+        rec = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + c);
+        rf = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)c);
+    };
+    auto desc_valid = [&](unsigned int pw) { return pw < n_pairs && 2u * pw + (unsigned int)half < n_cells; };
+    mlm_u32x4 rec_cur, rec_nxt;
+    mlm_u32x2 rf_cur, rf_nxt;
+    uint32_t r_cur[4], r_nxt[4];
+    bool v_cur = desc_valid(wave), v_nxt = desc_valid(wave + n_waves);
+    load_desc(wave, rec_cur, rf_cur);
+    load_desc(wave + n_waves, rec_nxt, rf_nxt);
+    if (!v_cur) rf_cur.y = 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r_cur[q] = load_ref(rf_cur, (uint32_t)hl + 32u * q);
-    }
-    if (wave + n_waves < n_pairs) load_desc(wave + n_waves, rec_nxt, rf_nxt);
+    for (int q = 0; q < 4; ++q) r_cur[q] = load_ref_ahead(rf_cur, (uint32_t)hl + 32u * q);
     for (unsigned int pw = wave; pw < n_pairs; pw += n_waves) {
-        mlm_u32x4 rec_nn = mlm_u32x4{0u, 0u, 0u, 0u};
-        mlm_u32x2 rf_nn = mlm_u32x2{0u, 0u};
-        if (pw + n_waves < n_pairs) {
+        mlm_u32x4 rec_nn;
+        mlm_u32x2 rf_nn;
+        if (!v_nxt) rf_nxt.y = 0u; // (rf_nxt was requested a pair ago: this is the loop's one wait for memory)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) r_nxt[q] = load_ref(rf_nxt, (uint32_t)hl + 32u * q);
-        }
-        if (pw + 2 * n_waves < n_pairs) load_desc(pw + 2 * n_waves, rec_nn, rf_nn);
-        const bool again = process_pair(rec_cur, rf_cur, 2u * pw + (unsigned int)half < n_cells, r_cur);
+        for (int q = 0; q < 4; ++q) r_nxt[q] = load_ref_ahead(rf_nxt, (uint32_t)hl + 32u * q);
+        load_desc(pw + 2 * n_waves, rec_nn, rf_nn);
+        const bool v_nn = desc_valid(pw + 2 * n_waves);
+        const bool again = process_pair(rec_cur, rf_cur, v_cur, r_cur);
         const unsigned long long again_lanes = __ballot(again);
         for (int h = 0; h < 2; ++h) // (uniform) the whole wave on a cell that did not fit half of it
             if ((again_lanes >> (32 * h)) & 1ull) {
@@ -1490,10 +1498,10 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         rf_cur = rf_nxt;
         rec_nxt = rec_nn;
         rf_nxt = rf_nn;
+        v_cur = v_nxt;
+        v_nxt = v_nn;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            r_cur[q] = r_nxt[q];
-        }
+        for (int q = 0; q < 4; ++q) r_cur[q] = r_nxt[q];
     }
 }
 
@@ -1516,6 +1524,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
     }
     __syncthreads();
     const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
+    if (n_cells == 0u) return; // (uniform)
     const int lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     uint32_t loc_next = 0, loc_end = 0; // (uniform) the wave's reserved cells not handed to a lane yet
@@ -1540,6 +1549,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
         // ---- what was requested in the previous round has arrived
         if (state == 2 || state == 3) kinds = kinds_in;
         if (state == 2) state = 3;
+        // (both loads of a round — the next sixteen kinds, the next descriptor — are issued by EVERY lane, from a harmless address where
+        // the lane needs nothing: the compiler counts outstanding loads only through straight-line code, behind a per-lane branch it
+        // waits for them on the spot instead of at the top of the next round)
+        uint32_t k_at = 0u; // offset in `subs` of the kinds this lane requests this round
         if (state == 1) {
             pos = desc_in.x;
             base = desc_in.y;
@@ -1548,13 +1561,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
             j0 = 0;
             first = true;
             p = 0.0f;
-            kinds_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.subs) + base);
+            k_at = base;
             state = 2;
         } else if (state == 3 && j0 + 16u < n) {
-            kinds_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.subs) + base + j0 + 16u); // (one round ahead)
+            k_at = base + j0 + 16u; // (one round ahead)
         }
+        kinds_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.subs) + k_at);
         // ---- idle lanes draw cells
         const unsigned long long need = __ballot(state == 0);
+        uint32_t d_at = 0u; // the descriptor this lane requests this round
         if (need && !exhausted) {
             if (loc_next >= loc_end) {
                 uint32_t b = 0;
@@ -1567,11 +1582,16 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
             if (!exhausted) {
                 const uint32_t idx = loc_next + (uint32_t)__popcll(need & lanes_below);
                 if (state == 0 && idx < loc_end) {
-                    desc_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + idx);
+                    d_at = idx;
                     state = 1;
                 }
                 loc_next = min(loc_end, loc_next + (uint32_t)__popcll(need));
             }
+        }
+        {   // (three of the descriptor's four words: a destination register the lane never reads is reused by the compiler at once,
+            // and a write to a register with a load in flight waits for the load)
+            const mlm_u32x3 d3 = *(const MLM_GLOBAL mlm_u32x3 *)(mlm_gp(P.mt_rec) + d_at);
+            desc_in = mlm_u32x4{d3.x, d3.y, d3.z, 0u};
         }
         if (exhausted && !__any(state != 0)) break;
         if (__popcll(__ballot(pend)) >= 40) flush();

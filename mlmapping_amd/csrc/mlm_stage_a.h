@@ -249,7 +249,8 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
             const long long cells = std::max<long long>(1, h->stats.n_multi_cells);
             cg = n > 4 ? (unsigned int)std::min<long long>(64, std::max<long long>(8, cells / 400)) : (unsigned int)std::min<long long>(128, std::max<long long>(16, cells / 128));
         }
-        tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
+        if (!h->no_spread)
+            tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
                 base);
         // the frame's hits and misses grouped by voxel, tile by tile (needs the increments and keys of the kernels above)
         if (!P.explore)

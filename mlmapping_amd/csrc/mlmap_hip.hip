@@ -223,6 +223,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             while ((float)d < sigma3[r] && r + d < P.nRho && d <= MLM_DIFF_RANGE) ++d;
             dmax = std::max(dmax, d - 1);
         }
+        h->no_spread = dmax == 0; // (a point only ever hits its own cell: no cell collects several kinds, nothing to rank or replay)
         if (dmax > 4) {
             P.node_lds = 1024;
             P.agg_lds = 512;
