@@ -520,7 +520,7 @@ def main():
         if world == 1 and args.workload == "cfg2" and not args.no_extra:
             # config 3 (1280x720, 0.05 m) in the same invocation: a short stream, same protocol (its own roofline; its CPU
             # baseline below)
-            B3, BPS3, K3, W3, D3 = 16, 2, 6, 1, 16
+            B3, BPS3, K3, W3, D3 = 32, 2, 6, 1, 32  # (96 frame slots of 2 GB each: 190 GB of the 288 GB)
             f3, q3, t3 = make_inputs(S3, D3, (K3 + W3) * B3 * BPS3, seed=42)
             d3 = torch.from_numpy(f3.view(np.int16)).cuda(local_rank)
             m3 = MLMap(S3, device=local_rank, max_blocks=65536, max_points=S3.width * S3.height, max_batch=B3)

@@ -227,6 +227,7 @@ __device__ __forceinline__ int mlm_block_find_k(const MlmDev &P, unsigned long l
     for (uint32_t probe = 0; probe <= P.ht_mask; ++probe) {
         const unsigned long long k = mlm_gp(P.ht_keys)[h];
         const int s = mlm_gp(P.ht_slot)[h];
+        asm volatile("" ::"v"(s)); // (keeps the slot's load next to the key's: the compiler otherwise sinks it behind the comparison — a second trip)
         if (k == key) return s;
         if (k == MLM_HT_EMPTY) return -1;
         h = (h + 1) & P.ht_mask;

@@ -675,6 +675,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 const uint32_t gi = rec_index(r, n_staged);
                 const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + gi);
                 const mlm_u32x4 a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
+                const unsigned long long rec_mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4); // (with the first 16 bytes: one trip to memory)
+                __builtin_amdgcn_sched_barrier(0); // (both loads are issued before the first is waited for)
                 const uint32_t kind = a.z >> 27;
                 if (kind == MLM_SEC_OUTER) {
                     if (pass == 0) { // ray of a point outside the map: one lane walks it into the LDS mask
@@ -686,7 +688,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         }
                         uint32_t p0 = 0;
                         if (EX) { // the record's first point (several records may start the same ray: the minimum wins)
-                            const int l0 = __ffsll((long long)*(const MLM_GLOBAL unsigned long long *)(rp + 4)) - 1;
+                            const int l0 = __ffsll((long long)rec_mask) - 1;
                             p0 = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
                         }
                         for (int rr = 1; rr < rho; ++rr) {
@@ -702,13 +704,13 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 }
                 const uint32_t cell = a.x;
                 if (pass == 1) {
-                    refs_of(cell, a.y, *(const MLM_GLOBAL unsigned long long *)(rp + 4));
+                    refs_of(cell, a.y, rec_mask);
                     continue;
                 }
                 const int z = (int)(cell / (uint32_t)P.nRhoPhi);
                 const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
                 {
-                    const unsigned long long mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
+                    const unsigned long long mask = rec_mask;
                     if (c0 == 0 && r == threadIdx.x) {
                         keep_cell = cell;
                         keep_yx = a.y;
