@@ -19,6 +19,13 @@
 // wrappers are the device-scope relaxed atomics of HIP's atomicOr/atomicAdd/atomicMin on such pointers.
 #define MLM_GLOBAL __attribute__((address_space(1)))
 template <class T> __device__ __forceinline__ MLM_GLOBAL T *mlm_gp(T *p) { return (MLM_GLOBAL T *)p; }
+// A word every lane of the workgroup reads at the same address and that no kernel-mate writes before the read: loaded through
+// the scalar cache (address space 4 makes the compiler emit s_load) — a hit there answers in a fraction of a vector load's time.
+// (the scalar cache is invalidated at every kernel start: what an earlier kernel wrote, atomics included, is seen)
+__device__ __forceinline__ unsigned int mlm_uniform_word(const unsigned int *p) {
+    return *(const __attribute__((address_space(4))) unsigned int *)(unsigned long long)p;
+}
+__device__ __forceinline__ double mlm_uniform_f64(const double *p) { return *(const __attribute__((address_space(4))) double *)(unsigned long long)p; }
 // The same for LDS: a generic pointer to __shared__ memory (e.g. a volatile one used for wave-synchronous exchange)
 // compiles to FLAT instructions with 64-bit address arithmetic; mlm_lp() re-types it as address space 3 (DS instructions).
 #define MLM_LDS __attribute__((address_space(3)))

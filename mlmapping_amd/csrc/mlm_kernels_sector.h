@@ -58,6 +58,7 @@ struct MlmSecCell {
     uint32_t cnt;   // contributions
 };
 #define MLM_SEC_REF_ALIGN 4u // a cell's references start at a multiple of this many (16 bytes) from the column's first
+#define MLM_SEC_KEEP_MORE 15u // count of a kept record whose targets did not fit the kept registers (see k_sector)
 #define MLM_SEC_KEY_MASK 0xFFFFu
 
 #define MLM_SEC_KIND_BITS 21 // MlmSecCell::kg: 2 * MLM_DIFF_RANGE + 1 kinds below the reference count
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
             }
         }
         rec_place[j] = MLM_NIL;
-        rec_cell[j] = leader ? (uint32_t)c0 : (uint32_t)rho;
+        rec_cell[j] = leader ? (uint32_t)zi << 16 | (uint32_t)rho : (uint32_t)rho; // (hit records: z and rho of the centre cell, nRho * nZ < 65 536)
         // hit records carry their tile's origin (row << 11 | column of lane 0; list modes: 64 items = one row) for k_rank
         uint32_t yx = i00 >> 6 << 11;
         if (MODE == 0) {
@@ -471,15 +472,17 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                                                   int rho_s, unsigned long long n_bkt, int big_armed, unsigned long long row_m, int row_s) {
     constexpr int PER_MAX = BIG ? 8 : 4; // cell-table entries per thread
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // (the column's first chunk descriptors are requested together with their count and arrive while the tables below are set
-    // up: one dependent trip to memory less in a column's life; what lies beyond the count is not looked at)
+    // (four columns in five of a camera frame hold nothing: the count comes through the scalar cache — sixteen columns share a
+    // line of it — and an empty column's workgroup is gone after a fraction of a trip to memory)
+    const unsigned int nch_all = mlm_uniform_word(P.col_cnt + phi);
+    if (nch_all == 0) return; // nothing fell into this column (uniform)
+    // (the column's first chunk descriptors are requested now and arrive while the tables below are set up: one dependent trip
+    // to memory less in a column's life; what lies beyond the count is not looked at)
     mlm_u32x2 chunk_first = mlm_u32x2{0u, 0u};
     constexpr uint32_t CH = NT < MLM_SEC_CHUNKS ? NT : MLM_SEC_CHUNKS; // chunk descriptors staged per pass: one per thread
-    // (one wave's worth: a column of a VGA frame has ~50, and every column — also the four in five that hold nothing — asks)
-    if (threadIdx.x < min(64u, P.chunk_cap))
+    if (threadIdx.x < min(64u, min(nch_all, P.chunk_cap))) // (one wave's worth: a column of a VGA frame has ~50)
         chunk_first = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)phi * P.chunk_cap + threadIdx.x));
-    const unsigned int nch_all = mlm_gp(P.col_cnt)[phi];
-    if (nch_all == 0) return; // nothing fell into this column (uniform)
+    MLM_PHASE_BEGIN
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t TAB = BIG ? P.sec_tab_big : P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
@@ -504,6 +507,48 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     __shared__ uint32_t s_base[8];
     __shared__ unsigned int s_fail, s_nouter, s_tab_full;
     __shared__ uint32_t s_ref_ov[8], s_ref_ov_n; // table entries whose reference count wrapped
+    const MLM_GLOBAL uint32_t *chunks = mlm_gp(P.col_chunks) + 2 * (size_t)phi * P.chunk_cap;
+    const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
+    // flat record r of the staged chunks -> index into `bnodes`
+    auto rec_index = [&](uint32_t r, uint32_t n_staged) -> uint32_t {
+        uint32_t lo = 0, hi = n_staged; // largest c with start[c] <= r
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_chunk_start[mid] <= r) lo = mid;
+            else hi = mid;
+        }
+        return s_chunk_first[lo] + (r - s_chunk_start[lo]);
+    };
+    // stage the chunk descriptors [c0, c0 + n_staged): first record and running record count of each; returns the records in all
+    auto stage_chunks = [&](uint32_t c0, uint32_t n_staged) -> uint32_t {
+        uint32_t total = 0;
+        const uint32_t j = threadIdx.x;
+        mlm_u32x2 d = mlm_u32x2{0u, 0u};
+        if (j < n_staged) d = (c0 == 0 && j < 64u) ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
+        const uint32_t off = mlm_block_excl_scan<NT / 64>(d.y, s_w, &total);
+        if (j < n_staged) {
+            s_chunk_first[j] = d.x;
+            s_chunk_start[j] = off;
+        }
+        __syncthreads();
+        return total;
+    };
+    const double col_cos = mlm_uniform_f64(P.cos_phi + phi), col_sin = mlm_uniform_f64(P.sin_phi + phi);
+    // (the tables that come from memory first: a wait for a later load is a wait for every earlier one, and nothing below may wait
+    // for the records)
+    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += NT) s_strength[e] = (uint8_t)mlm_sec_strength(mlm_gp(P.odds_table)[e]);
+    for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += NT) s_sigma[e] = mlm_gp(P.sigma3)[e];
+    // The first descriptors are staged and every thread's first record is requested BEFORE the tables are set up: the records
+    // (a trip to HBM, the longest wait of a column's life under load) arrive while the workgroup initialises its LDS.
+    const uint32_t pre_total = stage_chunks(0, min(nch, CH));
+    mlm_u32x4 pre_a = mlm_u32x4{0u, 0u, 0u, 0u};
+    unsigned long long pre_mask = 0;
+    if (threadIdx.x < pre_total) {
+        const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + rec_index(threadIdx.x, min(nch, CH)));
+        pre_a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
+        pre_mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
+    }
+    MLM_PHASE(7);
     for (uint32_t e = threadIdx.x; e < TAB; e += NT) {
         s_tab[e].key = MLM_NIL;
         s_tab[e].tmin = MLM_EMPTY_T;
@@ -512,9 +557,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         if (EX) s_p0[e] = MLM_EMPTY_T;
     }
     for (uint32_t e = threadIdx.x; e < NMISS; e += NT) s_miss[e] = EX ? MLM_EMPTY_T : 0u;
-    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += NT) s_strength[e] = (uint8_t)mlm_sec_strength(mlm_gp(P.odds_table)[e]);
     for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += NT) {
-        s_sigma[e] = mlm_gp(P.sigma3)[e];
         s_run_hits[e] = 0;
         s_rho_miss[e] = 0;
     }
@@ -536,7 +579,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     for (uint32_t e = threadIdx.x; e < (uint32_t)(P.nRho + P.nZ); e += NT) {
         double wx, wy, wz;
         if (e < (uint32_t)P.nRho) {
-            mlm_cell_center_w(P, F.t_wa, (int)e, phi, 0, wx, wy, wz);
+            // (mlm_cell_center_w with the column's cosine and sine from the scalar cache: no vector load between the request for the
+            // records and their use)
+            const double center_rho = P.dRho / 2 + ((int)e * P.dRho);
+            wx = center_rho * col_cos + F.t_wa[0];
+            wy = center_rho * col_sin + F.t_wa[1];
             int gx, gy, cx, cy;
             mlm_voxel_axis(P, wx, gx, cx);
             mlm_voxel_axis(P, wy, gy, cy);
@@ -550,7 +597,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             }
         } else {
             const int z = (int)e - P.nRho;
-            mlm_cell_center_w(P, F.t_wa, 0, phi, z, wx, wy, wz);
+            wz = (P.z_border_min + (P.dZ / 2) + (z * P.dZ)) + F.t_wa[2];
             int gz, cz;
             mlm_voxel_axis(P, wz, gz, cz);
             const bool bad = cz < 0 || cz >= P.n;
@@ -594,89 +641,101 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         if ((vr.z | vz.y) >> 16) cx = cy = cz = 0; // a coordinate outside [0, n): id 0 (mlm_voxel_of)
         cid = cz * P.n * P.n + cy * P.n + cx;
     };
-    MLM_PHASE_BEGIN
+    MLM_PHASE(0);
     const uint32_t tab_mask = TAB - 1;
-    const MLM_GLOBAL uint32_t *chunks = mlm_gp(P.col_chunks) + 2 * (size_t)phi * P.chunk_cap;
-    const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
     auto key_rz = [&](uint32_t key, int &rho, int &z) { // key = z * nRho + rho (exact division by multiplication, key < 2^27)
         z = (int)(((unsigned long long)key * rho_m) >> rho_s);
         rho = (int)key - z * P.nRho;
-    };
-    // flat record r of the staged chunks -> index into `bnodes`
-    auto rec_index = [&](uint32_t r, uint32_t n_staged) -> uint32_t {
-        uint32_t lo = 0, hi = n_staged; // largest c with start[c] <= r
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_chunk_start[mid] <= r) lo = mid;
-            else hi = mid;
-        }
-        return s_chunk_first[lo] + (r - s_chunk_start[lo]);
     };
     // pass = 0: book every record's contributions on the cells of the column (and walk the rays of points outside the
     // map); pass = 1: write a (record, kind) reference for every contribution group of a multi-kind cell.  A thread
     // keeps the record it handled first: a column with at most NT records (the usual case) is not read twice.
     uint32_t keep_cell = MLM_NIL, keep_yx = 0, keep_total = 0xFFFFFFFFu;
     unsigned long long keep_mask = 0;
-    auto refs_of = [&](uint32_t cell, uint32_t yx, unsigned long long mask) {
-        const int z = (int)(cell / (uint32_t)P.nRhoPhi);
-        const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
-        // the non-empty rows of the group's lane mask, once per record (three bits each): the same for every target cell
-        uint32_t rows3 = 0, n_rows = 0;
+    // ... and the table entries of its targets, so that the second pass neither recomputes them nor probes the table:
+    // (entry | kind << 12) in 16 bits each, four in keep_lo, the fifth in keep_hi's low half, the count in its high half
+    // (MLM_SEC_KEEP_MORE: more than five targets or a kind above 15 — the record is recomputed)
+    unsigned long long keep_lo = 0;
+    uint32_t keep_hi = 0;
+    // the non-empty rows of a group's lane mask, once per record (three bits each): the same for every target cell
+    auto rows_of = [&](unsigned long long mask, uint32_t &rows3, uint32_t &n_rows) {
+        rows3 = 0, n_rows = 0;
 #pragma unroll
         for (uint32_t row = 0; row < 8u; ++row)
             if ((uint32_t)(mask >> (8u * row)) & 0xFFu) rows3 |= row << (3u * n_rows++);
+    };
+    auto emit_refs = [&](int e, uint32_t sub, uint32_t yx, unsigned long long mask, uint32_t rows3, uint32_t n_rows) {
+        if (!mlm_sec_needs_order(s_tab[e])) return;
+        // one 4-byte reference per non-empty ROW of the group's lane mask (mlm_ref_pack): row byte, kind, and the row's
+        // position relative to the cell's first pixel — what k_rank needs, with no empty rows in its rounds (a group
+        // touches two or three of its eight rows)
+        // (the count of the cell's references, counted up by the booking pass, is counted down here: every group gets its own
+        // stretch of the cell's segment; the order of the references inside a segment does not matter)
+        const uint32_t left = atomicSub(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS;
+        const uint32_t at = s_base[2] + (s_tab[e].key >> 16) * MLM_SEC_REF_ALIGN + (left - n_rows);
+        const uint32_t pix0 = s_tab[e].tmin / MLM_TIME_SLOTS;
+        const uint32_t y0c = tile_w > 0 ? (uint32_t)(((unsigned long long)pix0 * row_m) >> row_s) : pix0 >> 6;
+        const uint32_t dy0 = (yx >> 11) - y0c; // (>= 0: the cell's first pixel is its contributions' smallest)
+        if (dy0 + 7u > (tile_w > 0 ? MLM_REF_DY_DENSE : MLM_REF_DY_LIST)) {
+            s_fail = 1; // (an image more than 2 047 rows tall below the cell's first pixel: not expressible — the frame falls back)
+        } else if (at + n_rows <= P.refs_cap) {
+            MLM_GLOBAL uint32_t *dst = mlm_gp(P.refs) + at;
+            for (uint32_t k = 0; k < n_rows; ++k) {
+                const uint32_t row = (rows3 >> (3u * k)) & 7u;
+                dst[k] = mlm_ref_pack((uint32_t)(mask >> (8u * row)) & 0xFFu, sub, tile_w > 0, dy0, row, yx & 2047u);
+            }
+        }
+    };
+    auto refs_of = [&](uint32_t cell, uint32_t yx, unsigned long long mask) {
+        const int z = (int)(cell >> 16), rho = (int)(cell & 0xFFFFu);
+        uint32_t rows3, n_rows;
+        rows_of(mask, rows3, n_rows);
         mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int) {
             const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
-            if (e >= 0 && mlm_sec_needs_order(s_tab[e])) {
-                // one 4-byte reference per non-empty ROW of the group's lane mask (mlm_ref_pack): row byte, kind, and the row's
-                // position relative to the cell's first pixel — what k_rank needs, with no empty rows in its rounds (a group
-                // touches two or three of its eight rows)
-                // (the count of the cell's references, counted up by the booking pass, is counted down here: every group gets its own
-                // stretch of the cell's segment; the order of the references inside a segment does not matter)
-                const uint32_t left = atomicSub(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS;
-                const uint32_t at = s_base[2] + (s_tab[e].key >> 16) * MLM_SEC_REF_ALIGN + (left - n_rows);
-                const uint32_t pix0 = s_tab[e].tmin / MLM_TIME_SLOTS;
-                const uint32_t y0c = tile_w > 0 ? (uint32_t)(((unsigned long long)pix0 * row_m) >> row_s) : pix0 >> 6;
-                const uint32_t dy0 = (yx >> 11) - y0c; // (>= 0: the cell's first pixel is its contributions' smallest)
-                if (dy0 + 7u > (tile_w > 0 ? MLM_REF_DY_DENSE : MLM_REF_DY_LIST)) {
-                    s_fail = 1; // (an image more than 2 047 rows tall below the cell's first pixel: not expressible — the frame falls back)
-                } else if (at + n_rows <= P.refs_cap) {
-                    MLM_GLOBAL uint32_t *dst = mlm_gp(P.refs) + at;
-                    for (uint32_t k = 0; k < n_rows; ++k) {
-                        const uint32_t row = (rows3 >> (3u * k)) & 7u;
-                        dst[k] = mlm_ref_pack((uint32_t)(mask >> (8u * row)) & 0xFFu, (uint32_t)sub, tile_w > 0, dy0, row, yx & 2047u);
-                    }
-                }
-            }
+            if (e >= 0) emit_refs(e, (uint32_t)sub, yx, mask, rows3, n_rows);
         });
+    };
+    auto refs_of_kept = [&]() {
+        const uint32_t nt = keep_hi >> 16;
+        if (nt == MLM_SEC_KEEP_MORE) {
+            refs_of(keep_cell, keep_yx, keep_mask);
+            return;
+        }
+        uint32_t rows3, n_rows;
+        rows_of(keep_mask, rows3, n_rows);
+        for (uint32_t k = 0; k < nt; ++k) {
+            const uint32_t t = k < 4u ? (uint32_t)(keep_lo >> (16u * k)) & 0xFFFFu : keep_hi & 0xFFFFu;
+            emit_refs((int)(t & 0xFFFu), t >> 12, keep_yx, keep_mask, rows3, n_rows);
+        }
     };
     auto for_records = [&](int pass) {
         if (pass == 1 && nch <= CH && keep_total <= NT) {
-            if (keep_cell != MLM_NIL) refs_of(keep_cell, keep_yx, keep_mask);
+            if (keep_cell != MLM_NIL) refs_of_kept();
             return;
         }
         for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
             const uint32_t n_staged = min(nch - c0, CH);
-            __syncthreads();
-            uint32_t total = 0;
-            {
-                const uint32_t j = threadIdx.x;
-                mlm_u32x2 d = mlm_u32x2{0u, 0u};
-                if (j < n_staged) d = (c0 == 0 && j < 64u) ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
-                const uint32_t off = mlm_block_excl_scan<NT / 64>(d.y, s_w, &total);
-                if (j < n_staged) {
-                    s_chunk_first[j] = d.x;
-                    s_chunk_start[j] = off;
-                }
+            uint32_t total = pre_total; // (pass 0, first descriptors: staged before the set-up)
+            if (pass != 0 || c0 != 0) {
+                __syncthreads();
+                total = stage_chunks(c0, n_staged);
             }
-            __syncthreads();
             for (uint32_t r = threadIdx.x; r < total; r += NT) {
                 if (pass == 0 && *(volatile unsigned int *)&s_tab_full) break; // (the column is given up: nothing more to book)
-                const uint32_t gi = rec_index(r, n_staged);
-                const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + gi);
-                const mlm_u32x4 a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
-                const unsigned long long rec_mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4); // (with the first 16 bytes: one trip to memory)
-                __builtin_amdgcn_sched_barrier(0); // (both loads are issued before the first is waited for)
+                mlm_u32x4 a = pre_a;
+                unsigned long long rec_mask = pre_mask;
+                if (pass != 0 || c0 != 0 || r != threadIdx.x) {
+                    const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + rec_index(r, n_staged));
+                    a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
+                    rec_mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4); // (with the first 16 bytes: one trip to memory)
+                    __builtin_amdgcn_sched_barrier(0); // (both loads are issued before the first is waited for)
+                }
+#ifdef MLM_PHASE_PROF
+                if (pass == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    MLM_PHASE(8);
+                }
+#endif
                 const uint32_t kind = a.z >> 27;
                 if (kind == MLM_SEC_OUTER) {
                     if (pass == 0) { // ray of a point outside the map: one lane walks it into the LDS mask
@@ -707,15 +766,16 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                     refs_of(cell, a.y, rec_mask);
                     continue;
                 }
-                const int z = (int)(cell / (uint32_t)P.nRhoPhi);
-                const int rho = (int)(cell - (uint32_t)z * (uint32_t)P.nRhoPhi - (uint32_t)phi * (uint32_t)P.nRho);
+                const int z = (int)(cell >> 16), rho = (int)(cell & 0xFFFFu);
                 {
                     const unsigned long long mask = rec_mask;
-                    if (c0 == 0 && r == threadIdx.x) {
+                    const bool kept = c0 == 0 && r == threadIdx.x;
+                    if (kept) {
                         keep_cell = cell;
                         keep_yx = a.y;
                         keep_mask = mask;
                     }
+                    uint32_t nt = 0;
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
                     const uint32_t i_first = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
                     const uint32_t cnt = (uint32_t)__popcll(mask), n_rows = mlm_mask_rows(mask);
@@ -724,6 +784,13 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         if (e < 0) {
                             s_tab_full = 1;
                             return;
+                        }
+                        if (kept) {
+                            const uint32_t t = (uint32_t)e | (uint32_t)sub << 12;
+                            if (nt < 4u) keep_lo |= (unsigned long long)t << (16u * nt);
+                            else keep_hi |= t & 0xFFFFu;
+                            if (nt >= 5u || sub > 15) nt = MLM_SEC_KEEP_MORE - 1u;
+                            ++nt;
                         }
                         atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
                         atomicOr(&s_tab[e].kg, 1u << sub);
@@ -739,13 +806,13 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         }
                         if (EX && sub == 0) atomicMin(&s_p0[e], i_first);
                     });
+                    if (kept) keep_hi |= nt << 16;
                 }
             }
             if (pass == 0 && c0 == 0) keep_total = total;
         }
     };
     __syncthreads();
-    MLM_PHASE(0);
     for_records(0);
     __syncthreads();
     if (s_tab_full) { // (uniform) nothing has left the workgroup yet

@@ -11,13 +11,13 @@ from mlmapping_amd import mlmap as mm
 from mlmapping_amd import synthetic as syn
 from mlmapping_amd.config import S1, S3
 
-NAMES = ["0 LDS init", "1 pass 0: book records on cells", "2 lists + reservations + multi-kind descriptors", "3 rays into the LDS mask (DDA)",
-         "4 hit list, single-kind odds, voxel pushes", "5 pass 1: references", "6 miss cells: voxel counts + queue", "7 -", "8 -"]
+NAMES = ["0 set-up: column count, LDS tables, voxel axes, tile runs", "1 pass 0: book records on cells (after the records arrived)", "2 lists + reservations + multi-kind descriptors", "3 rays into the LDS mask (DDA)",
+         "4 hit list, single-kind odds, voxel pushes", "5 pass 1: references", "6 miss cells: voxel counts + queue", "7 pass 0: chunk descriptors staged", "8 pass 0: records arrive"]
 L = mm.load_library(os.path.join(os.path.dirname(mm.LIB_PATH), "libmlmap_hip_prof.so"))
 L.mlm_debug_phases.argtypes = [ctypes.c_void_p]
 mm._lib = L
 cfg = S3 if "cfg3" in sys.argv else S1
-n = 16
+n = int(os.environ.get("MLM_PHASE_BATCH", "16"))
 m = mm.MLMap(cfg, max_blocks=32768, max_batch=n)
 frames = list(syn.stream(cfg, "room_jitter", "random", n))
 imgs = np.stack([f[0] for f in frames])
