@@ -254,6 +254,11 @@ int mlm_set_timed_kernel(mlm_handle *h, const char *name, int every);
  * no environment variable for behaviour; MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN only print diagnostics. */
 int mlm_debug_set(const char *name, long long value);
 int mlm_debug_reset(void);
+/* Host clocks of the synchronous single-frame path of mlm_integrate_callback (a development aid, like the knobs): microseconds
+ * summed over the calls since the last reset — [0] pose compensation, drain of the previous call, sampling; [1] frame set-up up
+ * to the launch; [2] the launch call (hipGraphLaunch); [3] host work between launch and wait; [4] waiting for the frame's ticket;
+ * [5] the rest of the call. */
+int mlm_debug_clocks(mlm_handle *h, double out_us[8], int reset);
 
 #ifdef __cplusplus
 }

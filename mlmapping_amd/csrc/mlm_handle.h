@@ -66,6 +66,7 @@ struct MlmSlot {
     double *d_pts = nullptr;
 };
 
+static inline double mlm_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct mlm_handle {
     int device = 0;
     hipStream_t stream = nullptr; // main stream: Stage B/C (ordered across frames), queries
@@ -171,6 +172,7 @@ struct mlm_handle {
     int ov_heavy = 0;                // confirmed batches in a row whose last frame had many overflowed columns
     bool want_widen = false;         // ... the cell table is doubled before the next submission (widen_sec_tab)
     int sec_threads = 512;           // threads of a column's workgroup (k_sector<.., 256 | 512>; MLM_SEC_THREADS)
+    double clk[8] = {}, clk_t = 0;   // host clocks of the single-frame path (mlm_debug_clocks): microseconds per section, summed over the calls
     unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
     unsigned int single_apply_grid = 256; // workgroups of k_apply_single: a VGA frame's ~33 k voxel records, one per thread (more: in turns)
     unsigned int tile_grid = 0;      // workgroups of k_tile per frame of a batch: they walk the frame's touched tiles (MLM_TILE_GRID)
@@ -316,3 +318,10 @@ int widen_sec_tab(mlm_handle *h);
 int ensure_free_blocks_idle(mlm_handle *h, size_t need);
 
 } // namespace
+
+// host clock of the single-frame path: the time since the previous mark goes to section i (i < 0: start of a call)
+static inline void clk_mark(mlm_handle *h, int i) {
+    const double t = mlm_now_us();
+    if (i >= 0) h->clk[i] += t - h->clk_t;
+    h->clk_t = t;
+}

@@ -2321,7 +2321,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
 // another kernel wrote crosses the XCDs: several microseconds each), so every thread fetches its first record together with the
 // frame's flags and counts instead of after them: parameters -> (flags, count, record) -> (log-odds, class) -> store.
 // Stops in front of the frame under the same conditions as k_apply_tiles.
-__global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS, MlmCounters *host_ctr, MlmGlobal *host_g) {
     MLM_SLOT_SETUP
     __builtin_amdgcn_s_setprio(3);
     const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
@@ -2331,26 +2331,47 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS) {
     const MLM_GLOBAL MlmCounters *c = mlm_gp(P.ctr);
     const uint32_t total = min(c->mvox_cnt[0][0], P.rec_cap);
     const bool ok = c->sector_overflow == 0u && c->pool_short == 0u && ((F.flags & MLM_FRAME_EXACT_KEYS) || c->u_hit <= F.rehash_thr);
-    if (F.flags & MLM_FRAME_SKIP) return;
-    if (__hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < F.seq) return; // an earlier frame is to be replayed first
-    if (!ok) { // (uniform)
+    bool run = !(F.flags & MLM_FRAME_SKIP) && __hip_atomic_load(&P.g->fail_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= F.seq; // (else: an earlier frame is to be replayed first)
+    if (run && !ok) { // (uniform)
         if (i0 == 0) atomicMin(&P.g->fail_frame, F.seq);
-        return;
+        run = false;
     }
-    MLM_GLOBAL float *const pool_L = mlm_gp(P.log_odds);
-    MLM_GLOBAL uint8_t *const pool_o = mlm_gp(P.occ);
-    const MLM_GLOBAL MlmVoxHit *hits = mlm_gp(P.vr_hit);
-    const MLM_GLOBAL unsigned long long *xkeys = (F.flags & MLM_FRAME_EXACT_KEYS) ? (const MLM_GLOBAL unsigned long long *)mlm_gp(P.hl_key) : nullptr;
-    for (uint32_t i = i0; i < total; i += stride) {
-        if (i != i0) r = recs[i];
-        if ((int)r.x < 0) continue; // (no block: cannot happen, such a frame is not applied)
-        const uint32_t at = r.x;
-        float L = pool_L[at];
-        uint8_t o = pool_o[at];
-        mlm_apply_record(P, r, hits, xkeys, L, o);
-        pool_L[at] = L;
-        pool_o[at] = o;
+    if (run) {
+        MLM_GLOBAL float *const pool_L = mlm_gp(P.log_odds);
+        MLM_GLOBAL uint8_t *const pool_o = mlm_gp(P.occ);
+        const MLM_GLOBAL MlmVoxHit *hits = mlm_gp(P.vr_hit);
+        const MLM_GLOBAL unsigned long long *xkeys = (F.flags & MLM_FRAME_EXACT_KEYS) ? (const MLM_GLOBAL unsigned long long *)mlm_gp(P.hl_key) : nullptr;
+        for (uint32_t i = i0; i < total; i += stride) {
+            if (i != i0) r = recs[i];
+            if ((int)r.x < 0) continue; // (no block: cannot happen, such a frame is not applied)
+            const uint32_t at = r.x;
+            float L = pool_L[at];
+            uint8_t o = pool_o[at];
+            mlm_apply_record(P, r, hits, xkeys, L, o);
+            pool_L[at] = L;
+            pool_o[at] = o;
+        }
     }
+    if (!host_ctr) return; // (a replayed frame: the host reads the counters back itself)
+    // Last node of the single-frame graph: the workgroup that finishes last hands the frame's counters and the map-wide flags to the
+    // host (pinned memory) and writes, as its last word, a ticket — the frame's sequence number + 1 in MlmGlobal::pad of the HOST
+    // copy.  The calling thread polls the ticket instead of sleeping in hipStreamSynchronize: a synchronous call's wake-up is part
+    // of its latency, and so would be a kernel of its own for these few stores (4 us between two dependent kernels).
+    __shared__ unsigned int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = g_atomic_add(&mlm_gp(P.ctr)->apply_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x)
+        ((uint32_t *)host_ctr)[i] = __hip_atomic_load((const uint32_t *)P.ctr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 3) ((uint32_t *)host_g)[threadIdx.x] = __hip_atomic_load((const uint32_t *)P.g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&host_g->pad, (unsigned int)F.seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // After the host has grown the block pool: the blocks a frame's voxel records still lack (k_tile found the pool full) are created
@@ -2383,24 +2404,12 @@ __global__ void k_alloc_retry_done(const MlmDev P) {
     if (threadIdx.x == 0 && blockIdx.x == 0) mlm_gp(P.ctr)->pool_short = mlm_gp(P.ctr)->pool_short == 2u ? 1u : 0u;
 }
 
-// First and last node of the single-frame graph: the frame's parameters come from pinned host memory (one 128-thread block
+// First node of the single-frame graph: the frame's parameters come from pinned host memory (one 128-thread block
 // copies them into the device-resident table and clears the slot's counters), the counters and the map-wide flags go back
-// the same way — kernel nodes with fixed arguments instead of memcpy / memset nodes.
+// the same way (the tail of k_apply_single) — kernel nodes with fixed arguments instead of memcpy / memset nodes.
 __global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_frame, MlmFrame *dev_frame, MlmCounters *ctr) {
     const uint32_t *src = (const uint32_t *)host_frame;
     uint32_t *dst = (uint32_t *)dev_frame, *c = (uint32_t *)ctr;
     for (unsigned int i = threadIdx.x; i < sizeof(MlmFrame) / 4; i += blockDim.x) dst[i] = src[i];
     for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) c[i] = 0u;
-}
-// The last word written is a ticket (the frame's sequence number + 1 in MlmGlobal::pad of the HOST copy): the calling thread
-// polls it instead of sleeping in hipStreamSynchronize — a synchronous call's wake-up is part of its latency.
-__global__ __launch_bounds__(128) void k_frame_epilogue(const MlmCounters *ctr, MlmCounters *host_ctr, const MlmGlobal *g, MlmGlobal *host_g,
-                                                        const MlmFrame *dev_frame) {
-    const uint32_t *src = (const uint32_t *)ctr;
-    uint32_t *dst = (uint32_t *)host_ctr;
-    for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) dst[i] = src[i];
-    if (threadIdx.x < 3) ((uint32_t *)host_g)[threadIdx.x] = __hip_atomic_load((const uint32_t *)g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&host_g->pad, (unsigned int)dev_frame->seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -39,7 +39,8 @@ int launch_apply_tiles(mlm_handle *h, int base, int n, int f_begin = 0) {
         }
         // (the kernel derives the box from the frames [base + j0, base + j1) itself: it gets that range as ITS slot range)
         if (j1 - j0 == 1) // (one frame: nothing to keep in LDS between frames)
-            tlaunch(h, "k_apply_single", k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0);
+            tlaunch(h, "k_apply_single", k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0,
+                    (MlmCounters *)nullptr, (MlmGlobal *)nullptr);
         else
             tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(h->apply_block),
                     (size_t)(P.lv_nz + (z1 - z0)) * 9u * (1u << (2 * sh)) + 16u, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0, z1 - z0);
@@ -209,6 +210,7 @@ int drain(mlm_handle *h, bool g_copied) {
             // sleeping in hipStreamSynchronize, whose wake-up would be a tenth of the call
             const volatile unsigned int *ticket = &h->h_g->pad;
             const auto t0 = std::chrono::steady_clock::now();
+            clk_mark(h, 3);
             for (unsigned int spins = 0; !(seen = *ticket == h->wait_ticket); ++spins)
                 if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
             std::atomic_thread_fence(std::memory_order_acquire);
@@ -397,7 +399,7 @@ bool single_fast_ok(const mlm_handle *h, int n) {
 // repaired by run_slots with an event between the two streams)
 inline hipStream_t upload_stream(const mlm_handle *h) { return fast_handle_ok(h) ? h->stream : h->stream_as[h->cur_set]; }
 // The launch sequence of ONE frame on stream `st` (the sector path, everything on one stream): a prologue kernel takes the frame's
-// parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, an epilogue kernel writes the
+// parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, whose last workgroup writes the
 // counters, the map-wide flags and — last — the completion ticket back to pinned memory.  Issued directly, or captured into a graph.
 hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int big, hipStream_t st) {
     const MlmSlot &S = h->slots[(size_t)base];
@@ -425,15 +427,13 @@ hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int bi
     if (!h->no_spread)
         hipLaunchKernelGGL(k_chain_lanes, dim3(32, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base);
     hipLaunchKernelGGL(k_tile, dim3((unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
-    hipLaunchKernelGGL(k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base);
-    hipLaunchKernelGGL(k_frame_epilogue, dim3(1), dim3(128), 0, st, (const MlmCounters *)(h->d_ctr_all + base), h->h_ctr_all + base, (const MlmGlobal *)h->P.g, h->h_g,
-                       (const MlmFrame *)(h->d_frame_tab + base));
+    hipLaunchKernelGGL(k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, h->h_ctr_all + base, h->h_g);
     return hipGetLastError();
 }
 
 // A single frame in synchronous mode: that sequence as ONE replay of a HIP graph, or (knob single_eager) issued launch by launch —
 // measured 8 us slower per call than the replay (profiles/r4o README entry).  Either way the calling thread then polls the ticket
-// the epilogue kernel writes (drain).
+// the last workgroup of k_apply_single writes (drain).
 int submit_single_graph(mlm_handle *h, int base) {
     MlmSlot &S = h->slots[(size_t)base];
     const MlmDev &P = S.P;
@@ -451,7 +451,7 @@ int submit_single_graph(mlm_handle *h, int base) {
     const int big = P.sec_tab_big && h->big_armed > 0 ? 1 : 0;
     if (h->big_armed > 0) --h->big_armed;
     h->h_frame_tab[base] = S.F;
-    h->h_g->pad = 0u; // (the epilogue kernel ends with a ticket in the host copy of the map-wide flags: drain polls it)
+    h->h_g->pad = 0u; // (k_apply_single ends with a ticket in the host copy of the map-wide flags: drain polls it)
     h->wait_ticket = (unsigned int)S.F.seq + 1u;
     if (h->single_eager) {
         const hipError_t e = enqueue_single_frame(h, base, nb, big, h->stream);
@@ -488,7 +488,9 @@ int submit_single_graph(mlm_handle *h, int base) {
             h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, exec});
             G = &h->graphs.back();
         }
+        clk_mark(h, 1);
         HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
+        clk_mark(h, 2);
     }
     h->n_graph_launches++;
     h->pending.push_back(&S);

@@ -56,6 +56,16 @@ int mlm_debug_reset(void) {
     return MLM_OK;
 }
 
+int mlm_debug_clocks(mlm_handle *h, double out_us[8], int reset) {
+    if (!h || !out_us) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    for (int i = 0; i < 8; ++i) {
+        out_us[i] = h->clk[i];
+        if (reset) h->clk[i] = 0.0;
+    }
+    return MLM_OK;
+}
+
 int mlm_host_register(mlm_handle *h, const void *ptr, size_t bytes) {
     if (!h || !ptr || bytes == 0) return MLM_ERR_INVALID;
     MLM_LOCK(h);
@@ -736,6 +746,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         return MLM_ERR_CAPACITY;
     }
     HIPCHK(h, hipSetDevice(h->device));
+    clk_mark(h, -1);
     // ---- pose latency compensation, mlmap.cpp:470-498 (mlm_host.h)
     double qa[4], ta[3];
     compensate_pose(odom_p, odom_q, odom_v, imu_w, t_img, t_odom, t_imu, latency, qa, ta);
@@ -744,7 +755,8 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         for (int i = 0; i < 3; ++i) T_wb_out[4 + i] = ta[i];
     }
     // ---- depth image: upload (and convert 32FC1 -> 16UC1 on the device)
-    int rc = drain(h);
+    // (nothing in flight — the synchronous case: no read-back of the map-wide flags and no stream synchronisation just to learn that)
+    int rc = (h->pending.empty() && !h->wait_ticket && !h->P.explore) ? MLM_OK : drain(h);
     if (rc) return rc;
     MlmSlot &S = cur_slot(h, 0);
     rc = ensure_img(h, S, n_px);
@@ -768,37 +780,40 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         int cnt = 0;
         const int max_iter = 2 * h->cfg.sample_cnt;
         int32_t *st_pix = h->h_stage, *st_raw = h->h_stage + want;
+        // (the pixel positions a stretch ahead of their reads: every position drawn is one iteration of the reference's loop, and a
+        // stretch is never longer than the iterations the loop is certain to make — rand() is called exactly as often, in the same
+        // order; the reads, scattered over the frame, then miss the cache together instead of one after the other)
+        size_t ahead[128];
         while (n_s < want && cnt < max_iter) {
-            cnt++;
-            const size_t v = static_cast<size_t>(rand() % height);
-            const size_t u = static_cast<size_t>(rand() % width);
-            const size_t at = v * (size_t)width + u;
-            int r;
-            if (is_f32) {
-                r = mlm_cv_f32_to_u16(((const float *)depth)[at]);
-            } else {
-                r = ((const uint16_t *)depth)[at];
+            const size_t m = std::min<size_t>(std::min<size_t>(want - n_s, (size_t)(max_iter - cnt)), 128);
+            for (size_t i = 0; i < m; ++i) {
+                const size_t v = static_cast<size_t>(rand() % height);
+                const size_t u = static_cast<size_t>(rand() % width);
+                ahead[i] = v * (size_t)width + u;
+                __builtin_prefetch(is_f32 ? (const void *)((const float *)depth + ahead[i]) : (const void *)((const uint16_t *)depth + ahead[i]));
             }
-            if (r == 0) continue;
-            st_pix[n_s] = (int32_t)at;
-            st_raw[n_s] = r;
-            ++n_s;
+            cnt += (int)m;
+            for (size_t i = 0; i < m; ++i) {
+                const size_t at = ahead[i];
+                const int r = is_f32 ? mlm_cv_f32_to_u16(((const float *)depth)[at]) : (int)((const uint16_t *)depth)[at];
+                if (r == 0) continue;
+                st_pix[n_s] = (int32_t)at;
+                st_raw[n_s] = r;
+                ++n_s;
+            }
         }
-        if ((rc = ensure_pix(h, S))) return rc;
-        if (n_s) {
-            hipStream_t up = upload_stream(h);
-            h->last_upload = up;
-            HIPCHK(h, hipMemcpyAsync(S.d_pix, h->h_stage, 2 * want * sizeof(int32_t), hipMemcpyHostToDevice, up));
-        }
-        return integrate_u16_dev(h, S.d_img, width, height, width, S.d_pix, S.d_pix + want, (int)n_s, qa, ta);
+        // (the 4 KB do not travel by a copy of their own — a call and a copy kernel, a tenth of the call: the pinned buffer is mapped
+        // into the device's address space and k_bin_sectors, the list's only reader, takes the samples from it across the link)
+        clk_mark(h, 0);
+        rc = integrate_u16_dev(h, S.d_img, width, height, width, h->h_stage, h->h_stage + want, (int)n_s, qa, ta);
+        clk_mark(h, 5);
+        return rc;
     }
     std::vector<uint16_t> host_u16; // needed only by the sampler when the input is float
     if (is_f32) {
         // the converted frame stays in a buffer owned by the handle (no allocation per call)
         if (h->f32_cap < n_px) {
             if (h->d_f32) hipFree(h->d_f32);
-    for (int k = 0; k < MLM_SETS; ++k)
-        if (h->d_img_set[k]) hipFree(h->d_img_set[k]);
             h->d_f32 = nullptr;
             h->f32_cap = 0;
             HIPCHK(h, hipMalloc((void **)&h->d_f32, n_px * sizeof(float)));

@@ -18,6 +18,8 @@ m = MLMap(cfg, max_blocks=32768, max_points=cfg.width * cfg.height, max_batch=2)
 z3 = np.zeros(3)
 ts = []
 for k in range(n + 16):
+    if k == 16:
+        m.debug_clocks()
     a = time.perf_counter()
     if what == "dense":
         m.update_map(frames[k % 16], q[k], t[k])
@@ -28,3 +30,5 @@ ts = np.array(ts[16:]) * 1e6
 st = m.frame_stats()
 print(what, "median %.1f us, p10 %.1f, p90 %.1f" % (np.median(ts), np.percentile(ts, 10), np.percentile(ts, 90)), "graph launches", st["n_graph_launches"], "points", st["n_points"],
       "hits", st["n_hit_cells"], "miss", st["n_miss_cells"])
+clk = m.debug_clocks() / n
+print("host clocks, us per call: sample %.1f | set-up %.1f | launch call %.1f | to the wait %.1f | wait %.1f | rest %.1f  (sum %.1f)" % (*clk[:6], clk[:6].sum()))

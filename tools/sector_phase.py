@@ -28,11 +28,13 @@ m.update_map_batch(imgs, q, t)
 L.mlm_debug_phases(buf)
 if "single" in sys.argv:  # frame by frame: a phase's cycles per wave = its share of a column's latency (80 columns x 8 waves at S1)
     m.set_async(False)
+    rng = np.random.default_rng(1)
+    pix = [rng.choice(cfg.width * cfg.height, 500, replace=False).astype(np.int32) if "sampled" in sys.argv else None for _ in range(n)]
     for k in range(n):
-        m.update_map(imgs[k], q[k], t[k])
+        m.update_map(imgs[k], q[k], t[k], pixel_idx=pix[k])
     L.mlm_debug_phases(buf)
     for k in range(n):
-        m.update_map(imgs[k], q[k], t[k])
+        m.update_map(imgs[k], q[k], t[k], pixel_idx=pix[k])
     L.mlm_debug_phases(buf)
     tot = sum(buf[:9])
     print(f"single frames: {tot / n / 640 / 2.4e3:.1f} us per wave (assuming 640 waves, 2.4 GHz)")

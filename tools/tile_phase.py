@@ -20,12 +20,14 @@ cfg, n = S1, 16
 m = mm.MLMap(cfg, max_blocks=32768, max_batch=2)
 frames = list(syn.stream(cfg, "room_jitter", "random", n))
 buf = (ctypes.c_ulonglong * 8)()
+rng = np.random.default_rng(1)
+pix = rng.choice(cfg.width * cfg.height, 500, replace=False).astype(np.int32) if "sampled" in sys.argv else None
 for img, (q, t) in frames[:4]:
-    m.update_map(img, q, t)
+    m.update_map(img, q, t, pixel_idx=pix)
 L.mlm_debug_tile_phases(buf)
 tiles = 0
 for img, (q, t) in frames:
-    m.update_map(img, q, t)
+    m.update_map(img, q, t, pixel_idx=pix)
 L.mlm_debug_tile_phases(buf)
 tot = sum(buf)
 print(f"k_tile, single frames: {tot / n / 100.0:.0f} tile-microseconds per frame at 100 MHz clock64 (sum over touched tiles)")
