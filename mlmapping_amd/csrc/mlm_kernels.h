@@ -238,6 +238,32 @@ __device__ unsigned long long g_mlm_phase[MLM_PHASE_BLOCKS * 16]; // per block: 
 #define MLM_PHASE_BEGIN
 #define MLM_PHASE_END
 #endif
+// When a kernel's workgroups start and end (tools/kernel_spans.py): first start, last end and the longest workgroup, on the
+// constant 100 MHz clock — what of a lone frame's kernel time is the workgroups' own and what is launch and drain
+#ifdef MLM_PHASE_PROF
+__device__ unsigned long long g_mlm_span[8 * 4];
+__device__ unsigned long long g_mlm_wg[2 * 2048 * 2]; // per kernel (2) and workgroup (blockIdx.x < 2048): start, end
+#define MLM_SPAN_BEGIN(k)                                                                                              \
+    const unsigned long long span_t0_ = wall_clock64();                                                               \
+    const long long span_c0_ = clock64();                                                                              \
+    if (threadIdx.x == 0) atomicMin(&g_mlm_span[(k) * 4 + 0], span_t0_);
+#define MLM_SPAN_END(k)                                                                                                \
+    __syncthreads();                                                                                                   \
+    if (threadIdx.x == 0) {                                                                                            \
+        const unsigned long long t1_ = wall_clock64();                                                                 \
+        atomicMax(&g_mlm_span[(k) * 4 + 1], t1_);                                                                      \
+        atomicMax(&g_mlm_span[(k) * 4 + 2], t1_ - span_t0_);                                                           \
+        atomicAdd(&g_mlm_span[(k) * 4 + 3], 1ull);                                                                     \
+        if (blockIdx.x == 70) g_mlm_span[28 + (k)] = (unsigned long long)(clock64() - span_c0_) * 1000ull / (t1_ - span_t0_ + 1ull); \
+        if (blockIdx.x < 2048) {                                                                                       \
+            g_mlm_wg[((k) * 2048 + blockIdx.x) * 2] = span_t0_;                                                        \
+            g_mlm_wg[((k) * 2048 + blockIdx.x) * 2 + 1] = t1_;                                                         \
+        }                                                                                                              \
+    }
+#else
+#define MLM_SPAN_BEGIN(k)
+#define MLM_SPAN_END(k)
+#endif
 // ... and of k_tile (tools/tile_phase.py), in an array of its own, accumulated over the launches
 #ifdef MLM_PHASE_PROF
 __device__ unsigned long long g_mlm_tphase[4096 * 8];

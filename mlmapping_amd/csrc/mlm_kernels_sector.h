@@ -77,7 +77,7 @@ struct MlmSecCell {
 // Such cells are finished without ranking their contributions (S is summed mod 4096 next to the count: a wrap only
 // makes a cell look weaker than it is).
 #define MLM_SEC_STRONG_ENOUGH 28u
-__device__ __forceinline__ uint32_t mlm_sec_strength(float a) { return a >= 0.875f ? 3u : (a >= 0.75f ? 2u : (a >= 0.5f ? 1u : 0u)); }
+__host__ __device__ __forceinline__ uint32_t mlm_sec_strength(float a) { return a >= 0.875f ? 3u : (a >= 0.75f ? 2u : (a >= 0.5f ? 1u : 0u)); }
 __device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
     return __popc(c.kg & MLM_SEC_KIND_MASK) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH;
 }
@@ -469,11 +469,17 @@ __device__ __forceinline__ void mlm_fold_bin_stats(const MlmDev &P, int n_bin_bl
 // alone is 10 % slower).
 template <bool EX, bool BIG, int NT>
 __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFrame &F, const int phi, int tile_w, int n_bin_blocks, unsigned long long rho_m,
-                                                  int rho_s, unsigned long long n_bkt, int big_armed, unsigned long long row_m, int row_s) {
+                                                  int rho_s, unsigned long long n_bkt, int col_flags, unsigned long long row_m, int row_s) {
+    // col_flags: bit 0 — k_sector_big follows this launch; bits 4-7 — lanes per ray = 4 << that (a lone frame's columns have the lanes)
+    const int big_armed = col_flags & 1;
+    const uint32_t ray_sh = 2u + (((uint32_t)col_flags >> 4) & 15u);
     constexpr int PER_MAX = BIG ? 8 : 4; // cell-table entries per thread
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // (four columns in five of a camera frame hold nothing: the count comes through the scalar cache — sixteen columns share a
     // line of it — and an empty column's workgroup is gone after a fraction of a trip to memory)
+#ifdef MLM_PHASE_PROF
+    const long long fn_t0_ = clock64();
+#endif
     const unsigned int nch_all = mlm_uniform_word(P.col_cnt + phi);
     if (nch_all == 0) return; // nothing fell into this column (uniform)
     // (the column's first chunk descriptors are requested now and arrive while the tables below are set up: one dependent trip
@@ -483,6 +489,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     if (threadIdx.x < min(64u, min(nch_all, P.chunk_cap))) // (one wave's worth: a column of a VGA frame has ~50)
         chunk_first = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)phi * P.chunk_cap + threadIdx.x));
     MLM_PHASE_BEGIN
+#ifdef MLM_PHASE_PROF
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_phase[9], (unsigned long long)(ph_t_ - fn_t0_));
+#endif
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t TAB = BIG ? P.sec_tab_big : P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
@@ -536,8 +545,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     const double col_cos = mlm_uniform_f64(P.cos_phi + phi), col_sin = mlm_uniform_f64(P.sin_phi + phi);
     // (the tables that come from memory first: a wait for a later load is a wait for every earlier one, and nothing below may wait
     // for the records)
-    for (uint32_t e = threadIdx.x; e < (2u * MLM_DIFF_RANGE + 1u) * (uint32_t)P.nRho; e += NT) s_strength[e] = (uint8_t)mlm_sec_strength(mlm_gp(P.odds_table)[e]);
-    for (uint32_t e = threadIdx.x; e < (uint32_t)P.nRho; e += NT) s_sigma[e] = mlm_gp(P.sigma3)[e];
+    // (strength bytes and sigma3 lie in memory as they lie in LDS — MlmDev::sec_const —: one copy, requested together with the chunk
+    // descriptors; a lone frame's column would otherwise spend two more trips to memory here)
+    for (uint32_t e = threadIdx.x; e < P.sec_const_words; e += NT) ((uint32_t *)(s_dyn + L.odds))[e] = mlm_gp(P.sec_const)[e];
     // The first descriptors are staged and every thread's first record is requested BEFORE the tables are set up: the records
     // (a trip to HBM, the longest wait of a column's life under load) arrive while the workgroup initialises its LDS.
     const uint32_t pre_total = stage_chunks(0, min(nch, CH));
@@ -934,23 +944,24 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     }
     __syncthreads();
     // ---- rays of the cells that hold a hit centre (every point of one (rho,phi,z) cell casts the identical ray,
-    //      map_awareness.cpp:243-274: once per cell), FOUR LANES per ray, each a quarter of its steps.
+    //      map_awareness.cpp:243-274: once per cell), FOUR LANES per ray (sixteen for a lone frame), each a share of its steps.
     //      z' = round(z - k (z - zc) / rho) for k = 1 .. rho-1 is followed by an integer DDA on
     //      N_k = 2 (z rho - k (z - zc)) + rho: z' = floor(N_k / 2 rho) unless N_k is a multiple of 2 rho — the exact value
     //      is then a half-integer and only the reference's own FP64 sequence (slope = dz / rho rounded, k * slope rounded,
     //      z - .. rounded, round half away) says which way it goes (those steps are collected and evaluated afterwards);
     //      everywhere else that sequence is at most ~1e-12 away from the exact value, which is at least 1 / (2 rho) away
     //      from the next half-integer.  Consecutive steps that fall into one word of the mask are merged in a register.
-    for (uint32_t i0 = 0; i0 < 4u * n_rays; i0 += NT) {
+    const uint32_t ray_lanes = 1u << ray_sh;
+    for (uint32_t i0 = 0; i0 < (n_rays << ray_sh); i0 += NT) {
         const uint32_t it = i0 + threadIdx.x;
         int rho = 0, z = 0;
         uint32_t t0 = 0; // EX: insertion time of the ray's step k is t0 + k - 1
-        if (it < 4u * n_rays) {
-            key_rz(s_tab[s_rays[it >> 2]].key & MLM_SEC_KEY_MASK, rho, z);
-            if (EX) t0 = s_ray_p0[it >> 2] * 256u;
+        if (it < (n_rays << ray_sh)) {
+            key_rz(s_tab[s_rays[it >> ray_sh]].key & MLM_SEC_KEY_MASK, rho, z);
+            if (EX) t0 = s_ray_p0[it >> ray_sh] * 256u;
         }
-        const int seg = (rho + 2) >> 2; // steps k = 1 .. rho-1 in four segments of `seg`
-        const int k_lo = 1 + (int)(it & 3u) * seg, k_hi = min(rho, k_lo + seg); // [k_lo, k_hi)
+        const int seg = (rho + (int)ray_lanes - 2) >> ray_sh; // steps k = 1 .. rho-1 in `ray_lanes` segments of `seg`
+        const int k_lo = 1 + (int)(it & (ray_lanes - 1u)) * seg, k_hi = min(rho, k_lo + seg); // [k_lo, k_hi)
         const int dz = z - P.zc, two_rho = 2 * rho;
         // per step: N -= 2 dz = sq * 2 rho + fr with 0 <= fr < 2 rho
         int sq = 0, fr = 0, q = 0, rem = 0;
@@ -1092,9 +1103,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         //      k_tile counts.  Miss cells per rho (LDS atomics), their offsets (one block scan), the list in LDS (the cell
         //      table's space is idle by now), one coalesced copy into the column's own stretch of the frame's miss list; then the
         //      descriptors of its tile runs (below).
-        for (uint32_t w = threadIdx.x; w < NMISS; w += NT) {
-            uint32_t bits = s_miss[w];
-            const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u;
+        // (a byte of a mask word per thread: the bits of a word are a serial chain of LDS atomics)
+        for (uint32_t it = threadIdx.x; it < 4u * NMISS; it += NT) {
+            const uint32_t w = it >> 2, part = (it & 3u) * 8u;
+            uint32_t bits = (s_miss[w] >> part) & 0xFFu;
+            const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u + part;
             while (bits) {
                 atomicAdd(&s_rho_miss[rho0 + (uint32_t)__ffs((int)bits) - 1u], 1u);
                 bits &= bits - 1;
@@ -1125,9 +1138,10 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         uint16_t *s_cells = (uint16_t *)s_tab; // [total] (nZ * nRho * 2 bytes <= the table's, checked by the host)
         if (total && !s_fail) {
             const uint32_t rec_base = s_base[7];
-            for (uint32_t w = threadIdx.x; w < NMISS; w += NT) {
-                uint32_t bits = s_miss[w];
-                const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u;
+            for (uint32_t it = threadIdx.x; it < 4u * NMISS; it += NT) {
+                const uint32_t w = it >> 2, part = (it & 3u) * 8u;
+                uint32_t bits = (s_miss[w] >> part) & 0xFFu;
+                const uint32_t z = w / (uint32_t)P.RW, rho0 = (w - z * (uint32_t)P.RW) * 32u + part;
                 const uint32_t zz = (uint32_t)s_vz[z].x;
                 while (bits) {
                     const uint32_t rho = rho0 + (uint32_t)__ffs((int)bits) - 1u;
@@ -1168,8 +1182,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 
                                                                                        int rho_s, unsigned long long n_bkt, int big_armed, unsigned long long row_m, int row_s) {
     // (row_m, row_s: exact division of a pixel index by the image width — the row of a cell's first pixel, mlm_ref_pack)
     MLM_SLOT_SETUP
+    MLM_SPAN_BEGIN(0)
     if (blockIdx.x == 0 && threadIdx.x < 64) mlm_fold_bin_stats(P, n_bin_blocks);
     mlm_sector_column<EX, false, NT>(P, F, (int)blockIdx.x, tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, big_armed, row_m, row_s);
+    MLM_SPAN_END(0)
 }
 // The columns on the overflow lists of a batch's frames, with the large cell table (dynamic LDS of MlmDev::sec_big_lds_bytes:
 // one workgroup per CU).  ONE launch per batch, a fixed number of workgroups that share all (frame, column) tasks.  A kernel
@@ -2017,6 +2033,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
 // fire-and-forget atomic each (k_sector).
 __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
     MLM_SLOT_SETUP
+    MLM_SPAN_BEGIN(1)
     __shared__ uint32_t s_cand[MLM_TILE_THREADS];
     __shared__ unsigned int s_state;
     if (threadIdx.x == 0) s_state = mlm_gp(P.ctr)->sector_overflow;
@@ -2041,6 +2058,7 @@ __global__ __launch_bounds__(MLM_TILE_THREADS) void k_tile(MLM_SLOT_ARGS) {
             __syncthreads(); // (the tile's shared state is no longer read)
         }
     }
+    MLM_SPAN_END(1)
 }
 
 // One voxel record applied to the voxel's state (L, o): its hits in the reference's iteration order (descending key,

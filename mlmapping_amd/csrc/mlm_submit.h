@@ -416,10 +416,10 @@ hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int bi
     // (a single frame is alone on the GPU: the 512-thread workgroup finishes a column sooner; the table is the same)
     if (h->sec_threads == 256 && P.sec_tab < 512u)
         hipLaunchKernelGGL((k_sector<false, 256>), dim3((unsigned int)P.nPhi, 1, 1), dim3(256), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                           S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
+                           S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big | (2 << 4), dm, ds); // (| 2 << 4: sixteen lanes per ray)
     else
         hipLaunchKernelGGL((k_sector<false, 512>), dim3((unsigned int)P.nPhi, 1, 1), dim3(512), P.sec_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base,
-                           S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big, dm, ds);
+                           S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, big | (2 << 4), dm, ds); // (| 2 << 4: sixteen lanes per ray)
     if (big)
         hipLaunchKernelGGL(k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1,
                            S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);

@@ -123,6 +123,8 @@ struct MlmDev {
     // ---- tables
     const float *odds_table;   // [21*nRho] get_odds_table (map_awareness.cpp:36-46)
     const float *sigma3;       // [nRho] 3*sigma_in_dr(rho)  (float, map_awareness.cpp:149)
+    const uint32_t *sec_const; // k_sector's constant LDS tables as it lays them out (mlm_sec_lds: odds .. sigma): a strength byte per entry of
+    unsigned int sec_const_words; // the odds table, then sigma3 — one copy, one trip to memory
     const double *cos_phi;     // [nPhi] cos/sin of the cell-centre azimuth (map_awareness.cpp:59-61)
     const double *sin_phi;
     // ---- per-frame awareness scratch

@@ -378,6 +378,17 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     HIPCHK(h, hipMemcpy(d_s, sphi.data(), sphi.size() * sizeof(double), hipMemcpyHostToDevice));
     P.odds_table = d_odds;
     P.sigma3 = d_s3;
+    {
+        const size_t nb = ((h->odds_table.size() + 3) & ~(size_t)3), nw = nb / 4 + ((sigma3.size() + 3) & ~(size_t)3);
+        std::vector<uint32_t> sc(nw, 0u);
+        for (size_t e = 0; e < h->odds_table.size(); ++e) ((uint8_t *)sc.data())[e] = (uint8_t)mlm_sec_strength(h->odds_table[e]);
+        std::memcpy(sc.data() + nb / 4, sigma3.data(), sigma3.size() * sizeof(float));
+        uint32_t *d_sc;
+        if ((rc = dev_alloc(h, &d_sc, nw))) return rc;
+        HIPCHK(h, hipMemcpy(d_sc, sc.data(), nw * sizeof(uint32_t), hipMemcpyHostToDevice));
+        P.sec_const = d_sc;
+        P.sec_const_words = (unsigned int)nw;
+    }
     P.cos_phi = d_c;
     P.sin_phi = d_s;
 
@@ -1303,6 +1314,19 @@ extern "C" int mlm_debug_tile_phases(unsigned long long *out8) {
     for (size_t i = 0; i < v.size(); ++i) out8[i & 7] += v[i];
     std::fill(v.begin(), v.end(), 0ull);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_mlm_tphase), v.data(), v.size() * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+// diagnostic build only: workgroup spans of k_sector [0..3] and k_tile [4..7] — first start, last end, longest workgroup (10 ns
+// ticks), workgroups — since the last call (cleared)
+extern "C" int mlm_debug_spans(unsigned long long *out32) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_mlm_span), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[32];
+    for (int k = 0; k < 32; ++k) z[k] = (k & 3) == 0 ? ~0ull : 0ull;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mlm_span), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+extern "C" int mlm_debug_wg_times(unsigned long long *out) { // [2][2048][2]
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlm_wg), 2 * 2048 * 2 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 // diagnostic build only: sum over blocks and clear the per-phase cycle counts of k_bin_points
 extern "C" int mlm_debug_phases(unsigned long long *out16) {
