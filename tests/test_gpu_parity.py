@@ -764,6 +764,38 @@ def test_long_stream_cfg2(mods):
     assert st["n_pool_grows"] >= 1 and st["block_capacity"] >= cpu.block_count() > 64, st
 
 
+def test_float_callback_between_packed_host_batches(mods):
+    """Packed host batches (one upload into the slot set's batch image buffer), then the first 32FC1 callback (allocates the float
+    conversion buffer), then packed host batches again — the batch image buffers must survive the float buffer's allocation
+    (round 4: a misplaced loop freed them there and the next batch uploaded into freed memory)."""
+    MLMap, OracleMap = mods
+    libc = ctypes.CDLL("libc.so.6")
+    cfg = SDEF
+    frames = np.stack([f[0] for f in syn.stream(cfg, "room_jitter", "smooth", 8)])
+    poses = [f[1] for f in syn.stream(cfg, "room_jitter", "smooth", 8)]
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=4096, max_batch=4), OracleMap(cfg)
+
+    def batches():
+        for k0 in (0, 4):
+            gpu.update_map_batch(frames[k0:k0 + 4], q[k0:k0 + 4], t[k0:k0 + 4])
+            for k in range(k0, k0 + 4):
+                cpu.update_depth(frames[k], q[k], t[k])
+
+    batches()
+    args = dict(t_img=1.0, odom_p=t[0], odom_q=q[0], odom_v=[0.1, 0.0, 0.0], t_odom=1.0, imu_w=[0.0, 0.0, 0.1], t_imu=1.0, latency=0.01)
+    f32 = frames[0].astype(np.float32) / 1000.0
+    for sampled in (False, True):
+        libc.srand(7)
+        gpu.depth_odom_callback(f32, sampled=sampled, **args)
+        libc.srand(7)
+        cpu.depth_odom_callback(f32, sampled=sampled, **args)
+    batches()
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "packed batches around a float callback")
+    gpu.close()
+
+
 def test_bench_batch64_parity(mods):
     """The configuration bench.py TIMES, compared with the oracle at its real size: 192 frames of the bench stream (64 distinct
     jittered room frames resident in HBM, random SE(3) poses) submitted as three asynchronous 64-frame contiguous
