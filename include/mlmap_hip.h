@@ -259,6 +259,10 @@ int mlm_debug_reset(void);
  * to the launch; [2] the launch call (hipGraphLaunch); [3] host work between launch and wait; [4] waiting for the frame's ticket;
  * [5] the rest of the call. */
 int mlm_debug_clocks(mlm_handle *h, double out_us[8], int reset);
+/* Test hook for the binning kernel's cheap arithmetic (mlm_bin_point_fast, mlm_device.h): the largest relative errors, over 2^26
+ * values, of the hardware's reciprocal and reciprocal-square-root seeds [0], [2] and of their once-refined forms [1], [3] — the
+ * error budget of the certified margins assumes [1], [3] <= 4e-12. */
+int mlm_debug_probe_seeds(mlm_handle *h, double out4[4]);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,69 @@ __device__ __forceinline__ bool mlm_bin_point(const MlmDev &P, double x, double 
     return can_do_cast && z_idx >= 0 && rho_idx < P.nRho && z_idx < P.nZ;
 }
 
+// ---- The same bins WITHOUT the correctly rounded divisions and square root (k_bin_sectors, a third of its FP64 instructions).
+// Only the three integer indices leave the chain projection -> pose -> sqrt / atan2 -> quotient, so the chain may be evaluated
+// with cheaper forms — products with reciprocals, a matrix instead of the quaternion formula, fused multiply-adds, v_rcp_f64 /
+// v_rsq_f64 refined once — as long as every quotient is PROVABLY on the same side of every integer as the reference's.  Error
+// budget (u = 2^-53, lengths in metres):
+//   * the sensor-frame coordinates: m * RN(1/f) against RN(m / f): <= 3.1 u |v|;
+//   * rotation and translation: the reference rounds each of 33 operations on intermediates <= g |v| (g = MlmFrame::m_gain, 3 for a
+//     unit quaternion); here the same linear map is a matrix (entries from the host, good to a few u g) applied with FMAs; the two
+//     results differ by at most ~50 u (g |v| + |t|): with S = g |v|_1 + |t_ls|_1 + 1, E = 1e-12 S is two hundred times that and is
+//     what the margin uses for |dx|, |dy|, |dz|;
+//   * the approximate reciprocal and square root: relative error <= 4e-12 after ONE refinement of a seed good to 2^-20
+//     (tests/test_gpu_parity.py::test_fast_bin_seeds measures the seeds on the device: v_rcp_f64 / v_rsq_f64 deliver far more);
+//   * rho = sqrt(x^2 + y^2): |d rho| <= |dx| + |dy| + 1e-11 rho;   z: |dz| <= E;
+//   * phi: the reference's polynomial in t = min(|x|,|y|) / max(|x|,|y|) is continuous over its branch (|y/x| = 1) and over the
+//     quadrant joins except at phi = 0 = 2 pi, an integer of the quotient; its slope is at most 1.1 rad per unit t;
+//     |dt| <= (|dx| + |dy|) / max(|x|,|y|) + 4e-12 <= 2.9 E / rho + 4e-12.  (x = +0 EXACTLY is a value of its own — the reference
+//     returns 3 pi / 2 for y > 0 there, pi / 2 on either side —: a lane within 4 E of x = 0 is never sure.)
+// A lane whose quotient lies nearer to an integer than that budget (with safety factors, see the margin) is not `sure`; the
+// caller then evaluates the reference's own sequence for the wave (mlm_bin_point) — about one wave in 10^5.
+__device__ __forceinline__ double mlm_rcp_approx(double b) {
+    const double r = __builtin_amdgcn_rcp(b);
+    return fma(r, fma(-b, r, 1.0), r);
+}
+__device__ __forceinline__ double mlm_sqrt_approx(double a) {
+    const double r = __builtin_amdgcn_rsq(a);
+    const double g = a * r, h = 0.5 * r;
+    return fma(g, fma(-h, g, 0.5), g);
+}
+// (vx, vy, vz): the point in the sensor frame; v_l1 >= |vx| + |vy| + |vz|
+__device__ __forceinline__ bool mlm_bin_point_fast(const MlmDev &P, const MlmFrame &F, double vx, double vy, double vz, double v_l1, int &rho_idx,
+                                                   int &phi_idx, int &z_idx, bool &can_do_cast, bool &sure) {
+    // p_l = T_ls p_s as a matrix product with fused multiply-adds: nothing here has to round like the reference
+    const double x = fma(F.m_ls[0], vx, fma(F.m_ls[1], vy, fma(F.m_ls[2], vz, F.t_ls[0])));
+    const double y = fma(F.m_ls[3], vx, fma(F.m_ls[4], vy, fma(F.m_ls[5], vz, F.t_ls[1])));
+    const double z = fma(F.m_ls[6], vx, fma(F.m_ls[7], vy, fma(F.m_ls[8], vz, F.t_ls[2])));
+    const double E = 1e-12 * fma(F.m_gain, v_l1, F.t_l1);
+    const double rho = mlm_sqrt_approx(fma(x, x, y * y));
+    // fast_atan2 (map_awareness.h:86-113) on t = smaller / larger component
+    const double ax = fabs(x), ay = fabs(y);
+    const bool steep = ay > ax; // |y / x| > 1
+    const double t = (steep ? ax : ay) * mlm_rcp_approx(steep ? ay : ax);
+    double deg = mlm_fast_atan(t);
+    if (steep) deg = 90 - deg;
+    double res = M_PI / 180 * deg;
+    if ((x < 0) != (y < 0)) res = -res; // sign of y / x
+    double phi = x > 0 ? res : (y >= 0 ? res + M_PI : res - M_PI);
+    if (phi < 0) phi += 2 * M_PI;
+    const double zz = z - P.z_border_min;
+    const double qr = rho * P.inv_dRho, qp = phi * P.inv_dPhi, qz = zz * P.inv_dZ;
+    // ONE margin for the three quotients, in their units: the largest of the three budgets above — 4 E (1 + 1 / rho) covers 3 E
+    // (rho), 2 E (z) and 4 E / rho (phi), 2e-11 (1 + rho) the approximate operations' share — times the largest of the three
+    // 1 / cell-size factors, plus the quotients' own roundings
+    const double M = (4.0 * E * (1.0 + mlm_rcp_approx(rho)) + 2e-11 * (1.0 + rho)) * P.inv_d_max + 2e-12 * (((1.0 + qr) + qp) + fabs(qz));
+    // (NaN and infinities fail the comparisons: a point on the axis, x = y = 0, goes to the exact sequence)
+    sure = fabs(qr - rint(qr)) > M && fabs(qp - rint(qp)) > M && fabs(qz - rint(qz)) > M && qr < 1e9 && fabs(qz) < 1e9 && rho > 1e-9 &&
+           ax > 4.0 * E; // (x = +0 exactly is a value of its own in the reference: 3 pi / 2 for y > 0)
+    rho_idx = (int)qr;
+    phi_idx = (int)qp;
+    z_idx = (int)floor(qz);
+    can_do_cast = (rho_idx >= 0 && phi_idx >= 0 && phi_idx < P.nPhi);
+    return can_do_cast && z_idx >= 0 && rho_idx < P.nRho && z_idx < P.nZ;
+}
+
 // VectorHasher (map_awareness.h:31-41): 32-bit wrap-around int arithmetic, arithmetic >>, result sign-extended
 // to size_t by libstdc++; bucket = code % bucket_count (std::__detail::_Mod_range_hashing).
 __device__ __forceinline__ uint32_t mlm_hash_step(uint32_t h, int v) {

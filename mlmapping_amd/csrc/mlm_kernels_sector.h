@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
                 have[j] = false;
             } else {
                 const double depth = raw[j] * P.inv_factor;
-                xs[j] = xs[j] * depth / P.fx;
-                ys[j] = ys[j] * depth / P.fy;
+                xs[j] = xs[j] * depth; // (the division by the focal length follows below: x = (u - cx) * depth / fx, mlmap.cpp:344-346)
+                ys[j] = ys[j] * depth;
                 zs[j] = depth;
             }
         }
@@ -206,17 +206,28 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
 #pragma unroll
     for (int j = 0; j < S; ++j) {
         int rho = 0, phi = 0, zi = 0, c0 = -1;
-        bool can_do_cast = false, inside = false;
+        bool can_do_cast = false, inside = false, sure = true;
+        // the bins by the cheap evaluation with certified margins (mlm_bin_point_fast) ...
+#ifndef MLM_BIN_EXACT // (experiment builds: make alt ALT_FLAGS=-DMLM_BIN_EXACT evaluates the reference's sequence for every wave)
         if (have[j]) {
-            // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
-            double x, y, z;
-            mlm_quat_rot(F.q_ls, xs[j], ys[j], zs[j], x, y, z);
-            x = x + F.t_ls[0];
-            y = y + F.t_ls[1];
-            z = z + F.t_ls[2];
-            inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
-            if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
+            const double vx = MODE == 2 ? xs[j] : xs[j] * P.inv_fx, vy = MODE == 2 ? ys[j] : ys[j] * P.inv_fy;
+            inside = mlm_bin_point_fast(P, F, vx, vy, zs[j], (fabs(vx) + fabs(vy)) + fabs(zs[j]), rho, phi, zi, can_do_cast, sure);
         }
+#else
+        sure = !have[j];
+#endif
+        if (!__all(sure)) { // ... and, for a wave with a lane too close to a cell boundary to be sure, by the reference's own sequence
+            if (have[j]) {
+                // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
+                double x, y, z;
+                mlm_quat_rot(F.q_ls, MODE == 2 ? xs[j] : xs[j] / P.fx, MODE == 2 ? ys[j] : ys[j] / P.fy, zs[j], x, y, z);
+                x = x + F.t_ls[0];
+                y = y + F.t_ls[1];
+                z = z + F.t_ls[2];
+                inside = mlm_bin_point(P, x, y, z, rho, phi, zi, can_do_cast);
+            }
+        }
+        if (inside) c0 = zi * P.nRhoPhi + phi * P.nRho + rho;
         const uint32_t i00 = (uint32_t)mlm_readlane(item[j], 0); // work item of lane 0 of this wave (see MlmNode)
         // lanes of one centre cell -> one record, held by their lowest lane (= earliest insertion time)
         unsigned long long my_mask = 0;
@@ -2430,4 +2441,27 @@ __global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_fra
     uint32_t *dst = (uint32_t *)dev_frame, *c = (uint32_t *)ctr;
     for (unsigned int i = threadIdx.x; i < sizeof(MlmFrame) / 4; i += blockDim.x) dst[i] = src[i];
     for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) c[i] = 0u;
+}
+
+// Test hook (mlm_debug_probe_seeds): the largest relative error of the v_rcp_f64 / v_rsq_f64 seeds and of their once-refined
+// forms (mlm_rcp_approx, mlm_sqrt_approx) over n values spread over [2^-40, 2^40], against the correctly rounded operations.
+// out[0..3]: bit patterns of the four maxima (non-negative doubles order like their bits).
+__global__ void k_probe_seeds(unsigned long long *out, unsigned int n) {
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        // a mantissa from a hash of i, an exponent that walks through the range
+        unsigned long long h = (unsigned long long)i * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        const double mant = 1.0 + (double)(h >> 12) * (1.0 / 4503599627370496.0); // [1, 2)
+        const double v = ldexp(mant, (int)(i % 81u) - 40);
+        const double inv = 1.0 / v, rt = sqrt(v);
+        m0 = fmax(m0, fabs(__builtin_amdgcn_rcp(v) - inv) / inv);
+        m1 = fmax(m1, fabs(mlm_rcp_approx(v) - inv) / inv);
+        m2 = fmax(m2, fabs(__builtin_amdgcn_rsq(v) * v - rt) / rt);
+        m3 = fmax(m3, fabs(mlm_sqrt_approx(v) - rt) / rt);
+    }
+    atomicMax(&out[0], (unsigned long long)__double_as_longlong(m0));
+    atomicMax(&out[1], (unsigned long long)__double_as_longlong(m1));
+    atomicMax(&out[2], (unsigned long long)__double_as_longlong(m2));
+    atomicMax(&out[3], (unsigned long long)__double_as_longlong(m3));
 }

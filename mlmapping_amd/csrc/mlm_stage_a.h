@@ -7,6 +7,18 @@ namespace {
 void frame_setup(const mlm_handle *h, const double q_wb_in[4], const double t_wb_in[3], MlmFrame &F) {
     frame_pose(h->q_bs, h->t_bs, q_wb_in, t_wb_in, F.q_ls, F.t_ls, F.t_wa);
     F.rehash_thr = 0xFFFFFFFFu; // only the speculative Stage B arms the check (submit_batch)
+    {
+        const double w = F.q_ls[0], x = F.q_ls[1], y = F.q_ls[2], z = F.q_ls[3];
+        // v + w (2 q x v) + q x (2 q x v)  =  (I + 2 w [q]x + 2 [q]x^2) v,   [q]x^2 = q q^T - |q_v|^2 I
+        const double n2 = x * x + y * y + z * z;
+        const double m[9] = {1 + 2 * (x * x - n2), 2 * (x * y - w * z),   2 * (x * z + w * y),
+                             2 * (x * y + w * z),   1 + 2 * (y * y - n2), 2 * (y * z - w * x),
+                             2 * (x * z - w * y),   2 * (y * z + w * x),   1 + 2 * (z * z - n2)};
+        for (int i = 0; i < 9; ++i) F.m_ls[i] = m[i];
+        const double q1 = std::fabs(x) + std::fabs(y) + std::fabs(z);
+        F.m_gain = 1 + 2 * std::fabs(w) * q1 + 2 * q1 * q1;
+        F.t_l1 = std::fabs(F.t_ls[0]) + std::fabs(F.t_ls[1]) + std::fabs(F.t_ls[2]) + 1.0;
+    }
     // origin of the frame-local voxel grid: the awareness cylinder around t_wa with a margin of four voxels
     const MlmDev &P = h->P;
     const double R = P.nRho * P.dRho;

@@ -120,6 +120,8 @@ struct MlmDev {
     // ---- camera (mlmap.h:85-92)
     float cx, cy, fx, fy;
     double inv_factor;
+    double inv_fx, inv_fy;     // 1 / fx, 1 / fy (k_bin_sectors' fast path: mlm_bin_point_fast)
+    double inv_d_max;          // max(1 / dRho, 1 / dPhi, 1 / dZ): scale of that path's margin
     // ---- tables
     const float *odds_table;   // [21*nRho] get_odds_table (map_awareness.cpp:36-46)
     const float *sigma3;       // [nRho] 3*sigma_in_dr(rho)  (float, map_awareness.cpp:149)
@@ -270,4 +272,9 @@ struct MlmFrame {
     int pad2;                  // frontier mode: running frame number (test hook MLM_SEC_FAIL_EVERY; seq stays 0 there)
     int flags;                 // sector path, k_apply_tiles: MLM_FRAME_EXACT_KEYS | MLM_FRAME_SKIP
     int pad3;
+    // k_bin_sectors' cheap evaluation (mlm_bin_point_fast): the linear map of QuaternionBase::_transformVector for q_ls as a matrix
+    // (I + 2 w [q]x + 2 [q]x^2, row major; exact for any q, unit or not), its gain 1 + 2 |w| |q_v|_1 + 2 |q_v|_1^2 (bound of the
+    // intermediates per unit |v|), and |t_ls|_1 + 1
+    double m_ls[9];
+    double m_gain, t_l1;
 };

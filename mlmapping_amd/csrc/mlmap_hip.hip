@@ -56,6 +56,26 @@ int mlm_debug_reset(void) {
     return MLM_OK;
 }
 
+int mlm_debug_probe_seeds(mlm_handle *h, double out4[4]) {
+    if (!h || !out4) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long *d = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), h->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_probe_seeds, dim3(1024), dim3(256), 0, h->stream, d, 1u << 26);
+        e = hipMemcpyAsync(out4, d, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) {
+        h->err = std::string("mlm_debug_probe_seeds: ") + hipGetErrorString(e);
+        return MLM_ERR_HIP;
+    }
+    return MLM_OK;
+}
+
 int mlm_debug_clocks(mlm_handle *h, double out_us[8], int reset) {
     if (!h || !out_us) return MLM_ERR_INVALID;
     MLM_LOCK(h);
@@ -185,6 +205,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     P.inv_dRho = 1.0 / P.dRho;
     P.inv_dPhi = 1.0 / P.dPhi;
     P.inv_dZ = 1.0 / P.dZ;
+    P.inv_d_max = std::max(P.inv_dRho, std::max(P.inv_dPhi, P.inv_dZ));
     P.inv_d_sub = 1.0 / P.d_sub;
     P.inv_d_glb = 1.0 / P.d_glb;
     P.cells = P.n * P.n * P.n;
@@ -198,6 +219,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
     P.fx = (float)cfg->cam_fx;
     P.fy = (float)cfg->cam_fy;
     P.inv_factor = 1.0 / 1000.0;
+    P.inv_fx = 1.0 / (double)P.fx;
+    P.inv_fy = 1.0 / (double)P.fy;
     P.record_awareness = h->lim.record_awareness;
     P.node_lds = 448;
     P.agg_lds = 256;

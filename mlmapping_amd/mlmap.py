@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "mlm_get_awareness_hits",
     "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
     "mlm_enable_kernel_timing", "mlm_set_timed_kernel", "mlm_host_register", "mlm_host_unregister", "mlm_debug_set", "mlm_debug_reset",
-    "mlm_debug_clocks",
+    "mlm_debug_clocks", "mlm_debug_probe_seeds",
 ]
 
 
@@ -144,6 +144,7 @@ def load_library(path: Optional[str] = None):
     L.mlm_debug_set.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     L.mlm_debug_reset.argtypes = []
     L.mlm_debug_clocks.argtypes = [vp, vp, i32]
+    L.mlm_debug_probe_seeds.argtypes = [vp, vp]
     if path is None and os.environ.get("MLM_KNOBS"):
         # tooling convenience (tools/*.py, experiments): MLM_KNOBS="rank_grid=64,sec_tab=1024" -> mlm_debug_set before the first create
         for kv in os.environ["MLM_KNOBS"].split(","):
@@ -224,6 +225,12 @@ class MLMap:
         """Host clocks of the single-frame callback path, microseconds summed over the calls (mlm_debug_clocks)."""
         out = np.zeros(8)
         self._chk(self._L.mlm_debug_clocks(self._h, _p(out), int(reset)), "mlm_debug_clocks")
+        return out
+
+    def debug_probe_seeds(self) -> np.ndarray:
+        """Largest relative errors of the reciprocal / reciprocal-square-root seeds and their refined forms (mlm_debug_probe_seeds)."""
+        out = np.zeros(4)
+        self._chk(self._L.mlm_debug_probe_seeds(self._h, _p(out)), "mlm_debug_probe_seeds")
         return out
 
     def host_unregister(self, arr: np.ndarray):

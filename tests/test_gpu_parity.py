@@ -796,6 +796,19 @@ def test_float_callback_between_packed_host_batches(mods):
     gpu.close()
 
 
+def test_fast_bin_seeds(mods):
+    """The binning kernel evaluates its FP64 chain with reciprocals and a reciprocal square root refined once, and certifies every
+    bin with margins that assume those forms are good to 4e-12 (mlm_bin_point_fast, mlm_device.h).  Measured here on the device over
+    2^26 values between 2^-40 and 2^40: the raw seeds and the refined forms."""
+    MLMap, _ = mods
+    gpu = MLMap(SDEF, max_blocks=256)
+    e = gpu.debug_probe_seeds()
+    print("seed errors: rcp %.3g -> %.3g, rsq %.3g -> %.3g" % tuple(e))
+    assert e[0] < 2.0 ** -20 and e[2] < 2.0 ** -20, e   # what ONE refinement needs
+    assert e[1] < 4e-12 and e[3] < 4e-12, e             # what the margins assume
+    gpu.close()
+
+
 def test_bench_batch64_parity(mods):
     """The configuration bench.py TIMES, compared with the oracle at its real size: 192 frames of the bench stream (64 distinct
     jittered room frames resident in HBM, random SE(3) poses) submitted as three asynchronous 64-frame contiguous
