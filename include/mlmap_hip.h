@@ -119,6 +119,8 @@ typedef struct mlm_frame_stats {
     int64_t block_capacity;     /* blocks the pool holds now */
     int64_t n_graph_launches;   /* single frames so far submitted as one HIP-graph replay (synchronous mode: the reference's one frame
                                  * per depth callback, src/mlmap.cpp:463-507) */
+    int64_t n_bin_exact_waves;  /* waves of the frame whose bins came from the reference's own FP64 sequence because a lane lay too near
+                                 * a cell boundary for the certified cheap evaluation (k_bin_sectors; usually 0) */
 } mlm_frame_stats;
 
 /* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */

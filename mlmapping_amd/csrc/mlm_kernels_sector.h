@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
         sure = !have[j];
 #endif
         if (!__all(sure)) { // ... and, for a wave with a lane too close to a cell boundary to be sure, by the reference's own sequence
+            if (lane == 0) g_atomic_add(&mlm_gp(P.ctr)->bin_exact, 1u); // (statistic: mlm_frame_stats.n_bin_exact_waves)
             if (have[j]) {
                 // p_l = T_ls * p_s (map_awareness.cpp:222; se3.cpp:91-95)
                 double x, y, z;

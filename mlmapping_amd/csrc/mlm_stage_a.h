@@ -319,6 +319,7 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
     h->stats.logit_bit_exact = h->P.logit_exact;
     h->stats.n_pool_grows = h->n_pool_grows;
     h->stats.n_graph_launches = h->n_graph_launches;
+    h->stats.n_bin_exact_waves = c.bin_exact;
     h->stats.block_capacity = h->P.max_blocks;
 }
 

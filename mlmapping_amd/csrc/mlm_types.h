@@ -27,6 +27,7 @@ struct MlmCounters {
                                   // overflowed wait on ov_list for a large-table pass that was not scheduled: the host runs it when it drains
     unsigned int n_refs;      // sector path: (record, kind) references of the multi-kind cells
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
+    unsigned int bin_exact;   // sector path: waves of k_bin_sectors that evaluated the reference's own sequence (a lane too near a cell boundary)
     unsigned int apply_done;  // single-frame graph: workgroups of k_apply_single that have finished (the last one reports to the host)
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart;
                                  // [k][1] = device-scope atomics the frame's kernels issued (sector path, counted by k_sector)

@@ -796,6 +796,56 @@ def test_float_callback_between_packed_host_batches(mods):
     gpu.close()
 
 
+def test_fast_bin_boundary_points(mods):
+    """k_bin_sectors takes its bins from a cheap FP64 evaluation and certifies each with a margin; a wave with a lane nearer to a
+    cell boundary than the margin evaluates the reference's own sequence (mlm_bin_point_fast, mlm_device.h).  Points aimed AT the
+    boundaries — rho, phi and z of the awareness frame at integer multiples of the cell sizes plus an offset, mapped back into the
+    sensor frame — under an identity-like and three random poses, in two rounds: offsets from 0 to 1e-9 of the coordinate (inside
+    the margin: the reference's sequence must take over) and offsets from 1e-7 to 1e-4 (outside it, on either side of the
+    boundary: the cheap evaluation decides and must be right).  Hit / miss cell sets, odds, out-of-range count and the map must
+    equal the oracle's: a bin on the wrong side of a boundary moves a hit cell."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    rng = np.random.default_rng(31)
+    poses = [syn.static_pose()] + syn.random_poses(3, seed=17)
+    inside = np.array([0.0, 1e-16, -1e-16, 1e-15, -1e-15, 1e-14, -1e-14, 1e-13, -1e-13, 1e-12, -1e-12, 1e-11, -1e-11, 1e-10, -1e-10, 1e-9, -1e-9])
+    outside = np.array([1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4])
+    n = 6000
+    d_rho, d_phi, d_z = cfg.am_d_Rho, 2 * np.pi / cfg.n_phi, cfg.am_d_Z
+    for k, (q, t) in enumerate(poses):
+        for offs, name in ((inside, "inside the margin"), (outside, "outside the margin")):
+            gpu, cpu = MLMap(cfg, max_blocks=8192, record_awareness=True), OracleMap(cfg)
+            gpu.update_map_points(np.array([[0.0, 0.0, 1.0]]), q, t)  # (fixes T_ls for this pose)
+            cpu.update_points(np.array([[0.0, 0.0, 1.0]]), q, t)
+            q_ls, t_ls = gpu.T_ls()
+            w, x, y, z = q_ls
+            Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            rho = rng.integers(1, cfg.am_n_Rho + 3, n) * d_rho
+            phi = rng.integers(0, cfg.n_phi + 1, n) * d_phi
+            zz = (rng.integers(-cfg.n_z // 2 - 2, cfg.n_z // 2 + 3, n) + 0.5) * d_z  # (cell boundaries in z lie at (k + 1/2) dZ)
+            which = rng.integers(0, 4, n)  # the coordinate(s) put on a boundary; the others land inside a cell
+            o = offs[rng.integers(0, len(offs), n)]
+            rho = np.where((which == 0) | (which == 3), rho * (1 + o), rho + rng.uniform(0.2, 0.8, n) * d_rho)
+            phi = np.where((which == 1) | (which == 3), phi + o, phi + rng.uniform(0.2, 0.8, n) * d_phi)
+            zz = np.where(which == 2, zz * (1 + o) + o, zz + rng.uniform(0.2, 0.8, n) * d_z)
+            p_l = np.stack([rho * np.cos(phi), rho * np.sin(phi), zz], axis=1)
+            p_s = (p_l - np.asarray(t_ls)) @ Rm  # R^T (p_l - t)
+            gpu.update_map_points(p_s, q, t)
+            cpu.update_points(p_s, q, t)
+            _awareness_equal(gpu, cpu)
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"boundary points {name}, pose {k}")
+            st = gpu.frame_stats()
+            waves = (n + 63) // 64
+            print(f"boundary points {name}, pose {k}: waves on the reference's sequence: {st['n_bin_exact_waves']} of {waves}")
+            if name.startswith("inside"):
+                assert st["n_bin_exact_waves"] >= waves // 2, st  # (the round must reach the fall-back)
+            else:
+                assert st["n_bin_exact_waves"] <= waves // 4, st  # (... and this one the cheap evaluation)
+            gpu.close()
+
+
 def test_fast_bin_seeds(mods):
     """The binning kernel evaluates its FP64 chain with reciprocals and a reciprocal square root refined once, and certifies every
     bin with margins that assume those forms are good to 4e-12 (mlm_bin_point_fast, mlm_device.h).  Measured here on the device over
