@@ -321,7 +321,8 @@ int ensure_free_blocks_idle(mlm_handle *h, size_t need);
 
 // host clock of the single-frame path: the time since the previous mark goes to section i (i < 0: start of a call)
 static inline void clk_mark(mlm_handle *h, int i) {
+    if (i >= 0 && h->clk_t == 0.0) return; // (not inside a clocked call: the marks of the submission and drain code are shared)
     const double t = mlm_now_us();
     if (i >= 0) h->clk[i] += t - h->clk_t;
-    h->clk_t = t;
+    h->clk_t = i == 5 ? 0.0 : t; // (5: the call's last mark)
 }

@@ -889,7 +889,10 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
             HIPCHK(h, hipMemcpyAsync(S.d_pix, pix.data(), pix.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream_as[h->cur_set]));
         HIPCHK(h, hipStreamSynchronize(h->stream_as[h->cur_set])); // pix is a local
     }
-    return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, width, sampled ? S.d_pix : nullptr, (int)pix.size(), qa, ta);
+    clk_mark(h, 0);
+    rc = mlm_integrate_depth_u16_dev(h, S.d_img, width, height, width, sampled ? S.d_pix : nullptr, (int)pix.size(), qa, ta);
+    clk_mark(h, 5);
+    return rc;
 }
 
 int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q_wb[4], const double t_wb[3]) {
