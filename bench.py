@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — depth frames/s integrated into the map on MI355X (BASELINE.json metric).
 
-A *step* is `--batches-per-step` (8) batches of `--batch` (64) synthetic depth frames of ONE stream pushed through the hot
-path (awareness raycast + log-odds block-map update) in order: 512 frames, ~5 ms — one 64-frame batch (0.7 ms) is too small
+A *step* is `--batches-per-step` (9: a multiple of the three slot sets) batches of `--batch` (64) synthetic depth frames of ONE
+stream pushed through the hot path (awareness raycast + log-odds block-map update) in order: 576 frames, ~5.7 ms — one 64-frame
+batch (0.7 ms) is too small
 a unit to be robust to a single hiccup of the host.  `value` = frames / total time of the K steps; `value_p50` = the same
 from the median step.  Inputs (uint16 depth frames + poses) are resident in
 HBM before the timed region starts.  Workload at N=1 = BASELINE config 2 (640x480 stream, 0.1 m local map,
@@ -361,7 +362,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per batched submission (one batched Stage A launch sequence)")
-    ap.add_argument("--batches-per-step", type=int, default=8, help="batched submissions per step (a step = this x --batch frames)")
+    ap.add_argument("--batches-per-step", type=int, default=9, help="batched submissions per step (a step = this x --batch frames)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--distinct", type=int, default=64, help="distinct depth frames kept in HBM (cycled; rounded up to a multiple of --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -520,7 +521,9 @@ def main():
         if world == 1 and args.workload == "cfg2" and not args.no_extra:
             # config 3 (1280x720, 0.05 m) in the same invocation: a short stream, same protocol (its own roofline; its CPU
             # baseline below)
-            B3, BPS3, K3, W3, D3 = 32, 2, 6, 1, 32  # (96 frame slots of 2 GB each: 190 GB of the 288 GB)
+            # (96 frame slots of 2 GB each: 190 GB of the 288 GB; a step = as many batches as there are slot sets, so that the host
+            # blocks the same way in every step and the per-step times behind value_p50 mean something)
+            B3, BPS3, K3, W3, D3 = 32, 3, 5, 1, 32
             f3, q3, t3 = make_inputs(S3, D3, (K3 + W3) * B3 * BPS3, seed=42)
             d3 = torch.from_numpy(f3.view(np.int16)).cuda(local_rank)
             m3 = MLMap(S3, device=local_rank, max_blocks=65536, max_points=S3.width * S3.height, max_batch=B3)
