@@ -523,7 +523,7 @@ def main():
             # baseline below)
             # (96 frame slots of 2 GB each: 190 GB of the 288 GB; a step = as many batches as there are slot sets, so that the host
             # blocks the same way in every step and the per-step times behind value_p50 mean something)
-            B3, BPS3, K3, W3, D3 = 32, 3, 5, 1, 32
+            B3, BPS3, K3, W3, D3 = 32, 3, 10, 2, 32
             f3, q3, t3 = make_inputs(S3, D3, (K3 + W3) * B3 * BPS3, seed=42)
             d3 = torch.from_numpy(f3.view(np.int16)).cuda(local_rank)
             m3 = MLMap(S3, device=local_rank, max_blocks=65536, max_points=S3.width * S3.height, max_batch=B3)
