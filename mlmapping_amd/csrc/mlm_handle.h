@@ -216,6 +216,7 @@ namespace {
         hipError_t e__ = (expr);                                                                                      \
         if (e__ != hipSuccess) {                                                                                      \
             (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                            \
+            (void)hipGetLastError(); /* (reported: a later hipGetLastError() of this thread must not find it again) */  \
             return MLM_ERR_HIP;                                                                                       \
         }                                                                                                             \
     } while (0)

@@ -339,6 +339,48 @@ def test_two_slot_sets(mods, monkeypatch, knobs):
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "two slot sets")
 
 
+def test_registered_host_frames_and_callback_clocks(mods):
+    """mlm_host_register / mlm_host_unregister (the caller pins its frame buffer once; packed batches then travel in one copy at the
+    link's rate): asynchronous packed host batches from a registered buffer give the oracle's map, the buffer can be unregistered
+    and used again pageable, and registering garbage is an error, not a crash.  Also the host clocks of the callback path
+    (mlm_debug_clocks): sections are non-negative, add up to less than the call's wall time and reset."""
+    import time
+
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    n = 12
+    frames = np.ascontiguousarray(np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "smooth", n)]))
+    poses = syn.smooth_trajectory(n, 42)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=4096, max_batch=4), OracleMap(cfg)
+    gpu.host_register(frames)
+    gpu.set_async(True)
+    for k0 in (0, 4):
+        gpu.update_map_batch(frames[k0:k0 + 4], q[k0:k0 + 4], t[k0:k0 + 4])
+    gpu.sync()
+    gpu.host_unregister(frames)
+    gpu.update_map_batch(frames[8:12], q[8:12], t[8:12])  # (pageable again)
+    gpu.sync()
+    for k in range(n):
+        cpu.update_depth(frames[k], q[k], t[k])
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "registered host frames")
+    with pytest.raises(Exception):
+        gpu.host_unregister(frames)  # (not registered any more)
+    # host clocks of the sampled callback
+    gpu.set_async(False)
+    zero3 = np.zeros(3)
+    gpu.debug_clocks()
+    t0 = time.perf_counter()
+    for k in range(20):
+        gpu.depth_odom_callback(frames[k % n], 0.0, t[k % n], q[k % n], zero3, 0.0, zero3, 0.0, 0.0, sampled=True)
+    wall = (time.perf_counter() - t0) * 1e6
+    clk = gpu.debug_clocks()
+    assert (clk >= 0).all() and clk[:6].sum() > 0 and clk[:6].sum() <= wall, (clk, wall)
+    assert gpu.debug_clocks().sum() == 0.0
+    gpu.close()
+
+
 def test_bench_launcher_contract_two_ranks():
     """`python bench.py --gpus 2` exactly as the driver invokes it when it does not wrap it in torch.distributed.run: the
     parent starts the two ranks itself (before it touches the GPU) — rank environment, barrier, max over ranks, the timed
