@@ -381,6 +381,41 @@ def test_registered_host_frames_and_callback_clocks(mods):
     gpu.close()
 
 
+def test_two_handles_interleaved_and_no_leak(mods):
+    """Two maps in one process fed alternately (knobs and graphs are per handle, the streams their own): each equals its own oracle
+    map.  Then handles are created and destroyed in a loop: the device memory a handle held comes back."""
+    import torch
+
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    n = 8
+    fa = [f for f in syn.stream(cfg, "room_jitter", "smooth", n)]
+    fb = [f for f in syn.stream(cfg, "corridor", "translating", n)]
+    ga, gb, ca, cb = MLMap(cfg, max_blocks=2048), MLMap(cfg, max_blocks=2048, max_batch=2), OracleMap(cfg), OracleMap(cfg)
+    gb.set_async(True)
+    rng = np.random.default_rng(3)
+    for k in range(n):
+        (ia, (qa, ta)), (ib, (qb, tb)) = fa[k], fb[k]
+        pix = rng.choice(cfg.width * cfg.height, 500, replace=False).astype(np.int32)
+        ga.update_map(ia, qa, ta, pixel_idx=pix)      # synchronous single frames through the graph
+        ca.update_depth_indexed(ia, pix, qa, ta)
+        gb.update_map(ib, qb, tb)                     # asynchronous dense frames
+        cb.update_depth(ib, qb, tb)
+    compare_maps(ga.export_blocks(), ca.export_blocks(), "handle A (sampled, synchronous)")
+    compare_maps(gb.export_blocks(), cb.export_blocks(), "handle B (dense, asynchronous)")
+    ga.close()
+    gb.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(4):
+        g = MLMap(cfg, max_blocks=2048, max_batch=2)
+        g.update_map(fa[0][0], *fa[0][1])
+        g.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)
+
+
 def test_bench_launcher_contract_two_ranks():
     """`python bench.py --gpus 2` exactly as the driver invokes it when it does not wrap it in torch.distributed.run: the
     parent starts the two ranks itself (before it touches the GPU) — rank environment, barrier, max over ranks, the timed
