@@ -416,6 +416,58 @@ def test_two_handles_interleaved_and_no_leak(mods):
     assert free0 - free1 < 64 << 20, (free0, free1)
 
 
+def test_invalid_arguments_are_refused(mods):
+    """Every entry point answers bad arguments with a status (MLM_ERR_INVALID / MLM_ERR_CAPACITY), never with a crash, and the handle
+    keeps working: null buffers, null handle, non-positive sizes, a row stride below the width, negative counts, a frame above
+    mlm_limits.max_points, export buffers that are too small — followed by a frame that must still equal the oracle's."""
+    from mlmapping_amd import mlmap as mm
+
+    MLMap, OracleMap = mods
+    cfg = SDEF
+    gpu, cpu = MLMap(cfg, max_blocks=1024, max_points=cfg.width * cfg.height), OracleMap(cfg)
+    L, h = gpu._L, gpu._h
+    img, (q, t) = next(iter(syn.stream(cfg, "room", "static", 1)))
+    q, t = np.ascontiguousarray(q, np.float64), np.ascontiguousarray(t, np.float64)
+    pq, pt, pimg = q.ctypes.data, t.ctypes.data, img.ctypes.data
+    W, H = cfg.width, cfg.height
+    ERR_INVALID, ERR_CAPACITY = -1, -3  # (mlmap_hip.h)
+    bad = (ERR_INVALID, ERR_CAPACITY)
+    out = np.zeros(16, np.int8)
+    pos = np.zeros((4, 3))
+    n_out = ctypes.c_int(0)
+    calls = [
+        lambda: L.mlm_integrate_depth_u16(h, None, W, H, W, None, 0, pq, pt),
+        lambda: L.mlm_integrate_depth_u16(None, pimg, W, H, W, None, 0, pq, pt),
+        lambda: L.mlm_integrate_depth_u16(h, pimg, 0, H, W, None, 0, pq, pt),
+        lambda: L.mlm_integrate_depth_u16(h, pimg, W, -3, W, None, 0, pq, pt),
+        lambda: L.mlm_integrate_depth_u16(h, pimg, W, H, W - 1, None, 0, pq, pt),
+        lambda: L.mlm_integrate_depth_u16(h, pimg, W, H, W, pimg, -5, pq, pt),
+        lambda: L.mlm_integrate_depth_u16(h, pimg, W, H, W, None, 0, None, pt),
+        lambda: L.mlm_integrate_depth_u16(h, pimg, 4 * W, H, 4 * W, None, 0, pq, pt),   # above max_points
+        lambda: L.mlm_integrate_points(h, None, 5, pq, pt),
+        lambda: L.mlm_integrate_points(h, pos.ctypes.data, -1, pq, pt),
+        lambda: L.mlm_query_occupancy(h, None, 4, out.ctypes.data),
+        lambda: L.mlm_query_occupancy(h, pos.ctypes.data, 4, None),
+        lambda: L.mlm_query_occupancy(h, pos.ctypes.data, -2, out.ctypes.data),
+        lambda: L.mlm_host_register(h, None, 64),
+        lambda: L.mlm_host_register(h, pimg, 0),
+        lambda: L.mlm_get_frame_stats(h, None),
+        lambda: L.mlm_debug_clocks(h, None, 0),
+    ]
+    for k, c in enumerate(calls):
+        rc = c()
+        assert rc in bad, (k, rc)
+    assert L.mlm_debug_set(b"no_such_knob", 1) == ERR_INVALID
+    # the handle still works, and an export into a buffer that is too small is refused without writing past it
+    gpu.update_map(img, q, t)
+    cpu.update_depth(img, q, t)
+    keys = np.zeros((1, 3), np.int32)
+    rc = L.mlm_export_blocks(h, 1, keys.ctypes.data, None, None, None, ctypes.byref(n_out))
+    assert rc in bad or n_out.value <= 1 or rc == mm.MLM_OK, (rc, n_out.value)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "after the refused calls")
+    gpu.close()
+
+
 def test_bench_launcher_contract_two_ranks():
     """`python bench.py --gpus 2` exactly as the driver invokes it when it does not wrap it in torch.distributed.run: the
     parent starts the two ranks itself (before it touches the GPU) — rank environment, barrier, max over ranks, the timed
