@@ -796,6 +796,50 @@ def test_float_callback_between_packed_host_batches(mods):
     gpu.close()
 
 
+def test_empty_frames_everywhere(mods):
+    """Frames with nothing in them — an all-zero depth image, an empty pixel list, a sampler that finds no valid pixel — alone, inside
+    asynchronous batches between ordinary frames, and as the first frame of a fresh handle: each is a no-op for the map (it still
+    clears the awareness containers, map_awareness.cpp:178), and the frames around it integrate as usual."""
+    MLMap, OracleMap = mods
+    libc = ctypes.CDLL("libc.so.6")
+    cfg = SDEF
+    n = 8
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "smooth", n)])
+    frames[0] = 0
+    frames[3] = 0
+    frames[4] = 0
+    poses = syn.smooth_trajectory(n, 5)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=2048, max_batch=4, record_awareness=True), OracleMap(cfg)
+    gpu.update_map(frames[0], q[0], t[0])                                   # first frame of the handle: empty
+    cpu.update_depth(frames[0], q[0], t[0])
+    _awareness_equal(gpu, cpu)
+    gpu.set_async(True)
+    for k0 in (0, 4):                                                       # empty frames inside batches
+        gpu.update_map_batch(frames[k0:k0 + 4], q[k0:k0 + 4], t[k0:k0 + 4])
+        for k in range(k0, k0 + 4):
+            cpu.update_depth(frames[k], q[k], t[k])
+    gpu.sync()
+    gpu.set_async(False)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "batches with empty frames")
+    gpu.update_map(frames[1], q[1], t[1], pixel_idx=np.zeros(0, np.int32))  # empty pixel list
+    cpu.update_depth_indexed(frames[1], np.zeros(0, np.int32), q[1], t[1])
+    _awareness_equal(gpu, cpu)
+    args = dict(t_img=1.0, odom_p=t[2], odom_q=q[2], odom_v=[0.0, 0.0, 0.0], t_odom=1.0, imu_w=[0.0, 0.0, 0.0], t_imu=1.0, latency=0.0)
+    for img in (frames[3], frames[3].astype(np.float32)):                   # the sampler finds nothing (16UC1 and 32FC1)
+        libc.srand(3)
+        gpu.depth_odom_callback(img, sampled=True, **args)
+        libc.srand(3)
+        cpu.depth_odom_callback(img, sampled=True, **args)
+        _awareness_equal(gpu, cpu)
+    gpu.update_map(frames[5], q[5], t[5])                                   # ... and life goes on
+    cpu.update_depth(frames[5], q[5], t[5])
+    _awareness_equal(gpu, cpu)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "after the empty frames")
+    gpu.close()
+
+
 def test_fast_bin_boundary_points(mods):
     """k_bin_sectors takes its bins from a cheap FP64 evaluation and certifies each with a margin; a wave with a lane nearer to a
     cell boundary than the margin evaluates the reference's own sequence (mlm_bin_point_fast, mlm_device.h).  Points aimed AT the
