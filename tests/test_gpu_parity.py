@@ -797,6 +797,26 @@ def test_float_callback_between_packed_host_batches(mods):
     gpu.close()
 
 
+@pytest.mark.parametrize("n", [(1 << 20) - 1, (1 << 20) + 4097])
+def test_point_count_limits(mods, n):
+    """The largest frame the sector path takes (2^20 - 1 points: insertion times and contribution counts are packed for that) and one
+    above it (the cell-table path), as explicit points scattered through the awareness cylinder: same awareness sets and map."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    rng = np.random.default_rng(n)
+    pts = np.stack([rng.uniform(-5.0, 5.0, n), rng.uniform(-1.5, 1.5, n), rng.uniform(0.2, 6.0, n)], axis=1)
+    q, t = syn.random_poses(1, seed=9)[0]
+    gpu, cpu = MLMap(cfg, max_blocks=8192, max_points=n, max_batch=1, record_awareness=True), OracleMap(cfg)
+    gpu.update_map_points(pts, q, t)
+    cpu.update_points(pts, q, t)
+    _awareness_equal(gpu, cpu)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{n} points")
+    st = gpu.frame_stats()
+    print(n, "points:", {k: st[k] for k in ("n_points", "n_hit_cells", "n_miss_cells", "n_sector_fallbacks", "n_device_atomics")})
+    assert (st["n_device_atomics"] > 0) == (n < (1 << 20)), st  # (the sector path counts its atomics; the cell-table path reports 0)
+    gpu.close()
+
+
 def test_empty_frames_everywhere(mods):
     """Frames with nothing in them — an all-zero depth image, an empty pixel list, a sampler that finds no valid pixel — alone, inside
     asynchronous batches between ordinary frames, and as the first frame of a fresh handle: each is a no-op for the map (it still
