@@ -817,6 +817,28 @@ def test_point_count_limits(mods, n):
     gpu.close()
 
 
+def test_unusual_poses(mods):
+    """Poses a careless caller may hand over: a quaternion that is not normalised (the reference's _transformVector is then a
+    scaled, sheared map — so3.cpp:80-84 —; the binning kernel's matrix form must be the same map), a nearly zero one, a huge
+    translation, NaN and infinity in the translation (every point leaves the map: static_cast<int>(NaN) semantics).  Awareness sets,
+    out-of-range counts and maps equal the oracle's."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    img = syn.room_depth(cfg)
+    q0, t0 = syn.random_poses(1, seed=4)[0]
+    q0, t0 = np.asarray(q0, np.float64), np.asarray(t0, np.float64)
+    cases = [("scaled quaternion", q0 * 1.3, t0), ("shrunk quaternion", q0 * 0.61, t0), ("tiny quaternion", q0 * 1e-9, t0),
+             ("far away", q0, t0 + np.array([3.0e5, -2.0e5, 1.0e3])), ("NaN translation", q0, np.array([np.nan, 0.0, 1.0])),
+             ("infinite translation", q0, np.array([0.0, np.inf, 1.0])), ("ordinary", q0, t0)]
+    gpu, cpu = MLMap(cfg, max_blocks=16384, record_awareness=True), OracleMap(cfg)
+    for name, q, t in cases:
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), name)
+    gpu.close()
+
+
 def test_empty_frames_everywhere(mods):
     """Frames with nothing in them — an all-zero depth image, an empty pixel list, a sampler that finds no valid pixel — alone, inside
     asynchronous batches between ordinary frames, and as the first frame of a fresh handle: each is a no-op for the map (it still
