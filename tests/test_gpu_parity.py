@@ -839,6 +839,39 @@ def test_unusual_poses(mods):
     gpu.close()
 
 
+@pytest.mark.parametrize("explore", [False, True])
+def test_sampled_callbacks_between_async_batches(mods, explore):
+    """The callback's sampler hands its samples to the kernels in a pinned buffer of the handle (no copy): sampled callbacks
+    interleaved with asynchronous batches — the buffer is rewritten by the next callback only after the previous frame has read
+    it — in the default mode and in frontier mode (nothing speculative there, another submission path)."""
+    MLMap, OracleMap = mods
+    libc = ctypes.CDLL("libc.so.6")
+    cfg = SDEF.with_(use_exploration_frontiers=True) if explore else SDEF
+    n = 12
+    frames = np.stack([img for img, _ in syn.stream(cfg, "room_jitter", "smooth", n)])
+    poses = syn.smooth_trajectory(n, 8)
+    q = np.stack([p[0] for p in poses])
+    t = np.stack([p[1] for p in poses])
+    gpu, cpu = MLMap(cfg, max_blocks=4096, max_batch=3), OracleMap(cfg)
+    gpu.set_async(True)
+    zero3 = [0.0, 0.0, 0.0]
+    for k0 in range(0, n, 4):
+        gpu.update_map_batch(frames[k0:k0 + 3], q[k0:k0 + 3], t[k0:k0 + 3])
+        for k in range(k0, k0 + 3):
+            cpu.update_depth(frames[k], q[k], t[k])
+        for rep in range(2):  # two callbacks back to back: the second rewrites the staging buffer
+            args = dict(t_img=1.0, odom_p=t[k0 + 3], odom_q=q[k0 + 3], odom_v=zero3, t_odom=1.0, imu_w=zero3, t_imu=1.0, latency=0.0)
+            libc.srand(100 + k0 + rep)
+            gpu.depth_odom_callback(frames[k0 + 3], sampled=True, **args)
+            libc.srand(100 + k0 + rep)
+            cpu.depth_odom_callback(frames[k0 + 3], sampled=True, **args)
+    gpu.sync()
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"callbacks between async batches (frontier mode: {explore})")
+    if explore:
+        assert np.array_equal(gpu.export_frontier(), cpu.export_frontier())
+    gpu.close()
+
+
 def test_empty_frames_everywhere(mods):
     """Frames with nothing in them — an all-zero depth image, an empty pixel list, a sampler that finds no valid pixel — alone, inside
     asynchronous batches between ordinary frames, and as the first frame of a fresh handle: each is a no-op for the map (it still
