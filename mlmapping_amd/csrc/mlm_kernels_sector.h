@@ -44,7 +44,7 @@
 #define MLM_SEC_COLS 256    // distinct columns one k_bin_sectors block can feed in the list modes: one per record at most (a pixel list
                             // scatters over the image); a dense 32x8 pixel strip spans a handful: 64 entries bucketed by one wave
 #define MLM_SEC_CHUNKS 256  // chunk descriptors staged per pass of k_sector (a column of a VGA frame has ~50)
-#define MLM_SEC_OUTER 31u   // MlmNode::i00_sub >> 27 of a record that only starts a ray (point outside the map)
+#define MLM_SEC_OUTER 0x80000000u // top bit of a column record's first word: the record only starts a ray (point outside the map)
 #define MLM_SEC_RANK_WORDS (2 * MLM_BMP_ROWS) // u64 words of a wave's ranking bitmap (128 columns x 128 rows)
 
 // one hit cell of the column while k_sector works on it (16 bytes: a 2 048-entry table is 32 KB of LDS)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
     }
     __syncthreads(); // (the column tables are clear)
     // ---- bins, records (in registers), column buckets
-    uint32_t rec_cell[S], rec_pos[S], rec_i00[S], rec_phi[S], rec_place[S]; // rec_place: column entry | position in its run << 16, MLM_NIL: no record
+    uint32_t rec_cell[S], rec_pos[S], rec_place[S]; // rec_place: column entry | position in its run << 16, MLM_NIL: no record
     unsigned long long rec_mask[S];
 #pragma unroll
     for (int j = 0; j < S; ++j) {
@@ -254,17 +254,18 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
             }
         }
         rec_place[j] = MLM_NIL;
-        rec_cell[j] = leader ? (uint32_t)zi << 16 | (uint32_t)rho : (uint32_t)rho; // (hit records: z and rho of the centre cell, nRho * nZ < 65 536)
+        rec_cell[j] = leader ? (uint32_t)zi << 16 | (uint32_t)rho : (MLM_SEC_OUTER | (uint32_t)rho); // (hit records: z and rho of the centre cell, nRho * nZ < 65 536)
         // hit records carry their tile's origin (row << 11 | column of lane 0; list modes: 64 items = one row) for k_rank
         uint32_t yx = i00 >> 6 << 11;
         if (MODE == 0) {
             const uint32_t y0 = i00 / (uint32_t)F.width;
             yx = (y0 << 11) | (i00 - y0 * (uint32_t)F.width);
         }
+        // a record is 16 bytes (MlmSecRec).  Hit: centre cell z << 16 | rho, tile origin yx, lane mask (the wave's first work item
+        // follows from yx: y0 * width + x0, lists (yx >> 11) << 6).  Ray of a point outside the map: MLM_SEC_OUTER | rho, z, and in the
+        // mask's place its first point (the leader's own work item: frontier mode orders miss cells by it)
         rec_pos[j] = leader ? yx : (uint32_t)zi;
-        rec_i00[j] = i00 | (leader ? 0u : (MLM_SEC_OUTER << 27));
-        rec_phi[j] = (uint32_t)phi;
-        rec_mask[j] = my_mask;
+        rec_mask[j] = leader ? my_mask : (unsigned long long)(uint32_t)item[j];
         if (leader || ray_leader) { // bucket the record by column
             const uint32_t ph = (uint32_t)phi;
             uint32_t e = (ph * 2654435761u) >> (MODE == 0 ? 26 : 24);
@@ -310,13 +311,8 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
 #pragma unroll
     for (int j = 0; j < S; ++j) {
         if (rec_place[j] != MLM_NIL) {
-            MlmNode nd;
-            nd.cell = rec_cell[j];
-            nd.pos = rec_pos[j];
-            nd.i00_sub = rec_i00[j];
-            nd.pad = rec_phi[j];
-            nd.mask = rec_mask[j];
-            mlm_store_node(mlm_gp(P.bnodes) + ((size_t)(strip0 + (unsigned int)j) * 256u + s_col_off[j][rec_place[j] & 0xFFFFu] + (rec_place[j] >> 16)), nd);
+            *((MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.bnodes) + ((size_t)(strip0 + (unsigned int)j) * 256u + s_col_off[j][rec_place[j] & 0xFFFFu] + (rec_place[j] >> 16))) =
+                mlm_u32x4{rec_cell[j], rec_pos[j], (uint32_t)rec_mask[j], (uint32_t)(rec_mask[j] >> 32)};
         }
     }
     const bool owner = MODE == 0 ? (wid < S && lane == 0) : threadIdx.x == 0; // the thread that knows strip `wid`'s record count
@@ -529,7 +525,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     __shared__ unsigned int s_fail, s_nouter, s_tab_full;
     __shared__ uint32_t s_ref_ov[8], s_ref_ov_n; // table entries whose reference count wrapped
     const MLM_GLOBAL uint32_t *chunks = mlm_gp(P.col_chunks) + 2 * (size_t)phi * P.chunk_cap;
-    const MLM_GLOBAL MlmNode *recs = mlm_gp(P.bnodes);
+    const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.bnodes); // 16-byte column records (k_bin_sectors)
     // flat record r of the staged chunks -> index into `bnodes`
     auto rec_index = [&](uint32_t r, uint32_t n_staged) -> uint32_t {
         uint32_t lo = 0, hi = n_staged; // largest c with start[c] <= r
@@ -564,12 +560,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     // (a trip to HBM, the longest wait of a column's life under load) arrive while the workgroup initialises its LDS.
     const uint32_t pre_total = stage_chunks(0, min(nch, CH));
     mlm_u32x4 pre_a = mlm_u32x4{0u, 0u, 0u, 0u};
-    unsigned long long pre_mask = 0;
-    if (threadIdx.x < pre_total) {
-        const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + rec_index(threadIdx.x, min(nch, CH)));
-        pre_a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
-        pre_mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4);
-    }
+    if (threadIdx.x < pre_total) pre_a = recs[rec_index(threadIdx.x, min(nch, CH))];
     MLM_PHASE(7);
     for (uint32_t e = threadIdx.x; e < TAB; e += NT) {
         s_tab[e].key = MLM_NIL;
@@ -745,33 +736,23 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             for (uint32_t r = threadIdx.x; r < total; r += NT) {
                 if (pass == 0 && *(volatile unsigned int *)&s_tab_full) break; // (the column is given up: nothing more to book)
                 mlm_u32x4 a = pre_a;
-                unsigned long long rec_mask = pre_mask;
-                if (pass != 0 || c0 != 0 || r != threadIdx.x) {
-                    const MLM_GLOBAL uint32_t *rp = (const MLM_GLOBAL uint32_t *)(recs + rec_index(r, n_staged));
-                    a = *(const MLM_GLOBAL mlm_u32x4 *)rp;
-                    rec_mask = *(const MLM_GLOBAL unsigned long long *)(rp + 4); // (with the first 16 bytes: one trip to memory)
-                    __builtin_amdgcn_sched_barrier(0); // (both loads are issued before the first is waited for)
-                }
+                if (pass != 0 || c0 != 0 || r != threadIdx.x) a = recs[rec_index(r, n_staged)];
+                const unsigned long long rec_mask = (unsigned long long)a.z | (unsigned long long)a.w << 32;
 #ifdef MLM_PHASE_PROF
                 if (pass == 0) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     MLM_PHASE(8);
                 }
 #endif
-                const uint32_t kind = a.z >> 27;
-                if (kind == MLM_SEC_OUTER) {
+                if (a.x & MLM_SEC_OUTER) {
                     if (pass == 0) { // ray of a point outside the map: one lane walks it into the LDS mask
-                        int rho = (int)a.x, z = (int)a.y;
+                        int rho = (int)(a.x & ~MLM_SEC_OUTER), z = (int)a.y;
                         const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
                         if (rho >= P.nRho) {
                             z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
                             rho = P.nRho - 1;
                         }
-                        uint32_t p0 = 0;
-                        if (EX) { // the record's first point (several records may start the same ray: the minimum wins)
-                            const int l0 = __ffsll((long long)rec_mask) - 1;
-                            p0 = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
-                        }
+                        const uint32_t p0 = a.z; // the record's first point (EX: several records may start the same ray, the minimum wins)
                         for (int rr = 1; rr < rho; ++rr) {
                             const int zr = mlm_cvt_int(round(z - ((rho - rr) * slope)));
                             if (0 <= zr && zr < P.nZ) {
@@ -799,7 +780,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                     }
                     uint32_t nt = 0;
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
-                    const uint32_t i_first = (a.z & 0x07FFFFFFu) + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
+                    // (the wave's first work item from the tile origin: dense y0 * width + x0, lists 64 items per "row")
+                    const uint32_t i00 = tile_w > 0 ? (a.y >> 11) * (uint32_t)tile_w + (a.y & 2047u) : (a.y >> 11) << 6;
+                    const uint32_t i_first = i00 + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
                     const uint32_t cnt = (uint32_t)__popcll(mask), n_rows = mlm_mask_rows(mask);
                     mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int rho_t) {
                         const int e = mlm_sec_entry<true>(s_tab, tab_mask, key);
