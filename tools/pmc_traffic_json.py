@@ -13,8 +13,12 @@ from collections import defaultdict
 
 def load(path, name):
     acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == name:
+    rows = list(csv.DictReader(open(path)))
+    # a marker kernel (tools/pmc_batch64.py warm=W): only the dispatches after it count
+    marks = [int(r["Dispatch_Id"]) for r in rows if "k_probe_seeds" in r["Kernel_Name"]]
+    first = max(marks) if marks else -1
+    for r in rows:
+        if r["Counter_Name"] == name and int(r["Dispatch_Id"]) > first:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
             acc[k][0] += float(r["Counter_Value"])
             acc[k][1] += 1
