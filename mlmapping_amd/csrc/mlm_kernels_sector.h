@@ -5,25 +5,29 @@
 // spread of a hit moves along rho (and z) at the point's phi (map_awareness.cpp:149-168) and its ray runs radially inwards
 // at that phi (map_awareness.cpp:243-274).  So the frame is cut into nPhi independent sectors:
 //
-//   k_bin_sectors   point -> (rho,phi,z); the lanes of a wave that share a centre cell become ONE record (cell, lane mask);
-//                   a block buckets its <= 256 records by column in LDS and hands each (block, column) run to the column
-//                   with one returning atomic (a chunk descriptor).  Nothing else leaves the block.
+//   k_bin_sectors   point -> (rho,phi,z), by a cheap FP64 evaluation with certified margins (mlm_bin_point_fast; the reference's own
+//                   sequence for a wave with a lane too near a cell boundary); the lanes of a wave that share a centre cell become
+//                   ONE 16-byte record (cell, tile origin, lane mask); a block buckets its <= 256 records by column in LDS and
+//                   hands each (block, column) run to the column with one returning atomic (a chunk descriptor).  Nothing else
+//                   leaves the block.
 //   k_sector        one workgroup per column: per-cell hit bookkeeping (first-touch time, kinds, counts) in an LDS hash
 //                   table, the column's miss bit mask in LDS (rays walked by an integer DDA), the unique-hit list
 //                   (cells that received ONE kind of contribution, or enough strong ones, get their odd right away), and
-//                   for every other cell the list of (record, kind) references.  Which world voxel a cell falls into is
+//                   for every other cell one 4-byte reference per non-empty row of a record's lane mask.  Which world voxel a cell falls into is
 //                   geometry that separates by axis inside a column (tables per rho and per z); the frame-local voxel grid
 //                   is cut into tiles, a column crosses a tile once, so the column's hits and miss cells — ordered by rho —
-//                   leave as one coalesced stream of voxel-in-tile indices plus ONE descriptor per tile it crosses.
-//                   Global atomics: list reservations per workgroup, one bucket-min per hit, one descriptor per tile run.
+//                   leave as one coalesced stream of voxel-in-tile indices plus ONE descriptor per tile it crosses, stored in the
+//                   (tile, column) slot of the tile's table and announced by the column's bit in the tile's column mask.
+//                   Global atomics: four list reservations per workgroup (the only ones it waits for), fire and forget: one
+//                   bucket-min per hit, one mask bit per tile run.
 //   k_rank          iteration-order keys of the frame's hits; one wave per multi-kind cell whose float chain depends on the
 //                   order: rank its contributions by pixel (bitmap ranking fed with the records' 8x8 lane masks) and
 //                   store the kinds in that order.
 //   k_chain_lanes   replays the float noisy-OR chains, one cell per lane, lanes drawing cells dynamically.
-//   k_tile          workgroups walk the frame's touched tiles of the frame-local voxel grid: count the tile's miss cells and hits
-//                   per voxel in LDS, create the blocks the frame touches there, and write ONE 32-byte record per touched voxel
-//                   (block key, cell id, counts, the increment of a single hit, the block's pool slot); the hits of voxels
-//                   with several go next to each other.
+//   k_tile          workgroups take the tiles of the frame-local voxel grid in turns (a column mask says which columns left a run):
+//                   count the tile's miss cells and hits per voxel in LDS, create the blocks the frame touches there, and write
+//                   ONE 16-byte record per touched voxel (address in the block pool, miss count | voxel-in-tile index, the
+//                   increment of a single hit, hit count); the hits of voxels with several go next to each other.
 //   k_apply_tiles   the part that needs the map, ONE launch per batch: the frame-local grids are aligned to tile boundaries, a
 //                   workgroup owns a WORLD tile, keeps its voxels in LDS and walks the batch's frames in order — per record the
 //                   voxel's hits in the reference's iteration order, then its misses.  k_apply_single: the same for one frame
