@@ -932,8 +932,6 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                 // (contributions | rho << 20: what k_chain_lanes needs of the cell comes with one load)
                 *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, g_subs, n_con | ((uint32_t)c_rho << MLM_SEC_CNT_BITS), c.tmin};
                 *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{g_refs, n_ref};
-                mlm_gp(P.hl_base)[pos] = g_subs;
-                mlm_gp(P.hl_cnt)[pos] = n_con;
                 c.key = (c.key & MLM_SEC_KEY_MASK) | ((o_refs / MLM_SEC_REF_ALIGN) << 16);
                 ++o_multi;
                 o_refs += (n_ref + MLM_SEC_REF_ALIGN - 1u) & ~(MLM_SEC_REF_ALIGN - 1u);
@@ -1035,16 +1033,15 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         const uint32_t pos = s_base[0] + i;
         mlm_gp(P.hl_cell)[pos] = (uint32_t)(z * P.nRhoPhi + phi * P.nRho + rho);
         mlm_gp(P.hl_t)[pos] = c.tmin;
-        mlm_gp(P.hl_vt)[pos] = c.tmin;
+        mlm_gp(P.hl_vt)[pos] = c.tmin; // (the replay kernels re-rank it: k_assign_rank)
         if (!mlm_sec_needs_order(c)) {
             // one kind: cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154), 1.0f is absorbing;
             // several kinds with enough strong contributions: 1.0f in any order (mlm_sec_needs_order)
             const float a = mlm_gp(P.odds_table)[mlm_contribution_index(P, rho, __ffs((int)(c.kg & MLM_SEC_KIND_MASK)) - 1)]; // (one value per hit cell: from memory)
             float p = __popc(c.kg & MLM_SEC_KIND_MASK) > 1 ? 1.0f : a;
             for (uint32_t j = 1; j < (c.cnt & MLM_SEC_CNT_MASK) && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
-            mlm_gp(P.hl_odd)[pos] = p;
+            if (EX || P.record_awareness) mlm_gp(P.hl_odd)[pos] = p; // (the odd itself is only read back by mlm_get_awareness_hits)
             mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
-            mlm_gp(P.hl_cnt)[pos] = 0;
         }
         if (EX) { // frontier mode: the hit's world voxel (its kernels look the block up themselves)
             int gx, gy, gz, cid;
@@ -1624,7 +1621,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
     float pend_p = 0.0f;
     auto flush = [&]() {
         if (pend) {
-            mlm_gp(P.hl_odd)[pend_pos] = pend_p;
+            if (P.record_awareness || P.explore) mlm_gp(P.hl_odd)[pend_pos] = pend_p;
             mlm_gp(P.hl_inc)[pend_pos] = mlm_logit(P, pend_p);
             pend = false;
         }

@@ -1241,6 +1241,10 @@ int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *od
         const int rc = drain(h);
         if (rc) return rc;
     }
+    if (odds && !h->P.record_awareness && !h->P.explore) { // (the kernels keep the odds themselves only for this read-back)
+        h->err = "mlm_limits.record_awareness was not set";
+        return MLM_ERR_INVALID;
+    }
     const MlmDev &P = h->slots[(size_t)h->last_slot].P;
     const size_t n = (size_t)h->stats.n_hit_cells;
     if (n_out) *n_out = (int)n;
