@@ -1,6 +1,7 @@
 # usage: bash tools/prof_round.sh [tag] [sections]   (everything under gpurun_out/<tag>/; copy the summaries to profiles/<tag>_*)
 # sections (default "test bench times rows kt pmc sq"): test = pytest -m gpu; bench = bench.py; times = isolated kernel times;
-# rows = the widened rows; kt = rocprofv3 kernel trace of bench.py; pmc = FETCH/WRITE passes over the batched path (cfg2 + cfg3) and
+# rows = the widened rows; kt = rocprofv3 kernel trace of bench.py; pmc = FETCH/WRITE passes over the batched path (cfg2 from a fresh
+# stream and in the steady state after eight warm-up batches, cfg3) and
 # over single frames; sq = SQ counter passes over the batched path
 set -x
 TAG=${1:-r4a}
@@ -28,15 +29,18 @@ if has pmc; then
 NB=6
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/bf -- python3 $R/tools/pmc_batch64.py $NB > $O/bf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/bw -- python3 $R/tools/pmc_batch64.py $NB > $O/bw.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/sf -- python3 $R/tools/pmc_batch64.py $NB warm=8 > $O/sf.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/sw -- python3 $R/tools/pmc_batch64.py $NB warm=8 > $O/sw.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cf -- python3 $R/tools/pmc_batch64.py cfg3 4 > $O/cf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cw -- python3 $R/tools/pmc_batch64.py cfg3 4 > $O/cw.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -- python3 $R/tools/pmc_workload.py 48 > $O/pf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -- python3 $R/tools/pmc_workload.py 48 > $O/pw.log 2>&1
 cc() { find $O/$1 -name '*counter_collection.csv' | head -1; }
 python $R/tools/pmc_traffic_json.py $(cc bf) $(cc bw) $O/pmc_traffic_batch.json frames=$((NB*64)) > $O/pmc_traffic_batch.log 2>&1
+python $R/tools/pmc_traffic_json.py $(cc sf) $(cc sw) $O/pmc_traffic_batch_steady.json frames=$((NB*64)) > $O/pmc_traffic_batch_steady.log 2>&1
 python $R/tools/pmc_traffic_json.py $(cc cf) $(cc cw) $O/pmc_traffic_batch_cfg3.json frames=$((4*16)) > $O/pmc_traffic_batch_cfg3.log 2>&1
 python $R/tools/pmc_traffic_json.py $(cc pf) $(cc pw) $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
-rm -rf $O/bf $O/bw $O/cf $O/cw $O/pf $O/pw
+rm -rf $O/bf $O/bw $O/sf $O/sw $O/cf $O/cw $O/pf $O/pw
 fi
 if has sq; then
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/sq -- python3 $R/tools/pmc_batch64.py 3 > $O/sq.log 2>&1
