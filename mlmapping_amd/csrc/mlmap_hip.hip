@@ -348,6 +348,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         const double cells_per_voxel = (std::ceil(P.d_sub / P.dRho) + 2) * (std::ceil(P.d_sub / P.dZ) + 2) * P.nPhi;
         h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
                          P.sec_tab <= 4u * (unsigned int)h->sec_threads && (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
+                         P.nZ < 32768 /* a column record holds z << 16 | rho below its top bit (MLM_SEC_OUTER) */ &&
                          P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
                          P.nPhi <= 32 * MLM_TILE_WORDS /* k_tile: a tile's column mask */ &&
                          (P.explore ? P.nRho <= 256
