@@ -24,10 +24,10 @@ struct KernelTime {
 // Test and experiment knobs (mlm_debug_set): named integers that mlm_create reads — launch geometries, forced fall-backs,
 // simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
-const char *const kKnobNames[] = {"agg_lds", "apply_block", "big_arm", "big_grid", "bin_block", "bin_strips", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
+const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
                                   "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
-                                  "sectors", "single_eager", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
+                                  "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
     std::mutex mu;
     std::unordered_map<std::string, long long> v;
@@ -194,7 +194,6 @@ struct mlm_handle {
     bool use_graph = true;       // (MLM_GRAPH=0: always the general submission)
     bool no_spread = false;      // the noise model never spreads a hit beyond its own cell (3 sigma < 1 cell everywhere, e.g. the reference's default
                                  // depth_noise_coe 1e-6): k_chain_lanes has nothing to do and is not launched
-    int single_eager = 0;        // 1: the single-frame launch sequence is issued launch by launch instead of as a graph replay (knob single_eager)
     hipStream_t last_upload = nullptr; // the stream the current call's inputs were uploaded on (run_slots orders Stage A behind it)
     hipEvent_t upload_ev = nullptr;
     long long n_graph_launches = 0;
@@ -202,8 +201,6 @@ struct mlm_handle {
     size_t stage_cap = 0;
     long long n_pool_grows = 0;
     long long n_big_redos = 0;   // frames whose overflowed columns were redone with the large table at drain time (redo_overflow_columns)
-    unsigned int apply_block = MLM_BLOCK; // threads of a k_apply_tiles workgroup (knob apply_block: 128 | 256)
-    int bin_strips = 1;          // strips per k_bin_sectors workgroup for the dense frames of a batch (MLM_BIN_STRIPS=2|4: experiments)
     size_t grow_failed_at = 0;   // a pool of this many blocks did not fit the device (grow_pool does not retry it)
     MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
     MlmPair *fb_pairs = nullptr;

@@ -140,12 +140,11 @@ template <int MODE> __device__ __forceinline__ MlmTile mlm_strip_item(const MlmF
     return t;
 }
 
-// S strips per workgroup, worked on TOGETHER (every phase runs for all S before the next starts): a strip on its own is a chain
-// pixel load -> ~150 dependent FP64 instructions -> peel loops -> column table -> barrier -> scan -> barrier -> record stores ->
-// returning atomic -> descriptor store, and a wave spends most of its life waiting for one of them; with two strips the loads,
-// the FP64 division sequences and the atomics of the two overlap (S = 2 for dense images).  A record never touches LDS: the lane
-// that leads a group of pixels keeps it in registers until its place in the strip's slice is known (a lane leads at most one
-// record) — what is staged per strip is the column table (phi, count, offset: 768 bytes for a dense strip).
+// S strips per workgroup, worked on TOGETHER (every phase runs for all S before the next starts).  The launches use S = 1: two
+// and four strips in flight measured 1-4 % slower in the pipeline (profiles/r4b_*) — the kernel is bound by vector-instruction issue,
+// not by the waits of a strip's chain.  A record never touches LDS: the lane that leads a group of pixels keeps it in registers until
+// its place in the strip's slice is known (a lane leads at most one record) — what is staged per strip is the column table (phi,
+// count, offset: 768 bytes for a dense strip).
 template <int MODE, int S>
 __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int n_strips) {
     MLM_SLOT_SETUP

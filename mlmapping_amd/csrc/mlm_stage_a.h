@@ -209,11 +209,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
         }
         // (one strip per workgroup: two or four strips worked on together are 5 % quicker with nothing else on the GPU — 3.22 -> 3.06
         // us per frame — and cost the pipeline 6 %: 91.0 -> 85.3 k frames/s, profiles/r4b; MLM_BIN_STRIPS selects them for experiments)
-        if (mode == 0 && n > 1 && h->bin_strips == 4)
-            tlaunch(h, "k_bin_sectors", k_bin_sectors<0, 4>, dim3((nb + 3) / 4, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
-        else if (mode == 0 && n > 1 && h->bin_strips == 2)
-            tlaunch(h, "k_bin_sectors", k_bin_sectors<0, 2>, dim3((nb + 1) / 2, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
-        else if (mode == 0)
+        if (mode == 0)
             tlaunch(h, "k_bin_sectors", k_bin_sectors<0, 1>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
         else if (mode == 1)
             tlaunch(h, "k_bin_sectors", k_bin_sectors<1, 1>, dim3(nb, 1, n), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);

@@ -42,7 +42,7 @@ int launch_apply_tiles(mlm_handle *h, int base, int n, int f_begin = 0) {
             tlaunch(h, "k_apply_single", k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0,
                     (MlmCounters *)nullptr, (MlmGlobal *)nullptr);
         else
-            tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(h->apply_block),
+            tlaunch(h, "k_apply_tiles", k_apply_tiles, dim3((unsigned int)grid), dim3(MLM_BLOCK),
                     (size_t)(P.lv_nz + (z1 - z0)) * 9u * (1u << (2 * sh)) + 16u, h->stream, h->d_slot_tab, h->d_frame_tab, base + j0, j1 - j0, 0, z1 - z0);
         j0 = j1;
     }
@@ -431,8 +431,8 @@ hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int bi
     return hipGetLastError();
 }
 
-// A single frame in synchronous mode: that sequence as ONE replay of a HIP graph, or (knob single_eager) issued launch by launch —
-// measured 8 us slower per call than the replay (profiles/r4o README entry).  Either way the calling thread then polls the ticket
+// A single frame in synchronous mode: that sequence as ONE replay of a HIP graph (issued launch by launch it measured 8 us slower
+// per call: profiles/README.md, r4o).  The calling thread then polls the ticket
 // the last workgroup of k_apply_single writes (drain).
 int submit_single_graph(mlm_handle *h, int base) {
     MlmSlot &S = h->slots[(size_t)base];
@@ -453,45 +453,37 @@ int submit_single_graph(mlm_handle *h, int base) {
     h->h_frame_tab[base] = S.F;
     h->h_g->pad = 0u; // (k_apply_single ends with a ticket in the host copy of the map-wide flags: drain polls it)
     h->wait_ticket = (unsigned int)S.F.seq + 1u;
-    if (h->single_eager) {
-        const hipError_t e = enqueue_single_frame(h, base, nb, big, h->stream);
-        if (e != hipSuccess) {
-            h->err = std::string("single-frame launch sequence: ") + hipGetErrorString(e);
+    mlm_handle::SingleGraph *G = nullptr;
+    for (auto &g : h->graphs)
+        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.sec_tab == P.sec_tab && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
+    if (!G) {
+        if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
+            for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
+            h->graphs.clear();
+        }
+        hipStream_t st = h->stream;
+        HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const hipError_t e = enqueue_single_frame(h, base, nb, big, st);
+        hipGraph_t graph = nullptr;
+        const hipError_t e2 = hipStreamEndCapture(st, &graph);
+        if (e != hipSuccess || e2 != hipSuccess || !graph) {
+            if (graph) hipGraphDestroy(graph);
+            h->err = std::string("single-frame graph capture: ") + hipGetErrorString(e != hipSuccess ? e : e2);
             return MLM_ERR_HIP;
         }
-    } else {
-        mlm_handle::SingleGraph *G = nullptr;
-        for (auto &g : h->graphs)
-            if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.sec_tab == P.sec_tab && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
-        if (!G) {
-            if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
-                for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
-                h->graphs.clear();
-            }
-            hipStream_t st = h->stream;
-            HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const hipError_t e = enqueue_single_frame(h, base, nb, big, st);
-            hipGraph_t graph = nullptr;
-            const hipError_t e2 = hipStreamEndCapture(st, &graph);
-            if (e != hipSuccess || e2 != hipSuccess || !graph) {
-                if (graph) hipGraphDestroy(graph);
-                h->err = std::string("single-frame graph capture: ") + hipGetErrorString(e != hipSuccess ? e : e2);
-                return MLM_ERR_HIP;
-            }
-            hipGraphExec_t exec = nullptr;
-            const hipError_t e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
-            if (e3 != hipSuccess) {
-                h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3);
-                return MLM_ERR_HIP;
-            }
-            h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, exec});
-            G = &h->graphs.back();
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e3 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e3 != hipSuccess) {
+            h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3);
+            return MLM_ERR_HIP;
         }
-        clk_mark(h, 1);
-        HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
-        clk_mark(h, 2);
+        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, exec});
+        G = &h->graphs.back();
     }
+    clk_mark(h, 1);
+    HIPCHK(h, hipGraphLaunch(G->exec, h->stream));
+    clk_mark(h, 2);
     h->n_graph_launches++;
     h->pending.push_back(&S);
     h->set_pending[set] = 1;

@@ -447,9 +447,6 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (knob("graph", kv)) h->use_graph = (int)kv != 0;
         if (knob("big_grid", kv)) h->big_grid = (unsigned int)std::max(1, (int)kv);
         if (knob("big_arm", kv)) h->big_arm_len = std::max(0, (int)kv);
-        if (knob("single_eager", kv)) h->single_eager = (int)kv != 0;
-        if (knob("apply_block", kv)) h->apply_block = (int)kv == 64 ? 64u : ((int)kv == 128 ? 128u : (unsigned int)MLM_BLOCK);
-        if (knob("bin_strips", kv)) h->bin_strips = (int)kv == 2 ? 2 : ((int)kv == 4 ? 4 : 1);
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
     std::memset(h->h_g, 0, sizeof(MlmGlobal));
