@@ -1752,12 +1752,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_query(const MlmDev P, int mode, c
     } else if (mode == 1) {
         // 19-point stencil, mlmap.h:142-169; Vec3(±inflate) promotes the float to double
         const double f = inflate;
-        const double o[19][3] = {{0, 0, 0},   {0, 0, f},   {0, 0, -f}, {0, f, 0},   {0, -f, 0}, {f, 0, 0},  {-f, 0, 0},
-                                 {-f, f, 0},  {-f, -f, 0}, {f, f, 0},  {f, -f, 0},  {0, -f, f}, {0, -f, -f}, {0, f, f},
-                                 {0, f, -f},  {-f, 0, f},  {-f, 0, -f}, {f, 0, f},  {f, 0, -f}};
+        // (the signs of the nineteen offsets as a constant table: a per-thread array of doubles indexed by the loop would live in
+        // scratch memory)
+        static const int8_t o[19][3] = {{0, 0, 0},   {0, 0, 1},   {0, 0, -1}, {0, 1, 0},   {0, -1, 0}, {1, 0, 0},  {-1, 0, 0},
+                                        {-1, 1, 0},  {-1, -1, 0}, {1, 1, 0},  {1, -1, 0},  {0, -1, 1}, {0, -1, -1}, {0, 1, 1},
+                                        {0, 1, -1},  {-1, 0, 1},  {-1, 0, -1}, {1, 0, 1},  {1, 0, -1}};
         int res = 1;
         for (int k = 0; k < 19; ++k)
-            if (mlm_get_occupancy(P, x + o[k][0], y + o[k][1], z + o[k][2]) == 0) {
+            if (mlm_get_occupancy(P, x + (o[k][0] ? (o[k][0] > 0 ? f : -f) : 0.0), y + (o[k][1] ? (o[k][1] > 0 ? f : -f) : 0.0),
+                                  z + (o[k][2] ? (o[k][2] > 0 ? f : -f) : 0.0)) == 0) {
                 res = 0;
                 break;
             }
