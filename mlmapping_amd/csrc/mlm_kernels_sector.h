@@ -82,8 +82,10 @@ struct MlmSecCell {
 // makes a cell look weaker than it is).
 #define MLM_SEC_STRONG_ENOUGH 28u
 __host__ __device__ __forceinline__ uint32_t mlm_sec_strength(float a) { return a >= 0.875f ? 3u : (a >= 0.75f ? 2u : (a >= 0.5f ? 1u : 0u)); }
+// A cell with exactly TWO contributions needs no order either: p = 1 - (1 - a)(1 - b) whichever comes first (the first step sets
+// p to the first value, the float product commutes) — the far cells of a frame, where a pixel's spread meets a neighbour's centre.
 __device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
-    return __popc(c.kg & MLM_SEC_KIND_MASK) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH;
+    return __popc(c.kg & MLM_SEC_KIND_MASK) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH && (c.cnt & MLM_SEC_CNT_MASK) > 2u;
 }
 
 // rows (bytes) of an 8x8 lane mask that hold a lane: a multi-kind cell gets one reference per such row of every contribution group
@@ -1035,10 +1037,20 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         mlm_gp(P.hl_vt)[pos] = c.tmin; // (the replay kernels re-rank it: k_assign_rank)
         if (!mlm_sec_needs_order(c)) {
             // one kind: cnt applications of one value (update_odds_hashmap, map_awareness.h:147-154), 1.0f is absorbing;
-            // several kinds with enough strong contributions: 1.0f in any order (mlm_sec_needs_order)
+            // several kinds with enough strong contributions: 1.0f in any order; two contributions: their product (mlm_sec_needs_order)
             const float a = mlm_gp(P.odds_table)[mlm_contribution_index(P, rho, __ffs((int)(c.kg & MLM_SEC_KIND_MASK)) - 1)]; // (one value per hit cell: from memory)
-            float p = __popc(c.kg & MLM_SEC_KIND_MASK) > 1 ? 1.0f : a;
-            for (uint32_t j = 1; j < (c.cnt & MLM_SEC_CNT_MASK) && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
+            float p = a;
+            if (__popc(c.kg & MLM_SEC_KIND_MASK) > 1) {
+                if ((c.cnt >> MLM_SEC_CNT_BITS) >= MLM_SEC_STRONG_ENOUGH) {
+                    p = 1.0f;
+                } else { // two contributions of two kinds: the same value in either order
+                    const uint32_t rest = c.kg & MLM_SEC_KIND_MASK & ((c.kg & MLM_SEC_KIND_MASK) - 1u);
+                    const float b = mlm_gp(P.odds_table)[mlm_contribution_index(P, rho, __ffs((int)rest) - 1)];
+                    p = 1 - (1 - a) * (1 - b);
+                }
+            } else {
+                for (uint32_t j = 1; j < (c.cnt & MLM_SEC_CNT_MASK) && p != 1.0f; ++j) p = 1 - (1 - p) * (1 - a);
+            }
             if (EX || P.record_awareness) mlm_gp(P.hl_odd)[pos] = p; // (the odd itself is only read back by mlm_get_awareness_hits)
             mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
         }

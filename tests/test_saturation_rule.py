@@ -55,3 +55,19 @@ def test_order_matters_below_the_threshold():
         if chain(np.sort(a)) != chain(np.sort(a)[::-1]):
             found += 1
     assert found > 20
+
+
+def test_two_contributions_commute():
+    """A cell with exactly two contributions needs no order (mlm_sec_needs_order): the first step sets p to the first value, the
+    second is 1 - (1 - a)(1 - b) with a commutative float product — while three contributions already depend on their order."""
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([rng.uniform(1e-6, 0.999999, 20000), [0.5, 0.75, 0.875, 1e-7, 0.9999999]]).astype(F)
+    a, b = rng.permutation(vals), rng.permutation(vals)
+    for x, y in zip(a, b):
+        assert chain(np.array([x, y], dtype=F)) == chain(np.array([y, x], dtype=F))
+    found = 0
+    for _ in range(300):
+        t = rng.uniform(0.05, 0.45, 3).astype(F)
+        if len({float(chain(t[list(p)])) for p in ((0, 1, 2), (1, 2, 0), (2, 0, 1), (0, 2, 1))}) > 1:
+            found += 1
+    assert found > 10
