@@ -1450,6 +1450,13 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
         const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64;
         const bool act = valid && n <= 512u;
+#ifdef MLM_PHASE_PROF // (diagnostic build: how many contributions the ranked cells have — tools/rank_hist.py)
+        if (valid && hl == 0) {
+            const uint32_t bkt = n <= 3u ? 0u : (n <= 4u ? 1u : (n <= 8u ? 2u : (n <= 16u ? 3u : (n <= 32u ? 4u : (n <= 64u ? 5u : (n <= 128u ? 6u : (n <= 256u ? 7u : 8u)))))));
+            atomicAdd(&g_mlm_span[9 + 2 * bkt], 1ull); // (odd slots: the multiples of four hold the spans' first-start minima)
+            atomicAdd(&g_mlm_span[27], (unsigned long long)n_refs);
+        }
+#endif
         const int my_rounds = act ? (int)min(4u, (n_refs + 31u) >> 5) : 0;
         const int rounds = max(mlm_readlane(my_rounds, 0), mlm_readlane(my_rounds, 32)); // (uniform)
         bool bad = false;
