@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MLM_ABI_VERSION 4
+#define MLM_ABI_VERSION 5
 
 typedef enum mlm_status {
     MLM_OK = 0,
@@ -121,6 +121,11 @@ typedef struct mlm_frame_stats {
                                  * per depth callback, src/mlmap.cpp:463-507) */
     int64_t n_bin_exact_waves;  /* waves of the frame whose bins came from the reference's own FP64 sequence because a lane lay too near
                                  * a cell boundary for the certified cheap evaluation (k_bin_sectors; usually 0) */
+    /* host mirror of the map (ABI 5): batches of up to a few hundred positions are answered on the host like the reference's inline
+     * queries (include/mlmap.h:170-295), from a pinned copy of the block planes that is refreshed after the map changed */
+    int64_t n_host_queries;     /* positions answered from the host mirror so far */
+    int64_t n_mirror_refreshes; /* times the mirror was brought up to date (one kernel + one synchronisation each) */
+    int64_t n_mirror_blocks;    /* blocks copied to the host by those refreshes */
 } mlm_frame_stats;
 
 /* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */

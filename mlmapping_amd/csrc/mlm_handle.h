@@ -25,7 +25,7 @@ struct KernelTime {
 // simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
 const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
-                                  "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "node_lds", "pool_grow",
+                                  "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
                                   "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
@@ -64,6 +64,29 @@ struct MlmSlot {
     size_t img_cap = 0;
     int32_t *d_pix = nullptr;
     double *d_pts = nullptr;
+};
+
+// Host-resident mirror of the map for small query batches (mlm_mirror.h): pinned host planes that mirror the block pool slot by
+// slot, a host table block key -> slot, and the record of what changed on the device since the last refresh.
+struct MlmMirror {
+    bool enabled = true;           // knob "mirror" = 0: every query runs as a kernel
+    int max_clean = 256;           // largest batch answered on the host while the mirror is up to date (knob "mirror_max") ...
+    int max_dirty = 32;            // ... and while it needs a refresh first (a large batch is then cheaper as one kernel)
+    size_t cap = 0;                // blocks the planes hold
+    float *lo = nullptr;           // [cap * cells] pinned, device-visible
+    uint8_t *occ = nullptr, *infl = nullptr; // [cap * cells]
+    uint8_t *col = nullptr;        // [cap] released ("collapsed") blocks: element 0 answers
+    int *keys = nullptr;           // [cap * 3]
+    unsigned int *stat = nullptr;  // pinned: [0] block count seen by the refresh kernel, [2 + i] blocks copied by its workgroup i
+    std::vector<unsigned long long> tk; // open-addressed host table: packed key (MLM_HT_EMPTY: free) ...
+    std::vector<int> ts;                // ... -> slot
+    uint32_t tmask = 0;
+    unsigned int n_known = 0;      // blocks [0, n_known) are in the table and have valid planes
+    bool dirty = true;             // the device map changed (or may have) since the last refresh
+    bool all = true;               // ... anywhere; else inside the boxes
+    int n_box = 0;
+    int box_lo[16][3], box_hi[16][3];
+    long long n_refresh = 0, n_copied = 0, n_host_queries = 0;
 };
 
 static inline double mlm_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -204,6 +227,7 @@ struct mlm_handle {
     size_t grow_failed_at = 0;   // a pool of this many blocks did not fit the device (grow_pool does not retry it)
     MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
     MlmPair *fb_pairs = nullptr;
+    MlmMirror mir;               // host mirror for small query batches (mlm_mirror.h)
 };
 
 namespace {
@@ -314,6 +338,9 @@ int grow_pool(mlm_handle *h, size_t want);
 int ensure_free_blocks(mlm_handle *h, size_t need);
 int widen_sec_tab(mlm_handle *h);
 int ensure_free_blocks_idle(mlm_handle *h, size_t need);
+void mirror_mark_all(mlm_handle *h);
+void mirror_mark_box(mlm_handle *h, const int lo[3], const int hi[3]);
+void mirror_mark_frames(mlm_handle *h, int n);
 
 } // namespace
 

@@ -1830,6 +1830,50 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_query_odds_at(const MlmDev P, con
     out[i] = mlm_get_odd_at(P, glb[3 * (size_t)i], glb[3 * (size_t)i + 1], glb[3 * (size_t)i + 2], sub[i]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Host mirror of the map (mlm_mirror.h): the reference answers getOccupancy / getOdd / getOddGrad with ONE hash lookup on the
+// host (mlmap.h:170-295, ~30 ns); a planner calls them position by position.  Small query batches are therefore answered from a
+// pinned host copy of the block planes that mirrors the pool slot by slot.  This kernel brings the copy up to date: a workgroup
+// per block copies the planes of the blocks that are new (slot >= n_known) or whose key lies inside one of the boxes of block
+// indices the host recorded for the map-changing calls since the last refresh, straight into the host planes over the link.
+// ---------------------------------------------------------------------------------------------------------------
+#define MLM_MIRROR_BOXES 16
+struct MlmMirrorBoxes {
+    int n, all;
+    int lo[MLM_MIRROR_BOXES][3], hi[MLM_MIRROR_BOXES][3]; // inclusive bounds in block indices
+};
+__global__ __launch_bounds__(MLM_BLOCK) void k_mirror_refresh(const MlmDev P, unsigned int n_known, const MlmMirrorBoxes B, float *m_lo, uint8_t *m_occ,
+                                                              uint8_t *m_infl, uint8_t *m_col, int *m_keys, unsigned int m_cap, unsigned int *m_stat) {
+    const unsigned int nb = min(mlm_gp(P.g)->n_blocks, (unsigned int)P.max_blocks);
+    __shared__ unsigned int s_copied;
+    if (threadIdx.x == 0) s_copied = 0u;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) m_stat[0] = nb; // (the host learns the block count here: more than m_cap -> it enlarges the planes and asks again)
+    const unsigned int lim = min(nb, m_cap);
+    for (unsigned int b = blockIdx.x; b < lim; b += gridDim.x) {
+        const int gx = P.block_keys[3 * (size_t)b], gy = P.block_keys[3 * (size_t)b + 1], gz = P.block_keys[3 * (size_t)b + 2];
+        bool dirty = B.all || b >= n_known;
+        for (int k = 0; k < B.n && !dirty; ++k)
+            dirty = gx >= B.lo[k][0] && gx <= B.hi[k][0] && gy >= B.lo[k][1] && gy <= B.hi[k][1] && gz >= B.lo[k][2] && gz <= B.hi[k][2];
+        if (!dirty) continue; // (uniform over the workgroup)
+        const size_t v0 = (size_t)b * P.cells;
+        for (int c = threadIdx.x; c < P.cells; c += blockDim.x) {
+            m_lo[v0 + c] = P.log_odds[v0 + c];
+            m_occ[v0 + c] = P.occ[v0 + c];
+            m_infl[v0 + c] = P.infl[v0 + c];
+        }
+        if (threadIdx.x == 0) {
+            m_keys[3 * (size_t)b] = gx;
+            m_keys[3 * (size_t)b + 1] = gy;
+            m_keys[3 * (size_t)b + 2] = gz;
+            m_col[b] = P.explore ? P.blk_collapsed[b] : (uint8_t)0;
+            s_copied++;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) m_stat[2 + blockIdx.x] = s_copied; // (statistic: blocks this workgroup copied — plain stores, no atomics across the link)
+}
+
 // mlm_import_blocks: find or create the block of every imported key (allocate_ram, map_local.h:215-231) ...
 // grow_pool: re-insert the blocks' keys into the new, larger table (slot = the block's index in the pool)
 __global__ __launch_bounds__(MLM_BLOCK) void k_rehash_blocks(const MlmDev P, unsigned int n) {

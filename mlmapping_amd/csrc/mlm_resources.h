@@ -38,11 +38,21 @@ int ensure_query(mlm_handle *h, size_t n) {
     return MLM_OK;
 }
 
+bool mirror_wanted(const mlm_handle *h, int mode, int n, int max_iter);
+int mirror_sync(mlm_handle *h);
+void mirror_answer(const mlm_handle *h, int mode, const double *pos, int n, float inflate, int max_iter, void *out);
 int run_query(mlm_handle *h, int mode, const double *pos, int n, float inflate, int max_iter, void *out,
               size_t out_elem) {
     if (!h || !pos || !out || n < 0) return MLM_ERR_INVALID;
     if (n == 0) return MLM_OK;
     MLM_LOCK(h);
+    if (mirror_wanted(h, mode, n, max_iter)) { // a planner's position-by-position calls: answered on the host (mlm_mirror.h)
+        const int rc = mirror_sync(h);
+        if (rc) return rc;
+        mirror_answer(h, mode, pos, n, inflate, max_iter, out);
+        h->mir.n_host_queries += n;
+        return MLM_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);
     if (rc) return rc;

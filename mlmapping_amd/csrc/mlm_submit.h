@@ -493,6 +493,7 @@ int submit_single_graph(mlm_handle *h, int base) {
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
 int run_slots(mlm_handle *h, int n) {
     (void)hipGetLastError(); // a stale error of unrelated HIP calls in this thread is not ours
+    mirror_mark_frames(h, n); // (the host mirror of the map is stale inside these frames' reach: mlm_mirror.h)
     if (h->want_widen) {
         h->want_widen = false;
         h->ov_heavy = 0;

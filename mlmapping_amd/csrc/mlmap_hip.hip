@@ -8,7 +8,8 @@
 // ONE device translation unit (the kernels live in headers and are launched from here); the host driver is cut into parts that
 // are included in this order: mlm_handle.h (the handle, knobs, launch helpers) -> mlm_stage_a.h (Stage A launches, exact
 // ordering, statistics) -> mlm_explore_host.h (frontier mode) -> mlm_submit.h (submission, drain / replay, single-frame graph)
-// -> mlm_resources.h (device memory: pool growth, frame slots, queries' launcher); this file holds the extern "C" entry points.
+// -> mlm_resources.h (device memory: pool growth, frame slots, queries' launcher) -> mlm_mirror.h (host mirror of the map for small
+// query batches); this file holds the extern "C" entry points.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -34,6 +35,7 @@
 #include "mlm_explore_host.h"
 #include "mlm_submit.h"
 #include "mlm_resources.h"
+#include "mlm_mirror.h"
 
 extern "C" {
 
@@ -447,6 +449,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (knob("graph", kv)) h->use_graph = (int)kv != 0;
         if (knob("big_grid", kv)) h->big_grid = (unsigned int)std::max(1, (int)kv);
         if (knob("big_arm", kv)) h->big_arm_len = std::max(0, (int)kv);
+        if (knob("mirror", kv)) h->mir.enabled = (int)kv != 0;
+        if (knob("mirror_max", kv)) h->mir.max_clean = std::max(0, (int)kv), h->mir.max_dirty = std::min(h->mir.max_dirty, h->mir.max_clean);
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
     std::memset(h->h_g, 0, sizeof(MlmGlobal));
@@ -601,6 +605,8 @@ int mlm_destroy(mlm_handle *h) {
         if (h->d_img_set[k]) hipFree(h->d_img_set[k]);
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
+    mirror_free(h);
+    if (h->mir.stat) hipHostFree(h->mir.stat);
     if (h->h_g) hipHostFree(h->h_g);
     for (int k = 0; k < MLM_SETS; ++k) {
         if (h->batch_done[k]) hipEventDestroy(h->batch_done[k]);
@@ -952,6 +958,10 @@ int mlm_set_free_in_bound(mlm_handle *h, const double bmin[3], const double bmax
     }
     const size_t total = ax[0].size() * ax[1].size() * ax[2].size();
     const size_t na = ax[0].size() + ax[1].size() + ax[2].size();
+    {
+        const double wlo[3] = {ax[0].front(), ax[1].front(), ax[2].front()}, whi[3] = {ax[0].back(), ax[1].back(), ax[2].back()};
+        mirror_mark_world(h, wlo, whi);
+    }
     int rc = drain(h);
     if (rc) return rc;
     rc = ensure_query(h, (na + 2) / 3 + 1);
@@ -985,6 +995,16 @@ int mlm_inflate_map(mlm_handle *h, const double ct_pos[3]) {
     const int cgx = (int)std::floor(ct_pos[0] / h->P.d_glb), cgy = (int)std::floor(ct_pos[1] / h->P.d_glb),
               cgz = (int)std::floor(ct_pos[2] / h->P.d_glb);
     const size_t total = (size_t)(2 * G + 1) * (2 * G + 1) * (2 * G + 1) * (size_t)h->P.cells;
+    {
+        // (the cube of blocks and the neighbours its dilation may reach; a position whose block index leaves int: anywhere)
+        const double c[3] = {std::floor(ct_pos[0] / h->P.d_glb), std::floor(ct_pos[1] / h->P.d_glb), std::floor(ct_pos[2] / h->P.d_glb)};
+        if (std::fabs(c[0]) < 1e6 && std::fabs(c[1]) < 1e6 && std::fabs(c[2]) < 1e6) {
+            const int lo[3] = {cgx - G - 1, cgy - G - 1, cgz - G - 1}, hi[3] = {cgx + G + 1, cgy + G + 1, cgz + G + 1};
+            mirror_mark_box(h, lo, hi);
+        } else {
+            mirror_mark_all(h);
+        }
+    }
     hipLaunchKernelGGL(k_inflate_reset, dim3(grid_for(total)), dim3(MLM_BLOCK), 0, h->stream, h->P, cgx, cgy, cgz, G);
     hipLaunchKernelGGL(k_inflate_spread, dim3(grid_for(total)), dim3(MLM_BLOCK), 0, h->stream, h->P, cgx, cgy, cgz, G, R,
                        0.1 /* flate_height, map_local.h:65 */);
@@ -1124,6 +1144,7 @@ int mlm_import_blocks(mlm_handle *h, int n, const int32_t *keys, const float *lo
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);
     if (rc || n == 0) return rc;
+    mirror_mark_all(h);
     rc = ensure_free_blocks_idle(h, (size_t)n);
     if (rc) return rc;
     const size_t C = (size_t)h->P.cells, N = (size_t)n;
@@ -1193,6 +1214,13 @@ int mlm_query_odds_at(mlm_handle *h, const int32_t *glb_id, const int32_t *subbo
         if (subbox_id[i] < 0 || subbox_id[i] >= h->P.cells) return MLM_ERR_INVALID;
     if (n == 0) return MLM_OK;
     MLM_LOCK(h);
+    if (mirror_wanted(h, 3, n, 0)) { // (mlm_mirror.h)
+        const int rc = mirror_sync(h);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) out[i] = mir_odd_at(h, glb_id[3 * (size_t)i], glb_id[3 * (size_t)i + 1], glb_id[3 * (size_t)i + 2], subbox_id[i]);
+        h->mir.n_host_queries += n;
+        return MLM_OK;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);
     if (rc) return rc;
@@ -1228,6 +1256,9 @@ int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {
     if (!h || !out) return MLM_ERR_INVALID;
     MLM_LOCK(h);
     *out = h->stats;
+    out->n_host_queries = h->mir.n_host_queries;
+    out->n_mirror_refreshes = h->mir.n_refresh;
+    out->n_mirror_blocks = h->mir.n_copied;
     return MLM_OK;
 }
 

@@ -1,0 +1,121 @@
+// query_latency — what ONE position costs through the drop-in query interface, measured the way a planner would call it: a C++
+// program (g++, no HIP headers: only include/mlmap_facade.hpp over the C ABI) that integrates a few frames and then calls
+// getOccupancy / getOdd / getOddGrad / getOccupancy(pos, inflate) / getInflateOccupancy one position per call, with a
+// std::chrono clock around every call.  The reference answers these with one hash lookup on the host (include/mlmap.h:170-295).
+// Input: the blob tests/test_gpu_boundary.py::test_cpp_facade_client_process writes (mlm_config, {frames, W, H, positions},
+// frames as pose[7] + uint16 image, positions as doubles).  Output: one JSON object on stdout.
+// Built by mlmapping_amd/csrc/Makefile into mlmapping_amd/lib/mlm_query_latency; run by bench.py (extra.single_query_us).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "mlmap_facade.hpp"
+
+struct Vec3 {
+    double d[3];
+    double operator[](int i) const { return d[i]; }
+};
+static bool read_exact(FILE *f, void *p, size_t n) { return std::fread(p, 1, n, f) == n; }
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Stat {
+    double p50, p99, mean;
+};
+static Stat stat_of(std::vector<double> &v) {
+    std::sort(v.begin(), v.end());
+    double s = 0;
+    for (double x : v) s += x;
+    return Stat{v[v.size() / 2], v[(size_t)(v.size() * 0.99)], s / v.size()};
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) return 2;
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    mlm_config cfg;
+    int32_t hdr[4];
+    if (!read_exact(f, &cfg, sizeof cfg) || !read_exact(f, hdr, sizeof hdr)) return 2;
+    const int n_frames = hdr[0], W = hdr[1], H = hdr[2], n_pos = hdr[3];
+    try {
+        mlmap_hip::mlmap map;
+        mlm_limits lim{};
+        lim.max_blocks = 16384;
+        lim.max_points = W * H;
+        lim.max_batch = 2;
+        map.init_map(cfg, 0, &lim);
+        std::vector<std::vector<uint16_t>> imgs((size_t)n_frames, std::vector<uint16_t>((size_t)W * H));
+        std::vector<double> poses((size_t)n_frames * 7);
+        for (int k = 0; k < n_frames; ++k)
+            if (!read_exact(f, &poses[(size_t)k * 7], 7 * 8) || !read_exact(f, imgs[(size_t)k].data(), imgs[(size_t)k].size() * 2)) return 2;
+        std::vector<double> pos((size_t)n_pos * 3);
+        if (!read_exact(f, pos.data(), pos.size() * 8)) return 2;
+        auto integrate = [&](int k) {
+            map.set_depth_image(imgs[(size_t)k].data(), W, H);
+            map.set_pose(&poses[(size_t)k * 7], &poses[(size_t)k * 7] + 4);
+            map.project_depth();
+            map.update_map();
+        };
+        for (int k = 0; k + 1 < n_frames; ++k) integrate(k);
+        const double ct[3] = {poses[4], poses[5], poses[6]};
+        map.inflate_map(Vec3{{ct[0], ct[1], ct[2]}});
+        // the first query after the map changed pays for bringing the host mirror up to date
+        std::vector<double> first;
+        long long sink = 0;
+        for (int r = 0; r < 20; ++r) {
+            integrate(n_frames - 1);
+            const Vec3 p{{pos[0], pos[1], pos[2]}};
+            const double t0 = now_us();
+            sink += map.getOccupancy(p);
+            first.push_back(now_us() - t0);
+        }
+        // steady state: the map does not change between the calls
+        std::vector<double> t_occ, t_odd, t_grad, t_occ_i, t_infl, t_clock;
+        double fsink = 0;
+        for (int rep = 0; rep < 4; ++rep)
+            for (int i = 0; i < n_pos; ++i) {
+                const Vec3 p{{pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]}};
+                double t0 = now_us();
+                sink += map.getOccupancy(p);
+                double t1 = now_us();
+                fsink += map.getOdd(p);
+                double t2 = now_us();
+                const mlmap_hip::Vec3d g = map.getOddGrad(p);
+                double t3 = now_us();
+                sink += map.getOccupancy(p, 0.15f);
+                double t4 = now_us();
+                sink += map.getInflateOccupancy(p);
+                double t5 = now_us();
+                double t6 = now_us();
+                fsink += g[0];
+                if (rep == 0) continue; // (warm-up pass)
+                t_occ.push_back(t1 - t0);
+                t_odd.push_back(t2 - t1);
+                t_grad.push_back(t3 - t2);
+                t_occ_i.push_back(t4 - t3);
+                t_infl.push_back(t5 - t4);
+                t_clock.push_back(t6 - t5);
+            }
+        mlm_frame_stats st{};
+        mlm_get_frame_stats(map.handle(), &st);
+        const Stat a = stat_of(t_occ), b = stat_of(t_odd), c = stat_of(t_grad), d = stat_of(t_occ_i), e = stat_of(t_infl), k = stat_of(t_clock), fi = stat_of(first);
+        std::printf("{\"calls_per_kind\": %zu, \"clock_overhead_us\": %.4f, "
+                    "\"getOccupancy\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
+                    "\"getOdd\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
+                    "\"getOddGrad\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
+                    "\"getOccupancy_inflate\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
+                    "\"getInflateOccupancy\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
+                    "\"first_query_after_integrate\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f}, "
+                    "\"n_host_queries\": %lld, \"n_mirror_refreshes\": %lld, \"n_mirror_blocks\": %lld, \"n_blocks\": %lld, \"sink\": %lld}\n",
+                    t_occ.size(), k.p50, a.p50, a.p99, a.mean, b.p50, b.p99, b.mean, c.p50, c.p99, c.mean, d.p50, d.p99, d.mean, e.p50, e.p99, e.mean,
+                    fi.p50, fi.p99, fi.mean, (long long)st.n_host_queries, (long long)st.n_mirror_refreshes, (long long)st.n_mirror_blocks,
+                    (long long)st.n_blocks, sink + (long long)fsink);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "query_latency: %s\n", e.what());
+        return 1;
+    }
+    std::fclose(f);
+    return 0;
+}
