@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — depth frames/s integrated into the map on MI355X (BASELINE.json metric).
 
-A *step* is `--batches-per-step` (9: a multiple of the three slot sets) batches of `--batch` (64) synthetic depth frames of ONE
-stream pushed through the hot path (awareness raycast + log-odds block-map update) in order: 576 frames, ~5.7 ms — one 64-frame
-batch (0.7 ms) is too small
-a unit to be robust to a single hiccup of the host.  `value` = frames / total time of the K steps; `value_p50` = the same
+A *step* is `--batches-per-step` (27: a multiple of the three slot sets) batches of `--batch` (64) synthetic depth frames of ONE
+stream pushed through the hot path (awareness raycast + log-odds block-map update) in order: 1 728 frames, ~17 ms, so that the
+driver's 20 steps time a third of a second — one 64-frame batch (0.7 ms) is too small a unit to be robust to a single hiccup of
+the host.  `value` = frames / total time of the K steps; `value_p50` = the same
 from the median step.  Inputs (uint16 depth frames + poses) are resident in
 HBM before the timed region starts.  Workload at N=1 = BASELINE config 2 (640x480 stream, 0.1 m local map,
 S1 parameters); `--workload cfg3` selects config 3 (1280x720, 0.05 m).  At N=1 the same run also times a short
@@ -359,10 +359,10 @@ def main():
         return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per batched submission (one batched Stage A launch sequence)")
-    ap.add_argument("--batches-per-step", type=int, default=9, help="batched submissions per step (a step = this x --batch frames)")
+    ap.add_argument("--batches-per-step", type=int, default=27, help="batched submissions per step (a step = this x --batch frames)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--distinct", type=int, default=64, help="distinct depth frames kept in HBM (cycled; rounded up to a multiple of --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -551,6 +551,14 @@ def main():
             m3.close()
             del d3
             out["extra"]["single_frame_us"] = single_frame_latency(MLMap, cfg, frames, q, t, d_frames, cpu=not args.no_cpu_baseline)
+            # the drop-in query interface the way a planner calls it: ONE position per call from a C++ client of the facade
+            # (tools/query_latency.cpp, a child process), the CPU oracle's per-position cost beside it
+            try:
+                from tools.query_latency import measure as query_latency
+
+                out["extra"]["single_query_us"] = query_latency(cfg, with_oracle=not args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001 (the headline must not depend on this row)
+                out["extra"]["single_query_us"] = {"error": str(e)[:300]}
             if not args.no_cpu_baseline:
                 out["extra"]["cfg3"]["cpu_baseline"], _ = cpu_baseline(S3, "cfg3", f3, q3, t3, args.cpu_budget, None, min_frames=3, per_core=False)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only

@@ -52,6 +52,8 @@ class MapConfig:
     cam_fx: float = 347.99755859375
     cam_fy: float = 347.99755859375
     T_B_S: List[float] = field(default_factory=lambda: list(T_BS_SIM))
+    # pose latency compensation of the depth/odom callback (mlmap.cpp:12,485-498); handed to mlm_integrate_callback per call
+    camera2odom_latency: float = 0.001
     # image size the preset is meant for (not a reference key; used by the synthetic harness)
     width: int = 640
     height: int = 360
@@ -98,7 +100,19 @@ S3 = MapConfig(
 # order-independent variant of S1 named in SURVEY.md §8d config 2 (config_sim.yaml:24,31)
 S1_SIGMA0 = S1.with_(depth_noise_coe=0.000001, lm_occupied_sh=3.0)
 
-PRESETS = {"S1": S1, "S3": S3, "SDEF": SDEF, "S1_SIGMA0": S1_SIGMA0}
+# the two shipped config files that carry the current keys, verbatim (tests/test_config_yaml.py holds them to the files):
+# launch/config/config_sim.yaml:8-55 is SDEF (640x360 gazebo camera); launch/config/config2.yaml:7-52 is the real-data set-up —
+# frontier mode, inflation, a 424x240 depth stream (cx 212.65, cy 117.24, f 213.73), noise 0.00375, occupied above 2.0
+CONFIG_SIM_YAML = SDEF
+CONFIG2_YAML = MapConfig(
+    am_d_Rho=0.20, am_d_Phi_deg=5.0, am_d_Z=0.20, am_n_Rho=40, am_n_Z_below=20, am_n_Z_over=20, use_raycasting=True,
+    depth_noise_coe=0.00375, subbox_d_xyz=0.2, subbox_n=10, use_exploration_frontiers=True, lm_log_odds_min=-2.0,
+    lm_log_odds_max=4.2, lm_measurement_hit=0.7, lm_measurement_miss=-0.9, lm_occupied_sh=2.0, inflate_n=2, inflate_global_n=2,
+    apply_inflate=True, sample_cnt=500, cam_cx=212.6516265869, cam_cy=117.238, cam_fx=213.728866577, cam_fy=213.728866577,
+    camera2odom_latency=0.085, width=424, height=240,
+)
+
+PRESETS = {"S1": S1, "S3": S3, "SDEF": SDEF, "S1_SIGMA0": S1_SIGMA0, "CONFIG_SIM_YAML": CONFIG_SIM_YAML, "CONFIG2_YAML": CONFIG2_YAML}
 
 
 class CConfig(ctypes.Structure):
@@ -164,24 +178,59 @@ def to_c(cfg: MapConfig) -> CConfig:
     return c
 
 
-def from_yaml(path: str, width: int = 640, height: int = 480) -> MapConfig:
-    """Read the keys the reference reads (``yamlRead.h:7-48``) from one of its config files."""
+# every key mlmap::init_map reads from the YAML for this path (src/mlmap.cpp:10-33,75-85); the reference dies with a yaml-cpp
+# exception when one is missing (yamlRead.h:25-48) — the three older shipped files (config.yaml, d435i_mit_flvis.yaml,
+# l515_t265.yaml) lack the subbox / camera / inflate keys and cannot be loaded by the current reference either
+YAML_KEYS = {
+    "am_d_Rho": ("mlmapping_am_d_Rho", float), "am_d_Phi_deg": ("mlmapping_am_d_Phi_deg", float), "am_d_Z": ("mlmapping_am_d_Z", float),
+    "am_n_Rho": ("mlmapping_am_n_Rho", int), "am_n_Z_below": ("mlmapping_am_n_Z_below", int), "am_n_Z_over": ("mlmapping_am_n_Z_over", int),
+    "use_raycasting": ("mlmapping_use_raycasting", bool), "depth_noise_coe": ("mlmapping_depth_noise_coe", float),
+    "subbox_d_xyz": ("mlmapping_subbox_d_xyz", float), "subbox_n": ("mlmapping_subbox_n", int),
+    "use_exploration_frontiers": ("use_exploration_frontiers", bool),
+    "lm_log_odds_min": ("mlmapping_lm_log_odds_min", float), "lm_log_odds_max": ("mlmapping_lm_log_odds_max", float),
+    "lm_measurement_hit": ("mlmapping_lm_measurement_hit", float), "lm_measurement_miss": ("mlmapping_lm_measurement_miss", float),
+    "lm_occupied_sh": ("mlmapping_lm_occupied_sh", float), "inflate_n": ("mlmapping_inflate_n", int),
+    "inflate_global_n": ("mlmapping_inflate_global_n", int), "apply_inflate": ("mlmapping_apply_inflate", bool),
+    "sample_cnt": ("mlmapping_sample_cnt", int), "cam_cx": ("mlmapping_cam_cx", float), "cam_cy": ("mlmapping_cam_cy", float),
+    "cam_fx": ("mlmapping_cam_fx", float), "cam_fy": ("mlmapping_cam_fy", float),
+    "camera2odom_latency": ("camera2odom_latency", float),
+}
+
+
+def from_params(y: dict, width: int, height: int) -> MapConfig:
+    """A MapConfig from the parsed YAML mapping of one of the reference's config files (all keys required, like the reference)."""
+    kw = {}
+    for name, (key, typ) in YAML_KEYS.items():
+        if key not in y:
+            raise KeyError(f"{key}: the reference reads this key at init (src/mlmap.cpp:10-33,75-85) and the file does not have it")
+        kw[name] = typ(y[key])
+    if "T_B_S" not in y or len(y["T_B_S"]) != 16:
+        raise KeyError("T_B_S: 16 row-major values (include/yamlRead.h:16-24)")
+    return MapConfig(T_B_S=[float(v) for v in y["T_B_S"]], width=width, height=height, **kw)
+
+
+def load_reference_yaml(path: str) -> dict:
+    """Parse one of the reference's config files.  yaml-cpp 0.6.2 (the reference's loader) accepts the T_B_S matrix written as a
+    flow sequence that starts in column 0 of the line AFTER its key (config_sim.yaml:51-55); strict YAML 1.1 loaders (PyYAML) do
+    not — a continuation line must be indented deeper than its key.  The rows of an open flow sequence are therefore indented
+    before parsing; nothing else is touched."""
     import yaml
 
+    out, depth = [], 0
     with open(path) as f:
-        y = yaml.safe_load(f)
-    g = lambda k, d=None: y.get("mlmapping_" + k, y.get(k, d))
-    return MapConfig(
-        am_d_Rho=float(g("am_d_Rho")), am_d_Phi_deg=float(g("am_d_Phi_deg")), am_d_Z=float(g("am_d_Z")),
-        am_n_Rho=int(g("am_n_Rho")), am_n_Z_below=int(g("am_n_Z_below")), am_n_Z_over=int(g("am_n_Z_over")),
-        use_raycasting=bool(g("use_raycasting", True)), depth_noise_coe=float(g("depth_noise_coe")),
-        subbox_d_xyz=float(g("subbox_d_xyz")), subbox_n=int(g("subbox_n")),
-        use_exploration_frontiers=bool(g("use_exploration_frontiers", False)),
-        lm_log_odds_min=float(g("lm_log_odds_min")), lm_log_odds_max=float(g("lm_log_odds_max")),
-        lm_measurement_hit=float(g("lm_measurement_hit")), lm_measurement_miss=float(g("lm_measurement_miss")),
-        lm_occupied_sh=float(g("lm_occupied_sh")), inflate_n=int(g("inflate_n", 2)),
-        inflate_global_n=int(g("inflate_global_n", 2)), apply_inflate=bool(g("apply_inflate", False)),
-        sample_cnt=int(g("sample_cnt", 500)), cam_cx=float(g("cam_cx")), cam_cy=float(g("cam_cy")),
-        cam_fx=float(g("cam_fx")), cam_fy=float(g("cam_fy")), T_B_S=[float(v) for v in y["T_B_S"]],
-        width=width, height=height,
-    )
+        for line in f:
+            body = line.split("#", 1)[0]
+            if depth > 0 or body.lstrip().startswith("["):
+                line = "  " + line
+            depth += body.count("[") - body.count("]")
+            out.append(line)
+    return yaml.safe_load("".join(out))
+
+
+def from_yaml(path: str, width: int = 0, height: int = 0) -> MapConfig:
+    """Read the keys the reference reads (``yamlRead.h:7-48``, ``mlmap.cpp:10-33,75-85``) from one of its config files.  Image size
+    (not a YAML key: the reference takes it from the image messages): 2 * round(cx) x 2 * round(cy) unless given."""
+    y = load_reference_yaml(path)
+    w = width or 2 * int(round(float(y.get("mlmapping_cam_cx", 320.0))))
+    h = height or 2 * int(round(float(y.get("mlmapping_cam_cy", 240.0))))
+    return from_params(y, w, h)

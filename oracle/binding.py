@@ -34,6 +34,7 @@ def lib():
         build()
         L = ctypes.CDLL(_LIB_PATH)
         vp, i32, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_size_t
+        L.mlo_set_quat_arch.argtypes = [i32]
         L.mlo_create.restype = vp
         L.mlo_create.argtypes = [vp]
         L.mlo_destroy.argtypes = [vp]
@@ -287,6 +288,11 @@ class OracleMap:
 
 
 # ---- SO3 / SE3 restatements on their own (for the Sophus property tests) -------------------------------------------
+def set_quat_arch(arch: int):
+    """0: Eigen's generic quaternion kernels (default); 1: the association of its SSE2 double kernels (mlmap_oracle.cpp: quat_mul)."""
+    lib().mlo_set_quat_arch(int(arch))
+
+
 def _call(name, out_n, *args):
     a = [_f64(x) for x in args]
     out = np.empty(out_n)

@@ -61,14 +61,29 @@ struct Quat {
 static inline V3 cross(const V3 &a, const V3 &b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-/* Eigen generic quat_product (Quaternion.h, internal::quat_product<Architecture::Generic>) */
+/* Which of Eigen's code paths the quaternion arithmetic follows (mlo_set_quat_arch).  Eigen is NOT under /root/reference (unpinned
+ * system dependency, CMakeLists.txt:7), so both are restated from its published sources:
+ *   0 (default) — the generic path: internal::quat_product<Architecture::Generic> and a sequential squaredNorm;
+ *   1 — what an x86-64 build of the reference (SSE2 is baseline; CMakeLists.txt:4 sets no -march) gets from Eigen 3.3 / 3.4:
+ *       quat_product<Architecture::SSE, ..., double> (Eigen/src/Geometry/arch/Geometry_SSE.h) evaluates, with two-lane packets,
+ *           t1 = aw*b.xy + ay*b.zw,  t2 = az*b.xy - ax*b.zw,  res.xy = t1 + (-swap(t2).lane0, +swap(t2).lane1)
+ *           t1 = aw*b.zw - ay*b.xy,  t2 = az*b.zw + ax*b.xy,  res.zw = t1 - (-swap(t2).lane0, +swap(t2).lane1)
+ *       i.e. the same four products per coefficient in a different association, and the vectorised redux of squaredNorm adds the
+ *       squares lane-wise first: (x^2 + z^2) + (y^2 + w^2).
+ * tests/test_quat_arch.py reports how many T_ls bits and how many map cells differ between the two on the parity fixtures. */
+static int g_quat_arch = 0;
 static inline Quat quat_mul(const Quat &a, const Quat &b) {
+    if (g_quat_arch == 1)
+        return {(a.w * b.w - a.y * b.y) - (a.z * b.z + a.x * b.x), (a.w * b.x + a.y * b.z) - (a.z * b.y - a.x * b.w),
+                (a.w * b.y + a.y * b.w) + (a.z * b.x - a.x * b.z), (a.w * b.z - a.y * b.x) + (a.z * b.w + a.x * b.y)};
+    /* Eigen generic quat_product (Quaternion.h, internal::quat_product<Architecture::Generic>) */
     return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
             a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
 }
 /* QuaternionBase::normalize: m_coeffs /= norm(), coefficient order (x,y,z,w), sequential sum */
 static inline Quat quat_normalized(const Quat &q) {
-    double n = std::sqrt(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
+    double n = g_quat_arch == 1 ? std::sqrt((q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w))
+                                : std::sqrt(((q.x * q.x + q.y * q.y) + q.z * q.z) + q.w * q.w);
     return {q.w / n, q.x / n, q.y / n, q.z / n};
 }
 /* QuaternionBase::_transformVector */
@@ -790,6 +805,8 @@ static SE3 make_T_wb(const double q_wb[4], const double t_wb[3]) {
 }
 
 extern "C" {
+
+void mlo_set_quat_arch(int arch) { g_quat_arch = arch == 1 ? 1 : 0; }
 
 mlo_handle *mlo_create(const mlo_config *c) {
     mlo_handle *h = new mlo_handle();

@@ -63,6 +63,9 @@ typedef struct mlo_config {
 
 typedef struct mlo_handle mlo_handle;
 
+/* process-wide: 0 = Eigen's generic quaternion product / norm (default), 1 = the association of Eigen's SSE2 double kernels
+ * (see mlmap_oracle.cpp: quat_mul) — a sensitivity switch for the one piece of third-party arithmetic on the path */
+void mlo_set_quat_arch(int arch);
 mlo_handle *mlo_create(const mlo_config *cfg);
 void mlo_destroy(mlo_handle *h);
 
