@@ -224,14 +224,18 @@ int mlm_merge_finish(mlm_handle *h, float *log_odds_dev, const uint8_t *seen_dev
 /* Pin a caller-owned host buffer (hipHostRegister) so that the host-buffer entry points (mlm_integrate_depth_batch,
  * mlm_integrate_depth_u16, mlm_integrate_callback, mlm_integrate_points) DMA straight from it: from pageable memory a copy is
  * staged by the HIP runtime at a third of the link's rate.  A replay tool registers its frame buffer once; the ROS callback
- * pattern (one frame per call) does not need it.  Unregister before freeing the buffer (waits for everything submitted). */
+ * pattern (one frame per call) does not need it.  Registering does not change the lifetime rule: every entry point is done with
+ * the buffer when it returns (see mlm_set_async).  Unregister before freeing the buffer (waits for everything submitted). */
 int mlm_host_register(mlm_handle *h, const void *ptr, size_t bytes);
 int mlm_host_unregister(mlm_handle *h, const void *ptr);
 
 int mlm_sync(mlm_handle *h);
-/* async = 1: integrate calls return once the work is SUBMITTED (two batches may be in flight); errors of a batch and
- * mlm_get_frame_stats lag by one call; mlm_sync, queries and exports wait for everything.  Default 0: integrate calls
- * return when the map is updated. */
+/* async = 1: integrate calls return once the work is SUBMITTED (up to three batches may be in flight, one per slot set); errors of
+ * a batch and mlm_get_frame_stats lag by one call; mlm_sync, queries and exports wait for everything.  Default 0: integrate
+ * calls return when the map is updated.  Host buffers stay BORROWED FOR THE CALL in both modes: an asynchronous call returns
+ * only after its copies out of the caller's buffer have completed (also from a buffer pinned with mlm_host_register, whose
+ * copies are truly asynchronous) — the buffer may be refilled as soon as the call returns.  Device inputs of the *_dev entry
+ * points are read by the frames' kernels and must stay unmodified until mlm_sync (or until three further batches were submitted). */
 int mlm_set_async(mlm_handle *h, int on);
 int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out);
 

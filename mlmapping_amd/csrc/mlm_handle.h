@@ -219,8 +219,14 @@ struct mlm_handle {
                                  // depth_noise_coe 1e-6): k_chain_lanes has nothing to do and is not launched
     hipStream_t last_upload = nullptr; // the stream the current call's inputs were uploaded on (run_slots orders Stage A behind it)
     hipEvent_t upload_ev = nullptr;
+    hipEvent_t host_read_ev = nullptr; // asynchronous mode: recorded behind the copies that read a caller's host buffer (borrowed_mark / borrowed_wait)
+    bool host_read_marked = false;
     long long n_graph_launches = 0;
-    int32_t *h_stage = nullptr;  // pinned staging of the callback's sampled pixels (indices, then raw depths)
+    // Pinned staging of the callback's sampled pixels (indices, then raw depths).  k_bin_sectors reads it ACROSS THE LINK while the
+    // frame is in flight, so it may only be rewritten when nothing is in flight: mlm_integrate_callback drains before it samples
+    // (its first statement after the pose), and no other entry point touches the buffer.  Keep it that way — or give every slot
+    // set a staging buffer of its own — when adding shortcuts.
+    int32_t *h_stage = nullptr;
     size_t stage_cap = 0;
     long long n_pool_grows = 0;
     long long n_big_redos = 0;   // frames whose overflowed columns were redone with the large table at drain time (redo_overflow_columns)
@@ -350,4 +356,23 @@ static inline void clk_mark(mlm_handle *h, int i) {
     const double t = mlm_now_us();
     if (i >= 0) h->clk[i] += t - h->clk_t;
     h->clk_t = i == 5 ? 0.0 : t; // (5: the call's last mark)
+}
+
+// Host buffers are BORROWED for the duration of a call (include/mlmap_hip.h).  In synchronous mode a call drains before it returns;
+// in asynchronous mode it returns once the work is submitted — and a copy from a REGISTERED (pinned) host buffer is then still in
+// flight (from pageable memory the runtime has staged it already).  The entry points that read host buffers therefore record an
+// event right behind their copies (before the frame's kernels go onto that stream) and wait for it — for the upload only, not for
+// the compute — before they return.
+static inline int borrowed_mark(mlm_handle *h, hipStream_t up) {
+    if (!h->async_mode) return MLM_OK;
+    if (!h->host_read_ev) HIPCHK(h, hipEventCreateWithFlags(&h->host_read_ev, hipEventDisableTiming));
+    HIPCHK(h, hipEventRecord(h->host_read_ev, up));
+    h->host_read_marked = true;
+    return MLM_OK;
+}
+static inline int borrowed_wait(mlm_handle *h) {
+    if (!h->host_read_marked) return MLM_OK;
+    h->host_read_marked = false;
+    HIPCHK(h, hipEventSynchronize(h->host_read_ev));
+    return MLM_OK;
 }

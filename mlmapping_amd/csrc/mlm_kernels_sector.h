@@ -1242,7 +1242,9 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     __shared__ uint16_t s_pref[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
     __shared__ __attribute__((aligned(16))) uint8_t s_kinds[MLM_BLOCK / 64][1024 + 64]; // ordered kinds of cells with n <= 1024 (+ a spare byte per lane)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
+    // (a frame whose Stage A gave up — sector_overflow 2 — is redone from its Stage A on: a column that failed after its reservations has
+    // counted its cells in n_multi without writing their descriptors, so nothing of this frame may be ranked from mt_rec / mt_ref)
+    const unsigned int n_cells = mlm_gp(P.ctr)->sector_overflow == 2u ? 0u : mlm_gp(P.ctr)->n_multi;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     if (!P.explore) {
@@ -1622,7 +1624,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
         s_odds_t[j] = (k <= 2 * MLM_DIFF_RANGE && rho_s >= 0 && rho_s < P.nRho) ? mlm_contribution_odd(P, P.odds_table, rho, k) : 0.0f;
     }
     __syncthreads();
-    const unsigned int n_cells = mlm_gp(P.ctr)->n_multi;
+    const unsigned int n_cells = mlm_gp(P.ctr)->sector_overflow == 2u ? 0u : mlm_gp(P.ctr)->n_multi; // (see k_rank)
     if (n_cells == 0u) return; // (uniform)
     const int lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;

@@ -350,7 +350,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         const double cells_per_voxel = (std::ceil(P.d_sub / P.dRho) + 2) * (std::ceil(P.d_sub / P.dZ) + 2) * P.nPhi;
         h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
                          P.sec_tab <= 4u * (unsigned int)h->sec_threads && (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
-                         P.nZ < 32768 /* a column record holds z << 16 | rho below its top bit (MLM_SEC_OUTER) */ &&
+                         /* (nZ * nRho < 65536 also keeps z below 2^15: a column record holds z << 16 | rho below its top bit, MLM_SEC_OUTER) */
                          P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
                          P.nPhi <= 32 * MLM_TILE_WORDS /* k_tile: a tile's column mask */ &&
                          (P.explore ? P.nRho <= 256
@@ -598,6 +598,7 @@ int mlm_destroy(mlm_handle *h) {
     for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
     if (h->h_stage) hipHostFree(h->h_stage);
     if (h->upload_ev) hipEventDestroy(h->upload_ev);
+    if (h->host_read_ev) hipEventDestroy(h->host_read_ev);
     if (h->inputs_ready) hipEventDestroy(h->inputs_ready);
     if (h->fb_done) hipEventDestroy(h->fb_done);
     if (h->d_f32) hipFree(h->d_f32);
@@ -714,8 +715,11 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
             S.F.n = width * height;
             S.mode = 0;
         }
-        const int rc = run_slots(h, n);
+        int rc = borrowed_mark(h, h->stream_as[set]); // (asynchronous mode: the caller's frames are read by the copies above only)
         if (rc) return rc;
+        rc = run_slots(h, n);
+        const int rc2 = borrowed_wait(h);
+        if (rc || rc2) return rc ? rc : rc2;
     }
     return MLM_OK;
 }
@@ -769,8 +773,10 @@ int mlm_integrate_depth_u16(mlm_handle *h, const uint16_t *img, int width, int h
         if ((rc = ensure_pix(h, S))) return rc;
         HIPCHK(h, hipMemcpyAsync(S.d_pix, pixel_idx, (size_t)n_idx * sizeof(int32_t), hipMemcpyHostToDevice, up));
     }
-    return mlm_integrate_depth_u16_dev(h, S.d_img, width, height, row_stride, pixel_idx ? S.d_pix : nullptr, n_idx, q_wb,
-                                       t_wb);
+    if ((rc = borrowed_mark(h, up))) return rc;
+    rc = mlm_integrate_depth_u16_dev(h, S.d_img, width, height, row_stride, pixel_idx ? S.d_pix : nullptr, n_idx, q_wb, t_wb);
+    const int rc2 = borrowed_wait(h);
+    return rc ? rc : rc2;
 }
 
 int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int width, int height, double t_img,
@@ -804,8 +810,9 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         // project_depth, mlmap.cpp:311-349 (glibc rand(), v first, zeros skipped).  Only the sampled pixels are ever read
         // by the kernels, so only they travel: the host converts them (same float arithmetic as k_convert_f32_u16), a tiny
         // kernel drops them into the device image at their pixel positions.
-        // The indices and depths are staged in a pinned buffer of the handle (the call drains before it returns, so the buffer
-        // is free again at the next call) and travel in one copy; the kernels take the depths from that list.
+        // The indices and depths are staged in a pinned buffer of the handle that the kernels read across the link.  In asynchronous
+        // mode the frame is still in flight when this call returns: the buffer is free again because THIS call drained above before
+        // sampling (see mlm_handle::h_stage for the invariant).
         const size_t want = (size_t)h->cfg.sample_cnt;
         if (h->stage_cap < 2 * want) {
             if (h->h_stage) hipHostFree(h->h_stage);
@@ -875,6 +882,7 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
         hipStream_t up = sampled ? h->stream_as[h->cur_set] : upload_stream(h); // (the sampled general path synchronises that stream below)
         HIPCHK(h, hipMemcpyAsync(S.d_img, depth, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, up));
         h->last_upload = up;
+        if (!sampled && (rc = borrowed_mark(h, up))) return rc;
     }
     if (sampled) { // (sample count larger than half the point capacity: the general path)
         const uint16_t *img = is_f32 ? host_u16.data() : (const uint16_t *)depth;
@@ -895,6 +903,10 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
     }
     clk_mark(h, 0);
     rc = mlm_integrate_depth_u16_dev(h, S.d_img, width, height, width, sampled ? S.d_pix : nullptr, (int)pix.size(), qa, ta);
+    {
+        const int rc2 = borrowed_wait(h);
+        if (!rc) rc = rc2;
+    }
     clk_mark(h, 5);
     return rc;
 }
@@ -916,6 +928,8 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
         hipStream_t up = upload_stream(h);
         h->last_upload = up;
         HIPCHK(h, hipMemcpyAsync(S.d_pts, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, up));
+        const int rc = borrowed_mark(h, up);
+        if (rc) return rc;
     }
     S.F = MlmFrame{};
     frame_setup(h, q_wb, t_wb, S.F);
@@ -923,7 +937,8 @@ int mlm_integrate_points(mlm_handle *h, const double *xyz, int n, const double q
     S.F.n = n;
     S.F.width = 1;
     S.mode = 2;
-    return run_slots(h, 1);
+    const int rc = run_slots(h, 1), rc2 = borrowed_wait(h);
+    return rc ? rc : rc2;
 }
 
 int mlm_query_occupancy(mlm_handle *h, const double *pos, int n, int8_t *out) {
