@@ -264,6 +264,8 @@ def roofline_of(res, cfg, B, BPS, K, fps_one_gpu, pmc, pmc_file, pmc_batch, pmc_
             "avg_launch_us_isolated": iso_ms * 1e3 if iso_ms else None,
             "frac_isolated": (mean_bytes * frames_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms else None,
             "algorithmic_bytes_per_frame": mean_bytes,
+            "issue": issue_bound(fps_one_gpu, "" if cfg.width == 640 else "_cfg3"),
+            "by_rocprof_rule": rocprof_dominant(mean_bytes, frames_per_launch, "" if cfg.width == 640 else "_cfg3"),
             "atomics": {"bound": "device_atomics", "achieved": a_ach, "peak": ATOMICS_PEAK_PER_S, "unit": "atomics/s",
                         "frac": a_ach / ATOMICS_PEAK_PER_S, "atomics_per_frame": mean_atomics,
                         "counted_by": "the Stage A kernels themselves (chunk descriptors, list reservations, per-voxel counts)",
@@ -273,6 +275,56 @@ def roofline_of(res, cfg, B, BPS, K, fps_one_gpu, pmc, pmc_file, pmc_batch, pmc_
                                         for k, v in ktime_c.items()},
                                      **{k + " (alone on the GPU)": v[0] * 1e3 / max(1, 2 * B) for k, v in iso.items()}}}
     return roof, mean_bytes
+
+
+SIMDS = 256 * 4        # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+ENGINE_CLOCK_HZ = 2.4e9  # peak engine clock; a wave's vector instruction takes an issue slot of one quad-cycle
+
+
+def issue_bound(fps_one_gpu: float, tag: str = ""):
+    """The bound that actually limits this path: vector-instruction issue.  SQ_ACTIVE_INST_VALU counts, in quad-cycles
+    and summed over the waves, the issue slots the kernels' vector instructions take; a SIMD has ONE vector pipe however many wave
+    slots are filled.  frac = slots per frame (newest profiles/*_pmc_sq*.json, rocprofv3 --pmc passes over the batched submissions
+    timed here) / slots the chip's 1 024 SIMDs offer in the time this run takes per frame."""
+    f = newest_profile(f"pmc_sq{tag}.json")
+    if not f:
+        return None
+    try:
+        d = json.load(open(f))
+        ker = d.get("kernels", {})
+        valu_q = sum(k.get("SQ_ACTIVE_INST_VALU", 0.0) for k in ker.values())
+        valu_n = sum(k.get("SQ_INSTS_VALU", 0.0) for k in ker.values())
+        salu_n = sum(k.get("SQ_INSTS_SALU", 0.0) for k in ker.values())
+    except Exception:
+        return None
+    if not valu_q or not fps_one_gpu:
+        return None
+    avail = SIMDS * ENGINE_CLOCK_HZ / 4.0 / fps_one_gpu
+    return {"bound": "valu_issue", "achieved": valu_q, "peak": avail, "unit": "issue slots (quad-cycles) per frame", "frac": valu_q / avail,
+            "valu_wave_instructions_per_frame": valu_n, "salu_wave_instructions_per_frame": salu_n,
+            "peak_source": "1 024 SIMDs x 2.4 GHz / 4 x the measured time per frame", "counters_source": os.path.basename(f),
+            "per_kernel_slots": {k: v.get("SQ_ACTIVE_INST_VALU", 0.0) for k, v in ker.items()}}
+
+
+def rocprof_dominant(mean_bytes: float, frames_per_launch: float, tag: str = ""):
+    """The dominant kernel by the rule of the rocprof summary (largest TotalDurationNs of the newest profiles/*_kernel_stats*.csv,
+    `rocprofv3 --kernel-trace --stats` of this command) with the same algorithmic bytes per launch priced against its average
+    duration there — beside `roofline.kernel`, which the live event pairs of this run pick."""
+    import csv
+
+    f = newest_profile(f"kernel_stats{tag}.csv")
+    if not f:
+        return None
+    try:
+        rows = list(csv.DictReader(open(f)))
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        name = re.sub(r"^void ", "", top["Name"]).split("(")[0].split("<")[0]
+        avg_us = float(top["AverageNs"]) / 1e3
+        ach = mean_bytes * frames_per_launch / (avg_us * 1e-6) / 1e9
+        return {"kernel": name, "avg_launch_us": avg_us, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "share_of_gpu_time_pct": float(top["Percentage"]),
+                "source": os.path.basename(f)}
+    except Exception:
+        return None
 
 
 def newest_profile(pattern: str):
