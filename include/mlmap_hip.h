@@ -88,8 +88,10 @@ typedef struct mlm_limits {
                               * device cannot hold the larger pool (or with the test knob "pool_grow" = 0) */
     int32_t max_points;      /* largest point count of one frame; 0 = 1280*720 */
     int32_t max_batch;       /* frames integrated per launch sequence (batch entry points); 0 = 8, at most 64;
-                              * every frame in flight owns ~0.35 GB (S1) .. 2.2 GB (S3) of scratch, three sets of them
-                              * (one being filled, one in the map-independent stage, one draining) */
+                              * every frame in flight owns a slot of scratch — ~0.06 GB at 640x480 / 0.1 m, ~0.25 GB at 1280x720 /
+                              * 0.05 m for camera scenes: its lists start at what frames of max_points pixels need and are enlarged
+                              * when a frame needs more (worst case 0.29 GB / 1.97 GB) — three sets of them (one being filled, one
+                              * in the map-independent stage, one draining) */
     int32_t record_awareness;/* keep per-frame hit/miss lists readable via mlm_get_awareness_* (tests) */
 } mlm_limits;
 
@@ -126,6 +128,8 @@ typedef struct mlm_frame_stats {
     int64_t n_host_queries;     /* positions answered from the host mirror so far */
     int64_t n_mirror_refreshes; /* times the mirror was brought up to date (one kernel + one synchronisation each) */
     int64_t n_mirror_blocks;    /* blocks copied to the host by those refreshes */
+    int64_t device_bytes;       /* device memory the handle holds now (map + frame slots + tables) */
+    int64_t n_slot_grows;       /* times the frame slots' lists — sized by what frames need, not by the worst case — were enlarged */
 } mlm_frame_stats;
 
 /* replaces mlmap::init_map (src/mlmap.cpp:3-149), minus ROS plumbing */

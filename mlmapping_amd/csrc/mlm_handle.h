@@ -25,7 +25,7 @@ struct KernelTime {
 // simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
 const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
-                                  "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "node_lds", "pool_grow",
+                                  "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "need_slots", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
                                   "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
@@ -60,6 +60,9 @@ struct MlmSlot {
     bool sector = false;      // the frame it holds went through the sector path (Stage A and the frame-local voxel grid)
     bool keys_exact = false;  // hl_key of the frame it holds was written by order_hits_exact (a replay must not recompute it:
                               // the emulated container's policy state has moved on)
+    MlmDev Pfb{};              // the parameter block a CELL-TABLE Stage A / apply of this slot's frame runs with: the buffers that path shares
+                               // across the slots (lean slots) and, where the slot's own lists are sized by need, the handle's one
+                               // full-size set of them (eff_params)
     uint16_t *d_img = nullptr; // staging for host images
     size_t img_cap = 0;
     int32_t *d_pix = nullptr;
@@ -234,6 +237,24 @@ struct mlm_handle {
     MlmNode *fb_bnodes = nullptr, *fb_nodes = nullptr; // lean slots: the cell-table path's shared buffers
     MlmPair *fb_pairs = nullptr;
     MlmMirror mir;               // host mirror for small query batches (mlm_mirror.h)
+    // Frame slots sized by NEED (sector-path handles with lean slots, not frontier mode): the per-frame lists whose worst case is
+    // "every awareness cell is a multi-kind hit" start at what a camera frame of max_points pixels needs and are doubled at a
+    // drained point when a frame's Stage A runs out of room (grow_slots, like grow_pool for the block pool).  The cell-table path,
+    // which a frame falls back to one at a time, gets ONE full-size set of those lists per handle, allocated at its first use.
+    bool need_sized = false;
+    struct SlotCaps {
+        size_t hl = 0, mt = 0, vh = 0, rec = 0, refs = 0, sub = 0, sbkt = 0;
+    } caps_worst, caps_now;
+    long long n_slot_grows = 0;
+    std::vector<std::pair<void *, size_t>> regrow_trash; // lists replaced by resize_slots, freed once the copies into the new ones are through
+    struct CtFull { // the cell-table path's full-size lists (ensure_ct_full)
+        bool ready = false;
+        uint32_t *mt_list = nullptr, *contrib = nullptr, *hl_cell = nullptr, *hl_t = nullptr, *hl_base = nullptr, *hl_cnt = nullptr, *hl_vt = nullptr, *hl_bkt = nullptr;
+        uint4 *mt_rec = nullptr;
+        uint8_t *subs = nullptr;
+        float *hl_odd = nullptr, *hl_inc = nullptr;
+        uint64_t *hl_key = nullptr;
+    } ct_full;
 };
 
 namespace {
@@ -344,6 +365,11 @@ int grow_pool(mlm_handle *h, size_t want);
 int ensure_free_blocks(mlm_handle *h, size_t need);
 int widen_sec_tab(mlm_handle *h);
 int ensure_free_blocks_idle(mlm_handle *h, size_t need);
+int grow_slots(mlm_handle *h, const MlmCounters &demand);
+int grow_sbkt(mlm_handle *h, size_t buckets);
+int ensure_ct_full(mlm_handle *h);
+// the parameter block the kernels of slot S's frame run with on the path the frame is on (see MlmSlot::Pfb)
+inline const MlmDev &eff_params(const mlm_handle *h, const MlmSlot &S) { return (S.sector || !h->lean) ? S.P : S.Pfb; }
 void mirror_mark_all(mlm_handle *h);
 void mirror_mark_box(mlm_handle *h, const int lo[3], const int hi[3]);
 void mirror_mark_frames(mlm_handle *h, int n);

@@ -116,8 +116,10 @@ __device__ __forceinline__ void mlm_ref_unpack(uint32_t ref, bool dense, uint32_
     x = dense ? (pos & 255u) << 3 : (pos & 7u) << 3;
 }
 
-__device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F) {
-    g_atomic_max(&mlm_gp(P.ctr)->sector_overflow, 2u); // (2: the frame takes the cell-table path; 1: see the column kernel's full-table branch)
+__device__ __forceinline__ void mlm_sector_fail(const MlmDev &P, const MlmFrame &F, bool capacity = false) {
+    // (3: a list sized by need was too short — the slots are enlarged and the frame's Stage A runs again; 2: the frame takes the
+    // cell-table path; 1: see the column kernel's full-table branch)
+    g_atomic_max(&mlm_gp(P.ctr)->sector_overflow, capacity ? 3u : 2u);
     // (frontier mode does not speculate: its host reads the flag before it enqueues what depends on the map)
     if (!P.explore) g_atomic_min(&mlm_gp(P.g)->fail_frame, F.seq);
 }
@@ -896,13 +898,17 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
         s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
         // (a cell's segment start is kept in 16 bits, in units of MLM_SEC_REF_ALIGN references from the column's first)
-        if (s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap || tot_refs >= 65536u * MLM_SEC_REF_ALIGN) s_fail = 1;
+        if (tot_refs >= 65536u * MLM_SEC_REF_ALIGN) s_fail = 1;
+        // (the frame's lists are sized by need: a column that does not fit writes nothing — s_fail 2, the slots are enlarged and the
+        // frame's Stage A runs again)
+        if (s_base[0] + n_occ > P.hl_cap || s_base[1] + n_multi > P.mt_cap || s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap)
+            s_fail = 2;
     }
     __syncthreads(); // (the runs' offsets and the column's places in the frame's lists are visible)
     MLM_PHASE(2);
-    if (s_fail) { // a table of this column overflowed: the frame is redone by the cell-table path (uniform branch)
+    if (s_fail) { // a table of this column overflowed: the frame is redone (uniform branch)
         if (threadIdx.x == 0) {
-            mlm_sector_fail(P, F);
+            mlm_sector_fail(P, F, s_fail == 2u);
             mlm_gp(P.col_cnt)[phi] = 0;
         }
         return;
@@ -1244,14 +1250,15 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // (a frame whose Stage A gave up — sector_overflow 2 — is redone from its Stage A on: a column that failed after its reservations has
     // counted its cells in n_multi without writing their descriptors, so nothing of this frame may be ranked from mt_rec / mt_ref)
-    const unsigned int n_cells = mlm_gp(P.ctr)->sector_overflow == 2u ? 0u : mlm_gp(P.ctr)->n_multi;
+    const bool gave_up = mlm_gp(P.ctr)->sector_overflow >= 2u; // (also: the counters of such a frame may exceed its lists' capacities)
+    const unsigned int n_cells = gave_up ? 0u : mlm_gp(P.ctr)->n_multi;
     const unsigned int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int n_waves = (gridDim.x * blockDim.x) >> 6;
     if (!P.explore) {
         // Iteration-order keys of the frame's unique hits, valid if the frame fits the emulated container without a rehash
         // (k_apply_tiles checks): (first insertion time of the hit's bucket, its own insertion time) — the bucket-first
         // table of this slot is complete now that every column of the frame has been through k_sector
-        const unsigned int n_hit = mlm_gp(P.ctr)->u_hit;
+        const unsigned int n_hit = gave_up ? 0u : mlm_gp(P.ctr)->u_hit;
         for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hit; i += gridDim.x * blockDim.x) {
             const uint32_t b = mlm_gp(P.hl_bkt)[i];
             const unsigned long long first = b < P.sbkt_cap ? mlm_gp(P.sbkt)[b] & 0xFFFFFFFFull : 0ull;
@@ -1624,7 +1631,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
         s_odds_t[j] = (k <= 2 * MLM_DIFF_RANGE && rho_s >= 0 && rho_s < P.nRho) ? mlm_contribution_odd(P, P.odds_table, rho, k) : 0.0f;
     }
     __syncthreads();
-    const unsigned int n_cells = mlm_gp(P.ctr)->sector_overflow == 2u ? 0u : mlm_gp(P.ctr)->n_multi; // (see k_rank)
+    const unsigned int n_cells = mlm_gp(P.ctr)->sector_overflow >= 2u ? 0u : mlm_gp(P.ctr)->n_multi; // (see k_rank)
     if (n_cells == 0u) return; // (uniform)
     const int lane = threadIdx.x & 63;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -2001,11 +2008,11 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
         if (t4[0] > 0xFFFFu || t4[1] >= 0xFFFFu) s_fail = 1; // (the packed places hold 16 bits each)
         s_base[0] = t4[0] ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[0][0], t4[0]) : 0u;
         s_base[1] = t4[1] ? g_atomic_add(&mlm_gp(P.ctr)->mvox_cnt[1][0], t4[1]) : 0u;
-        if (s_base[0] + t4[0] > P.rec_cap || s_base[1] + t4[1] > (unsigned int)P.nCells) s_fail = 1;
+        if (s_base[0] + t4[0] > P.rec_cap || s_base[1] + t4[1] > P.vh_cap) s_fail = 2; // (lists sized by need: enlarged, then the frame's Stage A runs again)
     }
     __syncthreads();
-    if (s_fail) { // (uniform) the frame is redone on the cell-table path
-        if (threadIdx.x == 0) mlm_sector_fail(P, F);
+    if (s_fail) { // (uniform) the frame is redone
+        if (threadIdx.x == 0) mlm_sector_fail(P, F, s_fail == 2u);
         return;
     }
     MLM_TPHASE(4); // compaction scan, reservations

@@ -165,16 +165,30 @@ void free_pool(mlm_handle *h, const MlmDev &P) {
 // least `want` blocks, the blocks copied over, the table rebuilt on the device, every parameter block re-pointed.  Nothing
 // may be in flight (callers drain first).  MLM_ERR_CAPACITY only if the device cannot hold the larger pool.
 // the slots' parameter blocks as the kernels see them (device-resident tables), after the host copies changed
+// MlmSlot::Pfb from MlmSlot::P: the buffers the cell-table path shares across lean slots, and — slots sized by need — the handle's
+// full-size set of the lists that path fills (null until ensure_ct_full has run: no cell-table frame before that)
+void make_fb_params(mlm_handle *h, MlmSlot &S) {
+    S.Pfb = S.P;
+    if (!h->lean) return;
+    S.Pfb.bnodes = h->fb_bnodes;
+    S.Pfb.pairs = h->fb_pairs;
+    S.Pfb.nodes = h->fb_nodes;
+    if (h->need_sized && h->ct_full.ready) {
+        const auto &c = h->ct_full;
+        S.Pfb.mt_list = c.mt_list, S.Pfb.mt_rec = c.mt_rec, S.Pfb.contrib = c.contrib, S.Pfb.subs = c.subs;
+        S.Pfb.hl_cell = c.hl_cell, S.Pfb.hl_t = c.hl_t, S.Pfb.hl_odd = c.hl_odd, S.Pfb.hl_inc = c.hl_inc, S.Pfb.hl_base = c.hl_base;
+        S.Pfb.hl_cnt = c.hl_cnt, S.Pfb.hl_vt = c.hl_vt, S.Pfb.hl_key = c.hl_key, S.Pfb.hl_bkt = c.hl_bkt;
+        S.Pfb.hl_cap = S.Pfb.mt_cap = (unsigned int)h->caps_worst.hl;
+        S.Pfb.contrib_cap = (unsigned int)h->caps_worst.sub;
+    }
+}
 int upload_slot_tab(mlm_handle *h) {
     std::vector<MlmDev> tab(h->slots.size());
     for (size_t i = 0; i < h->slots.size(); ++i) tab[i] = h->slots[i].P;
     HIPCHK(h, hipMemcpy(h->d_slot_tab, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
+    for (auto &S : h->slots) make_fb_params(h, S);
     if (h->lean && h->d_slot_tab_fb) {
-        for (size_t i = 0; i < tab.size(); ++i) {
-            tab[i].bnodes = h->fb_bnodes;
-            tab[i].pairs = h->fb_pairs;
-            tab[i].nodes = h->fb_nodes;
-        }
+        for (size_t i = 0; i < tab.size(); ++i) tab[i] = h->slots[i].Pfb;
         HIPCHK(h, hipMemcpy(h->d_slot_tab_fb, tab.data(), tab.size() * sizeof(MlmDev), hipMemcpyHostToDevice));
     }
     return MLM_OK;
@@ -310,6 +324,7 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     MlmDev &P = S.P;
     int rc;
     const size_t NC = (size_t)P.nCells;
+    const mlm_handle::SlotCaps &caps = h->caps_now; // (== caps_worst unless the slots are sized by need)
     S.h_ctr = h->h_ctr_all + index;
     P.ctr = h->d_ctr_all + index;
     // Lean slots of a sector-path handle (not frontier mode, whose own map-dependent part reads them per frame): the per-frame
@@ -324,8 +339,11 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     } while (0)
     MLM_CT_ALLOC(cs, NC);
     MLM_CT_ALLOC(miss_bits, (size_t)MLM_MISS_COPIES * P.nMissWords);
-    if ((rc = dev_alloc(h, &P.mt_list, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.mt_rec, NC))) return rc;
+    P.hl_cap = (unsigned int)caps.hl;
+    P.mt_cap = (unsigned int)caps.mt;
+    P.vh_cap = (unsigned int)caps.vh;
+    if ((rc = dev_alloc(h, &P.mt_list, caps.mt))) return rc;
+    if ((rc = dev_alloc(h, &P.mt_rec, caps.mt))) return rc;
     MLM_CT_ALLOC(mt_big, NC);
     P.touch_cap = (unsigned int)NC;
     MLM_CT_ALLOC(touched, (size_t)MLM_RAY_LISTS * P.touch_cap);
@@ -356,9 +374,9 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
             h->err = "contribution buffer too large";
             return MLM_ERR_UNSUPPORTED;
         }
-        P.contrib_cap = (unsigned int)cap_pad;
-        if ((rc = dev_alloc(h, &P.contrib, cap_pad))) return rc;
-        if ((rc = dev_alloc(h, &P.subs, cap_pad))) return rc;
+        P.contrib_cap = (unsigned int)caps.sub; // (<= cap_pad, the worst case: mlm_create)
+        if ((rc = dev_alloc(h, &P.contrib, caps.sub))) return rc;
+        if ((rc = dev_alloc(h, &P.subs, caps.sub))) return rc;
         P.node_cap = (unsigned int)(cap / MLM_RAY_LISTS + 4096);
         if (!h->lean && (rc = dev_alloc(h, &P.nodes, (size_t)MLM_RAY_LISTS * P.node_cap))) return rc;
     }
@@ -369,40 +387,41 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     if (h->use_sectors && !P.explore) { // (frontier mode's own Stage B+C takes over after k_sector: no tiles)
         P.mc_list_cap = (unsigned int)NC; // unique miss cells of a frame
         if ((rc = dev_alloc(h, &P.mc_list, (size_t)P.mc_list_cap + 8))) return rc;
-        if ((rc = dev_alloc(h, &P.hl_vt16, NC + 8))) return rc;
+        if ((rc = dev_alloc(h, &P.hl_vt16, caps.hl + 8))) return rc;
         if ((rc = dev_alloc(h, &P.tile_cols, (size_t)P.n_tiles * P.tile_words))) return rc;
         HIPCHK(h, hipMemset(P.tile_cols, 0, (size_t)P.n_tiles * P.tile_words * sizeof(uint32_t)));
         if ((rc = dev_alloc(h, &P.tile_desc, 4 * (size_t)P.n_tiles * (size_t)P.nPhi))) return rc;
         // a frame touches at most one voxel per awareness cell, and no more voxels than its grid has
-        P.rec_cap = (unsigned int)std::min<size_t>(NC, (size_t)P.lv_nx * P.lv_ny * P.lv_nz);
+        P.rec_cap = (unsigned int)caps.rec;
         if ((rc = dev_alloc(h, &P.vr_rec, (size_t)P.rec_cap))) return rc;
-        if ((rc = dev_alloc(h, &P.vr_hit, NC))) return rc;
+        if ((rc = dev_alloc(h, &P.vr_hit, caps.vh))) return rc;
         if ((rc = dev_alloc(h, &P.tile_dir, 4 * (size_t)P.n_tiles))) return rc;
         HIPCHK(h, hipMemset(P.tile_dir, 0xFF, 4 * (size_t)P.n_tiles * sizeof(uint32_t))); // (no frame carries that sequence number)
         // bucket-first table of this slot: room for the emulated container of a frame with up to 2 * max_points unique
         // hit cells (more: the handle continues on the cell-table path)
-        P.sbkt_cap = (unsigned int)std::min<size_t>(h->max_buckets, std::__detail::_Prime_rehash_policy()._M_next_bkt(4 * (size_t)h->lim.max_points + 2));
+        P.sbkt_cap = (unsigned int)caps.sbkt;
         if ((rc = dev_alloc(h, &P.sbkt, (size_t)P.sbkt_cap))) return rc;
         HIPCHK(h, hipMemset(P.sbkt, 0xFF, (size_t)P.sbkt_cap * sizeof(unsigned long long)));
     }
     // (a reference — one row of a group's lane mask — stands for at least one contribution; a cell's references start at a multiple
     // of MLM_SEC_REF_ALIGN, and a cell that needs references has at least two contributions)
-    P.refs_cap = (unsigned int)std::min<size_t>(0xFFFFFFF0ull, max_contrib + (MLM_SEC_REF_ALIGN - 1) * std::min<size_t>(NC, max_contrib / 2) + 64);
+    (void)max_contrib;
+    P.refs_cap = (unsigned int)caps.refs;
     if ((rc = dev_alloc(h, &P.refs, h->use_sectors ? (size_t)P.refs_cap : 4))) return rc;
-    if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * NC : 2))) return rc;
+    if ((rc = dev_alloc(h, &P.mt_ref, h->use_sectors ? 2 * caps.mt : 2))) return rc;
     HIPCHK(h, hipMemset(P.col_cnt, 0, (size_t)P.nPhi * sizeof(unsigned int)));
-    if ((rc = dev_alloc(h, &P.hl_cell, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_t, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_odd, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_inc, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_base, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_cnt, NC))) return rc;
-    if ((rc = dev_alloc(h, &P.hl_vt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_cell, caps.hl))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_t, caps.hl))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_odd, caps.hl))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_inc, caps.hl))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_base, caps.hl))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_cnt, caps.hl))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_vt, caps.hl))) return rc;
     MLM_CT_ALLOC(hl_arr, NC);
-    if ((rc = dev_alloc(h, &P.hl_key, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_key, caps.hl))) return rc;
     MLM_CT_ALLOC(hl_next, NC);
     MLM_CT_ALLOC(hl_vox, NC);
-    if ((rc = dev_alloc(h, &P.hl_bkt, NC))) return rc;
+    if ((rc = dev_alloc(h, &P.hl_bkt, caps.hl))) return rc;
     MLM_CT_ALLOC(hl_bkey, NC);
     MLM_CT_ALLOC(hl_cid, NC);
     MLM_CT_ALLOC(hl_slot, NC);
@@ -438,6 +457,149 @@ int alloc_slot(mlm_handle *h, MlmSlot &S, size_t index, const std::vector<float>
     // (the staging of host images, pixel lists and point lists is allocated by the calls that use it: ensure_img / ensure_list)
     S.alloc_end = h->allocs.size();
     return MLM_OK;
+}
+
+// The worst-case and the initial capacities of a frame slot's lists (mlm_create, before the slots are allocated).
+// Worst case: every awareness cell a multi-kind hit.  By need: what camera frames of max_points pixels produce, with room —
+// config 2 (307 k pixels): 20 k hits, 8 k ranked cells, 260 k references, 730 k ordered kinds, 33 k voxel records per frame;
+// config 3 (922 k pixels): 137 k hits, all ranked, 4.1 M references, 7.7 M kinds, 350 k records.
+void slot_capacities(mlm_handle *h, const std::vector<float> &sigma3) {
+    const MlmDev &P = h->P;
+    const size_t NC = (size_t)P.nCells, Pn = (size_t)std::max(1, h->lim.max_points);
+    int dmax = 0;
+    for (int r = 0; r < P.nRho; ++r) {
+        int d = 1;
+        while ((float)d < sigma3[r] && r + d < P.nRho && d <= MLM_DIFF_RANGE) ++d;
+        dmax = std::max(dmax, d - 1);
+    }
+    const size_t max_contrib = Pn * (size_t)(1 + 2 * dmax);
+    auto &w = h->caps_worst;
+    w.hl = w.mt = w.vh = NC;
+    w.rec = std::min<size_t>(NC, (size_t)P.lv_nx * P.lv_ny * P.lv_nz);
+    w.refs = std::min<size_t>(0xFFFFFFF0ull, max_contrib + (MLM_SEC_REF_ALIGN - 1) * std::min<size_t>(NC, max_contrib / 2) + 64);
+    w.sub = std::min<size_t>(0xFFFFFFF0ull, max_contrib + 15 * std::min<size_t>(NC, max_contrib / 2) + 64); // (checked against 2^32 by alloc_slot's caller)
+    w.sbkt = std::min<size_t>(h->max_buckets, std::__detail::_Prime_rehash_policy()._M_next_bkt(4 * Pn + 2));
+    h->caps_now = w;
+    if (!h->need_sized) return;
+    auto &c = h->caps_now;
+    c.hl = std::min(w.hl, std::max<size_t>(32768, Pn / 4));
+    c.mt = c.hl;
+    c.vh = c.hl;
+    c.rec = std::min(w.rec, 2 * c.hl);
+    c.refs = std::min(w.refs, std::max<size_t>(262144, 6 * Pn));
+    c.sub = std::min(w.sub, std::max<size_t>(1u << 20, 10 * Pn));
+    c.sbkt = std::min(w.sbkt, std::__detail::_Prime_rehash_policy()._M_next_bkt(2 * c.hl + 2));
+}
+
+// One list of one slot re-allocated with room for `n_new` elements; `keep`: the slot holds a frame whose Stage A output is still
+// needed (it is pending behind the frame that ran out of room), so the old contents move over.
+template <class T> int regrow(mlm_handle *h, T **field, size_t n_old, size_t n_new, bool keep, int fill = -1) {
+    if (n_new <= n_old) return MLM_OK;
+    T *fresh = nullptr;
+    const int rc = dev_alloc(h, &fresh, n_new);
+    if (rc) return rc;
+    if (fill >= 0) HIPCHK(h, hipMemsetAsync(fresh, fill, n_new * sizeof(T), h->stream));
+    if (keep && *field) HIPCHK(h, hipMemcpyAsync(fresh, *field, n_old * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    h->regrow_trash.emplace_back((void *)*field, n_old * sizeof(T)); // (freed by resize_slots once the copies are through)
+    *field = fresh;
+    return MLM_OK;
+}
+// Apply h->caps_now to every slot (lists only ever grow).  Nothing may be in flight.
+int resize_slots(mlm_handle *h) {
+    const auto &c = h->caps_now;
+    std::vector<char> keep(h->slots.size(), 0);
+    for (const MlmSlot *R : h->pending) keep[(size_t)(R - h->slots.data())] = 1;
+    for (size_t i = 0; i < h->slots.size(); ++i) {
+        MlmDev &P = h->slots[i].P;
+        const bool k = keep[i] != 0;
+        int rc = MLM_OK;
+        const size_t hl0 = P.hl_cap, mt0 = P.mt_cap;
+#define MLM_RG(field, n0, n1, ...)                                                                                    \
+    if (rc == MLM_OK) rc = regrow(h, &P.field, (size_t)(n0), (size_t)(n1), k, ##__VA_ARGS__)
+        MLM_RG(hl_cell, hl0, c.hl);
+        MLM_RG(hl_t, hl0, c.hl);
+        MLM_RG(hl_odd, hl0, c.hl);
+        MLM_RG(hl_inc, hl0, c.hl);
+        MLM_RG(hl_base, hl0, c.hl);
+        MLM_RG(hl_cnt, hl0, c.hl);
+        MLM_RG(hl_vt, hl0, c.hl);
+        MLM_RG(hl_key, hl0, c.hl);
+        MLM_RG(hl_bkt, hl0, c.hl);
+        MLM_RG(hl_vt16, hl0 + 8, c.hl + 8);
+        MLM_RG(mt_list, mt0, c.mt);
+        MLM_RG(mt_rec, mt0, c.mt);
+        MLM_RG(mt_ref, 2 * mt0, 2 * c.mt);
+        MLM_RG(vr_hit, P.vh_cap, c.vh);
+        MLM_RG(vr_rec, P.rec_cap, c.rec);
+        MLM_RG(refs, P.refs_cap, c.refs);
+        MLM_RG(contrib, P.contrib_cap, c.sub);
+        MLM_RG(subs, P.contrib_cap, c.sub);
+        MLM_RG(sbkt, P.sbkt_cap, c.sbkt, 0xFF); // (no frame carries that sequence number; entries of pending frames move over)
+#undef MLM_RG
+        if (rc) {
+            (void)hipStreamSynchronize(h->stream);
+            for (auto &t : h->regrow_trash) dev_free(h, t.first, t.second);
+            h->regrow_trash.clear();
+            return rc;
+        }
+        P.hl_cap = (unsigned int)std::max<size_t>(hl0, c.hl);
+        P.mt_cap = (unsigned int)std::max<size_t>(mt0, c.mt);
+        P.vh_cap = (unsigned int)std::max<size_t>(P.vh_cap, c.vh);
+        P.rec_cap = (unsigned int)std::max<size_t>(P.rec_cap, c.rec);
+        P.refs_cap = (unsigned int)std::max<size_t>(P.refs_cap, c.refs);
+        P.contrib_cap = (unsigned int)std::max<size_t>(P.contrib_cap, c.sub);
+        P.sbkt_cap = (unsigned int)std::max<size_t>(P.sbkt_cap, c.sbkt);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto &t : h->regrow_trash) dev_free(h, t.first, t.second);
+    h->regrow_trash.clear();
+    h->n_slot_grows++;
+    if (getenv("MLM_DEBUG_CREATE"))
+        fprintf(stderr, "[slots] lists enlarged: %zu hits, %zu ranked cells, %zu references, %zu kinds, %zu voxel records, %zu buckets per frame; device memory %.2f GB\n",
+                c.hl, c.mt, c.refs, c.sub, c.rec, c.sbkt, h->alloc_bytes / 1e9);
+    return upload_slot_tab(h);
+}
+// A frame's Stage A ran out of room in a list sized by need (sector_overflow 3): `demand` are that frame's counters — what its
+// columns and tiles asked for.  Every list that was too short grows to at least twice its size and 5/4 of the demand.
+int grow_slots(mlm_handle *h, const MlmCounters &demand) {
+    auto &c = h->caps_now;
+    const auto &w = h->caps_worst;
+    auto want = [](size_t now, size_t need, size_t worst) { return need > now ? std::min(worst, std::max(2 * now, need + need / 4)) : now; };
+    const mlm_handle::SlotCaps before = c;
+    c.hl = want(c.hl, demand.u_hit, w.hl);
+    c.mt = want(c.mt, demand.n_multi, w.mt);
+    c.refs = want(c.refs, demand.n_refs, w.refs);
+    c.sub = want(c.sub, demand.n_contrib, w.sub);
+    c.rec = want(c.rec, demand.mvox_cnt[0][0], w.rec);
+    c.vh = want(c.vh, demand.mvox_cnt[1][0], w.vh);
+    if (c.hl == before.hl && c.mt == before.mt && c.refs == before.refs && c.sub == before.sub && c.rec == before.rec && c.vh == before.vh) {
+        // (the counters of a frame that gave up may be short of its real demand: a column returns at its first full list) — double them all
+        c.hl = std::min(w.hl, 2 * c.hl), c.mt = std::min(w.mt, 2 * c.mt), c.refs = std::min(w.refs, 2 * c.refs);
+        c.sub = std::min(w.sub, 2 * c.sub), c.rec = std::min(w.rec, 2 * c.rec), c.vh = std::min(w.vh, 2 * c.vh);
+    }
+    return resize_slots(h);
+}
+// the emulated hit container has more buckets than the slots' bucket-first tables hold (they are sized by need too)
+int grow_sbkt(mlm_handle *h, size_t buckets) {
+    auto &c = h->caps_now;
+    if (buckets <= c.sbkt) return MLM_OK;
+    c.sbkt = std::min(h->caps_worst.sbkt, std::max(2 * c.sbkt, buckets));
+    return resize_slots(h);
+}
+// The cell-table path's own full-size lists, once per handle, at the first frame that takes that path (slots sized by need)
+int ensure_ct_full(mlm_handle *h) {
+    if (!h->need_sized || h->ct_full.ready) return MLM_OK;
+    auto &c = h->ct_full;
+    const size_t NC = h->caps_worst.hl, SUB = h->caps_worst.sub;
+    int rc;
+    if ((rc = dev_alloc(h, &c.mt_list, NC)) || (rc = dev_alloc(h, &c.mt_rec, NC)) || (rc = dev_alloc(h, &c.contrib, SUB)) || (rc = dev_alloc(h, &c.subs, SUB)) ||
+        (rc = dev_alloc(h, &c.hl_cell, NC)) || (rc = dev_alloc(h, &c.hl_t, NC)) || (rc = dev_alloc(h, &c.hl_odd, NC)) || (rc = dev_alloc(h, &c.hl_inc, NC)) ||
+        (rc = dev_alloc(h, &c.hl_base, NC)) || (rc = dev_alloc(h, &c.hl_cnt, NC)) || (rc = dev_alloc(h, &c.hl_vt, NC)) || (rc = dev_alloc(h, &c.hl_key, NC)) ||
+        (rc = dev_alloc(h, &c.hl_bkt, NC)))
+        return rc;
+    c.ready = true;
+    if (getenv("MLM_DEBUG_CREATE")) fprintf(stderr, "[slots] full-size lists of the cell-table path allocated; device memory %.2f GB\n", h->alloc_bytes / 1e9);
+    return upload_slot_tab(h);
 }
 
 } // namespace

@@ -36,7 +36,7 @@ std::vector<std::pair<size_t, size_t>> plan_epochs(mlm_handle *h, size_t U) {
 
 // Stage B for one frame whose unique-hit count U is known on the host: exact, with rehash epochs.
 int order_hits_exact(mlm_handle *h, MlmSlot &S, unsigned int U, int frame_idx) {
-    const MlmDev &P = S.P;
+    const MlmDev &P = eff_params(h, S);
     const auto ep = plan_epochs(h, U);
     h->stats.n_rehash_epochs = (int64_t)ep.size();
     if (h->hit_n_bkt > h->max_buckets) {
@@ -100,6 +100,10 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n, bool on_main = false) {
             if (rc) return rc;
         }
         return MLM_OK;
+    }
+    {
+        const int rc = ensure_ct_full(h); // (slots sized by need: this path's own full-size lists, at its first use)
+        if (rc) return rc;
     }
     const MlmDev *slot_tab = h->lean ? h->d_slot_tab_fb : h->d_slot_tab;
     const MlmSlot &S0 = h->slots[(size_t)base];
@@ -271,7 +275,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n) {
 // Stage B+C of one frame on the main stream.  n_bkt != 0: speculative single-epoch ordering inside k_voxelize;
 // n_bkt == 0: hl_key was produced by order_hits_exact.
 void launch_stage_bc(mlm_handle *h, MlmSlot &S, unsigned long long n_bkt) {
-    const MlmDev &P = S.P;
+    const MlmDev &P = eff_params(h, S); // (a cell-table frame: see MlmSlot::Pfb)
     // exact keys: nothing to check; speculative relaunch: against the policy state the host holds NOW
     S.F.rehash_thr = n_bkt ? (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu) : 0xFFFFFFFFu;
     {
@@ -321,7 +325,7 @@ void fill_stats(mlm_handle *h, const MlmSlot &S) {
 
 int check_queues(mlm_handle *h, const MlmSlot &S) {
     const MlmCounters &c = *S.h_ctr;
-    const MlmDev &P = S.P;
+    const MlmDev &P = eff_params(h, S);
     bool over = c.n_contrib > P.contrib_cap;
     for (int k = 0; k < MLM_RAY_LISTS; ++k)
         over = over || c.touch_cnt[k][0] > P.touch_cap || c.node_cnt[k][0] > P.node_cap || c.mc_cnt[k][0] > P.mc_cap;

@@ -78,6 +78,12 @@ int submit_batch(mlm_handle *h, int base, int n) {
     }
     const int set = base / (h->lim.max_batch);
     int rc;
+    if (h->need_sized && h->hit_n_bkt > h->slots[(size_t)base].P.sbkt_cap && h->hit_n_bkt <= h->caps_worst.sbkt) {
+        // (the slots' bucket-first tables are sized by need as well: the emulated container has outgrown them — a dozen times in a stream's life)
+        rc = drain(h);
+        if (rc == MLM_OK) rc = grow_sbkt(h, h->hit_n_bkt);
+        if (rc) return rc;
+    }
     // (the sector path packs a tile's image column into 8 bits of a reference: images up to 2040 pixels wide; its bucket-first
     // tables hold sbkt_cap buckets)
     const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040 &&
@@ -139,8 +145,8 @@ int submit_batch(mlm_handle *h, int base, int n) {
         for (int j = 0; j <= n; ++j) {
             MlmSlot &Sa = h->slots[(size_t)(base + (j > 0 ? j - 1 : 0))];
             MlmSlot &Sv = h->slots[(size_t)(base + (j < n ? j : n - 1))];
-            tlaunch(h, "k_apply_voxelize", k_apply_voxelize, dim3(scg * (MLM_BLOCK / h->sc_block), 2 * (1 + MLM_RAY_LISTS)), dim3(h->sc_block), 0, h->stream, Sa.P,
-                    Sa.F.seq, j > 0 ? 1 : 0, Sv.P, Sv.F, h->hit_n_bkt, j < n ? 1 : 0);
+            tlaunch(h, "k_apply_voxelize", k_apply_voxelize, dim3(scg * (MLM_BLOCK / h->sc_block), 2 * (1 + MLM_RAY_LISTS)), dim3(h->sc_block), 0, h->stream, eff_params(h, Sa),
+                    Sa.F.seq, j > 0 ? 1 : 0, eff_params(h, Sv), Sv.F, h->hit_n_bkt, j < n ? 1 : 0);
             if (j < n) h->pending.push_back(&Sv);
         }
     }
@@ -256,6 +262,26 @@ int drain(mlm_handle *h, bool g_copied) {
                 if (R.sector && R.h_ctr->sector_overflow == 1u) { // columns wait for the large-table pass (it was not scheduled)
                     rc = redo_overflow_columns(h, R);
                     if (rc) return rc;
+                }
+                // a list of the frame's slot, sized by need, was too short: enlarge the slots (every pending frame's Stage A output moves
+                // over) and run this frame's Stage A again on the sector path — nothing of the attempt is left (k_tile consumed what the
+                // columns that did finish handed out).  Still short after a few rounds, or the lists at their worst case: the cell-table path.
+                for (int round = 0; R.sector && R.h_ctr->sector_overflow == 3u && h->need_sized && round < 6; ++round) {
+                    const int si = (int)(&R - h->slots.data());
+                    const int set = si / (h->lim.max_batch);
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    rc = grow_slots(h, *R.h_ctr);
+                    if (rc) return rc;
+                    rc = launch_stage_a_sector(h, si, 1);
+                    if (rc) return rc;
+                    HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
+                    HIPCHK(h, hipMemcpyAsync(R.h_ctr, R.P.ctr, sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+                    HIPCHK(h, hipStreamSynchronize(h->stream));
+                    HIPCHK(h, hipMemcpyAsync(&h->P.g->fail_frame, &h->h_g->fail_frame, sizeof(int), hipMemcpyHostToDevice, h->stream)); // (the rerun may have set it again)
+                    if (R.h_ctr->sector_overflow == 1u) { // (its crowded columns now wait for the large table: as above)
+                        rc = redo_overflow_columns(h, R);
+                        if (rc) return rc;
+                    }
                 }
                 if (R.h_ctr->sector_overflow || (!R.sector && share_ct(h))) {
                     if (R.sector) {

@@ -23,7 +23,8 @@ struct MlmCounters {
                               // once the host has grown the pool and k_alloc_retry has filled the records' slots
     unsigned int n_big;       // multi-kind cells with more than 1024 contributions
     unsigned int n_groups;    // contribution groups kept in the blocks' own slices of `bnodes` (folded by k_collect_hits)
-    unsigned int sector_overflow; // sector path: 2 = Stage A gave up, the frame is redone by the cell-table path; 1 = columns whose cell table
+    unsigned int sector_overflow; // sector path: 3 = a list sized by need was too short: the host enlarges the frame slots and runs the frame's
+                                  // Stage A again; 2 = Stage A gave up, the frame is redone by the cell-table path; 1 = columns whose cell table
                                   // overflowed wait on ov_list for a large-table pass that was not scheduled: the host runs it when it drains
     unsigned int n_refs;      // sector path: (record, kind) references of the multi-kind cells
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
@@ -245,6 +246,11 @@ struct MlmDev {
                                // column phi's run through the tile (a column's ray crosses a tile once)
     MlmVoxRec *vr_rec;         // [rec_cap] one record per voxel the frame touches (count: MlmCounters::mvox_cnt[0][0])
     unsigned int rec_cap;
+    // capacities of the frame's lists that are sized by NEED (mlm_handle::need_sized; otherwise the worst case, nCells): a Stage A
+    // that would overrun one of them gives the frame up with sector_overflow 3, the host enlarges the slots and runs it again
+    unsigned int hl_cap;       // unique hits: hl_* (and hl_vt16)
+    unsigned int mt_cap;       // cells whose contributions are ranked: mt_list, mt_rec, mt_ref
+    unsigned int vh_cap;       // entries of vr_hit
     MlmVoxHit *vr_hit;         // [nCells] the hits of voxels with two or more, a voxel's hits contiguous (count: mvox_cnt[1][0])
     uint32_t *tile_dir;        // [n_tiles][4] {first record of the tile in vr_rec, count, frame sequence number, -}: written by k_tile,
                                // valid for the frame whose sequence number it carries (never cleared)

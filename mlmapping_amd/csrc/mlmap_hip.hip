@@ -494,6 +494,10 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         HIPCHK(h, hipEventCreateWithFlags(&h->set_free[k], hipEventDisableTiming));
     }
     h->map_bytes = h->alloc_bytes;
+    // frame slots sized by need (see mlm_handle::need_sized; knob "need_slots" = 0: every list at its worst case, as up to round 4)
+    h->need_sized = h->lean && h->use_sectors && !P.explore;
+    if (knob("need_slots", kv)) h->need_sized = h->need_sized && (int)kv != 0;
+    slot_capacities(h, sigma3);
     {
         // the frame slots are most of the footprint (S1 ~1 GB, S3 ~3.8 GB each): three sets of max_batch if they fit the device
         // memory, else the same with lean slots (sector-path handles), else two sets (a few percent less throughput on config
@@ -512,6 +516,8 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
                 if (S.d_img) hipFree(S.d_img);
             h->slots.assign(NS, MlmSlot{});
             h->lean = true;
+            h->need_sized = !P.explore && !(knob("need_slots", kv) && (int)kv == 0);
+            slot_capacities(h, sigma3);
             h->err.clear();
             rc = MLM_OK;
             for (got = 0; got < NS; ++got)
@@ -551,15 +557,16 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
             if ((rc = dev_alloc(h, &h->fb_pairs, (size_t)P0.nb_cap * P0.agg_lds))) return rc;
             if ((rc = dev_alloc(h, &h->fb_nodes, (size_t)MLM_RAY_LISTS * P0.node_cap))) return rc;
             for (size_t i = 0; i < NS; ++i) {
-                tab[i].bnodes = h->fb_bnodes;
-                tab[i].pairs = h->fb_pairs;
-                tab[i].nodes = h->fb_nodes;
+                make_fb_params(h, h->slots[i]);
+                tab[i] = h->slots[i].Pfb;
             }
             if ((rc = dev_alloc(h, &h->d_slot_tab_fb, NS))) return rc;
             HIPCHK(h, hipMemcpy(h->d_slot_tab_fb, tab.data(), NS * sizeof(MlmDev), hipMemcpyHostToDevice));
             HIPCHK(h, hipEventCreateWithFlags(&h->fb_done, hipEventDisableTiming));
         }
     }
+    if (!h->lean)
+        for (auto &S : h->slots) S.Pfb = S.P;
     HIPCHK(h, hipDeviceSynchronize());
     if (getenv("MLM_DEBUG_CREATE"))
         fprintf(stderr, "[create] device memory: %.2f GB (%zu frame slots in %d sets of %d, %.3f GB each; the map and the shared tables %.2f GB)\n",
@@ -1274,6 +1281,8 @@ int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {
     out->n_host_queries = h->mir.n_host_queries;
     out->n_mirror_refreshes = h->mir.n_refresh;
     out->n_mirror_blocks = h->mir.n_copied;
+    out->device_bytes = (int64_t)h->alloc_bytes;
+    out->n_slot_grows = h->n_slot_grows;
     return MLM_OK;
 }
 
@@ -1289,7 +1298,7 @@ int mlm_get_awareness_hits(mlm_handle *h, int cap, uint32_t *cell_idx, float *od
         h->err = "mlm_limits.record_awareness was not set";
         return MLM_ERR_INVALID;
     }
-    const MlmDev &P = h->slots[(size_t)h->last_slot].P;
+    const MlmDev &P = eff_params(h, h->slots[(size_t)h->last_slot]);
     const size_t n = (size_t)h->stats.n_hit_cells;
     if (n_out) *n_out = (int)n;
     const size_t m = std::min<size_t>(n, (size_t)cap);

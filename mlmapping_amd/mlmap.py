@@ -60,7 +60,8 @@ class FrameStats(ctypes.Structure):
                 ("n_spec_replays", ctypes.c_int64), ("n_device_atomics", ctypes.c_int64), ("n_sector_fallbacks", ctypes.c_int64),
                 ("logit_bit_exact", ctypes.c_int64), ("n_pool_grows", ctypes.c_int64), ("block_capacity", ctypes.c_int64),
                 ("n_graph_launches", ctypes.c_int64), ("n_bin_exact_waves", ctypes.c_int64),
-                ("n_host_queries", ctypes.c_int64), ("n_mirror_refreshes", ctypes.c_int64), ("n_mirror_blocks", ctypes.c_int64)]
+                ("n_host_queries", ctypes.c_int64), ("n_mirror_refreshes", ctypes.c_int64), ("n_mirror_blocks", ctypes.c_int64),
+                ("device_bytes", ctypes.c_int64), ("n_slot_grows", ctypes.c_int64)]
 
     def as_dict(self) -> Dict[str, int]:
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
