@@ -7,8 +7,11 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "mlmap_hip.h"
@@ -19,6 +22,51 @@ struct Vec3d {
     double v[3];
     double operator[](int i) const { return v[i]; }
     double &operator[](int i) { return v[i]; }
+};
+
+// What visualisers read by iterating local_map->observed_group_map (src/rviz_vis.cpp:267-327, src/mlmap.cpp:226-276): a host
+// SNAPSHOT with the reference's member names (include/map_local.h:42-60,92,201-213), so that code written against
+// `local_map_cartesian *localmap` — `for (auto it = localmap->observed_group_map.begin(); ...)`, `it->second.inflate_occupancy`,
+// `it->second.frontier`, `localmap->subbox_id2xyz_glb(it->first, id)` — compiles against `mlmap::local_map_snapshot().get()`.
+struct Vec3I {
+    int v[3];
+    int operator[](int i) const { return v[i]; }
+    int &operator[](int i) { return v[i]; }
+    int size() const { return 3; }
+    bool operator==(const Vec3I &o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2]; }
+};
+struct PointF { // pcl::PointXYZ's payload
+    float x, y, z;
+};
+struct local_map_view {
+    struct VectorHasher { // include/map_local.h:42-52
+        int operator()(const Vec3I &V) const {
+            int hash = V.size();
+            hash ^= V[0] + 0x9e3779b9 + (hash << 6) + (hash >> 2);
+            hash ^= V[1] + 0x9e3779b9 + (hash << 6) + (hash >> 2);
+            hash ^= V[2] + 0x9e3779b9 + (hash << 6) + (hash >> 2);
+            return hash;
+        }
+    };
+    struct subbox { // include/map_local.h:53-60; a released block holds ONE element per vector (map_local.cpp:221-226)
+        std::vector<char> occupancy, inflate_occupancy;
+        std::vector<float> log_odds;
+        std::unordered_set<int> frontier;
+    };
+    std::unordered_map<Vec3I, subbox, VectorHasher> observed_group_map;
+    double map_dxyz_obv_sub = 0, map_dxyz_obv_glb = 0, map_dxyz_obv_sub_half = 0;
+    int subbox_nxyz = 0;
+    // include/map_local.h:201-213
+    PointF subbox_id2xyz_glb(const Vec3I &origin, int idx) const {
+        const Vec3d c = subbox_id2xyz_glb_vec(origin, idx);
+        return PointF{(float)c[0], (float)c[1], (float)c[2]};
+    }
+    Vec3d subbox_id2xyz_glb_vec(const Vec3I &origin, int idx) const {
+        const int n = subbox_nxyz, cz = idx / (n * n), cy = (idx - cz * n * n) / n, cx = idx - cz * n * n - cy * n;
+        return Vec3d{{origin[0] * map_dxyz_obv_glb + cx * map_dxyz_obv_sub + map_dxyz_obv_sub_half,
+                      origin[1] * map_dxyz_obv_glb + cy * map_dxyz_obv_sub + map_dxyz_obv_sub_half,
+                      origin[2] * map_dxyz_obv_glb + cz * map_dxyz_obv_sub + map_dxyz_obv_sub_half}};
+    }
 };
 
 class mlmap {
@@ -39,6 +87,7 @@ class mlmap {
     void init_map(const mlm_config &cfg, int device = 0, const mlm_limits *limits = nullptr) {
         if (h_) mlm_destroy(h_);
         h_ = nullptr;
+        cfg_ = cfg;
         const int rc = mlm_create(&cfg, limits, device, &h_);
         if (rc != MLM_OK) {
             std::string msg = h_ ? mlm_last_error(h_) : "";
@@ -133,6 +182,45 @@ class mlmap {
         check(mlm_inflate_map(h_, p), "mlm_inflate_map");
     }
 
+    // `local_map` for visualisers: a snapshot of observed_group_map (one D2H of the block planes; waits for everything submitted)
+    std::shared_ptr<local_map_view> local_map_snapshot() {
+        auto lm = std::make_shared<local_map_view>();
+        const int n = cfg_.subbox_n, C = n * n * n;
+        lm->subbox_nxyz = n;
+        lm->map_dxyz_obv_sub = cfg_.subbox_d_xyz;
+        lm->map_dxyz_obv_glb = cfg_.subbox_d_xyz * n; // map_local.cpp:60
+        lm->map_dxyz_obv_sub_half = cfg_.subbox_d_xyz * 0.5;
+        int nb = 0;
+        check(mlm_block_count(h_, &nb), "mlm_block_count");
+        std::vector<int32_t> keys((size_t)nb * 3);
+        std::vector<float> lo((size_t)nb * C);
+        std::vector<uint8_t> occ((size_t)nb * C), infl((size_t)nb * C), col((size_t)nb);
+        int m = 0;
+        if (nb) {
+            check(mlm_export_blocks(h_, nb, keys.data(), lo.data(), occ.data(), infl.data(), &m), "mlm_export_blocks");
+            check(mlm_export_block_flags(h_, nb, col.data(), &m), "mlm_export_block_flags");
+        }
+        lm->observed_group_map.reserve((size_t)nb);
+        for (int b = 0; b < nb; ++b) {
+            auto &sb = lm->observed_group_map[Vec3I{{keys[3 * (size_t)b], keys[3 * (size_t)b + 1], keys[3 * (size_t)b + 2]}}];
+            const size_t cnt = col[(size_t)b] ? 1 : (size_t)C, o = (size_t)b * C;
+            sb.occupancy.assign(occ.begin() + o, occ.begin() + o + cnt);
+            sb.inflate_occupancy.assign(infl.begin() + o, infl.begin() + o + cnt);
+            sb.log_odds.assign(lo.begin() + o, lo.begin() + o + cnt);
+        }
+        int nf = 0;
+        check(mlm_export_frontier(h_, 0, nullptr, &nf), "mlm_export_frontier");
+        if (nf) {
+            std::vector<int32_t> fr((size_t)nf * 4);
+            check(mlm_export_frontier(h_, nf, fr.data(), &nf), "mlm_export_frontier");
+            for (int i = 0; i < nf; ++i) {
+                auto it = lm->observed_group_map.find(Vec3I{{fr[4 * (size_t)i], fr[4 * (size_t)i + 1], fr[4 * (size_t)i + 2]}});
+                if (it != lm->observed_group_map.end()) it->second.frontier.insert(fr[4 * (size_t)i + 3]);
+            }
+        }
+        return lm;
+    }
+
     // planners that query thousands of positions per cycle should use the batched entry points directly
     mlm_handle *handle() { return h_; }
 
@@ -141,6 +229,7 @@ class mlmap {
         if (rc != MLM_OK) throw std::runtime_error(std::string(what) + ": " + (h_ ? mlm_last_error(h_) : "no handle"));
     }
     mlm_handle *h_ = nullptr;
+    mlm_config cfg_{};
     const uint16_t *img_ = nullptr;
     int width_ = 0, height_ = 0, stride_ = 0;
     double q_[4] = {1, 0, 0, 0}, t_[3] = {0, 0, 0};

@@ -58,6 +58,28 @@ int main(int argc, char **argv) {
         std::printf("at %a %a\n", (double)map.getOdd(Vec3I{{0, 0, 1}}, 7), (double)map.getOdd(Vec3I{{40, 40, 40}}, 0));
         map.setFree_map_in_bound(Vec3{{0.5, -0.5, 1.0}}, Vec3{{1.0, 0.5, 1.5}});
         std::printf("free %d %d\n", map.getOccupancy(Vec3{{0.75, 0.0, 1.25}}), (int)(map.getOccupancy(Vec3{{0.75, 0.0, 1.25}}) == mlmap_hip::mlmap::FREE));
+        // the visualisers' loops over local_map->observed_group_map, written as in src/rviz_vis.cpp:280-321, against the snapshot
+        {
+            const auto snap = map.local_map_snapshot();
+            const mlmap_hip::local_map_view *localmap = snap.get();
+            size_t n_o = 0, n_f = 0, n_infl = 0, n_front = 0;
+            double sx = 0, sy = 0, sz = 0, sl = 0;
+            for (auto iter = localmap->observed_group_map.begin(); iter != localmap->observed_group_map.end(); iter++) {
+                int subbox_id = 0;
+                for (auto it = iter->second.inflate_occupancy.begin(); it != iter->second.inflate_occupancy.end(); it++) {
+                    if (*it == 'o') {
+                        const mlmap_hip::PointF p = localmap->subbox_id2xyz_glb(iter->first, subbox_id);
+                        sx += p.x, sy += p.y, sz += p.z;
+                        ++n_infl;
+                    }
+                    subbox_id++;
+                }
+                for (auto it = iter->second.frontier.begin(); it != iter->second.frontier.end(); it++) ++n_front;
+                for (char c : iter->second.occupancy) n_o += c == 'o', n_f += c == 'f';
+                for (float l : iter->second.log_odds) sl += l;
+            }
+            std::printf("snapshot %zu %zu %zu %zu %zu %a %a %a %a\n", localmap->observed_group_map.size(), n_o, n_f, n_infl, n_front, sx, sy, sz, sl);
+        }
     } catch (const std::exception &e) {
         std::fprintf(stderr, "facade_client: %s\n", e.what());
         return 1;

@@ -71,6 +71,15 @@ def test_cpp_facade_client_process(mods, tmp_path):
     cpu.setFree_map_in_bound([0.5, -0.5, 1.0], [1.0, 0.5, 1.5])
     o_free = int(cpu.getOccupancy(np.array([[0.75, 0.0, 1.25]]))[0])
     assert out[n_pos + 1].split()[1:] == [str(o_free), str(int(o_free == 1))]
+    # local_map_snapshot(): the visualisers' loops over observed_group_map (rviz_vis.cpp:280-321) give the oracle's sums
+    snap = out[n_pos + 2].split()
+    assert snap[0] == "snapshot"
+    b = cpu.export_blocks()
+    gm = cpu.global_map_points().astype(np.float64)
+    assert [int(x) for x in snap[1:6]] == [b["keys"].shape[0], int((b["occ"] == ord("o")).sum()), int((b["occ"] == ord("f")).sum()), gm.shape[0],
+                                           cpu.export_frontier().shape[0]]
+    assert np.allclose([float.fromhex(x) for x in snap[6:9]], gm.sum(0), rtol=1e-9, atol=1e-6)
+    assert abs(float.fromhex(snap[9]) - float(b["log_odds"].astype(np.float64).sum())) <= 1e-6 * max(1.0, abs(float(b["log_odds"].astype(np.float64).sum())))
     # and the same answers through the ctypes path
     gpu = MLMap(cfg, max_blocks=8192)
     for img, (q, t) in syn.stream(cfg, "room_jitter", "smooth", n_frames):
