@@ -403,6 +403,49 @@ def single_frame_latency(MLMap, cfg, frames, q, t, d_frames, n_calls=120, cpu=Tr
         o.close()
         out["cpu_baseline_sampled500"] = {"value": float(np.median(ts) * 1e6), "unit": "us per call (median)", "cores": 1, "kind": "port",
                                           "sample": f"{len(ts)} sampled-500 callbacks of the same stream on 1 thread; oracle/libmlmap_oracle.so"}
+    # ... and the reference's shipped real-data configuration VERBATIM (launch/config/config2.yaml: 0.2 m map, frontier mode +
+    # inflation, 424x240 32FC1 depth stream, 500 rand() samples per callback, inflate_map every 3rd frame like the 10 Hz timer)
+    from mlmapping_amd import synthetic as syn
+    from mlmapping_amd.config import CONFIG2_YAML as C2
+
+    m = MLMap(C2, max_blocks=16384, max_points=C2.width * C2.height, max_batch=2)
+    depth = [(syn.jitter_depth(syn.room_depth(C2), k).astype(np.float32) / 1000.0) for k in range(8)]
+    traj = syn.smooth_trajectory(8 + n_calls, 7)
+
+    def cb(h, k):
+        qq, tt = traj[k]
+        T = h.depth_odom_callback(depth[k % 8], 0.0, tt, qq, zero3, 0.0, zero3, 0.0, C2.camera2odom_latency, sampled=True)
+        if k % 3 == 2:
+            h.inflate_map(T[4:])
+
+    gc.collect()
+    gc.disable()
+    for k in range(8):
+        cb(m, k)
+    ts = []
+    for k in range(8, 8 + n_calls):
+        a = time.perf_counter()
+        cb(m, k)
+        ts.append(time.perf_counter() - a)
+    gc.enable()
+    m.close()
+    row = {"value": float(np.median(ts) * 1e6), "unit": "us per callback (median; every 3rd also runs inflate_map)",
+           "workload": "config2.yaml verbatim: frontier mode + inflation, 424x240 32FC1, 500 samples"}
+    if cpu:
+        from oracle.binding import OracleMap
+
+        o = OracleMap(C2)
+        for k in range(8):
+            cb(o, k)
+        tc = []
+        for k in range(8, 8 + min(n_calls, 60)):
+            a = time.perf_counter()
+            cb(o, k)
+            tc.append(time.perf_counter() - a)
+        o.close()
+        row["cpu_baseline"] = {"value": float(np.median(tc) * 1e6), "unit": "us per callback (median)", "cores": 1, "kind": "port",
+                               "sample": f"{len(tc)} callbacks of the same stream on 1 thread; oracle/libmlmap_oracle.so"}
+    out["callback_config2_yaml"] = row
     return out
 
 

@@ -73,6 +73,7 @@ struct MlmSlot {
 // slot, a host table block key -> slot, and the record of what changed on the device since the last refresh.
 struct MlmMirror {
     bool enabled = true;           // knob "mirror" = 0: every query runs as a kernel
+    bool alloc_failed = false;     // the pinned planes could not be allocated: disabled for good, queries run as kernels
     int max_clean = 256;           // largest batch answered on the host while the mirror is up to date (knob "mirror_max") ...
     int max_dirty = 32;            // ... and while it needs a refresh first (a large batch is then cheaper as one kernel)
     size_t cap = 0;                // blocks the planes hold

@@ -126,6 +126,8 @@ int mirror_reserve(mlm_handle *h, size_t blocks) {
         (void)hipGetLastError();
         mirror_free(h);
         h->err = std::string("host mirror: ") + hipGetErrorString(e);
+        M.alloc_failed = true; // (the queries fall back to the kernel path for good: run_query)
+        M.enabled = false;
         return MLM_ERR_HIP;
     }
     M.cap = cap;

@@ -48,10 +48,13 @@ int run_query(mlm_handle *h, int mode, const double *pos, int n, float inflate, 
     MLM_LOCK(h);
     if (mirror_wanted(h, mode, n, max_iter)) { // a planner's position-by-position calls: answered on the host (mlm_mirror.h)
         const int rc = mirror_sync(h);
-        if (rc) return rc;
-        mirror_answer(h, mode, pos, n, inflate, max_iter, out);
-        h->mir.n_host_queries += n;
-        return MLM_OK;
+        if (rc == MLM_OK) {
+            mirror_answer(h, mode, pos, n, inflate, max_iter, out);
+            h->mir.n_host_queries += n;
+            return MLM_OK;
+        }
+        if (!h->mir.alloc_failed) return rc; // (an error of the frames in flight, reported by the drain)
+        // (no pinned host memory for the mirror: this and all later queries run as kernels)
     }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);

@@ -1238,10 +1238,12 @@ int mlm_query_odds_at(mlm_handle *h, const int32_t *glb_id, const int32_t *subbo
     MLM_LOCK(h);
     if (mirror_wanted(h, 3, n, 0)) { // (mlm_mirror.h)
         const int rc = mirror_sync(h);
-        if (rc) return rc;
-        for (int i = 0; i < n; ++i) out[i] = mir_odd_at(h, glb_id[3 * (size_t)i], glb_id[3 * (size_t)i + 1], glb_id[3 * (size_t)i + 2], subbox_id[i]);
-        h->mir.n_host_queries += n;
-        return MLM_OK;
+        if (rc == MLM_OK) {
+            for (int i = 0; i < n; ++i) out[i] = mir_odd_at(h, glb_id[3 * (size_t)i], glb_id[3 * (size_t)i + 1], glb_id[3 * (size_t)i + 2], subbox_id[i]);
+            h->mir.n_host_queries += n;
+            return MLM_OK;
+        }
+        if (!h->mir.alloc_failed) return rc;
     }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);
