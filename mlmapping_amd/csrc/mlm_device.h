@@ -307,7 +307,7 @@ __device__ __forceinline__ int mlm_block_find_k(const MlmDev &P, unsigned long l
 __device__ __forceinline__ int mlm_block_find(const MlmDev &P, int gx, int gy, int gz) {
     // (a block index beyond the key's 21 bits per axis — a query a million blocks from the origin — names no block of the map: absent,
     // like observed_group_map.find; it must not alias a block inside the range)
-    if ((unsigned int)(gx + (1 << 20)) >> 21 || (unsigned int)(gy + (1 << 20)) >> 21 || (unsigned int)(gz + (1 << 20)) >> 21) return -1;
+    if (((unsigned int)gx + (1u << 20)) >> 21 || ((unsigned int)gy + (1u << 20)) >> 21 || ((unsigned int)gz + (1u << 20)) >> 21) return -1;
     return mlm_block_find_k(P, mlm_pack_key(gx, gy, gz));
 }
 // allocate_ram (map_local.h:215-231): find or create.  One loop whose divergent arms reconverge every

@@ -82,9 +82,7 @@ struct MlmMirror {
     uint8_t *col = nullptr;        // [cap] released ("collapsed") blocks: element 0 answers
     int *keys = nullptr;           // [cap * 3]
     unsigned int *stat = nullptr;  // pinned: [0] block count seen by the refresh kernel, [2 + i] blocks copied by its workgroup i
-    std::vector<unsigned long long> tk; // open-addressed host table: packed key (MLM_HT_EMPTY: free) ...
-    std::vector<int> ts;                // ... -> slot
-    uint32_t tmask = 0;
+    mlm_host::MapView view;        // the planes above + the host table block key -> slot, with the reference's query inlines on top (mlm_mapview.h)
     unsigned int n_known = 0;      // blocks [0, n_known) are in the table and have valid planes
     bool dirty = true;             // the device map changed (or may have) since the last refresh
     bool all = true;               // ... anywhere; else inside the boxes

@@ -16,22 +16,6 @@
 #pragma once
 namespace {
 
-inline uint32_t mir_mix(unsigned long long k) { // (the device's mlm_mix)
-    k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdull;
-    k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ull;
-    k ^= k >> 33;
-    return (uint32_t)k;
-}
-inline bool mir_key_ok(int gx, int gy, int gz) {
-    return !(((unsigned int)(gx + (1 << 20)) >> 21) || ((unsigned int)(gy + (1 << 20)) >> 21) || ((unsigned int)(gz + (1 << 20)) >> 21));
-}
-inline unsigned long long mir_pack(int gx, int gy, int gz) {
-    return ((unsigned long long)((uint32_t)(gx + (1 << 20)) & 0x1FFFFFu) << 42) | ((unsigned long long)((uint32_t)(gy + (1 << 20)) & 0x1FFFFFu) << 21) |
-           (unsigned long long)((uint32_t)(gz + (1 << 20)) & 0x1FFFFFu);
-}
-
 void mirror_mark_all(mlm_handle *h) {
     h->mir.dirty = true;
     h->mir.all = true;
@@ -102,9 +86,9 @@ void mirror_free(mlm_handle *h) {
     M.keys = nullptr;
     M.cap = 0;
     M.n_known = 0;
-    M.tk.clear();
-    M.ts.clear();
-    M.tmask = 0;
+    M.view.table_clear();
+    M.view.lo = nullptr;
+    M.view.occ = M.view.infl = M.view.col = nullptr;
     mirror_mark_all(h);
 }
 constexpr unsigned int kMirrorGrid = 1024;
@@ -131,11 +115,10 @@ int mirror_reserve(mlm_handle *h, size_t blocks) {
         return MLM_ERR_HIP;
     }
     M.cap = cap;
-    size_t ht = 1024;
-    while (ht < cap * 4) ht <<= 1;
-    M.tk.assign(ht, MLM_HT_EMPTY);
-    M.ts.assign(ht, -1);
-    M.tmask = (uint32_t)(ht - 1);
+    M.view.table_reset(cap);
+    M.view.d_sub = h->P.d_sub, M.view.d_glb = h->P.d_glb, M.view.d_sub_half = h->P.d_sub_half;
+    M.view.n = h->P.n, M.view.cells = h->P.cells;
+    M.view.lo = M.lo, M.view.occ = M.occ, M.view.infl = M.infl, M.view.col = M.col;
     return MLM_OK;
 }
 // Bring the mirror up to date.  The caller holds the lock and has drained the handle.
@@ -164,13 +147,8 @@ int mirror_refresh(mlm_handle *h) {
             continue;
         }
         for (unsigned int i = 0; i < kMirrorGrid; ++i) M.n_copied += M.stat[2 + i];
-        for (unsigned int b = M.n_known; b < nb; ++b) { // the new blocks' keys
-            const unsigned long long key = mir_pack(M.keys[3 * (size_t)b], M.keys[3 * (size_t)b + 1], M.keys[3 * (size_t)b + 2]);
-            uint32_t p = mir_mix(key) & M.tmask;
-            while (M.tk[p] != MLM_HT_EMPTY) p = (p + 1) & M.tmask;
-            M.tk[p] = key;
-            M.ts[p] = (int)b;
-        }
+        for (unsigned int b = M.n_known; b < nb; ++b) // the new blocks' keys
+            M.view.table_insert(M.keys[3 * (size_t)b], M.keys[3 * (size_t)b + 1], M.keys[3 * (size_t)b + 2], (int)b);
         M.n_known = nb;
         M.dirty = false;
         M.all = false;
@@ -182,141 +160,12 @@ int mirror_refresh(mlm_handle *h) {
     return MLM_ERR_HIP;
 }
 
-// ---- the reference's query arithmetic on the host ------------------------------------------------------------------------
-inline int mir_cvt_int(double v) { // x86 cvttsd2si (mlm_cvt_int)
-    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int)0x80000000;
-    return (int)v;
-}
-inline int mir_mul(int a, int b) { return (int)((unsigned int)a * (unsigned int)b); } // (wraps like the hardware; INT_MIN * n is UB in C++)
-// get_global_idx / get_subbox_id, map_local.h:148-152,167-173 — two independent divisions per axis; a cell coordinate outside
-// [0, n) maps to id 0 (operator[] default-inserts in the reference)
-inline void mir_voxel_of(const MlmDev &P, double x, double y, double z, int g[3], int &cid) {
-    g[0] = mir_cvt_int(std::floor(x / P.d_glb));
-    g[1] = mir_cvt_int(std::floor(y / P.d_glb));
-    g[2] = mir_cvt_int(std::floor(z / P.d_glb));
-    const int cx = mir_cvt_int(std::floor(x / P.d_sub) - mir_mul(g[0], P.n));
-    const int cy = mir_cvt_int(std::floor(y / P.d_sub) - mir_mul(g[1], P.n));
-    const int cz = mir_cvt_int(std::floor(z / P.d_sub) - mir_mul(g[2], P.n));
-    if (cx < 0 || cy < 0 || cz < 0 || cx >= P.n || cy >= P.n || cz >= P.n) cid = 0;
-    else cid = cz * P.n * P.n + cy * P.n + cx;
-}
-inline int mir_find(const MlmMirror &M, int gx, int gy, int gz) {
-    if (!mir_key_ok(gx, gy, gz) || !M.tmask) return -1;
-    const unsigned long long key = mir_pack(gx, gy, gz);
-    for (uint32_t p = mir_mix(key) & M.tmask;; p = (p + 1) & M.tmask) {
-        const unsigned long long k = M.tk[p];
-        if (k == key) return M.ts[p];
-        if (k == MLM_HT_EMPTY) return -1;
-    }
-}
-// getOccupancy, mlmap.h:170-193
-inline int mir_occupancy(const mlm_handle *h, double x, double y, double z) {
-    const MlmMirror &M = h->mir;
-    int g[3], cid;
-    mir_voxel_of(h->P, x, y, z, g, cid);
-    const int slot = mir_find(M, g[0], g[1], g[2]);
-    if (slot < 0) return MLM_UNKNOWN;
-    if (M.col[slot]) cid = 0; // occupancy.size() == 1 -> occupancy[0], mlmap.h:183-184
-    const uint8_t r = M.occ[(size_t)slot * h->P.cells + cid];
-    return r == 'o' ? MLM_OCCUPIED : (r == 'f' ? MLM_FREE : MLM_UNKNOWN);
-}
-// logit_inv, mlmap.h:40: pow(10, x) / (1 + pow(10, x)) in double, narrowed by getOdd's float return
-inline float mir_logit_inv(float L) {
-    const double p = std::pow(10.0, (double)L);
-    return (float)(p / (1 + p));
-}
-// getOdd(glb_id, subbox_id), mlmap.h:227-235
-inline float mir_odd_at(const mlm_handle *h, int gx, int gy, int gz, int cid) {
-    const MlmMirror &M = h->mir;
-    const int slot = mir_find(M, gx, gy, gz);
-    if (slot < 0) return 0.5f;
-    if (M.col[slot]) cid = 0; // log_odds.size() == 1 -> log_odds[0], mlmap.h:221-222
-    return mir_logit_inv(M.lo[(size_t)slot * h->P.cells + cid]);
-}
-// one step along direction dir of subbox_neighbors (map_local.cpp:77-120): order +z,-z,+y,-y,+x,-x
-inline void mir_neighbor(const MlmDev &P, int dir, int g[3], int &cid) {
-    int c[3];
-    c[2] = cid / (P.n * P.n);
-    c[1] = (cid - c[2] * P.n * P.n) / P.n;
-    c[0] = cid - c[2] * P.n * P.n - c[1] * P.n;
-    const int axis = 2 - dir / 2, step = (dir & 1) ? -1 : 1;
-    c[axis] += step;
-    if (c[axis] >= P.n) {
-        g[axis] += 1;
-        c[axis] = 0;
-    } else if (c[axis] < 0) {
-        g[axis] -= 1;
-        c[axis] = P.n - 1;
-    }
-    cid = c[2] * P.n * P.n + c[1] * P.n + c[0];
-}
-// mode 0: getOccupancy  1: getOccupancy(pos, inflate)  2: getInflateOccupancy  3: getOdd  4: getOddGrad (k_query's modes)
+// (the query arithmetic itself — get_global_idx, getOccupancy, getOdd, getOddGrad on the mirrored planes — is pure host code:
+// mlm_mapview.h, tested on the CPU against the oracle)
 void mirror_answer(const mlm_handle *h, int mode, const double *pos, int n, float inflate, int max_iter, void *out) {
-    const MlmDev &P = h->P;
-    const MlmMirror &M = h->mir;
-    for (int i = 0; i < n; ++i) {
-        const double x = pos[3 * (size_t)i], y = pos[3 * (size_t)i + 1], z = pos[3 * (size_t)i + 2];
-        if (mode == 0) {
-            ((int8_t *)out)[i] = (int8_t)mir_occupancy(h, x, y, z);
-        } else if (mode == 1) {
-            // the 19-point stencil in the reference's order, mlmap.h:142-169; Vec3(+-inflate) promotes the float to double
-            const double f = inflate;
-            static const int8_t o[19][3] = {{0, 0, 0},  {0, 0, 1},   {0, 0, -1}, {0, 1, 0},   {0, -1, 0}, {1, 0, 0},  {-1, 0, 0},
-                                            {-1, 1, 0}, {-1, -1, 0}, {1, 1, 0},  {1, -1, 0},  {0, -1, 1}, {0, -1, -1}, {0, 1, 1},
-                                            {0, 1, -1}, {-1, 0, 1},  {-1, 0, -1}, {1, 0, 1},  {1, 0, -1}};
-            int res = MLM_FREE;
-            for (int k = 0; k < 19 && res == MLM_FREE; ++k)
-                if (mir_occupancy(h, x + (o[k][0] ? (o[k][0] > 0 ? f : -f) : 0.0), y + (o[k][1] ? (o[k][1] > 0 ? f : -f) : 0.0),
-                                  z + (o[k][2] ? (o[k][2] > 0 ? f : -f) : 0.0)) == MLM_OCCUPIED)
-                    res = MLM_OCCUPIED;
-            ((int8_t *)out)[i] = (int8_t)res;
-        } else if (mode == 2) { // getInflateOccupancy, mlmap.h:195-211
-            int g[3], cid;
-            mir_voxel_of(P, x, y, z, g, cid);
-            const int slot = mir_find(M, g[0], g[1], g[2]);
-            int res = MLM_UNKNOWN;
-            if (slot >= 0 && !M.col[slot] && M.infl[(size_t)slot * P.cells + cid] == 'o') res = MLM_OCCUPIED;
-            ((int8_t *)out)[i] = (int8_t)res;
-        } else if (mode == 3) {
-            int g[3], cid;
-            mir_voxel_of(P, x, y, z, g, cid);
-            ((float *)out)[i] = mir_odd_at(h, g[0], g[1], g[2], cid);
-        } else { // getOddGrad, mlmap.h:237-295
-            int g[3], cid;
-            mir_voxel_of(P, x, y, z, g, cid);
-            float min_odd = mir_odd_at(h, g[0], g[1], g[2], cid);
-            const float ori_odd = min_odd;
-            int ng[6][3], ncid[6], mg[3] = {0, 0, 0}, mcid = 0;
-            bool flag = false;
-            for (int iter = 0; iter < max_iter && !flag; ++iter)
-                for (int d = 0; d < 6; ++d) {
-                    if (iter == 0) {
-                        ng[d][0] = g[0], ng[d][1] = g[1], ng[d][2] = g[2];
-                        ncid[d] = cid;
-                    }
-                    mir_neighbor(P, d, ng[d], ncid[d]); // (keeps searching along the original direction, mlmap.h:267-268)
-                    const float tmp = mir_odd_at(h, ng[d][0], ng[d][1], ng[d][2], ncid[d]);
-                    if (tmp < min_odd) {
-                        min_odd = tmp;
-                        mg[0] = ng[d][0], mg[1] = ng[d][1], mg[2] = ng[d][2];
-                        mcid = ncid[d];
-                        flag = true;
-                    }
-                }
-            double r[3] = {0.0, 0.0, 0.0};
-            if (flag) { // subbox_id2xyz_glb_vec, map_local.h:208-213
-                const int cz = mcid / (P.n * P.n), cy = (mcid - cz * P.n * P.n) / P.n, cx = mcid - cz * P.n * P.n - cy * P.n;
-                const double s = (double)(ori_odd - min_odd);
-                r[0] = ((mg[0] * P.d_glb + cx * P.d_sub + P.d_sub_half) - x) * s;
-                r[1] = ((mg[1] * P.d_glb + cy * P.d_sub + P.d_sub_half) - y) * s;
-                r[2] = ((mg[2] * P.d_glb + cz * P.d_sub + P.d_sub_half) - z) * s;
-            }
-            ((double *)out)[3 * (size_t)i] = r[0];
-            ((double *)out)[3 * (size_t)i + 1] = r[1];
-            ((double *)out)[3 * (size_t)i + 2] = r[2];
-        }
-    }
+    h->mir.view.answer(mode, pos, n, inflate, max_iter, out);
 }
+inline float mir_odd_at(const mlm_handle *h, int gx, int gy, int gz, int cid) { return h->mir.view.odd_at(gx, gy, gz, cid); }
 
 // Is this batch answered on the host?  Small batches are a planner sampling positions one by one; a large batch after the map
 // changed is cheaper as one kernel than a refresh plus a host loop.

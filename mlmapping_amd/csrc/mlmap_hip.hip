@@ -29,6 +29,7 @@
 #include "mlm_kernels_explore.h"
 #include "mlm_kernels_sector.h"
 #include "mlm_host.h"
+#include "mlm_mapview.h"
 
 #include "mlm_handle.h"
 #include "mlm_stage_a.h"
