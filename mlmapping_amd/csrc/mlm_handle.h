@@ -84,10 +84,8 @@ struct MlmMirror {
     unsigned int *stat = nullptr;  // pinned: [0] block count seen by the refresh kernel, [2 + i] blocks copied by its workgroup i
     mlm_host::MapView view;        // the planes above + the host table block key -> slot, with the reference's query inlines on top (mlm_mapview.h)
     unsigned int n_known = 0;      // blocks [0, n_known) are in the table and have valid planes
-    bool dirty = true;             // the device map changed (or may have) since the last refresh
-    bool all = true;               // ... anywhere; else inside the boxes
-    int n_box = 0;
-    int box_lo[16][3], box_hi[16][3];
+    bool dirty = true;             // the device map changed (or may have) since the last refresh ...
+    mlm_host::DirtyBoxes boxes;    // ... anywhere, or inside these boxes of block indices (mlm_mapview.h)
     long long n_refresh = 0, n_copied = 0, n_host_queries = 0;
 };
 

@@ -195,4 +195,62 @@ struct MapView {
     }
 };
 
+// Where the device map may differ from the mirror: up to kMax boxes of block indices (inclusive bounds) or "anywhere".  The rule the
+// refresh relies on: a block inside ANY box ever marked since the last clear() is covered() — boxes are only merged into larger ones.
+struct DirtyBoxes {
+    static constexpr int kMax = 16;
+    bool all = true;
+    int n = 0;
+    int lo[kMax][3], hi[kMax][3];
+    void mark_all() {
+        all = true;
+        n = 0;
+    }
+    void clear() {
+        all = false;
+        n = 0;
+    }
+    void mark(const int blo[3], const int bhi[3]) {
+        if (all) return;
+        for (int k = 0; k < n; ++k) { // already covered?
+            bool in = true;
+            for (int a = 0; a < 3; ++a) in = in && blo[a] >= lo[k][a] && bhi[a] <= hi[k][a];
+            if (in) return;
+        }
+        if (n == kMax) { // the list is full: one box around everything recorded so far
+            for (int k = 1; k < n; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    lo[0][a] = lo[k][a] < lo[0][a] ? lo[k][a] : lo[0][a];
+                    hi[0][a] = hi[k][a] > hi[0][a] ? hi[k][a] : hi[0][a];
+                }
+            n = 1;
+        }
+        for (int a = 0; a < 3; ++a) {
+            lo[n][a] = blo[a];
+            hi[n][a] = bhi[a];
+        }
+        n++;
+    }
+    // a box of world coordinates with one block of margin each side; anything not finite or beyond the key range: "anywhere"
+    void mark_world(const double wlo[3], const double whi[3], double d_glb) {
+        int blo[3], bhi[3];
+        for (int a = 0; a < 3; ++a) {
+            const double l = std::floor(wlo[a] / d_glb) - 1.0, u = std::floor(whi[a] / d_glb) + 1.0;
+            if (!(l > -1048000.0 && u < 1048000.0 && l <= u)) { // (NaN fails)
+                mark_all();
+                return;
+            }
+            blo[a] = (int)l;
+            bhi[a] = (int)u;
+        }
+        mark(blo, bhi);
+    }
+    bool covered(int gx, int gy, int gz) const { // (what k_mirror_refresh evaluates per block)
+        if (all) return true;
+        for (int k = 0; k < n; ++k)
+            if (gx >= lo[k][0] && gx <= hi[k][0] && gy >= lo[k][1] && gy <= hi[k][1] && gz >= lo[k][2] && gz <= hi[k][2]) return true;
+        return false;
+    }
+};
+
 } // namespace mlm_host

@@ -18,45 +18,16 @@ namespace {
 
 void mirror_mark_all(mlm_handle *h) {
     h->mir.dirty = true;
-    h->mir.all = true;
-    h->mir.n_box = 0;
+    h->mir.boxes.mark_all();
 }
 void mirror_mark_box(mlm_handle *h, const int lo[3], const int hi[3]) {
-    MlmMirror &M = h->mir;
-    M.dirty = true;
-    if (M.all) return;
-    for (int k = 0; k < M.n_box; ++k) { // already covered?
-        bool in = true;
-        for (int a = 0; a < 3; ++a) in = in && lo[a] >= M.box_lo[k][a] && hi[a] <= M.box_hi[k][a];
-        if (in) return;
-    }
-    if (M.n_box == MLM_MIRROR_BOXES) { // the list is full: one box around everything recorded so far
-        for (int k = 1; k < M.n_box; ++k)
-            for (int a = 0; a < 3; ++a) {
-                M.box_lo[0][a] = std::min(M.box_lo[0][a], M.box_lo[k][a]);
-                M.box_hi[0][a] = std::max(M.box_hi[0][a], M.box_hi[k][a]);
-            }
-        M.n_box = 1;
-    }
-    for (int a = 0; a < 3; ++a) {
-        M.box_lo[M.n_box][a] = lo[a];
-        M.box_hi[M.n_box][a] = hi[a];
-    }
-    M.n_box++;
+    h->mir.dirty = true;
+    h->mir.boxes.mark(lo, hi);
 }
 // a box of world coordinates (+ one block of margin each side); anything not finite or beyond the key range: "anywhere"
 void mirror_mark_world(mlm_handle *h, const double wlo[3], const double whi[3]) {
-    int lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) {
-        const double l = std::floor(wlo[a] / h->P.d_glb) - 1.0, u = std::floor(whi[a] / h->P.d_glb) + 1.0;
-        if (!(l > -1048000.0 && u < 1048000.0 && l <= u)) { // (NaN fails)
-            mirror_mark_all(h);
-            return;
-        }
-        lo[a] = (int)l;
-        hi[a] = (int)u;
-    }
-    mirror_mark_box(h, lo, hi);
+    h->mir.dirty = true;
+    h->mir.boxes.mark_world(wlo, whi, h->P.d_glb);
 }
 // The frames described in the current slot set are about to be integrated: every hit and miss cell of a frame is an awareness cell,
 // whose world position is its centre + t_wa (map_local.cpp:151,180) — inside the cylinder of radius nRho * dRho around t_wa between
@@ -65,7 +36,7 @@ void mirror_mark_world(mlm_handle *h, const double wlo[3], const double whi[3]) 
 void mirror_mark_frames(mlm_handle *h, int n) {
     const MlmDev &P = h->P;
     const double R = P.nRho * P.dRho + P.d_sub;
-    for (int j = 0; j < n && !h->mir.all; ++j) {
+    for (int j = 0; j < n && !h->mir.boxes.all; ++j) {
         const MlmFrame &F = h->slots[(size_t)(h->cur_set * h->lim.max_batch + j)].F;
         const double wlo[3] = {F.t_wa[0] - R, F.t_wa[1] - R, F.t_wa[2] + P.z_border_min - P.d_sub};
         const double whi[3] = {F.t_wa[0] + R, F.t_wa[1] + R, F.t_wa[2] + P.z_border_min + P.nZ * P.dZ + P.d_sub};
@@ -130,12 +101,12 @@ int mirror_refresh(mlm_handle *h) {
         int rc = mirror_reserve(h, M.cap >= guess ? M.cap : 2 * guess);
         if (rc) return rc;
         MlmMirrorBoxes B{};
-        B.all = M.all ? 1 : 0;
-        B.n = M.all ? 0 : M.n_box;
+        B.all = M.boxes.all ? 1 : 0;
+        B.n = M.boxes.all ? 0 : M.boxes.n;
         for (int k = 0; k < B.n; ++k)
             for (int a = 0; a < 3; ++a) {
-                B.lo[k][a] = M.box_lo[k][a];
-                B.hi[k][a] = M.box_hi[k][a];
+                B.lo[k][a] = M.boxes.lo[k][a];
+                B.hi[k][a] = M.boxes.hi[k][a];
             }
         hipLaunchKernelGGL(k_mirror_refresh, dim3(kMirrorGrid), dim3(MLM_BLOCK), 0, h->stream, h->P, M.n_known, B, M.lo, M.occ, M.infl, M.col, M.keys,
                            (unsigned int)M.cap, M.stat);
@@ -151,8 +122,7 @@ int mirror_refresh(mlm_handle *h) {
             M.view.table_insert(M.keys[3 * (size_t)b], M.keys[3 * (size_t)b + 1], M.keys[3 * (size_t)b + 2], (int)b);
         M.n_known = nb;
         M.dirty = false;
-        M.all = false;
-        M.n_box = 0;
+        M.boxes.clear();
         M.n_refresh++;
         return MLM_OK;
     }

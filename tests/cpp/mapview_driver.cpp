@@ -3,6 +3,7 @@
 // -fsanitize=address,undefined (no HIP, no GPU).  Input blob: d_sub, n, n_blocks, n_pos, max_iter, inflate; keys [n_blocks*3] i32;
 // collapsed [n_blocks] u8; log_odds [n_blocks*cells] f32; occ, infl [n_blocks*cells] u8; positions [n_pos*3] f64; glb ids
 // [n_pos*3] i32 + cell ids [n_pos] i32.  Output: per position "occ occ_inflate inflate_occ odd grad[3] odd_at" as hex floats.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -43,6 +44,40 @@ int main(int argc, char **argv) {
         v.answer(0, q, 1, 0.f, 0, &o);
         v.answer(3, q, 1, 0.f, 0, &p);
         if (o != mlm_host::MapView::UNKNOWN || p != 0.5f) return 3;
+    }
+    // DirtyBoxes: whatever is marked stays covered (boxes only merge into larger ones), "anywhere" for non-finite / far boxes
+    {
+        uint64_t st = 88172645463325252ull;
+        auto rnd = [&]() { st ^= st << 13, st ^= st >> 7, st ^= st << 17; return st; };
+        for (int trial = 0; trial < 200; ++trial) {
+            mlm_host::DirtyBoxes B;
+            B.clear();
+            std::vector<int> pts;
+            const int marks = 1 + (int)(rnd() % 60);
+            for (int m = 0; m < marks; ++m) {
+                int lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = (int)(rnd() % 200) - 100;
+                    hi[a] = lo[a] + (int)(rnd() % 12);
+                }
+                B.mark(lo, hi);
+                for (int k = 0; k < 4; ++k)
+                    for (int a = 0; a < 3; ++a) pts.push_back(lo[a] + (int)(rnd() % (uint64_t)(hi[a] - lo[a] + 1)));
+                for (size_t i = 0; i + 2 < pts.size(); i += 3)
+                    if (!B.covered(pts[i], pts[i + 1], pts[i + 2])) return 4;
+            }
+            if (B.n > mlm_host::DirtyBoxes::kMax || B.all) return 4;
+        }
+        mlm_host::DirtyBoxes B;
+        B.clear();
+        const double a0[3] = {0.0, 0.0, 0.0}, a1[3] = {1.0, 2.0, 3.0}, bad[3] = {0.0, std::nan(""), 0.0}, far[3] = {3e9, 0.0, 0.0};
+        B.mark_world(a0, a1, 1.0);
+        if (B.all || !B.covered(-1, 3, 4) || B.covered(-2, 0, 0)) return 4; // one block of margin each side
+        B.mark_world(a0, bad, 1.0);
+        if (!B.all) return 4;
+        B.clear();
+        B.mark_world(a0, far, 1.0);
+        if (!B.all) return 4;
     }
     v.table_reset((size_t)nb);
     for (int b = 0; b < nb; ++b) v.table_insert(keys[3 * (size_t)b], keys[3 * (size_t)b + 1], keys[3 * (size_t)b + 2], b);
