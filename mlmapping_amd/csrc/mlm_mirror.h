@@ -95,6 +95,9 @@ int mirror_reserve(mlm_handle *h, size_t blocks) {
 // Bring the mirror up to date.  The caller holds the lock and has drained the handle.
 int mirror_refresh(mlm_handle *h) {
     MlmMirror &M = h->mir;
+    // (the geometry first: an empty map has no planes yet, but getOddGrad walks neighbours of absent blocks all the same)
+    M.view.d_sub = h->P.d_sub, M.view.d_glb = h->P.d_glb, M.view.d_sub_half = h->P.d_sub_half;
+    M.view.n = h->P.n, M.view.cells = h->P.cells;
     // (after a drain the host copy of the map-wide state usually knows the block count already; the kernel reports the exact one)
     size_t guess = std::min<size_t>(h->h_g ? h->h_g->n_blocks : 0u, (size_t)h->P.max_blocks);
     for (int attempt = 0; attempt < 3; ++attempt) {

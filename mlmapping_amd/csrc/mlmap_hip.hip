@@ -725,6 +725,10 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
         }
         int rc = borrowed_mark(h, h->stream_as[set]); // (asynchronous mode: the caller's frames are read by the copies above only)
         if (rc) return rc;
+        // (the frames went up on the slot set's Stage A stream; a chunk of ONE frame in synchronous mode is submitted as the
+        // single-frame graph on the MAIN stream: run_slots orders it behind the upload — without this the graph raced the copy,
+        // found by tests/test_gpu_random_ops.py)
+        h->last_upload = h->stream_as[set];
         rc = run_slots(h, n);
         const int rc2 = borrowed_wait(h);
         if (rc || rc2) return rc ? rc : rc2;

@@ -319,3 +319,22 @@ def test_registered_host_buffer_may_be_refilled_after_an_async_call(mods):
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "registered buffers refilled after every asynchronous call")
     gpu.host_unregister(ring)
     gpu.host_unregister(one)
+
+
+def test_sync_host_batch_with_a_one_frame_remainder(mods):
+    """mlm_integrate_depth_batch in synchronous mode with n_frames = k * max_batch + 1: the last chunk is ONE frame and goes
+    through the single-frame graph on the main stream while its image went up on the slot set's Stage A stream — the graph has to
+    wait for the copy (round 5: it did not; tests/test_gpu_random_ops.py found the race)."""
+    MLMap, OracleMap = mods
+    cfg = SDEF.with_(depth_noise_coe=0.00375, lm_occupied_sh=2.0)
+    gpu, cpu = MLMap(cfg, max_blocks=8192, max_batch=4), OracleMap(cfg)
+    frames = list(syn.stream(cfg, "room_jitter", "smooth", 45))
+    k = 0
+    for n in (5, 9, 1, 5, 13, 5, 2, 5):
+        fr = frames[k:k + n]
+        k += n
+        gpu.update_map_batch(np.stack([f[0] for f in fr]), np.stack([f[1][0] for f in fr]), np.stack([f[1][1] for f in fr]))
+        for img, (q, t) in fr:
+            cpu.update_depth(img, q, t)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"after a synchronous batch of {n}")
+    assert gpu.frame_stats()["n_graph_launches"] >= 6

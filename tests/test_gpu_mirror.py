@@ -225,3 +225,21 @@ def test_single_position_queries_from_a_second_thread(mods):
     assert len({a.tobytes() for a in answers}) >= 3, "the planner should have seen the map at several frame boundaries"
     assert np.array_equal(_one_by_one(gpu.getOccupancy, pos), cpu.getOccupancy(pos))
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "after concurrent single-position queries")
+
+
+def test_queries_on_an_empty_map(mods):
+    """before the first frame: every query kind, one position per call and in bulk, answers like the reference's empty
+    observed_group_map (UNKNOWN, 0.5, zero gradient) — found by tests/test_gpu_random_ops.py: the host mirror of an empty map"""
+    MLMap, OracleMap = mods
+    for cfg in (S1, S1.with_(use_exploration_frontiers=True)):
+        gpu, cpu = MLMap(cfg, max_blocks=256), OracleMap(cfg)
+        pos = np.random.default_rng(0).uniform(-5, 5, size=(300, 3))
+        _check_all_kinds(gpu, cpu, pos, "empty map")
+        assert np.array_equal(gpu.getOccupancy(np.tile(pos, (20, 1))), cpu.getOccupancy(np.tile(pos, (20, 1))))
+        assert not gpu.getOddGrad(np.tile(pos, (20, 1))).any()
+        assert gpu.getOddAt(np.array([[0, 0, 0]], dtype=np.int32), np.array([3], dtype=np.int32))[0] == 0.5
+        gpu.setFree_map_in_bound([0, 0, 0], [1, 1, 1])
+        gpu.inflate_map([0.0, 0.0, 1.0])
+        cpu.inflate_map([0.0, 0.0, 1.0])
+        _check_all_kinds(gpu, cpu, pos[:50], "empty map after setFree + inflate")
+        gpu.close()

@@ -1,0 +1,115 @@
+"""Random sequences of every map-changing and map-reading entry point on one handle — dense / sampled / point-list frames, asynchronous
+batches, setFree_map_in_bound, inflate_map, single-position and bulk queries of every kind, sync, mode switches — mirrored on the
+oracle; answers are compared where they are asked and the maps at the end.  What this guards: the bookkeeping BETWEEN the calls (the
+host mirror's dirty boxes, drains, frontier mode's deferred tail, slot sets, growth of pool and slots)."""
+import numpy as np
+import pytest
+
+from mlmapping_amd import synthetic as syn
+from mlmapping_amd.config import SDEF
+from tests.util import ODDS_TOL, compare_maps, voxel_centres
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from mlmapping_amd.mlmap import MLMap
+    from oracle.binding import OracleMap
+
+    return MLMap, OracleMap
+
+
+@pytest.mark.parametrize("explore", [False, True])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_operation_sequences(mods, explore, seed):
+    MLMap, OracleMap = mods
+    cfg = SDEF.with_(depth_noise_coe=0.00375, lm_occupied_sh=2.0, use_exploration_frontiers=explore)
+    gpu, cpu = MLMap(cfg, max_blocks=256, max_points=cfg.width * cfg.height, max_batch=4), OracleMap(cfg)
+    rng = np.random.default_rng(100 * seed + int(explore))
+    base = syn.room_depth(cfg)
+    traj = syn.smooth_trajectory(400, seed)
+    k = 0  # frames integrated so far
+    is_async = False
+    log = []
+
+    def frame():
+        nonlocal k
+        img = syn.jitter_depth(base, k, seed=seed)
+        q, t = traj[k]
+        t = t + np.array([0.02 * k, -0.015 * k, 0.0])  # (the camera wanders: new blocks keep appearing)
+        k += 1
+        return img, q, t
+
+    def positions(n):
+        b = cpu.export_blocks()
+        if b["keys"].shape[0] == 0:
+            return rng.uniform(-3, 6, size=(n, 3))
+        lo, hi = b["keys"].min(0) * cfg.subbox_d_xyz * cfg.subbox_n - 1.0, (b["keys"].max(0) + 1) * cfg.subbox_d_xyz * cfg.subbox_n + 1.0
+        return np.concatenate([rng.uniform(lo, hi, size=(n // 2, 3)), voxel_centres(b, cfg, n - n // 2, seed=int(rng.integers(1 << 30)))])
+
+    for step in range(70):
+        op = rng.choice(["dense", "sampled", "points", "batch", "setfree", "inflate", "q1", "qbulk", "sync", "mode"],
+                        p=[0.16, 0.12, 0.06, 0.14, 0.06, 0.08, 0.2, 0.08, 0.05, 0.05])
+        log.append(op)
+        if op == "dense":
+            img, q, t = frame()
+            gpu.update_map(img, q, t)
+            cpu.update_depth(img, q, t)
+        elif op == "sampled":
+            img, q, t = frame()
+            pix = (rng.integers(0, cfg.height, 500) * cfg.width + rng.integers(0, cfg.width, 500)).astype(np.int32)
+            gpu.update_map(img, q, t, pixel_idx=pix)
+            cpu.update_depth_indexed(img, pix, q, t)
+        elif op == "points":
+            _, q, t = frame()
+            pts = rng.uniform([-2, -1.5, 0.3], [2, 1.5, 5.0], size=(int(rng.integers(0, 400)), 3))
+            gpu.update_map_points(pts, q, t)
+            cpu.update_points(pts, q, t)
+        elif op == "batch":
+            fr = [frame() for _ in range(int(rng.integers(2, 9)))]
+            gpu.update_map_batch(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
+            for img, q, t in fr:
+                cpu.update_depth(img, q, t)
+        elif op == "setfree":
+            c = positions(2)[0]
+            lo_, hi_ = c - rng.uniform(0.1, 0.8, 3), c + rng.uniform(0.1, 0.8, 3)
+            gpu.setFree_map_in_bound(lo_, hi_)
+            cpu.setFree_map_in_bound(lo_, hi_)
+        elif op == "inflate":
+            c = traj[max(k - 1, 0)][1]
+            gpu.inflate_map(c)
+            cpu.inflate_map(c)
+        elif op == "q1":  # a planner sampling positions one by one, every query kind
+            pos = positions(12)
+            for i in range(pos.shape[0]):
+                p = pos[i:i + 1]
+                kind = int(rng.integers(0, 5))
+                if kind == 0:
+                    assert gpu.getOccupancy(p)[0] == cpu.getOccupancy(p)[0], (step, log)
+                elif kind == 1:
+                    assert gpu.getOccupancy(p, inflate=0.25)[0] == cpu.getOccupancy(p, inflate=0.25)[0], (step, log)
+                elif kind == 2:
+                    assert gpu.getInflateOccupancy(p)[0] == cpu.getInflateOccupancy(p)[0], (step, log)
+                elif kind == 3:
+                    assert gpu.getOdd(p).view(np.uint32)[0] == cpu.getOdd(p).view(np.uint32)[0], (step, log)
+                else:
+                    assert np.array_equal(gpu.getOddGrad(p, 4), cpu.getOddGrad(p, 4)), (step, log)
+        elif op == "qbulk":
+            pos = positions(3000)
+            assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos)), (step, log)
+            assert np.array_equal(gpu.getInflateOccupancy(pos), cpu.getInflateOccupancy(pos)), (step, log)
+            assert np.abs(gpu.getOdd(pos) - cpu.getOdd(pos)).max() <= ODDS_TOL, (step, log)
+        elif op == "sync":
+            gpu.sync()
+        elif op == "mode":
+            is_async = not is_async
+            gpu.set_async(is_async)
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"after {log}")
+    if explore:
+        gf, cf = gpu.export_frontier(), cpu.export_frontier()
+        assert gf.shape == cf.shape and np.array_equal(gf, cf)
+    pos = positions(400)
+    assert np.array_equal(np.concatenate([gpu.getOccupancy(pos[i:i + 1]) for i in range(400)]), cpu.getOccupancy(pos))
+    st = gpu.frame_stats()
+    assert st["n_host_queries"] > 0 and st["n_pool_grows"] >= 1, st
