@@ -99,7 +99,8 @@ int explore_stage_bc(mlm_handle *h, int slot_index) {
     h->ex_tail = &S; // its miss phase and release scan ride with the next frame's ordering launches (or explore_flush_tail)
     return MLM_OK;
 }
-// end of a batch (or of a single frame): the last frame's tail, the map-wide counters
+// end of a batch (or of a single frame): the last frame's tail, the map-wide counters.  (Deferring that tail to the next synchronous
+// call's ordering launches was tried in round 5: the next call then needs another slot set — cold lists — and came out 5 % slower.)
 int explore_end_batch(mlm_handle *h) {
     explore_flush_tail(h);
     HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
@@ -178,7 +179,7 @@ int drain_explore(mlm_handle *h) {
 
 // Frontier mode, Stage A of the slots base..base+n: by azimuth sector when the handle can (k_sector<true>), else (and for
 // frames whose sector tables overflowed, explore_redo_overflows) on the cell-table path.
-int explore_stage_a(mlm_handle *h, int base, int n) {
+int explore_stage_a(mlm_handle *h, int base, int n, bool on_main = false) {
     const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040;
     if (h->sector_backoff > 0) --h->sector_backoff;
     for (int j = 0; j < n; ++j) {
@@ -188,8 +189,8 @@ int explore_stage_a(mlm_handle *h, int base, int n) {
         S.F.pad2 = (int)(h->ex_frame_no++ & 0x3FFFFFFF); // (frame counter for the MLM_SEC_FAIL_EVERY test hook)
         S.sector = sectors;
     }
-    Timed t(h, h->stream_as[base / h->lim.max_batch], "stage_a_batch");
-    return sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
+    Timed t(h, on_main ? h->stream : h->stream_as[base / h->lim.max_batch], "stage_a_batch");
+    return sectors ? launch_stage_a_sector(h, base, n, on_main) : launch_stage_a_batch(h, base, n, on_main);
 }
 // The frames' counters are on the host: those with an overflowed sector table get their Stage A redone on the cell-table
 // path (nothing that depends on the map has been enqueued for them yet).  Returns with their new counters on the host.

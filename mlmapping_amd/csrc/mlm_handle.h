@@ -399,3 +399,16 @@ static inline int borrowed_wait(mlm_handle *h) {
     HIPCHK(h, hipEventSynchronize(h->host_read_ev));
     return MLM_OK;
 }
+
+// Wait for a stream the way a latency-bound caller wants it: hipStreamSynchronize may put the thread to sleep, and the wake-up costs
+// more (50-100 us measured on frontier mode's per-frame calls) than the work it waits for; so poll the stream for up to a couple of
+// milliseconds first (a frame's launches take 0.1-0.3 ms), then fall back to the blocking call.
+static inline hipError_t mlm_spin_sync(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned int spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    return hipStreamSynchronize(st);
+}

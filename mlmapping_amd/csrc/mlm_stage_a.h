@@ -188,15 +188,18 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n, bool on_main = false) {
 }
 
 // Stage A by azimuth sector (mlm_kernels_sector.h): two launches per batch.
-int launch_stage_a_sector(mlm_handle *h, int base, int n) {
+// on_main: on the main stream, in front of the frames' map-dependent launches (frontier mode's synchronous calls: nothing to overlap
+// with, and a dependency between two streams costs such a call up to 60 us — measured: the first stream a process creates after the
+// main one shares a hardware queue with it, tools/frontier_latency.py)
+int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) {
     const MlmSlot &S0 = h->slots[(size_t)base];
     const MlmDev &P = S0.P;
     const MlmFrame &F = S0.F;
     const int mode = S0.mode;
     const int set = base / (h->lim.max_batch);
-    hipStream_t st = h->stream_as[set];
-    HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
-    if (!h->own_stream) { // see launch_stage_a_batch
+    hipStream_t st = on_main ? h->stream : h->stream_as[set];
+    if (!on_main) HIPCHK(h, hipStreamWaitEvent(st, h->set_free[set], 0));
+    if (!h->own_stream && !on_main) { // see launch_stage_a_batch
         HIPCHK(h, hipEventRecord(h->inputs_ready, h->stream));
         HIPCHK(h, hipStreamWaitEvent(st, h->inputs_ready, 0));
     }

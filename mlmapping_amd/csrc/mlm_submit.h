@@ -423,7 +423,9 @@ bool single_fast_ok(const mlm_handle *h, int n) {
 }
 // the stream uploads of a call's inputs go to: the one its Stage A will run on (a frame-level veto of the graph path is
 // repaired by run_slots with an event between the two streams)
-inline hipStream_t upload_stream(const mlm_handle *h) { return fast_handle_ok(h) ? h->stream : h->stream_as[h->cur_set]; }
+inline hipStream_t upload_stream(const mlm_handle *h) {
+    return (fast_handle_ok(h) || (h->P.explore && !h->async_mode)) ? h->stream : h->stream_as[h->cur_set]; // (frontier mode's synchronous calls: all on the main stream)
+}
 // The launch sequence of ONE frame on stream `st` (the sector path, everything on one stream): a prologue kernel takes the frame's
 // parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, whose last workgroup writes the
 // counters, the map-wide flags and — last — the completion ticket back to pinned memory.  Issued directly, or captured into a graph.
@@ -533,6 +535,21 @@ int run_slots(mlm_handle *h, int n) {
     if (h->P.explore) { // frontier mode: exact ordering of both containers, no speculation
         const int K = h->lim.max_batch;
         {
+            // the call's inputs went up on one stream, its Stage A runs on another (synchronous calls: the main stream): order it behind
+            hipStream_t target = h->async_mode ? h->stream_as[h->cur_set] : h->stream;
+            if (h->last_upload && h->last_upload != target) {
+                hipError_t e = hipSuccess;
+                if (!h->upload_ev) e = hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(h->upload_ev, h->last_upload);
+                if (e == hipSuccess) e = hipStreamWaitEvent(target, h->upload_ev, 0);
+                if (e != hipSuccess) {
+                    h->err = std::string("ordering the upload: ") + hipGetErrorString(e);
+                    return MLM_ERR_HIP;
+                }
+            }
+            h->last_upload = nullptr;
+        }
+        {
             size_t in_flight = 0;
             for (const auto &b : h->ex_q) in_flight += (size_t)b.n;
             const int rc = ensure_free_blocks(h, (in_flight + (size_t)n) * h->frame_block_bound); // (no replay in this mode)
@@ -565,11 +582,10 @@ int run_slots(mlm_handle *h, int n) {
         // Stage A of all frames in one launch sequence (it does not depend on the map), one synchronisation to learn the
         // frames' hit/miss counts, then the map-dependent part frame by frame without further synchronisation
         auto sync_path = [&]() -> int {
-            int rc = explore_stage_a(h, base, n);
+            int rc = explore_stage_a(h, base, n, true); // (on the main stream: nothing to overlap with in a synchronous call)
             if (rc) return rc;
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[h->cur_set], 0));
             HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, mlm_spin_sync(h->stream));
             HIPCHK(h, hipGetLastError());
             rc = explore_redo_overflows(h, base, n);
             if (rc) return rc;
@@ -580,7 +596,7 @@ int run_slots(mlm_handle *h, int n) {
             rc = explore_end_batch(h);
             if (rc) return rc;
             HIPCHK(h, hipEventRecord(h->set_free[h->cur_set], h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, mlm_spin_sync(h->stream));
             HIPCHK(h, hipGetLastError());
             for (int j = 0; j < n; ++j) {
                 rc = explore_finish(h, base + j);

@@ -812,7 +812,8 @@ int mlm_integrate_callback(mlm_handle *h, const void *depth, int is_f32, int wid
     }
     // ---- depth image: upload (and convert 32FC1 -> 16UC1 on the device)
     // (nothing in flight — the synchronous case: no read-back of the map-wide flags and no stream synchronisation just to learn that)
-    int rc = (h->pending.empty() && !h->wait_ticket && !h->P.explore) ? MLM_OK : drain(h);
+    // (frontier mode, nothing queued: the previous call has synchronised)
+    int rc = (h->pending.empty() && !h->wait_ticket && (!h->P.explore || h->ex_q.empty())) ? MLM_OK : drain(h);
     if (rc) return rc;
     MlmSlot &S = cur_slot(h, 0);
     rc = ensure_img(h, S, n_px);

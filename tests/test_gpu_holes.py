@@ -338,3 +338,37 @@ def test_sync_host_batch_with_a_one_frame_remainder(mods):
             cpu.update_depth(img, q, t)
         compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"after a synchronous batch of {n}")
     assert gpu.frame_stats()["n_graph_launches"] >= 6
+
+
+@pytest.mark.parametrize("reads", ["none", "single-position queries", "exports"])
+def test_frontier_mode_synchronous_call_stream(mods, reads):
+    """Frontier mode, one frame (or a small batch) per synchronous call — Stage A and the map-dependent launches on the main stream —
+    as a stream of calls without reads in between, and with single-position queries / exports between the calls."""
+    MLMap, OracleMap = mods
+    cfg = S1.with_(use_exploration_frontiers=True, subbox_n=5)
+    gpu, cpu = MLMap(cfg, max_blocks=16384, max_batch=2), OracleMap(cfg)
+    rng = np.random.default_rng(4)
+    frames = list(syn.stream(cfg, "room_jitter", "smooth", 14))
+    for k, (img, (q, t)) in enumerate(frames):
+        if k % 5 == 3:  # a two-frame synchronous batch in between
+            continue
+        if k % 5 == 4:
+            fr = frames[k - 1:k + 1]
+            gpu.update_map_batch(np.stack([f[0] for f in fr]), np.stack([f[1][0] for f in fr]), np.stack([f[1][1] for f in fr]))
+            for f in fr:
+                cpu.update_depth(f[0], *f[1])
+        else:
+            gpu.update_map(img, q, t)
+            cpu.update_depth(img, q, t)
+        if reads == "single-position queries":
+            pos = rng.uniform([-1, -3, 0], [5, 3, 3], size=(6, 3))
+            for i in range(6):
+                assert gpu.getOccupancy(pos[i:i + 1])[0] == cpu.getOccupancy(pos[i:i + 1])[0]
+        elif reads == "exports" and k % 2:
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"frame {k}")
+            assert np.array_equal(gpu.export_frontier(), cpu.export_frontier())
+    b = cpu.export_blocks()
+    assert b["collapsed"].sum() > 20
+    compare_maps(gpu.export_blocks(), b, f"frontier stream, reads: {reads}")
+    gf, cf = gpu.export_frontier(), cpu.export_frontier()
+    assert gf.shape == cf.shape and np.array_equal(gf, cf)
