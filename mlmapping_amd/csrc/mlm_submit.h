@@ -122,8 +122,11 @@ int submit_batch(mlm_handle *h, int base, int n) {
         return MLM_OK;
     }
     {
-        Timed t(h, h->stream_as[set], "stage_a_batch");
-        rc = sectors ? launch_stage_a_sector(h, base, n) : launch_stage_a_batch(h, base, n);
+        // (a synchronous call has nothing to overlap its Stage A with: on the main stream, no dependency between two streams — which
+        // costs a call up to 60 us on the first slot set, see launch_stage_a_sector)
+        const bool on_main = !h->async_mode;
+        Timed t(h, on_main ? h->stream : h->stream_as[set], "stage_a_batch");
+        rc = sectors ? launch_stage_a_sector(h, base, n, on_main) : launch_stage_a_batch(h, base, n, on_main);
     }
     if (rc) return rc;
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
@@ -424,7 +427,7 @@ bool single_fast_ok(const mlm_handle *h, int n) {
 // the stream uploads of a call's inputs go to: the one its Stage A will run on (a frame-level veto of the graph path is
 // repaired by run_slots with an event between the two streams)
 inline hipStream_t upload_stream(const mlm_handle *h) {
-    return (fast_handle_ok(h) || (h->P.explore && !h->async_mode)) ? h->stream : h->stream_as[h->cur_set]; // (frontier mode's synchronous calls: all on the main stream)
+    return (fast_handle_ok(h) || !h->async_mode) ? h->stream : h->stream_as[h->cur_set]; // (synchronous calls: everything on the main stream)
 }
 // The launch sequence of ONE frame on stream `st` (the sector path, everything on one stream): a prologue kernel takes the frame's
 // parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, whose last workgroup writes the
@@ -615,7 +618,7 @@ int run_slots(mlm_handle *h, int n) {
     const bool fast = single_fast_ok(h, n);
     {
         // the call's inputs went up on one stream, its Stage A may run on another: order it behind
-        hipStream_t target = fast ? h->stream : h->stream_as[set];
+        hipStream_t target = (fast || !h->async_mode) ? h->stream : h->stream_as[set];
         if (h->last_upload && h->last_upload != target) {
             hipError_t e = hipSuccess;
             if (!h->upload_ev) e = hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming);

@@ -692,6 +692,7 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
         // reach a third of the link's rate); others frame by frame into the slots' own buffers
         const bool packed = frame_stride == n_px && n > 1;
         const int set = h->cur_set;
+        hipStream_t up = h->async_mode ? h->stream_as[set] : h->stream; // (the stream this chunk's Stage A runs on, unless it is one frame: run_slots orders that case)
         if (packed) {
             if (h->img_set_cap[set] < (size_t)K * n_px) {
                 if (h->d_img_set[set]) {
@@ -703,16 +704,14 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
                 HIPCHK(h, hipMalloc((void **)&h->d_img_set[set], (size_t)K * n_px * sizeof(uint16_t)));
                 h->img_set_cap[set] = (size_t)K * n_px;
             }
-            HIPCHK(h, hipMemcpyAsync(h->d_img_set[set], img_host + (size_t)k0 * frame_stride, (size_t)n * n_px * sizeof(uint16_t), hipMemcpyHostToDevice,
-                                     h->stream_as[set]));
+            HIPCHK(h, hipMemcpyAsync(h->d_img_set[set], img_host + (size_t)k0 * frame_stride, (size_t)n * n_px * sizeof(uint16_t), hipMemcpyHostToDevice, up));
         }
         for (int j = 0; j < n; ++j) {
             MlmSlot &S = cur_slot(h, j);
             if (!packed) {
                 int rc = ensure_img(h, S, n_px);
                 if (rc) return rc;
-                HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t),
-                                         hipMemcpyHostToDevice, h->stream_as[set]));
+                HIPCHK(h, hipMemcpyAsync(S.d_img, img_host + (size_t)(k0 + j) * frame_stride, n_px * sizeof(uint16_t), hipMemcpyHostToDevice, up));
             }
             S.F = MlmFrame{};
             frame_setup(h, q_wb + 4 * (size_t)(k0 + j), t_wb + 3 * (size_t)(k0 + j), S.F);
@@ -723,12 +722,12 @@ int mlm_integrate_depth_batch(mlm_handle *h, const uint16_t *img_host, int n_fra
             S.F.n = width * height;
             S.mode = 0;
         }
-        int rc = borrowed_mark(h, h->stream_as[set]); // (asynchronous mode: the caller's frames are read by the copies above only)
+        int rc = borrowed_mark(h, up); // (asynchronous mode: the caller's frames are read by the copies above only)
         if (rc) return rc;
         // (the frames went up on the slot set's Stage A stream; a chunk of ONE frame in synchronous mode is submitted as the
         // single-frame graph on the MAIN stream: run_slots orders it behind the upload — without this the graph raced the copy,
         // found by tests/test_gpu_random_ops.py)
-        h->last_upload = h->stream_as[set];
+        h->last_upload = up;
         rc = run_slots(h, n);
         const int rc2 = borrowed_wait(h);
         if (rc || rc2) return rc ? rc : rc2;
