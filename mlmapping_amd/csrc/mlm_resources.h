@@ -539,10 +539,12 @@ int resize_slots(mlm_handle *h) {
         MLM_RG(subs, P.contrib_cap, c.sub);
         MLM_RG(sbkt, P.sbkt_cap, c.sbkt, 0xFF); // (no frame carries that sequence number; entries of pending frames move over)
 #undef MLM_RG
-        if (rc) {
+        if (rc) { // (the device ran out of memory half-way: the lists replaced so far stay — every slot's capacities describe what it holds)
             (void)hipStreamSynchronize(h->stream);
             for (auto &t : h->regrow_trash) dev_free(h, t.first, t.second);
             h->regrow_trash.clear();
+            (void)upload_slot_tab(h); // (the kernels' copies of the slots must not keep pointing at what was just freed)
+            h->err = "device memory exhausted while enlarging the frame slots: " + h->err;
             return rc;
         }
         P.hl_cap = (unsigned int)std::max<size_t>(hl0, c.hl);
