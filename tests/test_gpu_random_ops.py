@@ -228,3 +228,68 @@ def test_random_operation_sequences_s1_with_growth(mods, seed):
     st = gpu.frame_stats()
     print(st)
     assert st["n_pool_grows"] >= 1 and st["n_sector_fallbacks"] == 0, (st, log)
+
+
+def test_two_handles_driven_from_two_threads(mods):
+    """Two maps on one GPU, each driven by its own thread — frames, single-position and bulk queries, setFree, inflation — at the same
+    time: nothing in the library is shared between handles except the device; both maps must equal their oracles."""
+    import threading
+
+    MLMap, OracleMap = mods
+    cfgs = [SDEF.with_(depth_noise_coe=0.00375, lm_occupied_sh=2.0), SDEF.with_(use_exploration_frontiers=True, lm_occupied_sh=2.0, depth_noise_coe=0.00375)]
+    errors = []
+
+    def drive(i):
+        try:
+            cfg = cfgs[i]
+            gpu, cpu = MLMap(cfg, max_blocks=256, max_points=cfg.width * cfg.height, max_batch=4), OracleMap(cfg)
+            rng = np.random.default_rng(70 + i)
+            base = syn.room_depth(cfg)
+            traj = syn.smooth_trajectory(200, 30 + i)
+            k = 0
+            for step in range(60):
+                op = rng.choice(["dense", "batch", "q1", "qbulk", "setfree", "inflate", "mode"], p=[0.3, 0.15, 0.25, 0.1, 0.08, 0.07, 0.05])
+                if op == "dense":
+                    img, (q, t) = syn.jitter_depth(base, k, seed=i), traj[k]
+                    k += 1
+                    gpu.update_map(img, q, t)
+                    cpu.update_depth(img, q, t)
+                elif op == "batch":
+                    n = int(rng.integers(2, 7))
+                    fr = [(syn.jitter_depth(base, k + j, seed=i), traj[k + j]) for j in range(n)]
+                    k += n
+                    gpu.update_map_batch(np.stack([f[0] for f in fr]), np.stack([f[1][0] for f in fr]), np.stack([f[1][1] for f in fr]))
+                    for img, (q, t) in fr:
+                        cpu.update_depth(img, q, t)
+                elif op in ("q1", "qbulk"):
+                    pos = rng.uniform([-2, -5, 0], [6, 5, 3], size=(8 if op == "q1" else 2000, 3))
+                    if op == "q1":
+                        for j in range(8):
+                            assert gpu.getOccupancy(pos[j:j + 1])[0] == cpu.getOccupancy(pos[j:j + 1])[0]
+                            assert gpu.getOdd(pos[j:j + 1]).view(np.uint32)[0] == cpu.getOdd(pos[j:j + 1]).view(np.uint32)[0]
+                    else:
+                        assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+                elif op == "setfree":
+                    c = rng.uniform([0, -2, 0.5], [4, 2, 2.5])
+                    gpu.setFree_map_in_bound(c - 0.4, c + 0.4)
+                    cpu.setFree_map_in_bound(c - 0.4, c + 0.4)
+                elif op == "inflate":
+                    gpu.inflate_map(traj[max(k - 1, 0)][1])
+                    cpu.inflate_map(traj[max(k - 1, 0)][1])
+                else:
+                    gpu.set_async(bool(rng.integers(0, 2)))
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"handle {i}")
+            if cfg.use_exploration_frontiers:
+                assert np.array_equal(gpu.export_frontier(), cpu.export_frontier())
+            gpu.close()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            errors.append((i, traceback.format_exc()))
+
+    ths = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
