@@ -67,7 +67,8 @@ struct MlmSecCell {
 
 #define MLM_SEC_KIND_BITS 21 // MlmSecCell::kg: 2 * MLM_DIFF_RANGE + 1 kinds below the reference count
 #define MLM_SEC_KIND_MASK ((1u << MLM_SEC_KIND_BITS) - 1u)
-#define MLM_SEC_CNT_BITS 20 // MlmSecCell::cnt: contributions in the low bits (mlm_limits.max_points < 2^20 on this path)
+#define MLM_SEC_CNT_BITS 21 // MlmSecCell::cnt: contributions in the low bits (mlm_limits.max_points < 2^21 on this path: a full-HD depth image),
+                            // the sum of their strengths above them (mod 2^11: a wrap only makes a cell look weaker than it is)
 #define MLM_SEC_CNT_MASK ((1u << MLM_SEC_CNT_BITS) - 1u)
 // Does the float noisy-OR chain of the cell (update_odds_hashmap, map_awareness.h:147-154: p <- 1 - (1 - p)(1 - a), each
 // operation rounded) depend on the order of its contributions?  Not with one kind only.  And not once the contributions
@@ -75,10 +76,10 @@ struct MlmSecCell {
 // s = 1 (a < 0.75), 2 (a < 0.875) or 3: b = 1 - a is exact and <= 2^-s.  The first strong step of any order puts p into
 // [0.5, 1], where 1 - p is exact: an integer k <= 2^24 in units of 2^-24.  From then on p never decreases; a strong step maps
 // k to at most k (1 + 2^-24) / 2^s + 0.5 (the product m = k 2^-24 b is rounded to float, then 1 - m to the grid), any other
-// step to at most k.  Unrolled over the strong steps before the LAST one of the order (fewer than 2^20, strengths summing
-// to at least S - 3 with S the sum of all): k <= 1.07 (2^24 / 2^(S - 3) + 1), i.e. k <= 1 once S >= 28; the last strong step
+// step to at most k.  Unrolled over the strong steps before the LAST one of the order (fewer than 2^21: (1 + 2^-24)^(2^21) < 1.14;
+// strengths summing to at least S - 3 with S the sum of all): k <= 1.14 (2^24 / 2^(S - 3) + 1) < 2, i.e. k <= 1 once S >= 28; the last strong step
 // turns k <= 1 into m <= 2^-25 (exact), and 1 - m rounds to 1.0f (ties to even), which is absorbing.
-// Such cells are finished without ranking their contributions (S is summed mod 4096 next to the count: a wrap only
+// Such cells are finished without ranking their contributions (S is summed mod 2048 next to the count: a wrap only
 // makes a cell look weaker than it is).
 #define MLM_SEC_STRONG_ENOUGH 28u
 __host__ __device__ __forceinline__ uint32_t mlm_sec_strength(float a) { return a >= 0.875f ? 3u : (a >= 0.75f ? 2u : (a >= 0.5f ? 1u : 0u)); }
@@ -100,7 +101,7 @@ __device__ __forceinline__ uint32_t mlm_mask_rows(unsigned long long m) {
 //   bits 0-7 the row's byte of the mask, 8-12 the kind, 13-31 where the row's first lane lies relative to the cell's FIRST pixel
 //   (its earliest contribution, MlmSecCell::tmin: no contribution lies in a row above it):
 //     dense images   (rows below the first pixel's) << 8 | column >> 3          11 + 8 bits (images up to 2040 wide)
-//     lists          (64-item rows below the first item's) << 3 | mask row      16 + 3 bits (2^20 items)
+//     lists          (64-item rows below the first item's) << 3 | mask row      16 + 3 bits (2^22 items)
 #define MLM_REF_DY_DENSE 2047u
 #define MLM_REF_DY_LIST 65535u
 __device__ __forceinline__ uint32_t mlm_ref_pack(uint32_t bits, uint32_t kind, bool dense, uint32_t dy0, uint32_t row, uint32_t x0) {
@@ -806,7 +807,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         }
                         atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
                         atomicOr(&s_tab[e].kg, 1u << sub);
-                        // contributions, and in the upper 12 bits (mod 4096) the sum of their strengths (mlm_sec_needs_order)
+                        // contributions, and in the upper 11 bits (mod 2048) the sum of their strengths (mlm_sec_needs_order)
                         const uint32_t strength = s_strength[mlm_contribution_index(P, rho_t, sub)];
                         atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
                         if ((atomicAdd(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) + n_rows > (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) {

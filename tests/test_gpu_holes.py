@@ -372,3 +372,20 @@ def test_frontier_mode_synchronous_call_stream(mods, reads):
     compare_maps(gpu.export_blocks(), b, f"frontier stream, reads: {reads}")
     gf, cf = gpu.export_frontier(), cpu.export_frontier()
     assert gf.shape == cf.shape and np.array_equal(gf, cf)
+
+
+@pytest.mark.parametrize("w,h", [(1024, 1024), (1920, 1080)])
+def test_megapixel_depth_images_on_the_sector_path(mods, w, h):
+    """Depth images above 2^20 pixels (a 1024x1024 wide-field-of-view frame, full HD) stay on the sector path since round 5 (the
+    columns' contribution counts take 21 bits): same awareness sets and maps as the oracle, no cell-table fall-back."""
+    MLMap, OracleMap = mods
+    cfg = S1.with_(width=w, height=h, cam_cx=w / 2.0, cam_cy=h / 2.0, cam_fx=0.6 * w, cam_fy=0.6 * w)
+    gpu, cpu = MLMap(cfg, max_blocks=8192, max_points=w * h, max_batch=2, record_awareness=True), OracleMap(cfg)
+    for k, (img, (q, t)) in enumerate(syn.stream(cfg, "room_jitter", "random", 3, seed=2)):
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        if k == 0:
+            _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{w}x{h} frame {k}")
+    st = gpu.frame_stats()
+    assert st["n_points"] == w * h and st["n_device_atomics"] > 0 and st["n_sector_fallbacks"] == 0, st

@@ -797,10 +797,11 @@ def test_float_callback_between_packed_host_batches(mods):
     gpu.close()
 
 
-@pytest.mark.parametrize("n", [(1 << 20) - 1, (1 << 20) + 4097])
+@pytest.mark.parametrize("n", [(1 << 20) + 4097, (1 << 21) - 1, (1 << 21) + 4097])
 def test_point_count_limits(mods, n):
-    """The largest frame the sector path takes (2^20 - 1 points: insertion times and contribution counts are packed for that) and one
-    above it (the cell-table path), as explicit points scattered through the awareness cylinder: same awareness sets and map."""
+    """The largest frame the sector path takes (2^21 - 1 points — a full-HD depth image: contribution counts are packed for that), one
+    above it (the cell-table path) and one above round 4's limit of 2^20, as explicit points scattered through the awareness cylinder:
+    same awareness sets and map."""
     MLMap, OracleMap = mods
     cfg = S1
     rng = np.random.default_rng(n)
@@ -813,7 +814,7 @@ def test_point_count_limits(mods, n):
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{n} points")
     st = gpu.frame_stats()
     print(n, "points:", {k: st[k] for k in ("n_points", "n_hit_cells", "n_miss_cells", "n_sector_fallbacks", "n_device_atomics")})
-    assert (st["n_device_atomics"] > 0) == (n < (1 << 20)), st  # (the sector path counts its atomics; the cell-table path reports 0)
+    assert (st["n_device_atomics"] > 0) == (n < (1 << 21)), st  # (the sector path counts its atomics; the cell-table path reports 0)
     gpu.close()
 
 
