@@ -67,8 +67,10 @@ struct MlmSecCell {
 
 #define MLM_SEC_KIND_BITS 21 // MlmSecCell::kg: 2 * MLM_DIFF_RANGE + 1 kinds below the reference count
 #define MLM_SEC_KIND_MASK ((1u << MLM_SEC_KIND_BITS) - 1u)
+#ifndef MLM_SEC_CNT_BITS
 #define MLM_SEC_CNT_BITS 21 // MlmSecCell::cnt: contributions in the low bits (mlm_limits.max_points < 2^21 on this path: a full-HD depth image),
                             // the sum of their strengths above them (mod 2^11: a wrap only makes a cell look weaker than it is)
+#endif
 #define MLM_SEC_CNT_MASK ((1u << MLM_SEC_CNT_BITS) - 1u)
 // Does the float noisy-OR chain of the cell (update_odds_hashmap, map_awareness.h:147-154: p <- 1 - (1 - p)(1 - a), each
 // operation rounded) depend on the order of its contributions?  Not with one kind only.  And not once the contributions

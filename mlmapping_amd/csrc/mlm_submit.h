@@ -162,6 +162,16 @@ int submit_batch(mlm_handle *h, int base, int n) {
     return MLM_OK;
 }
 
+// A frame of the sector path gave up (sector_overflow >= 2) and is redone from its Stage A on.  The columns that finished, and the
+// ones that failed, have cleared their chunk counts — but a crowded column that was WAITING for the large-table pass when another
+// column gave the frame up (sector_overflow 1 raised to 2 or 3) still holds its chunks: binned again on top of them, its points would
+// count twice (in the rerun, or — after a fall-back to the cell-table path — in the slot's next frame).  Nothing is in flight.
+int forget_columns(mlm_handle *h, const MlmSlot &R) {
+    HIPCHK(h, hipMemsetAsync(R.P.col_cnt, 0, (size_t)R.P.nPhi * sizeof(unsigned int), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MLM_OK;
+}
+
 // A frame whose crowded columns overflowed the small cell table while the large-table pass was not scheduled (sector_overflow == 1:
 // the columns kept their records and sit on the frame's overflow list; nothing of the frame has been grouped by tile or applied).
 // Nothing is in flight: the large-table pass and the rest of Stage A run for this frame alone on the main stream, and the pass is
@@ -275,6 +285,8 @@ int drain(mlm_handle *h, bool g_copied) {
                     HIPCHK(h, hipStreamSynchronize(h->stream));
                     rc = grow_slots(h, *R.h_ctr);
                     if (rc) return rc;
+                    rc = forget_columns(h, R);
+                    if (rc) return rc;
                     rc = launch_stage_a_sector(h, si, 1);
                     if (rc) return rc;
                     HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
@@ -296,6 +308,7 @@ int drain(mlm_handle *h, bool g_copied) {
                     HIPCHK(h, hipStreamSynchronize(h->stream));
                     rc = ensure_free_blocks_idle(h, h->frame_block_bound); // (its k_voxelize cannot be replayed)
                     if (rc) return rc;
+                    if (R.sector && (rc = forget_columns(h, R))) return rc;
                     // (k_tile has consumed the descriptors the columns that did finish handed out: nothing of the attempt is left)
                     rc = launch_stage_a_batch(h, si, 1);
                     if (rc) return rc;

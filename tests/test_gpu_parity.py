@@ -9,7 +9,7 @@ import pytest
 
 from mlmapping_amd import synthetic as syn
 from mlmapping_amd.config import S1, S1_SIGMA0, S3, SDEF
-from tests.util import ODDS_TOL, compare_maps, voxel_centres
+from tests.util import ODDS_TOL, compare_maps, fuzz_trial, voxel_centres
 
 pytestmark = pytest.mark.gpu
 
@@ -688,26 +688,9 @@ def test_random_configurations(mods):
     # MLM_FUZZ_SEED / MLM_FUZZ_TRIALS: longer or different runs of the same fuzz (default: 30 trials, seed 2024)
     rng = np.random.default_rng(int(os.environ.get("MLM_FUZZ_SEED", "2024")))
     for trial in range(int(os.environ.get("MLM_FUZZ_TRIALS", "30"))):
-        d = float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.25]))
-        cfg = S1.with_(
-            am_d_Rho=d, am_d_Phi_deg=float(rng.choice([0.5, 1.0, 2.0, 3.0, 5.0])), am_d_Z=float(rng.choice([d, 2 * d, 0.5 * d])),
-            am_n_Rho=int(rng.integers(20, 100)), am_n_Z_below=int(rng.integers(5, 30)), am_n_Z_over=int(rng.integers(5, 30)),
-            depth_noise_coe=float(rng.choice([1e-6, 0.001, 0.00375, 0.008])),
-            subbox_d_xyz=float(rng.choice([d, 2 * d, 0.5 * d])), subbox_n=int(rng.choice([4, 5, 8, 10, 16])),
-            lm_log_odds_min=float(rng.uniform(-3, -1)), lm_log_odds_max=float(rng.uniform(3, 5)),
-            lm_measurement_miss=float(rng.uniform(-1.2, -0.3)), lm_occupied_sh=float(rng.uniform(1.0, 3.0)),
-            use_exploration_frontiers=bool(trial % 3 == 2),
-            cam_fx=float(rng.uniform(150, 400)), cam_fy=float(rng.uniform(150, 400)), cam_cx=163.3, cam_cy=117.9,
-            width=320, height=240)
-        # keep the noise spread inside the reference's 21-row odds table (3*sigma <= 10)
-        if 3 * cfg.depth_noise_coe * (cfg.am_n_Rho * cfg.am_d_Rho) ** 2 / cfg.am_d_Rho > 10:
-            cfg = cfg.with_(depth_noise_coe=1e-6)
+        cfg, depths, pos = fuzz_trial(rng, trial)
         gpu, cpu = MLMap(cfg, max_blocks=4096, max_points=320 * 240, record_awareness=True), OracleMap(cfg)
-        for k in range(3):
-            depth = rng.integers(300, int(1000 * cfg.am_n_Rho * cfg.am_d_Rho * 1.3), size=(240, 320)).astype(np.uint16)
-            depth[rng.random((240, 320)) < 0.02] = 0
-            if k == 1:  # a smooth surface as well as speckle
-                depth[:] = (1000 * 0.6 * cfg.am_n_Rho * cfg.am_d_Rho + 200 * np.sin(np.arange(320) / 25.0)[None, :]).astype(np.uint16)
+        for k, depth in enumerate(depths):
             q, t = syn.random_poses(3, seed=trial)[k]
             cpu.update_depth(depth, q, t)
             gpu.update_map(depth, q, t)  # (tiny blocks over a long range need more than the 4096 initial blocks: the pool grows)
@@ -715,9 +698,7 @@ def test_random_configurations(mods):
             compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"fuzz trial {trial} frame {k} cfg {cfg}")
             if cfg.use_exploration_frontiers:
                 assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"fuzz trial {trial}: frontier"
-        else:
-            pos = rng.uniform(-8, 8, size=(20000, 3))
-            assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+        assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
         gpu.close()
 
 

@@ -49,3 +49,34 @@ def voxel_centres(b: dict, cfg, limit: int = 200000, seed: int = 0) -> np.ndarra
     if pos.shape[0] > limit:
         pos = pos[np.random.default_rng(seed).choice(pos.shape[0], limit, replace=False)]
     return pos
+
+
+def fuzz_trial(rng, trial: int):
+    """The inputs of trial `trial` of tests/test_gpu_parity.py::test_random_configurations drawn from `rng` (a trial's draws follow
+    the previous trial's: replaying trial k of a seed means drawing trials 0 .. k): a random map geometry / noise level / thresholds /
+    camera model, three depth images (speckle, a smooth surface, speckle) and 20 000 query positions."""
+    from mlmapping_amd.config import S1
+
+    d = float(rng.choice([0.05, 0.1, 0.15, 0.2, 0.25]))
+    cfg = S1.with_(
+        am_d_Rho=d, am_d_Phi_deg=float(rng.choice([0.5, 1.0, 2.0, 3.0, 5.0])), am_d_Z=float(rng.choice([d, 2 * d, 0.5 * d])),
+        am_n_Rho=int(rng.integers(20, 100)), am_n_Z_below=int(rng.integers(5, 30)), am_n_Z_over=int(rng.integers(5, 30)),
+        depth_noise_coe=float(rng.choice([1e-6, 0.001, 0.00375, 0.008])),
+        subbox_d_xyz=float(rng.choice([d, 2 * d, 0.5 * d])), subbox_n=int(rng.choice([4, 5, 8, 10, 16])),
+        lm_log_odds_min=float(rng.uniform(-3, -1)), lm_log_odds_max=float(rng.uniform(3, 5)),
+        lm_measurement_miss=float(rng.uniform(-1.2, -0.3)), lm_occupied_sh=float(rng.uniform(1.0, 3.0)),
+        use_exploration_frontiers=bool(trial % 3 == 2),
+        cam_fx=float(rng.uniform(150, 400)), cam_fy=float(rng.uniform(150, 400)), cam_cx=163.3, cam_cy=117.9,
+        width=320, height=240)
+    # keep the noise spread inside the reference's 21-row odds table (3*sigma <= 10, SURVEY App. B)
+    if 3 * cfg.depth_noise_coe * (cfg.am_n_Rho * cfg.am_d_Rho) ** 2 / cfg.am_d_Rho > 10:
+        cfg = cfg.with_(depth_noise_coe=1e-6)
+    depths = []
+    for k in range(3):
+        depth = rng.integers(300, int(1000 * cfg.am_n_Rho * cfg.am_d_Rho * 1.3), size=(240, 320)).astype(np.uint16)
+        depth[rng.random((240, 320)) < 0.02] = 0
+        if k == 1:  # a smooth surface as well as speckle
+            depth[:] = (1000 * 0.6 * cfg.am_n_Rho * cfg.am_d_Rho + 200 * np.sin(np.arange(320) / 25.0)[None, :]).astype(np.uint16)
+        depths.append(depth)
+    pos = rng.uniform(-8, 8, size=(20000, 3))
+    return cfg, depths, pos
