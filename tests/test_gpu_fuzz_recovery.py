@@ -1,0 +1,82 @@
+"""Fuzz of the RECOVERY paths: the random map geometries of test_random_configurations (tests/util.py fuzz_trial) on handles whose
+limits and knobs force what a camera stream rarely does — column tables too small for the scene (large-table pass, its arming and
+the redo at drain), forced sector fall-backs every 2nd / 3rd frame, a pool of 16 blocks and lists sized for a quarter of the frame
+(growth of pool and slots while frames are in flight), no graph — fed frame by frame, in batches, synchronously and asynchronously.
+Every combination must leave the oracle's map, bit for bit.  (Fuzz seed 4242 found a rerun of Stage A counting a column's points
+twice exactly where two of these paths met: test_gpu_slots.py::test_rerun_with_a_column_waiting_for_the_large_table.)
+MLM_RFUZZ_SEED / MLM_RFUZZ_TRIALS: other or longer runs."""
+import os
+
+import numpy as np
+import pytest
+
+from mlmapping_amd import synthetic as syn
+from tests.util import compare_maps, fuzz_trial
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_configurations_on_the_recovery_paths(knobs):
+    from mlmapping_amd.mlmap import MLMap
+    from oracle.binding import OracleMap
+
+    seed = int(os.environ.get("MLM_RFUZZ_SEED", "31"))
+    rng = np.random.default_rng(seed)
+    krng = np.random.default_rng(seed + 1)  # (limits, knobs and call pattern: a stream of its own, so the inputs are fuzz_trial's)
+    seen = {"n_sector_fallbacks": 0, "n_slot_grows": 0, "n_pool_grows": 0, "n_spec_replays": 0}
+    for trial in range(int(os.environ.get("MLM_RFUZZ_TRIALS", "40"))):
+        cfg, depths, pos = fuzz_trial(rng, trial)
+        kn = {}
+        if krng.random() < 0.5:
+            kn["sec_tab"] = int(krng.choice([256, 512]))
+        if krng.random() < 0.3:
+            kn["sec_fail_every"] = int(krng.choice([2, 3]))
+        if krng.random() < 0.2:
+            kn["sec_tab_big"] = 0
+        if krng.random() < 0.3:
+            kn["big_arm"] = int(krng.choice([0, 1, 2]))
+        if krng.random() < 0.2:
+            kn["graph"] = 0
+        if krng.random() < 0.3:
+            kn["tile_sh"] = int(krng.choice([1, 2, 3]))
+        if krng.random() < 0.2:
+            kn["slot_sets"] = 2
+        for name, v in kn.items():
+            knobs.set(name, v)
+        max_blocks = int(krng.choice([16, 64, 4096]))
+        max_points = int(krng.choice([320 * 240, 320 * 240, 4 * 320 * 240]))
+        max_batch = int(krng.choice([1, 2, 3, 4]))
+        pattern = str(krng.choice(["single", "single_async", "batch", "batch_async", "twice"]))
+        what = f"recovery fuzz seed {seed} trial {trial}: knobs {kn} max_blocks {max_blocks} max_points {max_points} max_batch {max_batch} {pattern} cfg {cfg}"
+        gpu, cpu = MLMap(cfg, max_blocks=max_blocks, max_points=max_points, max_batch=max_batch), OracleMap(cfg)
+        from mlmapping_amd import mlmap
+
+        mlmap.debug_reset()  # (the knobs are read by mlm_create)
+        poses = syn.random_poses(3, seed=trial)
+        frames = [(depths[k], poses[k][0], poses[k][1]) for k in range(3)]
+        if pattern == "twice":  # six frames: the slots come round again after whatever the first three left in them
+            frames = frames + [(depths[2 - k], poses[k][0], poses[k][1] + np.array([0.3, -0.2, 0.1])) for k in range(3)]
+        gpu.set_async(pattern.endswith("async"))
+        if pattern.startswith("batch") and max_batch >= 2:
+            for k0 in range(0, len(frames), max_batch):
+                fr = frames[k0:k0 + max_batch]
+                gpu.update_map_batch(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]))
+            for img, q, t in frames:
+                cpu.update_depth(img, q, t)
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), what)
+        else:
+            for k, (img, q, t) in enumerate(frames):
+                gpu.update_map(img, q, t)
+                cpu.update_depth(img, q, t)
+                if not pattern.endswith("async") or k == len(frames) - 1:
+                    compare_maps(gpu.export_blocks(), cpu.export_blocks(), what + f" frame {k}")
+        if cfg.use_exploration_frontiers:
+            assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), what + ": frontier"
+        assert np.array_equal(gpu.getOccupancy(pos[:2000]), cpu.getOccupancy(pos[:2000])), what
+        st = gpu.frame_stats()
+        for name in seen:
+            seen[name] += int(st[name])
+        gpu.close()
+    print("recovery paths taken:", seen)
+    if "MLM_RFUZZ_SEED" not in os.environ:
+        assert all(v > 0 for v in seen.values()), seen  # (the default run does reach every one of them)
