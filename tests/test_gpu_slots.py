@@ -126,3 +126,38 @@ def test_rerun_with_a_column_waiting_for_the_large_table(mods):
         compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"speckle frame {k}")
     st = gpu.frame_stats()
     assert st["n_slot_grows"] >= 1 and st["n_sector_fallbacks"] == 0, st
+
+
+def test_crowded_scene_then_camera_frames_then_crowded_again(mods):
+    """a scene that overflows the small cell table in nearly every column (large-table pass armed, the table widened after two
+    confirmed batches), then camera frames (the pass disarms), then the crowded scene again — frame by frame and in asynchronous
+    batches, camera and scatter frames mixed inside a batch: the map equals the oracle's after every phase"""
+    MLMap, OracleMap = mods
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=8192, max_points=640 * 480, max_batch=4, record_awareness=True), OracleMap(cfg)
+    scatter = list(syn.stream(cfg, "scatter", "smooth", 14))
+    room = list(syn.stream(cfg, "room_jitter", "random", 8, seed=3))
+
+    def single(frames, what):
+        for img, (q, t) in frames:
+            gpu.update_map(img, q, t)
+            cpu.update_depth(img, q, t)
+            gc, go, _ = gpu.awareness_hits()
+            cc, co = cpu.hit_cells_sorted()
+            assert np.array_equal(gc, cc) and np.array_equal(go.view(np.uint32), co.view(np.uint32)), what
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), what)
+
+    def batch(frames, what):
+        for k0 in range(0, len(frames), 4):
+            fr = frames[k0:k0 + 4]
+            gpu.update_map_batch(np.stack([f[0] for f in fr]), np.stack([f[1][0] for f in fr]), np.stack([f[1][1] for f in fr]))
+        for img, (q, t) in frames:
+            cpu.update_depth(img, q, t)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), what)
+
+    single(scatter[:4], "scatter, frame by frame")
+    single(room[:3], "camera frames after the crowded scene")
+    gpu.set_async(True)
+    batch(scatter[4:12], "scatter, asynchronous batches")
+    batch(room[3:8] + scatter[12:14], "camera frames and scatter frames mixed in the batches")
+    assert gpu.frame_stats()["n_sector_fallbacks"] == 0

@@ -19,7 +19,7 @@ mm._lib = L
 cfg = S3 if "cfg3" in sys.argv else S1
 n = int(os.environ.get("MLM_PHASE_BATCH", "16"))
 m = mm.MLMap(cfg, max_blocks=32768, max_batch=n)
-frames = list(syn.stream(cfg, "room_jitter", "random", n))
+frames = list(syn.stream(cfg, "scatter", "smooth", n)) if "scatter" in sys.argv else list(syn.stream(cfg, "room_jitter", "random", n))
 imgs = np.stack([f[0] for f in frames])
 q = np.stack([f[1][0] for f in frames])
 t = np.stack([f[1][1] for f in frames])
@@ -44,7 +44,7 @@ if "single" in sys.argv:  # frame by frame: a phase's cycles per wave = its shar
     for nm, v in zip(NAMES, acc):
         print(f"  {nm:72s} {100.0 * v / tot:5.1f} %   {v / n / 2.4e3:8.1f} wave-us per frame")
     sys.exit(0)
-for rep in range(2):
+for rep in range(4 if "scatter" in sys.argv else 2):
     m.update_map_batch(imgs, q, t)
     L.mlm_debug_phases(buf)
     tot = sum(buf[:10])
