@@ -27,7 +27,7 @@ struct KernelTime {
 const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
                                   "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "need_slots", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
-                                  "sectors", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
+                                  "sectors", "single_chain_grid", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
     std::mutex mu;
     std::unordered_map<std::string, long long> v;
@@ -197,6 +197,7 @@ struct mlm_handle {
     int sec_threads = 512;           // threads of a column's workgroup (k_sector<.., 256 | 512>; MLM_SEC_THREADS)
     double clk[8] = {}, clk_t = 0;   // host clocks of the single-frame path (mlm_debug_clocks): microseconds per section, summed over the calls
     unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
+    unsigned int single_chain_grid = 64;  // workgroups of a lone frame's k_chain_lanes: 256 waves x 64 cells cover a dense VGA frame's ranked cells in one turn
     unsigned int single_apply_grid = 256; // workgroups of k_apply_single: a VGA frame's ~33 k voxel records, one per thread (more: in turns)
     unsigned int tile_grid = 0;      // workgroups of k_tile per frame of a batch: they walk the frame's touched tiles (MLM_TILE_GRID)
     unsigned int apply_lds_bytes = 0; // dynamic LDS of k_apply_tiles: 9 bytes per voxel of a tile

@@ -1468,6 +1468,23 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
             atomicAdd(&g_mlm_span[9 + 2 * bkt], 1ull); // (odd slots: the multiples of four hold the spans' first-start minima)
             atomicAdd(&g_mlm_span[27], (unsigned long long)n_refs);
         }
+        {   // (would the cell fit a bitmap of ONE 64-pixel word per row — segments -3 .. +4 around its first pixel's —, and 32 rows?)
+            bool out64 = false, row32 = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r_ref[q] & 0xFFu) {
+                    uint32_t b_, yx_, s_;
+                    unpack(r_ref[q], b_, yx_, s_);
+                    const int dxs = (int)(yx_ & 2047u) - (xlo + 40);
+                    out64 = out64 || dxs < 0 || dxs > 56;
+                    row32 = row32 || (yx_ >> 11) >= 32u;
+                }
+            const unsigned long long o_l = __ballot(valid && out64), r_l = __ballot(valid && row32);
+            if (valid && hl == 0) {
+                if ((uint32_t)(o_l >> (32 * half))) atomicAdd(&g_mlm_span[29], 1ull);
+                if ((uint32_t)(r_l >> (32 * half))) atomicAdd(&g_mlm_span[31], 1ull);
+            }
+        }
 #endif
         const int my_rounds = act ? (int)min(4u, (n_refs + 31u) >> 5) : 0;
         const int rounds = max(mlm_readlane(my_rounds, 0), mlm_readlane(my_rounds, 32)); // (uniform)
@@ -1619,11 +1636,12 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
 // The float noisy-OR chains of the ranked cells (update_odds_hashmap, map_awareness.h:147-154, over the kinds k_rank put in
 // pixel order): one cell per LANE, and a lane that finishes its cell draws the next one — chains are 2 to several hundred
 // steps long, so with a fixed cell per lane a wave would run as long as its longest chain with most lanes idle.  A wave
-// reserves cells from the frame's counter 128 at a time; loads are issued one round ahead of their use (cell descriptor,
+// reserves cells from the frame's counter `reserve` at a time (128 in a batch; 64 — one per lane — for a frame on its own, whose
+// 8 000 cells would otherwise keep 66 waves busy with two cells per lane while the rest of the grid has none: a lone frame's
+// k_chain_lanes lasts as long as a lane's cells do); loads are issued one round ahead of their use (cell descriptor,
 // then 16 kinds per 16-byte load), so a round's arithmetic covers the next round's memory latency.  The odds table is kept
 // transposed in LDS ([rho][kind], 32 kinds per row): one shift-add per lookup.  p == 1.0f is absorbing and ends a chain.
-#define MLM_CHAIN_RESERVE 128u
-__global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
+__global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS, unsigned int reserve) {
     MLM_SLOT_SETUP
     extern __shared__ float s_odds_t[]; // [nRho][32]: odd of a contribution of kind k into a cell at rho
     for (int j = threadIdx.x; j < P.nRho * 32; j += blockDim.x) {
@@ -1684,10 +1702,10 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS) {
         if (need && !exhausted) {
             if (loc_next >= loc_end) {
                 uint32_t b = 0;
-                if (lane == 0) b = g_atomic_add(&mlm_gp(P.ctr)->chain_next, MLM_CHAIN_RESERVE);
+                if (lane == 0) b = g_atomic_add(&mlm_gp(P.ctr)->chain_next, reserve);
                 b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
                 loc_next = b;
-                loc_end = min(b + MLM_CHAIN_RESERVE, n_cells);
+                loc_end = min(b + reserve, n_cells);
                 exhausted = b >= n_cells;
             }
             if (!exhausted) {

@@ -266,7 +266,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
         }
         if (!h->no_spread)
             tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
-                base);
+                base, n > 4 ? 128u : 64u);
         // the frame's hits and misses grouped by voxel, tile by tile (needs the increments and keys of the kernels above)
         if (!P.explore)
             tlaunch(h, "k_tile", k_tile, dim3(n > 1 ? h->tile_grid : (unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, n), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);

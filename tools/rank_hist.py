@@ -28,5 +28,6 @@ L.mlm_debug_spans(buf)
 h = np.array([buf[9 + 2 * b] for b in range(9)], dtype=np.float64) / (n - 1)
 names = ["3", "4", "5-8", "9-16", "17-32", "33-64", "65-128", "129-256", ">256"]
 print(("cfg3" if cfg is S3 else "cfg2"), scene, "ranked cells per frame: %.0f, references per cell %.1f" % (h.sum(), buf[27] / (n - 1) / max(1.0, h.sum())))
+print("  cells that would not fit one 64-pixel word per row: %.0f (%.1f %%); cells taller than 32 rows: %.0f (%.1f %%)" % (buf[29] / (n - 1), 100.0 * buf[29] / (n - 1) / max(1.0, h.sum()), buf[31] / (n - 1), 100.0 * buf[31] / (n - 1) / max(1.0, h.sum())))
 for nm, v in zip(names, h):
     print("  n = %-8s %8.0f cells  %5.1f %%" % (nm, v, 100.0 * v / max(1.0, h.sum())))
