@@ -99,6 +99,40 @@ int explore_stage_bc(mlm_handle *h, int slot_index) {
     h->ex_tail = &S; // its miss phase and release scan ride with the next frame's ordering launches (or explore_flush_tail)
     return MLM_OK;
 }
+// ONE synchronous frame, enqueued before the host has seen its counts: the whole map-dependent part — ordering, registration, hits,
+// observation, misses, release scan — behind the frame's Stage A without a synchronisation in between (the host used to wait for the
+// counts, replay both rehash policies and only then enqueue seven launches: the GPU idled through a copy, a wake-up and the first
+// launch's way down).  The kernels read the counts themselves and do nothing unless the frame fits both containers as they are
+// (MlmDev::spec_on, mlm_ex_spec_skip); the host checks the same condition once the frame has drained and, if it did not hold — the
+// first frames of a stream, while the emulated containers still grow, or a Stage A that left the sector path —, runs the general
+// path with the counts it now has.  Returns with everything enqueued; thresholds in thr[2].
+int explore_stage_bc_spec(mlm_handle *h, int slot_index, unsigned int thr[2]) {
+    MlmSlot &S = h->slots[(size_t)slot_index];
+    hipStream_t st = h->stream;
+    const dim3 blk(MLM_BLOCK);
+    thr[0] = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
+    thr[1] = (unsigned int)std::min<size_t>(h->miss_pol._M_next_resize, 0xFFFFFFFFu);
+    if (h->ex_spec == 2) thr[0] = thr[1] = 0u; // (test knob: every frame with a hit or a miss cell misses the speculation)
+    MlmDev Ps = S.P;
+    Ps.spec_on = 1;
+    Ps.spec_hit_thr = thr[0];
+    Ps.spec_miss_thr = thr[1];
+    const int tag = h->ex_tag++;
+    if (h->ex_tag > 0x3FFFFFFF) { // tags restart: the tables must forget them
+        h->ex_tag = 0;
+        HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long), st));
+    }
+    const unsigned long long hn = h->hit_n_bkt, mn = h->miss_n_bkt;
+    tlaunch(h, "k_ex_order_min", k_ex_order_min, dim3(kListGrid, 2), blk, 0, st, Ps, 0u, 0u, hn, mn, tag, Ps);
+    tlaunch(h, "k_ex_order_keys", k_ex_order_keys, dim3(kListGrid, 2), blk, 0, st, Ps, 0u, 0u, hn, mn, Ps);
+    tlaunch(h, "k_ex_register", k_ex_register, dim3(4 * kListGrid, 2), blk, 0, st, Ps, S.F);
+    tlaunch(h, "k_apply", k_apply, dim3(64, 1), blk, 0, st, Ps, 0, 1);
+    tlaunch(h, "k_ex_observe", k_ex_observe, dim3(4 * kListGrid), blk, 0, st, Ps, S.F);
+    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, st, Ps);
+    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, st, Ps);
+    HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
+    return MLM_OK;
+}
 // end of a batch (or of a single frame): the last frame's tail, the map-wide counters.  (Deferring that tail to the next synchronous
 // call's ordering launches was tried in round 5: the next call then needs another slot set — cold lists — and came out 5 % slower.)
 int explore_end_batch(mlm_handle *h) {

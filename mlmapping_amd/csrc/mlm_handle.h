@@ -25,7 +25,7 @@ struct KernelTime {
 // simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
 const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
-                                  "debug_fail_slot", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "need_slots", "node_lds", "pool_grow",
+                                  "debug_fail_slot", "ex_spec", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "need_slots", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
                                   "sectors", "single_chain_grid", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
@@ -202,6 +202,8 @@ struct mlm_handle {
     unsigned int tile_grid = 0;      // workgroups of k_tile per frame of a batch: they walk the frame's touched tiles (MLM_TILE_GRID)
     unsigned int apply_lds_bytes = 0; // dynamic LDS of k_apply_tiles: 9 bytes per voxel of a tile
     unsigned int big_grid = 256;     // workgroups of k_sector_big per batch: one per CU (MLM_BIG_GRID)
+    int ex_spec = 1;                 // frontier mode: a synchronous frame's map-dependent part is enqueued before its counts are known (explore_stage_bc_spec);
+                                     // knob "ex_spec": 0 never, 2 with thresholds of zero (every frame misses: the test of the way back)
     int big_armed = 0;               // batches (single frames) for which the pass with the large cell table stays scheduled
     int big_armed_from = 0;          // first frame (sequence number; frontier mode: frame number) submitted after it was scheduled
     int big_arm_len = 64;            // (MLM_BIG_ARM: 0 never schedules it)

@@ -1671,7 +1671,14 @@ __device__ __forceinline__ void mlm_apply_body(const MlmDev &P, int frame_idx, i
         P.occ[v] = o;
     }
 }
+// see MlmDev::spec_on
+__device__ __forceinline__ bool mlm_ex_spec_skip(const MlmDev &P) {
+    if (!P.spec_on) return false;
+    const MlmCounters *c = P.ctr;
+    return c->sector_overflow != 0u || c->u_hit > P.spec_hit_thr || c->n_ex_miss > P.spec_miss_thr;
+}
 __global__ __launch_bounds__(MLM_BLOCK) void k_apply(const MlmDev P, int frame_idx, int explicit_keys) {
+    if (mlm_ex_spec_skip(P)) return;
     mlm_apply_body(P, frame_idx, explicit_keys, blockIdx.y);
 }
 

@@ -137,6 +137,11 @@ __device__ __forceinline__ void mlm_ex_release_body(const MlmDev &P);
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_min(const MlmDev P, unsigned int n_hit, unsigned int n_miss, unsigned long long nb_hit,
                                                             unsigned long long nb_miss, int tag, const MlmDev Pprev) {
     __builtin_amdgcn_s_setprio(3); // (the serial chain of this mode: ahead of the next batch's Stage A)
+    if (mlm_ex_spec_skip(P)) return;
+    if (P.spec_on) { // (the host has not seen the counts yet)
+        n_hit = P.ctr->u_hit;
+        n_miss = P.ctr->n_ex_miss;
+    }
     const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (blockIdx.y == 2) {
         mlm_ex_apply_misses_body(Pprev);
@@ -155,6 +160,11 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_min(const MlmDev P, unsi
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_order_keys(const MlmDev P, unsigned int n_hit, unsigned int n_miss, unsigned long long nb_hit,
                                                              unsigned long long nb_miss, const MlmDev Pprev) {
     __builtin_amdgcn_s_setprio(3); // (the serial chain of this mode: ahead of the next batch's Stage A)
+    if (mlm_ex_spec_skip(P)) return;
+    if (P.spec_on) {
+        n_hit = P.ctr->u_hit;
+        n_miss = P.ctr->n_ex_miss;
+    }
     const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     if (blockIdx.y == 2) {
         mlm_ex_release_body(Pprev);
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_miss_tau(const MlmDev P, const
 // different per-voxel words (blockIdx.y = 0 hits, 1 misses)
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_register(const MlmDev P, const MlmFrame F) {
     __builtin_amdgcn_s_setprio(3);
+    if (mlm_ex_spec_skip(P)) return;
     if (blockIdx.y == 0) mlm_voxelize_body(P, F, 0ull, 0u);
     else mlm_ex_miss_tau_body(P);
 }
@@ -214,6 +225,7 @@ __device__ __forceinline__ bool mlm_inside_exp_bd(double x, double y, double z) 
 // is still unknown (it turns 'f' at this very miss: L <= occupied_sh for an unknown cell and the miss lowers it).
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_observe(const MlmDev P, const MlmFrame F) {
     __builtin_amdgcn_s_setprio(3);
+    if (mlm_ex_spec_skip(P)) return;
     const unsigned int n = P.ctr->n_ex_miss;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int v = P.ex_vox[i];
@@ -316,7 +328,10 @@ __device__ __forceinline__ void mlm_ex_apply_misses_body(const MlmDev &P) {
         if (o == 'f' && o0 != 'f') P.frnt[v] = 0;
     }
 }
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) { mlm_ex_apply_misses_body(P); }
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) {
+    if (mlm_ex_spec_skip(P)) return;
+    mlm_ex_apply_misses_body(P);
+}
 
 // release scan (map_local.cpp:208-232): one workgroup per allocated block; blocks observed this frame whose frontier is
 // empty and whose occupancy is uniform are collapsed (they stop accepting updates; element 0 answers queries)
@@ -342,7 +357,10 @@ __device__ __forceinline__ void mlm_ex_release_body(const MlmDev &P) {
         }
     }
 }
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) { mlm_ex_release_body(P); }
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) {
+    if (mlm_ex_spec_skip(P)) return;
+    mlm_ex_release_body(P);
+}
 
 // frontier read-out: (gx,gy,gz,cell) of every frontier cell
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_export_frontier(const MlmDev P, unsigned int n_blocks, int32_t *out,

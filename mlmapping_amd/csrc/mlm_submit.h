@@ -601,8 +601,28 @@ int run_slots(mlm_handle *h, int n) {
             int rc = explore_stage_a(h, base, n, true); // (on the main stream: nothing to overlap with in a synchronous call)
             if (rc) return rc;
             HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, mlm_spin_sync(h->stream));
-            HIPCHK(h, hipGetLastError());
+            // one frame, both emulated containers past their first insertion, nothing deferred: the map-dependent part goes out now,
+            // guarded on the device by the condition the host checks afterwards (explore_stage_bc_spec)
+            if (n == 1 && h->ex_spec && !h->ex_tail && h->hit_pol._M_next_resize >= 1 && h->miss_pol._M_next_resize >= 1 &&
+                h->hit_n_bkt <= h->max_buckets && h->miss_n_bkt <= h->max_buckets) {
+                unsigned int thr[2];
+                rc = explore_stage_bc_spec(h, base, thr);
+                if (rc) return rc;
+                HIPCHK(h, mlm_spin_sync(h->stream));
+                HIPCHK(h, hipGetLastError());
+                MlmSlot &S = h->slots[(size_t)base];
+                const MlmCounters &c = *S.h_ctr;
+                if (c.sector_overflow == 0u && c.u_hit <= thr[0] && c.n_ex_miss <= thr[1]) {
+                    S.ex_um = c.n_ex_miss;
+                    h->stats.n_rehash_epochs = 1;
+                    HIPCHK(h, hipEventRecord(h->set_free[h->cur_set], h->stream));
+                    return explore_finish(h, base);
+                }
+                h->n_spec_miss++; // (nothing of the map-dependent part ran: the general path follows, with the counts on the host)
+            } else {
+                HIPCHK(h, mlm_spin_sync(h->stream));
+                HIPCHK(h, hipGetLastError());
+            }
             rc = explore_redo_overflows(h, base, n);
             if (rc) return rc;
             for (int j = 0; j < n; ++j) {

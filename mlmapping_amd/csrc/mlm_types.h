@@ -258,6 +258,11 @@ struct MlmDev {
     unsigned int sbkt_cap;     // never cleared (a newer frame's entries win the min)
     MlmCounters *ctr;          // this slot's per-frame counters
     MlmGlobal *g;
+    // frontier mode, a synchronous frame whose map-dependent kernels are enqueued BEFORE the host has seen the frame's counts
+    // (mlm_explore_host.h, explore_stage_bc_spec): they take the counts from `ctr` and do nothing unless the frame fits both emulated
+    // containers without a rehash and its Stage A stayed on the sector path (mlm_ex_spec_skip); the host checks the same afterwards
+    int spec_on;
+    unsigned int spec_hit_thr, spec_miss_thr;
 };
 
 #define MLM_FRAME_EXACT_KEYS 1 // hl_key holds the exact iteration-order keys (order_hits_exact): no speculation check, keys from hl_key

@@ -12,6 +12,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # A test that hangs (a kernel that never ends, a lost wake-up) must fail with the stacks of its threads instead of holding the
+    # whole run until somebody's outer limit kills it without a line of output: 15 minutes per test where pytest-timeout is installed
+    # (the longest test, the 1 000-frame stream, takes three).
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(900, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import binding

@@ -1,5 +1,6 @@
 """Replay tests/test_gpu_parity.py::test_random_configurations for one seed (same draws: tests/util.py fuzz_trial) and report the
-first trial and frame whose hit cells or odds differ from the oracle's, with the cells:  python tools/fuzz_repro.py SEED TRIALS"""
+first trial and frame whose hit cells or odds differ from the oracle's, with the cells:  python tools/fuzz_repro.py SEED TRIALS [-v]
+(MLM_KNOBS=name=value,... sets experiment knobs of the library: mlmapping_amd/mlmap.py)"""
 import os
 import sys
 
@@ -15,6 +16,8 @@ seed, trials = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
 for trial in range(trials):
     cfg, depths, _ = fuzz_trial(rng, trial)
+    if "-v" in sys.argv:
+        print("trial", trial, "explore", cfg.use_exploration_frontiers, flush=True)
     gpu, cpu = MLMap(cfg, max_blocks=4096, max_points=320 * 240, record_awareness=True), OracleMap(cfg)
     for k, depth in enumerate(depths):
         q, t = syn.random_poses(3, seed=trial)[k]

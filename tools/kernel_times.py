@@ -9,11 +9,6 @@ from bench import make_inputs  # noqa: E402
 from mlmapping_amd.config import S1, S3  # noqa: E402
 from mlmapping_amd.mlmap import MLMap  # noqa: E402
 
-for kv in os.environ.get("MLM_KNOBS", "").split(","):  # experiment knobs of the library, e.g. MLM_KNOBS=defer_cols=0,big_grid=512
-    if "=" in kv:
-        from mlmapping_amd import mlmap as _mm
-        _mm.debug_set(kv.split("=")[0], int(kv.split("=")[1]))
-
 cfg = S3 if "cfg3" in sys.argv else S1
 if os.environ.get("MLM_BENCH_NO_RAYCAST"):  # diagnostic: hits without rays
     import dataclasses
