@@ -449,6 +449,65 @@ def single_frame_latency(MLMap, cfg, frames, q, t, d_frames, n_calls=120, cpu=Tr
     return out
 
 
+def other_scenes(MLMap, cfg, frames, q, t, d_frames, device):
+    """Rows that are NOT the headline, measured by the same run so that they are on the driver's record: frontier mode
+    (use_exploration_frontiers, the shipped config2.yaml's mode) on the bench stream — asynchronous 32-frame batches from HBM as the
+    headline is measured, and one frame per synchronous call — and the worst-case "scatter" scene (every pixel in a cell of its own)
+    in the default mode.  A few hundred frames each; a row that fails reports its error instead of a number."""
+    import torch
+
+    from mlmapping_amd import synthetic as syn
+
+    out = {}
+    B = 32
+    fsz = cfg.width * cfg.height
+    try:
+        ex = cfg.with_(use_exploration_frontiers=True)
+        m = MLMap(ex, device=device, max_blocks=32768, max_points=fsz, max_batch=B)
+        m.set_async(True)
+        for j in range(4):  # (the pool and the emulated containers grow to their working size)
+            m.update_map_batch_dev(d_frames.data_ptr(), B, cfg.width, cfg.height, q[j * B:(j + 1) * B], t[j * B:(j + 1) * B])
+        m.sync()
+        t0 = time.perf_counter()
+        for j in range(4, 16):
+            m.update_map_batch_dev(d_frames.data_ptr(), B, cfg.width, cfg.height, q[j * B:(j + 1) * B], t[j * B:(j + 1) * B])
+        m.sync()
+        out["frontier_mode_async_batches"] = {"value": 12 * B / (time.perf_counter() - t0), "unit": "frames/s", "frames": 12 * B, "batch": B}
+        m.set_async(False)
+        ts = []
+        for k in range(16 * B, 16 * B + 72):
+            a = time.perf_counter()
+            m.update_map_dev(d_frames.data_ptr() + (k % B) * fsz * 2, cfg.width, cfg.height, q[k], t[k])
+            ts.append(time.perf_counter() - a)
+        out["frontier_mode_frame_by_frame"] = {"value": 1.0 / float(np.mean(ts[8:])), "unit": "frames/s", "us_per_frame_median": float(np.median(ts[8:]) * 1e6),
+                                               "frames": len(ts) - 8}
+        m.close()
+    except Exception as e:  # noqa: BLE001 (the headline must not depend on these rows)
+        out["frontier_mode_error"] = str(e)[:300]
+    try:
+        sc = list(syn.stream(cfg, "scatter", "smooth", B))
+        d = torch.from_numpy(np.stack([f for f, _ in sc]).view(np.int16)).cuda(device)
+        qs, ts_ = np.stack([p[0] for _, p in sc]), np.stack([p[1] for _, p in sc])
+        torch.cuda.synchronize()
+        m = MLMap(cfg, device=device, max_blocks=32768, max_points=fsz, max_batch=B)
+        m.set_async(True)
+        for _ in range(6):  # (slots grow, the large-table pass arms, the column table widens)
+            m.update_map_batch_dev(d.data_ptr(), B, cfg.width, cfg.height, qs, ts_)
+        m.sync()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            m.update_map_batch_dev(d.data_ptr(), B, cfg.width, cfg.height, qs, ts_)
+        m.sync()
+        st = m.frame_stats()
+        out["scatter_scene_async_batches"] = {"value": 10 * B / (time.perf_counter() - t0), "unit": "frames/s", "frames": 10 * B, "batch": B,
+                                              "hit_cells_per_frame": st["n_hit_cells"], "sector_fallbacks": st["n_sector_fallbacks"]}
+        m.close()
+        del d
+    except Exception as e:  # noqa: BLE001
+        out["scatter_scene_error"] = str(e)[:300]
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2:])
@@ -654,6 +713,7 @@ def main():
                 out["extra"]["single_query_us"] = query_latency(cfg, with_oracle=not args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001 (the headline must not depend on this row)
                 out["extra"]["single_query_us"] = {"error": str(e)[:300]}
+            out["extra"]["other_scenes"] = other_scenes(MLMap, cfg, frames, q, t, d_frames, local_rank)
             if not args.no_cpu_baseline:
                 out["extra"]["cfg3"]["cpu_baseline"], _ = cpu_baseline(S3, "cfg3", f3, q3, t3, args.cpu_budget, None, min_frames=3, per_core=False)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
