@@ -87,6 +87,15 @@ struct MlmMirror {
     bool dirty = true;             // the device map changed (or may have) since the last refresh ...
     mlm_host::DirtyBoxes boxes;    // ... anywhere, or inside these boxes of block indices (mlm_mapview.h)
     long long n_refresh = 0, n_copied = 0, n_host_queries = 0;
+    // EAGER refresh (mirror_eager): a planner that asks after every frame pays the refresh — a launch, ~1 MB across the link, a
+    // synchronisation: ~48 us — on its first query.  Once a query has found the mirror stale, every synchronous integrate call that
+    // follows launches the refresh itself as it returns (nothing waits for it); the first query then only waits for an event that
+    // has usually fired.  Switched off again by the first integrate call that finds the previous eager refresh unused.
+    bool eager_on = false;         // queries do follow the integrate calls
+    bool eager_pending = false;    // a refresh kernel is in flight or done, its results not yet taken in (mirror_collect)
+    hipEvent_t eager_ev = nullptr; // behind that kernel
+    long long q_at_eager = -1;     // n_host_queries when it was launched
+    long long n_eager = 0;
 };
 
 static inline double mlm_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

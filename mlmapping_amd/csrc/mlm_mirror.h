@@ -47,6 +47,10 @@ void mirror_mark_frames(mlm_handle *h, int n) {
 
 void mirror_free(mlm_handle *h) {
     MlmMirror &M = h->mir;
+    if (M.eager_pending) { // (a refresh kernel may still be writing the planes)
+        hipEventSynchronize(M.eager_ev);
+        M.eager_pending = false;
+    }
     if (M.lo) hipHostFree(M.lo);
     if (M.occ) hipHostFree(M.occ);
     if (M.infl) hipHostFree(M.infl);
@@ -92,7 +96,37 @@ int mirror_reserve(mlm_handle *h, size_t blocks) {
     M.view.lo = M.lo, M.view.occ = M.occ, M.view.infl = M.infl, M.view.col = M.col;
     return MLM_OK;
 }
-// Bring the mirror up to date.  The caller holds the lock and has drained the handle.
+// The refresh kernel for the boxes recorded so far, on the main stream (the planes hold M.cap blocks).
+int mirror_launch(mlm_handle *h) {
+    MlmMirror &M = h->mir;
+    MlmMirrorBoxes B{};
+    B.all = M.boxes.all ? 1 : 0;
+    B.n = M.boxes.all ? 0 : M.boxes.n;
+    for (int k = 0; k < B.n; ++k)
+        for (int a = 0; a < 3; ++a) {
+            B.lo[k][a] = M.boxes.lo[k][a];
+            B.hi[k][a] = M.boxes.hi[k][a];
+        }
+    hipLaunchKernelGGL(k_mirror_refresh, dim3(kMirrorGrid), dim3(MLM_BLOCK), 0, h->stream, h->P, M.n_known, B, M.lo, M.occ, M.infl, M.col, M.keys,
+                       (unsigned int)M.cap, M.stat);
+    HIPCHK(h, hipGetLastError());
+    return MLM_OK;
+}
+// ... and what it left behind, once it has finished: the new blocks' keys go into the host table.  false: there are more blocks than
+// the planes hold — nothing is taken in, the planes must be enlarged and everything copied again.
+bool mirror_collect(mlm_handle *h, unsigned int *n_blocks_seen = nullptr) {
+    MlmMirror &M = h->mir;
+    const unsigned int nb = M.stat[0];
+    if (n_blocks_seen) *n_blocks_seen = nb;
+    if (nb > M.cap) return false;
+    for (unsigned int i = 0; i < kMirrorGrid; ++i) M.n_copied += M.stat[2 + i];
+    for (unsigned int b = M.n_known; b < nb; ++b) // the new blocks' keys
+        M.view.table_insert(M.keys[3 * (size_t)b], M.keys[3 * (size_t)b + 1], M.keys[3 * (size_t)b + 2], (int)b);
+    M.n_known = nb;
+    M.n_refresh++;
+    return true;
+}
+// Bring the mirror up to date.  The caller holds the lock and has drained the handle; no eager refresh is pending.
 int mirror_refresh(mlm_handle *h) {
     MlmMirror &M = h->mir;
     // (the geometry first: an empty map has no planes yet, but getOddGrad walks neighbours of absent blocks all the same)
@@ -103,34 +137,63 @@ int mirror_refresh(mlm_handle *h) {
     for (int attempt = 0; attempt < 3; ++attempt) {
         int rc = mirror_reserve(h, M.cap >= guess ? M.cap : 2 * guess);
         if (rc) return rc;
-        MlmMirrorBoxes B{};
-        B.all = M.boxes.all ? 1 : 0;
-        B.n = M.boxes.all ? 0 : M.boxes.n;
-        for (int k = 0; k < B.n; ++k)
-            for (int a = 0; a < 3; ++a) {
-                B.lo[k][a] = M.boxes.lo[k][a];
-                B.hi[k][a] = M.boxes.hi[k][a];
-            }
-        hipLaunchKernelGGL(k_mirror_refresh, dim3(kMirrorGrid), dim3(MLM_BLOCK), 0, h->stream, h->P, M.n_known, B, M.lo, M.occ, M.infl, M.col, M.keys,
-                           (unsigned int)M.cap, M.stat);
-        HIPCHK(h, hipGetLastError());
+        if ((rc = mirror_launch(h))) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        const unsigned int nb = M.stat[0];
-        if (nb > M.cap) { // more blocks than the planes hold: enlarge (everything is copied again) and repeat
+        unsigned int nb = 0;
+        if (!mirror_collect(h, &nb)) { // more blocks than the planes hold: enlarge (everything is copied again) and repeat
             guess = nb;
             continue;
         }
-        for (unsigned int i = 0; i < kMirrorGrid; ++i) M.n_copied += M.stat[2 + i];
-        for (unsigned int b = M.n_known; b < nb; ++b) // the new blocks' keys
-            M.view.table_insert(M.keys[3 * (size_t)b], M.keys[3 * (size_t)b + 1], M.keys[3 * (size_t)b + 2], (int)b);
-        M.n_known = nb;
         M.dirty = false;
         M.boxes.clear();
-        M.n_refresh++;
         return MLM_OK;
     }
     h->err = "host mirror: the block count kept growing while nothing was in flight";
     return MLM_ERR_HIP;
+}
+// A synchronous integrate call is about to return (nothing in flight, the map-wide state on the host): launch the refresh now if
+// queries have been following the integrate calls (MlmMirror::eager_on).  Never fails the call: whatever goes wrong here is left to
+// the first query's own refresh.
+void mirror_eager(mlm_handle *h) {
+    MlmMirror &M = h->mir;
+    if (!M.enabled || M.alloc_failed || !M.dirty || !M.eager_on) return;
+    if (h->async_mode || !h->pending.empty() || !h->ex_q.empty() || h->wait_ticket || h->timing) return;
+    if (M.eager_pending || M.n_host_queries == M.q_at_eager) { // the previous eager refresh found no taker: stop until a query asks again
+        M.eager_on = false;
+        return;
+    }
+    const size_t nb = std::min<size_t>(h->h_g ? h->h_g->n_blocks : 0u, (size_t)h->P.max_blocks);
+    if (M.cap == 0 || nb > M.cap || M.boxes.all) return; // (the planes must grow, or everything is stale: the query's refresh does that)
+    if (!M.eager_ev && hipEventCreateWithFlags(&M.eager_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        M.eager_ev = nullptr;
+        return;
+    }
+    if (mirror_launch(h) != MLM_OK || hipEventRecord(M.eager_ev, h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        hipStreamSynchronize(h->stream); // (whatever did get launched has finished before anybody touches the planes again)
+        mirror_mark_all(h);
+        return;
+    }
+    M.eager_pending = true;
+    M.q_at_eager = M.n_host_queries;
+    M.n_eager++;
+    M.dirty = false; // (what the boxes named is on its way; a later change marks the mirror again)
+    M.boxes.clear();
+}
+// take in a pending eager refresh (wait for it if it is still running)
+int mirror_finish_eager(mlm_handle *h) {
+    MlmMirror &M = h->mir;
+    if (!M.eager_pending) return MLM_OK;
+    M.eager_pending = false;
+    hipError_t e = hipErrorNotReady;
+    for (int spins = 0; spins < 4096 && e == hipErrorNotReady; ++spins) e = hipEventQuery(M.eager_ev); // (usually fired long ago)
+    if (e == hipErrorNotReady) e = hipEventSynchronize(M.eager_ev);
+    if (e != hipSuccess || !mirror_collect(h)) { // (a failed wait, or more blocks than the planes hold: everything again, by the regular refresh)
+        (void)hipGetLastError();
+        mirror_mark_all(h);
+    }
+    return MLM_OK;
 }
 
 // (the query arithmetic itself — get_global_idx, getOccupancy, getOdd, getOddGrad on the mirrored planes — is pure host code:
@@ -152,7 +215,12 @@ bool mirror_wanted(const mlm_handle *h, int mode, int n, int max_iter) {
 }
 // drain + refresh if the map changed since the mirror was filled; the caller holds the lock
 int mirror_sync(mlm_handle *h) {
+    if (h->mir.eager_pending) {
+        HIPCHK(h, hipSetDevice(h->device));
+        mirror_finish_eager(h);
+    }
     if (!h->mir.dirty) return MLM_OK;
+    h->mir.eager_on = true; // (a query found the mirror stale: queries do follow the map's changes)
     HIPCHK(h, hipSetDevice(h->device));
     int rc = drain(h);
     if (rc) return rc;

@@ -535,7 +535,14 @@ int submit_single_graph(mlm_handle *h, int base) {
 }
 
 // Integrate the frames already described in slots[base..base+n) (F, mode set), in order.
+int run_slots_inner(mlm_handle *h, int n);
+void mirror_eager(mlm_handle *h);
 int run_slots(mlm_handle *h, int n) {
+    const int rc = run_slots_inner(h, n);
+    if (rc == MLM_OK) mirror_eager(h); // (a planner that queries after every frame: its refresh of the host mirror starts now, mlm_mirror.h)
+    return rc;
+}
+int run_slots_inner(mlm_handle *h, int n) {
     (void)hipGetLastError(); // a stale error of unrelated HIP calls in this thread is not ours
     mirror_mark_frames(h, n); // (the host mirror of the map is stale inside these frames' reach: mlm_mirror.h)
     if (h->want_widen) {

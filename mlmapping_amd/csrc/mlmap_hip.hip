@@ -621,6 +621,7 @@ int mlm_destroy(mlm_handle *h) {
     if (h->d_qpos) hipFree(h->d_qpos);
     if (h->d_qout) hipFree(h->d_qout);
     mirror_free(h);
+    if (h->mir.eager_ev) hipEventDestroy(h->mir.eager_ev);
     if (h->mir.stat) hipHostFree(h->mir.stat);
     if (h->h_g) hipHostFree(h->h_g);
     for (int k = 0; k < MLM_SETS; ++k) {

@@ -243,3 +243,43 @@ def test_queries_on_an_empty_map(mods):
         cpu.inflate_map([0.0, 0.0, 1.0])
         _check_all_kinds(gpu, cpu, pos[:50], "empty map after setFree + inflate")
         gpu.close()
+
+
+@pytest.mark.parametrize("explore", [False, True])
+def test_planner_that_asks_after_every_frame(mods, explore):
+    """queries after every synchronous frame switch the EAGER refresh on (the integrate call launches it as it returns, the first
+    query only takes it in); frames without queries in between switch it off again; a pool that outgrows the mirror's planes sends the
+    refresh back to the query — the answers equal the oracle's all the way (every kind, one position per call)"""
+    MLMap, OracleMap = mods
+    cfg = S1.with_(use_exploration_frontiers=explore)
+    gpu, cpu = MLMap(cfg, max_blocks=64, max_points=cfg.width * cfg.height, max_batch=2), OracleMap(cfg)
+    rng = np.random.default_rng(8)
+    frames = list(syn.stream(cfg, "room_jitter", "smooth", 22, seed=4))
+
+    def ask(n, what):
+        b = cpu.export_blocks()
+        pos = np.concatenate([voxel_centres(b, cfg, n - n // 3, seed=int(rng.integers(1 << 30))), rng.uniform(-3, 6, size=(n // 3, 3))])
+        _check_all_kinds(gpu, cpu, pos, what)
+
+    for k, (img, (q, t)) in enumerate(frames):
+        t = t + np.array([0.15 * k, -0.1 * k, 0.0])  # (the camera wanders: the pool of 64 blocks and the mirror's planes grow on the way)
+        if k % 5 == 4:  # the reference's sampler pattern now and then
+            pix = (rng.integers(0, cfg.height, 500) * cfg.width + rng.integers(0, cfg.width, 500)).astype(np.int32)
+            gpu.update_map(img, q, t, pixel_idx=pix)
+            cpu.update_depth_indexed(img, pix, q, t)
+        else:
+            gpu.update_map(img, q, t)
+            cpu.update_depth(img, q, t)
+        if k in (9, 10, 11, 15):  # (frames nobody asks about: the eager refresh stops, and starts again with the next question)
+            continue
+        if k == 13:  # another kind of change between the frame and the question
+            lo_, hi_ = t - 0.4, t + 0.4
+            gpu.setFree_map_in_bound(lo_, hi_)
+            cpu.setFree_map_in_bound(lo_, hi_)
+        if k == 17:
+            gpu.inflate_map(t)
+            cpu.inflate_map(t)
+        ask(24, f"after frame {k}")
+    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "planner stream")
+    st = gpu.frame_stats()
+    assert st["n_mirror_refreshes"] >= 16 and st["n_host_queries"] > 1000 and st["n_pool_grows"] >= 1, st
