@@ -2068,9 +2068,3 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_convert_f32_u16(const float *src,
     }
 }
 
-__global__ __launch_bounds__(MLM_BLOCK) void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}
-__global__ __launch_bounds__(MLM_BLOCK) void k_fill_u8(uint8_t *p, uint8_t v, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}

@@ -207,7 +207,6 @@ __device__ __forceinline__ void mlm_ex_miss_tau_body(const MlmDev &P) {
         P.ex_vox[i] = v;
     }
 }
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_miss_tau(const MlmDev P, const MlmFrame F) { mlm_ex_miss_tau_body(P); }
 // the hit push (k_voxelize's hit side, explicit keys) and the miss registration of a frame in ONE launch: they touch
 // different per-voxel words (blockIdx.y = 0 hits, 1 misses)
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_register(const MlmDev P, const MlmFrame F) {

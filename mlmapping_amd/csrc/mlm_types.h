@@ -210,7 +210,7 @@ struct MlmDev {
     uint32_t *ex_vt;           // ... virtual insertion time (rehash replay)
     uint32_t *ex_arr;          // ... arrival rank
     unsigned long long *ex_key;// ... iteration-order key (larger = earlier)
-    int *ex_vox;               // ... voxel address (see k_ex_miss_tau)
+    int *ex_vox;               // ... voxel address (see mlm_ex_miss_tau_body)
     unsigned long long *ex_bkey; // ... packed block key of its world voxel
     uint32_t *ex_cid;          // ... cell id inside that block
     uint32_t *bktm_first;      // [max buckets of the miss container] min vt per bucket
