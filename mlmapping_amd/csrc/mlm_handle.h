@@ -26,7 +26,7 @@ struct KernelTime {
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
 const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
                                   "debug_fail_slot", "ex_spec", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "need_slots", "node_lds", "pool_grow",
-                                  "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_ent_cap", "sec_fail_every", "sec_rec_cap", "sec_tab", "sec_tab_big", "sec_threads",
+                                  "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
                                   "sectors", "single_chain_grid", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
     std::mutex mu;

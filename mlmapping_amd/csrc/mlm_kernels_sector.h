@@ -147,9 +147,6 @@ template <int MODE> __device__ __forceinline__ MlmTile mlm_strip_item(const MlmF
     return t;
 }
 
-// sum of the four bytes of a word (k_bin_sectors: a column entry's per-wave record counts)
-__device__ __forceinline__ uint32_t mlm_bytes_sum(uint32_t w) { return (w & 0xFFu) + ((w >> 8) & 0xFFu) + ((w >> 16) & 0xFFu) + (w >> 24); }
-
 // S strips per workgroup, worked on TOGETHER (every phase runs for all S before the next starts).  The launches use S = 1: two
 // and four strips in flight measured 1-4 % slower in the pipeline (profiles/r4b_*) — the kernel is bound by vector-instruction issue,
 // not by the waits of a strip's chain.  A record never touches LDS: the lane that leads a group of pixels keeps it in registers until
@@ -291,10 +288,7 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
                 }
                 e = (e + 1) & (COLS - 1);
             }
-            // (a column's run is ordered by wave — a byte of the entry's counter per wave, at most 64 records each —: a wave is an 8x8
-            // pixel tile or 64 list items, so the records of a run lie in pixel-tile order, which k_sector's in-column ordering of the
-            // noisy-OR contributions relies on)
-            if (placed) rec_place[j] = e | (((atomicAdd(&s_col_cnt[j][e], 1u << (8 * wid)) >> (8 * wid)) & 0xFFu) << 16);
+            if (placed) rec_place[j] = e | (atomicAdd(&s_col_cnt[j][e], 1u) << 16);
             else s_over = 1; // (dense tiles only: more than 64 columns in one 32x8 pixel strip)
         }
         const unsigned int n_pts = (unsigned int)__popcll(__ballot(have[j]));
@@ -307,14 +301,14 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
     uint32_t run_cnt = 0, run_off = 0, run_tot = 0;
     if (MODE == 0) {
         if (wid < S) {
-            run_cnt = mlm_bytes_sum(s_col_cnt[wid][lane]);
+            run_cnt = s_col_cnt[wid][lane];
             const uint32_t incl = mlm_wave_incl_scan(run_cnt);
             run_off = incl - run_cnt;
             run_tot = mlm_readlane(incl, 63);
             s_col_off[wid][lane] = run_off;
         }
     } else {
-        run_cnt = mlm_bytes_sum(s_col_cnt[0][threadIdx.x]);
+        run_cnt = s_col_cnt[0][threadIdx.x];
         run_off = mlm_wave_incl_scan(run_cnt);
         if (lane == 63) s_wsum[wid] = run_off;
         __syncthreads();
@@ -327,9 +321,7 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
 #pragma unroll
     for (int j = 0; j < S; ++j) {
         if (rec_place[j] != MLM_NIL) {
-            // (place in the run: the records of the waves below this one, then the record's own number in its wave)
-            const uint32_t below = mlm_bytes_sum(s_col_cnt[j][rec_place[j] & 0xFFFFu] & ((1u << (8 * wid)) - 1u));
-            *((MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.bnodes) + ((size_t)(strip0 + (unsigned int)j) * 256u + s_col_off[j][rec_place[j] & 0xFFFFu] + below + (rec_place[j] >> 16))) =
+            *((MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.bnodes) + ((size_t)(strip0 + (unsigned int)j) * 256u + s_col_off[j][rec_place[j] & 0xFFFFu] + (rec_place[j] >> 16))) =
                 mlm_u32x4{rec_cell[j], rec_pos[j], (uint32_t)rec_mask[j], (uint32_t)(rec_mask[j] >> 32)};
         }
     }
@@ -431,23 +423,16 @@ __device__ __forceinline__ void mlm_sec_targets(const MlmDev &P, int rho, int ph
 
 // LDS plan of k_sector (dynamic): the host computes the same offsets
 struct MlmSecLds {
-    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, vox, aux, rec, ent, total;
+    uint32_t tab, miss, odds, sigma, rays, occ, multi, chunk, ray_p0, vox, aux, total;
 };
-// A column orders the noisy-OR contributions of its multi-kind cells itself (see mlm_sector_column): its records stay in LDS (rec_cap
-// of 16 bytes, at most 2 048) and every cell that needs its order gets one entry per (record, kind) group that contributes to it —
-// record << 5 | kind in 16 bits —, ent_cap entries per round.  The large-table pass takes columns of any size: its entries hold the
-// record's index in `bnodes` (32 bits) and it reads the records from memory.
-#define MLM_SEC_ENT_KIND_BITS 5
-// chunk descriptors a column can stage (it needs all its records at once): MLM_SEC_CHUNKS, the large-table pass twice that
-__host__ __device__ inline uint32_t mlm_sec_chunk_cap(bool big) { return big ? 2u * MLM_SEC_CHUNKS : (uint32_t)MLM_SEC_CHUNKS; }
 // n_miss: words of the column's miss table (bit mask: nZ * RW; frontier mode keeps insertion times: nZ * nRho)
-__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, uint32_t n_z, bool explore, uint32_t rec_cap, uint32_t ent_cap, bool big) {
+__host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, uint32_t n_rho, uint32_t n_z, bool explore) {
     MlmSecLds L;
     uint32_t o = 0;
     L.tab = o;      o += TAB * (uint32_t)sizeof(MlmSecCell);
     {
-        // staged chunk descriptors of the record pass; later the list of occupied table entries (L.occ)
-        uint32_t b = 2u * mlm_sec_chunk_cap(big) * 4u;
+        // staged chunk descriptors of the record passes; later the list of occupied table entries (L.occ)
+        uint32_t b = 2u * MLM_SEC_CHUNKS * 4u;
         if (b < TAB * 2u) b = TAB * 2u;
         L.chunk = o;
         o += (b + 15u) & ~15u;
@@ -455,19 +440,15 @@ __host__ __device__ inline MlmSecLds mlm_sec_lds(uint32_t TAB, uint32_t n_miss, 
     L.odds = o;     o += ((2u * MLM_DIFF_RANGE + 1u) * n_rho + 3u) & ~3u; // a byte per entry of the odds table: its strength
     L.sigma = o;    o += ((n_rho + 3u) & ~3u) * 4u;
     L.miss = o;     o += ((n_miss + 3u) & ~3u) * 4u;
-    L.rays = o;     o += TAB * 2u;                       // table entries that start a ray; later the cells whose contributions are ordered
+    L.rays = o;     o += TAB * 2u;                       // table entries that start a ray
     L.occ = L.chunk;                                     // occupied table entries (= the column's unique hits): in the chunk
-                                                         // staging, idle once the records are in LDS (the large-table pass reads
-    if (big) { L.occ = o; o += TAB * 2u; }               // its records from memory and keeps the staging)
+                                                         // staging, idle between the first record pass and the second
     L.multi = o;    if (explore) o += TAB * 4u;          // frontier mode: per table entry, the first point whose hit centre is the cell
     L.ray_p0 = o;   if (explore) o += TAB * 4u;          // frontier mode: first point of every ray start
     o = (o + 15u) & ~15u;
     L.vox = o;      o += (n_rho + n_z) * 16u;            // world voxel per axis: x, y by rho; z by z (see k_sector)
     L.aux = o;      o += n_rho * 24u;                    // per tile run along rho: tile, first rho, hits (count, offset); per rho: miss cells
                                                          // (count -> fill cursor, offset)
-    o = (o + 15u) & ~15u;
-    L.rec = o;      o += (big ? 0u : rec_cap) * 16u;     // the column's records, in pixel-tile order (the large-table pass: from memory)
-    L.ent = o;      o += ent_cap * (big ? 4u : 2u);      // (record, kind) entries of the cells being ordered, a cell's next to each other
     L.total = (o + 15u) & ~15u;
     return L;
 }
@@ -522,6 +503,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     // (the column's first chunk descriptors are requested now and arrive while the tables below are set up: one dependent trip
     // to memory less in a column's life; what lies beyond the count is not looked at)
     mlm_u32x2 chunk_first = mlm_u32x2{0u, 0u};
+    constexpr uint32_t CH = NT < MLM_SEC_CHUNKS ? NT : MLM_SEC_CHUNKS; // chunk descriptors staged per pass: one per thread
     if (threadIdx.x < min(64u, min(nch_all, P.chunk_cap))) // (one wave's worth: a column of a VGA frame has ~50)
         chunk_first = *(const MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.col_chunks) + 2 * ((size_t)phi * P.chunk_cap + threadIdx.x));
     MLM_PHASE_BEGIN
@@ -531,26 +513,18 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     const unsigned int nch = min(nch_all, P.chunk_cap);
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     const uint32_t TAB = BIG ? P.sec_tab_big : P.sec_tab, NMISS = (uint32_t)(P.nZ * (EX ? P.nRho : P.RW));
-    const uint32_t REC_CAP = BIG ? 0xFFFFFFFFu : P.sec_rec_cap, ENT_CAP = BIG ? P.sec_ent_cap_big : P.sec_ent_cap;
-    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, EX, REC_CAP, ENT_CAP, BIG);
+    const MlmSecLds L = mlm_sec_lds(TAB, NMISS, (uint32_t)P.nRho, (uint32_t)P.nZ, EX);
     MlmSecCell *s_tab = (MlmSecCell *)(s_dyn + L.tab);
     uint32_t *s_miss = (uint32_t *)(s_dyn + L.miss);
     uint8_t *s_strength = (uint8_t *)(s_dyn + L.odds); // strength (mlm_sec_strength) of every entry of the odds table: what the booking pass needs of it
     float *s_sigma = (float *)(s_dyn + L.sigma);
     uint16_t *s_rays = (uint16_t *)(s_dyn + L.rays);
-    uint16_t *s_ord = s_rays;                       // (once the rays are walked) the cells whose contributions are ordered: place in s_occ
     uint16_t *s_occ = (uint16_t *)(s_dyn + L.occ);
     uint32_t *s_p0 = (uint32_t *)(s_dyn + L.multi); // (EX only) first point whose hit centre is the cell, per table entry
-    constexpr uint32_t CH = BIG ? 2u * MLM_SEC_CHUNKS : (NT < MLM_SEC_CHUNKS ? NT : MLM_SEC_CHUNKS); // chunk descriptors a column can stage: one per thread
-    static_assert(CH <= (uint32_t)NT, "one chunk descriptor per thread");
     uint32_t *s_chunk_first = (uint32_t *)(s_dyn + L.chunk);
-    uint32_t *s_chunk_start = s_chunk_first + CH;
+    uint32_t *s_chunk_start = s_chunk_first + MLM_SEC_CHUNKS;
     uint32_t *s_ray_p0 = (uint32_t *)(s_dyn + L.ray_p0); // (EX only)
     int4 *s_vr = (int4 *)(s_dyn + L.vox), *s_vz = s_vr + P.nRho;
-    mlm_u32x4 *s_rec = (mlm_u32x4 *)(s_dyn + L.rec); // the column's records (MlmSecRec: cell, tile origin, lane mask), in pixel-tile order
-    typedef typename std::conditional<BIG, uint32_t, uint16_t>::type ent_t;
-    ent_t *s_ent = (ent_t *)(s_dyn + L.ent);         // record << 5 | kind of every contribution group of the cells being ordered
-                                                     // (record: its flat number r in the column; BIG: its index in `bnodes` — both ascend in pixel-tile order)
     // per tile run r along rho: its tile, its first rho, its hits (count, then offset in the column's hit list);
     // per rho: its unique miss cells (count, then fill cursor) and their offset in the column's miss list
     uint32_t *s_run_tile = (uint32_t *)(s_dyn + L.aux), *s_run_rho = s_run_tile + P.nRho, *s_run_hits = s_run_rho + P.nRho,
@@ -558,8 +532,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     __shared__ int s_kr;
     __shared__ uint32_t s_w[4 * (NT / 64)];
     __shared__ uint32_t s_base[8];
-    __shared__ unsigned int s_fail, s_nouter, s_tab_full, s_nord, s_nmulti, s_next_lo;
-    __shared__ uint32_t s_ref_ov[8], s_ref_ov_n; // table entries whose group count wrapped
+    __shared__ unsigned int s_fail, s_nouter, s_tab_full;
+    __shared__ uint32_t s_ref_ov[8], s_ref_ov_n; // table entries whose reference count wrapped
     const MLM_GLOBAL uint32_t *chunks = mlm_gp(P.col_chunks) + 2 * (size_t)phi * P.chunk_cap;
     const MLM_GLOBAL mlm_u32x4 *recs = (const MLM_GLOBAL mlm_u32x4 *)mlm_gp(P.bnodes); // 16-byte column records (k_bin_sectors)
     // flat record r of the staged chunks -> index into `bnodes`
@@ -572,31 +546,17 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         }
         return s_chunk_first[lo] + (r - s_chunk_start[lo]);
     };
-    // Stage the column's chunk descriptors — first record and running record count of each — SORTED by their first record: a chunk
-    // is the run one strip of k_bin_sectors (32 x 8 pixels, or 256 list items) left for this column, strips are numbered in pixel
-    // order and a run is ordered by wave (8 x 8 pixel tile / 64 items), so flat record r of the sorted chunks walks the column's
-    // records in pixel-tile order: records of one tile next to each other, tiles by (row band, column).  That order is what the
-    // in-column ordering of the noisy-OR contributions needs (below).  Returns the records in all.
-    // (rank by counting: a column has a few dozen chunks, every thread compares its own with all of them through LDS broadcasts)
-    auto stage_chunks = [&](uint32_t n_staged) -> uint32_t {
+    // stage the chunk descriptors [c0, c0 + n_staged): first record and running record count of each; returns the records in all
+    auto stage_chunks = [&](uint32_t c0, uint32_t n_staged) -> uint32_t {
         uint32_t total = 0;
         const uint32_t j = threadIdx.x;
         mlm_u32x2 d = mlm_u32x2{0u, 0u};
-        if (j < n_staged) d = j < 64u ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)j);
-        if (j < n_staged) s_chunk_start[j] = d.x;
-        __syncthreads();
-        uint32_t rank = 0;
-        if (j < n_staged)
-            for (uint32_t k = 0; k < n_staged; ++k) rank += s_chunk_start[k] < d.x ? 1u : 0u; // (first records are distinct)
-        __syncthreads();
+        if (j < n_staged) d = (c0 == 0 && j < 64u) ? chunk_first : *(const MLM_GLOBAL mlm_u32x2 *)(chunks + 2 * (size_t)(c0 + j));
+        const uint32_t off = mlm_block_excl_scan<NT / 64>(d.y, s_w, &total);
         if (j < n_staged) {
-            s_chunk_first[rank] = d.x;
-            s_chunk_start[rank] = d.y;
+            s_chunk_first[j] = d.x;
+            s_chunk_start[j] = off;
         }
-        __syncthreads();
-        const uint32_t cnt = j < n_staged ? s_chunk_start[j] : 0u;
-        const uint32_t off = mlm_block_excl_scan<NT / 64>(cnt, s_w, &total);
-        if (j < n_staged) s_chunk_start[j] = off;
         __syncthreads();
         return total;
     };
@@ -606,14 +566,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     // (strength bytes and sigma3 lie in memory as they lie in LDS — MlmDev::sec_const —: one copy, requested together with the chunk
     // descriptors; a lone frame's column would otherwise spend two more trips to memory here)
     for (uint32_t e = threadIdx.x; e < P.sec_const_words; e += NT) ((uint32_t *)(s_dyn + L.odds))[e] = mlm_gp(P.sec_const)[e];
-    // The descriptors are staged and every thread's first record is requested BEFORE the tables are set up: the records
+    // The first descriptors are staged and every thread's first record is requested BEFORE the tables are set up: the records
     // (a trip to HBM, the longest wait of a column's life under load) arrive while the workgroup initialises its LDS.
-    // A column with more chunks or records than its LDS holds is left to the pass with the large tables (like a full cell table).
-    const bool too_many_chunks = nch > CH;
-    const uint32_t n_rec = too_many_chunks ? 0u : stage_chunks(nch);
-    const bool too_big = too_many_chunks || n_rec > REC_CAP;
+    const uint32_t pre_total = stage_chunks(0, min(nch, CH));
     mlm_u32x4 pre_a = mlm_u32x4{0u, 0u, 0u, 0u};
-    if (!too_big && threadIdx.x < n_rec) pre_a = recs[rec_index(threadIdx.x, nch)];
+    if (threadIdx.x < pre_total) pre_a = recs[rec_index(threadIdx.x, min(nch, CH))];
     MLM_PHASE(7);
     for (uint32_t e = threadIdx.x; e < TAB; e += NT) {
         s_tab[e].key = MLM_NIL;
@@ -630,10 +587,8 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     if (threadIdx.x == 0) {
         s_fail = (nch_all > P.chunk_cap || (P.sec_fail_every && (unsigned int)(EX ? F.pad2 : F.seq) % P.sec_fail_every == 0)) ? 1u : 0u;
         s_nouter = 0;
-        s_tab_full = too_big ? 1u : 0u;
+        s_tab_full = 0;
         s_ref_ov_n = 0;
-        s_nord = 0;
-        s_nmulti = 0;
     }
     __syncthreads();
     // Which world voxel a cell of this column falls into (get_global_idx / get_subbox_id of its centre moved by T_wa,
@@ -715,82 +670,165 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         z = (int)(((unsigned long long)key * rho_m) >> rho_s);
         rho = (int)key - z * P.nRho;
     };
-    // ---- booking pass: every record's contributions on the cells of the column (and the rays of points outside the map); the
-    //      records go to LDS on the way.  A thread remembers the table entries of the targets of the record it handled first, so that
-    //      the entry pass below neither recomputes them nor probes the table: (entry | kind << 12) in 16 bits each, four in keep_lo,
-    //      the fifth in keep_hi's low half, the count in its high half (MLM_SEC_KEEP_MORE: more than five targets or a kind above
-    //      15 — the record is recomputed)
+    // pass = 0: book every record's contributions on the cells of the column (and walk the rays of points outside the
+    // map); pass = 1: write a (record, kind) reference for every contribution group of a multi-kind cell.  A thread
+    // keeps the record it handled first: a column with at most NT records (the usual case) is not read twice.
+    uint32_t keep_cell = MLM_NIL, keep_yx = 0, keep_total = 0xFFFFFFFFu;
+    unsigned long long keep_mask = 0;
+    // ... and the table entries of its targets, so that the second pass neither recomputes them nor probes the table:
+    // (entry | kind << 12) in 16 bits each, four in keep_lo, the fifth in keep_hi's low half, the count in its high half
+    // (MLM_SEC_KEEP_MORE: more than five targets or a kind above 15 — the record is recomputed)
     unsigned long long keep_lo = 0;
-    uint32_t keep_hi = MLM_SEC_KEEP_MORE << 16;
-    for (uint32_t r = threadIdx.x; r < n_rec; r += NT) {
-        if (*(volatile unsigned int *)&s_tab_full) break; // (the column is given up: nothing more to book)
-        mlm_u32x4 a = pre_a;
-        if (r != threadIdx.x) a = recs[rec_index(r, nch)];
-        if (!BIG) s_rec[r] = a;
-        const unsigned long long rec_mask = (unsigned long long)a.z | (unsigned long long)a.w << 32;
-#ifdef MLM_PHASE_PROF
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MLM_PHASE(8);
-#endif
-        if (a.x & MLM_SEC_OUTER) { // ray of a point outside the map: one lane walks it into the LDS mask
-            int rho = (int)(a.x & ~MLM_SEC_OUTER), z = (int)a.y;
-            const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
-            if (rho >= P.nRho) {
-                z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
-                rho = P.nRho - 1;
+    uint32_t keep_hi = 0;
+    // the non-empty rows of a group's lane mask, once per record (three bits each): the same for every target cell
+    auto rows_of = [&](unsigned long long mask, uint32_t &rows3, uint32_t &n_rows) {
+        rows3 = 0, n_rows = 0;
+#pragma unroll
+        for (uint32_t row = 0; row < 8u; ++row)
+            if ((uint32_t)(mask >> (8u * row)) & 0xFFu) rows3 |= row << (3u * n_rows++);
+    };
+    auto emit_refs = [&](int e, uint32_t sub, uint32_t yx, unsigned long long mask, uint32_t rows3, uint32_t n_rows) {
+        if (!mlm_sec_needs_order(s_tab[e])) return;
+        // one 4-byte reference per non-empty ROW of the group's lane mask (mlm_ref_pack): row byte, kind, and the row's
+        // position relative to the cell's first pixel — what k_rank needs, with no empty rows in its rounds (a group
+        // touches two or three of its eight rows)
+        // (the count of the cell's references, counted up by the booking pass, is counted down here: every group gets its own
+        // stretch of the cell's segment; the order of the references inside a segment does not matter)
+        const uint32_t left = atomicSub(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS;
+        const uint32_t at = s_base[2] + (s_tab[e].key >> 16) * MLM_SEC_REF_ALIGN + (left - n_rows);
+        const uint32_t pix0 = s_tab[e].tmin / MLM_TIME_SLOTS;
+        const uint32_t y0c = tile_w > 0 ? (uint32_t)(((unsigned long long)pix0 * row_m) >> row_s) : pix0 >> 6;
+        const uint32_t dy0 = (yx >> 11) - y0c; // (>= 0: the cell's first pixel is its contributions' smallest)
+        if (dy0 + 7u > (tile_w > 0 ? MLM_REF_DY_DENSE : MLM_REF_DY_LIST)) {
+            s_fail = 1; // (an image more than 2 047 rows tall below the cell's first pixel: not expressible — the frame falls back)
+        } else if (at + n_rows <= P.refs_cap) {
+            MLM_GLOBAL uint32_t *dst = mlm_gp(P.refs) + at;
+            for (uint32_t k = 0; k < n_rows; ++k) {
+                const uint32_t row = (rows3 >> (3u * k)) & 7u;
+                dst[k] = mlm_ref_pack((uint32_t)(mask >> (8u * row)) & 0xFFu, sub, tile_w > 0, dy0, row, yx & 2047u);
             }
-            const uint32_t p0 = a.z; // the record's first point (EX: several records may start the same ray, the minimum wins)
-            for (int rr = 1; rr < rho; ++rr) {
-                const int zr = mlm_cvt_int(round(z - ((rho - rr) * slope)));
-                if (0 <= zr && zr < P.nZ) {
-                    if (EX) atomicMin(&s_miss[zr * P.nRho + rr], p0 * 256u + (uint32_t)(rho - rr - 1));
-                    else atomicOr(&s_miss[zr * P.RW + (rr >> 5)], 1u << (rr & 31));
+        }
+    };
+    auto refs_of = [&](uint32_t cell, uint32_t yx, unsigned long long mask) {
+        const int z = (int)(cell >> 16), rho = (int)(cell & 0xFFFFu);
+        uint32_t rows3, n_rows;
+        rows_of(mask, rows3, n_rows);
+        mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int) {
+            const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
+            if (e >= 0) emit_refs(e, (uint32_t)sub, yx, mask, rows3, n_rows);
+        });
+    };
+    auto refs_of_kept = [&]() {
+        const uint32_t nt = keep_hi >> 16;
+        if (nt == MLM_SEC_KEEP_MORE) {
+            refs_of(keep_cell, keep_yx, keep_mask);
+            return;
+        }
+        uint32_t rows3, n_rows;
+        rows_of(keep_mask, rows3, n_rows);
+        for (uint32_t k = 0; k < nt; ++k) {
+            const uint32_t t = k < 4u ? (uint32_t)(keep_lo >> (16u * k)) & 0xFFFFu : keep_hi & 0xFFFFu;
+            emit_refs((int)(t & 0xFFFu), t >> 12, keep_yx, keep_mask, rows3, n_rows);
+        }
+    };
+    auto for_records = [&](int pass) {
+        if (pass == 1 && nch <= CH && keep_total <= NT) {
+            if (keep_cell != MLM_NIL) refs_of_kept();
+            return;
+        }
+        for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
+            const uint32_t n_staged = min(nch - c0, CH);
+            uint32_t total = pre_total; // (pass 0, first descriptors: staged before the set-up)
+            if (pass != 0 || c0 != 0) {
+                __syncthreads();
+                total = stage_chunks(c0, n_staged);
+            }
+            for (uint32_t r = threadIdx.x; r < total; r += NT) {
+                if (pass == 0 && *(volatile unsigned int *)&s_tab_full) break; // (the column is given up: nothing more to book)
+                mlm_u32x4 a = pre_a;
+                if (pass != 0 || c0 != 0 || r != threadIdx.x) a = recs[rec_index(r, n_staged)];
+                const unsigned long long rec_mask = (unsigned long long)a.z | (unsigned long long)a.w << 32;
+#ifdef MLM_PHASE_PROF
+                if (pass == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    MLM_PHASE(8);
+                }
+#endif
+                if (a.x & MLM_SEC_OUTER) {
+                    if (pass == 0) { // ray of a point outside the map: one lane walks it into the LDS mask
+                        int rho = (int)(a.x & ~MLM_SEC_OUTER), z = (int)a.y;
+                        const double slope = (rho > 0) ? (z - P.zc) / (rho * 1.0) : 0.0;
+                        if (rho >= P.nRho) {
+                            z = mlm_cvt_int(round(z - ((rho - P.nRho + 1) * slope)));
+                            rho = P.nRho - 1;
+                        }
+                        const uint32_t p0 = a.z; // the record's first point (EX: several records may start the same ray, the minimum wins)
+                        for (int rr = 1; rr < rho; ++rr) {
+                            const int zr = mlm_cvt_int(round(z - ((rho - rr) * slope)));
+                            if (0 <= zr && zr < P.nZ) {
+                                if (EX) atomicMin(&s_miss[zr * P.nRho + rr], p0 * 256u + (uint32_t)(rho - rr - 1));
+                                else atomicOr(&s_miss[zr * P.RW + (rr >> 5)], 1u << (rr & 31));
+                            }
+                        }
+                        atomicAdd(&s_nouter, 1u);
+                    }
+                    continue;
+                }
+                const uint32_t cell = a.x;
+                if (pass == 1) {
+                    refs_of(cell, a.y, rec_mask);
+                    continue;
+                }
+                const int z = (int)(cell >> 16), rho = (int)(cell & 0xFFFFu);
+                {
+                    const unsigned long long mask = rec_mask;
+                    const bool kept = c0 == 0 && r == threadIdx.x;
+                    if (kept) {
+                        keep_cell = cell;
+                        keep_yx = a.y;
+                        keep_mask = mask;
+                    }
+                    uint32_t nt = 0;
+                    const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
+                    // (the wave's first work item from the tile origin: dense y0 * width + x0, lists 64 items per "row")
+                    const uint32_t i00 = tile_w > 0 ? (a.y >> 11) * (uint32_t)tile_w + (a.y & 2047u) : (a.y >> 11) << 6;
+                    const uint32_t i_first = i00 + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
+                    const uint32_t cnt = (uint32_t)__popcll(mask), n_rows = mlm_mask_rows(mask);
+                    mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int rho_t) {
+                        const int e = mlm_sec_entry<true>(s_tab, tab_mask, key);
+                        if (e < 0) {
+                            s_tab_full = 1;
+                            return;
+                        }
+                        if (kept) {
+                            const uint32_t t = (uint32_t)e | (uint32_t)sub << 12;
+                            if (nt < 4u) keep_lo |= (unsigned long long)t << (16u * nt);
+                            else keep_hi |= t & 0xFFFFu;
+                            if (nt >= 5u || sub > 15) nt = MLM_SEC_KEEP_MORE - 1u;
+                            ++nt;
+                        }
+                        atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
+                        atomicOr(&s_tab[e].kg, 1u << sub);
+                        // contributions, and in the upper 11 bits (mod 2048) the sum of their strengths (mlm_sec_needs_order)
+                        const uint32_t strength = s_strength[mlm_contribution_index(P, rho_t, sub)];
+                        atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
+                        if ((atomicAdd(&s_tab[e].kg, n_rows << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) + n_rows > (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) {
+                            // more than 2 047 references: the count has wrapped.  That happens to cells a few decimetres in front of
+                            // the sensor (thousands of pixels), which have one kind or saturate and need no references at all: the entry
+                            // is remembered and the frame only gives up if such a cell does need its order (checked below)
+                            const uint32_t k = atomicAdd(&s_ref_ov_n, 1u);
+                            if (k < 8u) s_ref_ov[k] = (uint32_t)e;
+                        }
+                        if (EX && sub == 0) atomicMin(&s_p0[e], i_first);
+                    });
+                    if (kept) keep_hi |= nt << 16;
                 }
             }
-            atomicAdd(&s_nouter, 1u);
-            continue;
+            if (pass == 0 && c0 == 0) keep_total = total;
         }
-        const uint32_t cell = a.x;
-        const int z = (int)(cell >> 16), rho = (int)(cell & 0xFFFFu);
-        const unsigned long long mask = rec_mask;
-        const bool kept = r == threadIdx.x;
-        uint32_t nt = 0;
-        if (kept) keep_hi = 0;
-        const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
-        // (the wave's first work item from the tile origin: dense y0 * width + x0, lists 64 items per "row")
-        const uint32_t i00 = tile_w > 0 ? (a.y >> 11) * (uint32_t)tile_w + (a.y & 2047u) : (a.y >> 11) << 6;
-        const uint32_t i_first = i00 + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
-        const uint32_t cnt = (uint32_t)__popcll(mask);
-        mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int rho_t) {
-            const int e = mlm_sec_entry<true>(s_tab, tab_mask, key);
-            if (e < 0) {
-                s_tab_full = 1;
-                return;
-            }
-            if (kept) {
-                const uint32_t t = (uint32_t)e | (uint32_t)sub << 12;
-                if (nt < 4u) keep_lo |= (unsigned long long)t << (16u * nt);
-                else keep_hi |= t & 0xFFFFu;
-                if (nt >= 5u || sub > 15) nt = MLM_SEC_KEEP_MORE - 1u;
-                ++nt;
-            }
-            atomicMin(&s_tab[e].tmin, i_first * MLM_TIME_SLOTS + (uint32_t)sub);
-            atomicOr(&s_tab[e].kg, 1u << sub);
-            // contributions, and in the upper 11 bits (mod 2048) the sum of their strengths (mlm_sec_needs_order)
-            const uint32_t strength = s_strength[mlm_contribution_index(P, rho_t, sub)];
-            atomicAdd(&s_tab[e].cnt, cnt | ((cnt * strength) << MLM_SEC_CNT_BITS));
-            // (record, kind) groups of the cell, counted above its kinds
-            if ((atomicAdd(&s_tab[e].kg, 1u << MLM_SEC_KIND_BITS) >> MLM_SEC_KIND_BITS) + 1u > (0xFFFFFFFFu >> MLM_SEC_KIND_BITS)) {
-                // more than 2 047 groups: the count has wrapped.  That happens to cells a few decimetres in front of
-                // the sensor (thousands of pixels), which have one kind or saturate and need no order at all: the entry
-                // is remembered and the frame only gives up if such a cell does need its order (checked below)
-                const uint32_t k = atomicAdd(&s_ref_ov_n, 1u);
-                if (k < 8u) s_ref_ov[k] = (uint32_t)e;
-            }
-            if (EX && sub == 0) atomicMin(&s_p0[e], i_first);
-        });
-        if (kept) keep_hi |= nt << 16;
-    }
+    };
+    __syncthreads();
+    for_records(0);
     __syncthreads();
     if (s_tab_full) { // (uniform) nothing has left the workgroup yet
         if (threadIdx.x == 0) {
@@ -812,19 +850,19 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         }
         return;
     }
-    if (threadIdx.x == 0 && s_ref_ov_n) { // (see the booking pass: a wrapped group count only matters for a cell that needs its order)
+    if (threadIdx.x == 0 && s_ref_ov_n) { // (see the booking pass: a wrapped reference count only matters for a cell that needs its order)
         if (s_ref_ov_n > 8u) s_fail = 1;
         for (uint32_t k = 0; k < min(s_ref_ov_n, 8u); ++k)
             if (mlm_sec_needs_order(s_tab[s_ref_ov[k]])) s_fail = 1;
     }
     MLM_PHASE(1);
     // ---- lists of the occupied entries (= the column's unique hits), of those with several kinds, of the ray starts;
-    //      the column's reservation in the frame's hit list (one round trip)
+    //      the column's reservations in the frame's lists (one round trip)
     //      The hit list is ordered by tile run (the hits of one tile are contiguous): rank inside the run from a returning
     //      LDS atomic, the runs' offsets from the same block scan that places the other lists.
     const uint32_t per = TAB / NT; // entries e = threadIdx.x * per + q: contiguous per thread (per <= PER_MAX)
-    uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, entries of the cells that need their order, ray starts, hits of tile run `threadIdx.x`
-    uint32_t n_ord_mine = 0;
+    uint32_t v[4] = {0u, 0u, 0u, 0u}; // occupied, multi, ray starts, hits of tile run `threadIdx.x`
+    uint32_t w[4] = {0u, 0u, 0u, 0u}; // reference slots (a cell's count rounded up to MLM_SEC_REF_ALIGN) / ordered-kinds slots of this thread's multi-kind cells
     uint32_t hk[PER_MAX];           // this thread's entries: rank among their tile run's hits
     uint32_t p0r[EX ? PER_MAX : 1]; // (EX) first point whose centre is the cell
 #pragma unroll
@@ -836,9 +874,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         ++v[0];
         v[2] += c.kg & 1u;
         if (mlm_sec_needs_order(c)) {
-            ++n_ord_mine;
-            v[1] += c.kg >> MLM_SEC_KIND_BITS;
-            if ((c.kg >> MLM_SEC_KIND_BITS) > ENT_CAP) s_fail = 1; // (a cell's entries do not fit a round: cannot happen with 2 048 entries or more)
+            ++v[1];
+            w[0] += ((c.kg >> MLM_SEC_KIND_BITS) + MLM_SEC_REF_ALIGN - 1u) & ~(MLM_SEC_REF_ALIGN - 1u);
+            w[1] += ((c.cnt & MLM_SEC_CNT_MASK) + 15u) & ~15u;
         }
         if (EX) { // (frontier mode has no tiles: the hits keep the table's order)
             hk[q] = v[0] - 1u;
@@ -851,24 +889,25 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     }
     __syncthreads(); // (the runs' hit counts are complete)
     if ((int)threadIdx.x < n_run) v[3] = s_run_hits[threadIdx.x]; // (n_run <= nRho <= NT)
-    uint32_t tot[4];
+    uint32_t tot[4], wtot[4];
     mlm_block_excl_scan4<NT / 64>(v, s_w, tot);
+    mlm_block_excl_scan4<NT / 64>(w, s_w, wtot);
     if ((int)threadIdx.x < n_run) s_run_off[threadIdx.x] = v[3];
-    const uint32_t n_occ = tot[0], n_ent = tot[1], n_rays = P.visibility ? tot[2] : 0u;
+    const uint32_t n_occ = tot[0], n_multi = tot[1], n_rays = P.visibility ? tot[2] : 0u;
+    const uint32_t tot_refs = wtot[0], tot_subs = wtot[1];
     if (threadIdx.x == 0) {
         s_base[0] = n_occ ? g_atomic_add(&mlm_gp(P.ctr)->u_hit, n_occ) : 0u;
-        // (a cell's segment start is kept in 16 bits)
-        if (n_ent >= 65536u) s_fail = 1;
+        s_base[1] = n_multi ? g_atomic_add(&mlm_gp(P.ctr)->n_multi, n_multi) : 0u;
+        s_base[2] = tot_refs ? g_atomic_add(&mlm_gp(P.ctr)->n_refs, tot_refs) : 0u;
+        s_base[3] = tot_subs ? g_atomic_add(&mlm_gp(P.ctr)->n_contrib, tot_subs) : 0u;
+        // (a cell's segment start is kept in 16 bits, in units of MLM_SEC_REF_ALIGN references from the column's first)
+        if (tot_refs >= 65536u * MLM_SEC_REF_ALIGN) s_fail = 1;
         // (the frame's lists are sized by need: a column that does not fit writes nothing — s_fail 2, the slots are enlarged and the
         // frame's Stage A runs again)
-        if (s_base[0] + n_occ > P.hl_cap) s_fail = 2;
+        if (s_base[0] + n_occ > P.hl_cap || s_base[1] + n_multi > P.mt_cap || s_base[2] + tot_refs > P.refs_cap || s_base[3] + tot_subs > P.contrib_cap)
+            s_fail = 2;
     }
-    if (n_ord_mine) atomicAdd(&s_nmulti, n_ord_mine);
-    __syncthreads(); // (the runs' offsets and the column's place in the frame's hit list are visible)
-    if (threadIdx.x == 0 && n_ent && !s_fail) { // statistics (fire and forget): cells whose contributions are ordered here, their (record, kind) groups
-        __hip_atomic_fetch_add(&mlm_gp(P.ctr)->n_multi, s_nmulti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&mlm_gp(P.ctr)->n_refs, n_ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __syncthreads(); // (the runs' offsets and the column's places in the frame's lists are visible)
     MLM_PHASE(2);
     if (s_fail) { // a table of this column overflowed: the frame is redone (uniform branch)
         if (threadIdx.x == 0) {
@@ -879,10 +918,10 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     }
     // ---- lists of the occupied entries (= the column's unique hits, ordered by tile run: the hits of one tile are contiguous;
     //      rank inside the run from the returning LDS atomic above, the runs' offsets from the block scan) and of the ray starts;
-    //      a cell that needs its order learns where its entries start (key's upper half) — the thread that owns a table entry
-    //      knows all of it (places from the scans above)
+    //      multi-kind cells that need their order: segments in `refs` and `subs`, descriptors for k_rank / k_chain_lanes — the
+    //      thread that owns a table entry knows all of it (places from the scans above)
     {
-        uint32_t o_rays = v[2], o_ent = v[1];
+        uint32_t o_multi = v[1], o_rays = v[2], o_refs = w[0], o_subs = w[1];
 #pragma unroll
         for (uint32_t q = 0; q < (uint32_t)PER_MAX; ++q) {
             if (q >= per) break;
@@ -898,8 +937,15 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             const uint32_t place = (EX ? v[0] : s_run_off[s_vr[c_rho].w]) + hk[q];
             s_occ[place] = (uint16_t)e;
             if (mlm_sec_needs_order(c)) {
-                c.key = (c.key & MLM_SEC_KEY_MASK) | (o_ent << 16);
-                o_ent += c.kg >> MLM_SEC_KIND_BITS;
+                const uint32_t n_ref = c.kg >> MLM_SEC_KIND_BITS, n_con = c.cnt & MLM_SEC_CNT_MASK;
+                const uint32_t pos = s_base[0] + place, m = s_base[1] + o_multi, g_refs = s_base[2] + o_refs, g_subs = s_base[3] + o_subs;
+                // (contributions | rho << 20: what k_chain_lanes needs of the cell comes with one load)
+                *(MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.mt_rec) + m) = mlm_u32x4{pos, g_subs, n_con | ((uint32_t)c_rho << MLM_SEC_CNT_BITS), c.tmin};
+                *(MLM_GLOBAL mlm_u32x2 *)(mlm_gp(P.mt_ref) + 2 * (size_t)m) = mlm_u32x2{g_refs, n_ref};
+                c.key = (c.key & MLM_SEC_KEY_MASK) | ((o_refs / MLM_SEC_REF_ALIGN) << 16);
+                ++o_multi;
+                o_refs += (n_ref + MLM_SEC_REF_ALIGN - 1u) & ~(MLM_SEC_REF_ALIGN - 1u);
+                o_subs += (n_con + 15u) & ~15u;
             }
         }
     }
@@ -988,11 +1034,10 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     __syncthreads(); // (the miss mask is complete)
     MLM_PHASE(3);
     // ---- the column's unique hits (ordered by tile run): cell, first-touch time, voxel-in-tile index; single-kind cells get
-    //      their odd and increment here, cells whose contributions have to be ordered are listed (s_ord: the ray starts are done with)
+    //      their odd and increment here (multi-kind cells: k_rank / k_chain_lanes)
     const unsigned int sl = blockIdx.x & 7;
     for (uint32_t i = threadIdx.x; i < n_occ; i += NT) {
-        const uint32_t e_i = s_occ[i];
-        const MlmSecCell c = s_tab[e_i];
+        const MlmSecCell c = s_tab[s_occ[i]];
         int rho, z;
         key_rz(c.key & MLM_SEC_KEY_MASK, rho, z);
         const uint32_t pos = s_base[0] + i;
@@ -1017,9 +1062,6 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
             }
             if (EX || P.record_awareness) mlm_gp(P.hl_odd)[pos] = p; // (the odd itself is only read back by mlm_get_awareness_hits)
             mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
-        } else {
-            s_ord[atomicAdd(&s_nord, 1u)] = (uint16_t)i;
-            s_tab[e_i].tmin = 0u; // (from here on: the fill cursor of the cell's entries)
         }
         if (EX) { // frontier mode: the hit's world voxel (its kernels look the block up themselves)
             int gx, gy, gz, cid;
@@ -1032,140 +1074,15 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         // its voxel (k_tile groups the frame's hits and misses by voxel, tile by tile) and the bucket-first time of the
         // emulated container (iteration order, see Stage B in mlm_kernels.h) for the bucket count the frame was submitted with
         mlm_gp(P.hl_vt16)[pos] = (uint16_t)(s_vr[rho].y * P.lv_nz + s_vz[z].x);
-        // (a fire-and-forget atomic: measured 32-byte transactions, 1.2 MB per VGA frame with k_tile's read-back — walking the hit
+        // (a fire-and-forget atomic: measured 32-byte transactions, 1.2 MB per VGA frame with k_rank's read-back — walking the hit
         // list once per class of buckets with the minima in LDS instead, profiles/r4c, cost 4.6 MB of re-reads and 2.5 us per frame)
         const unsigned long long b = mlm_hash_rpz(rho, phi, z) % n_bkt;
         mlm_gp(P.hl_bkt)[pos] = (uint32_t)b;
         if (b < P.sbkt_cap) g_atomic_min(&mlm_gp(P.sbkt)[b], mlm_bkt_entry(F.seq, c.tmin));
     }
     MLM_PHASE(4);
-    // ---- The float noisy-OR chain of a cell with several kinds of contributions (update_odds_hashmap, map_awareness.h:147-154:
-    //      p <- 1 - (1 - p)(1 - a), every operation rounded) depends on the ORDER of its contributions, which is the order of their
-    //      pixels (a pixel contributes to a cell at most once; update_hits, map_awareness.cpp:135-171).  The column orders them itself:
-    //      every (record, kind) group that contributes to such a cell leaves one entry — record << 5 | kind — in the cell's own stretch
-    //      of s_ent; the records lie in LDS in pixel-tile order (stage_chunks), so a cell's entries sorted by VALUE are its groups by
-    //      tile: tiles of one row band of eight image rows next to each other and ordered by column, groups of one tile next to each
-    //      other.  ONE LANE per cell then sorts its few entries and walks them band by band, image row by image row, tile by tile,
-    //      bit by bit of the groups' lane masks — pixel order — and runs the chain on the way.  (List modes: a "tile" is a run of 64
-    //      items, a band holds one tile, the eight "rows" of its mask are eight items each.)
-    //      Rounds: s_ent holds ENT_CAP entries; a round takes the cells — in segment order — whose entries fit from s_lo on.
-    __syncthreads(); // (the list of those cells is complete, their cursors are reset)
-    {
-        const uint32_t n_ord = s_nord;
-        const MLM_GLOBAL float *odds = mlm_gp(P.odds_table);
-        auto rec_yx = [&](uint32_t rec) -> uint32_t { return BIG ? ((const MLM_GLOBAL uint32_t *)(recs + rec))[1] : ((const uint32_t *)(s_rec + rec))[1]; };
-        auto rec_row = [&](uint32_t rec, uint32_t row) -> uint32_t {
-            return BIG ? (uint32_t)((const MLM_GLOBAL uint8_t *)(recs + rec))[8u + row] : (uint32_t)((const uint8_t *)(s_rec + rec))[8u + row];
-        };
-        uint32_t lo = 0;
-        while (n_ord && lo != 0xFFFFFFFFu) { // (uniform)
-            if (threadIdx.x == 0) s_next_lo = 0xFFFFFFFFu;
-            // entries of this round's cells: a (record, kind) group finds its place in the cell's stretch with the cell's cursor
-            auto emit = [&](uint32_t e, uint32_t sub, uint32_t rid) {
-                const MlmSecCell c = s_tab[e];
-                if (!mlm_sec_needs_order(c)) return;
-                const uint32_t seg = c.key >> 16, ng = c.kg >> MLM_SEC_KIND_BITS;
-                if (seg < lo || seg + ng > lo + ENT_CAP) return;
-                const uint32_t k = atomicAdd(&s_tab[e].tmin, 1u);
-                s_ent[seg - lo + k] = (ent_t)((rid << MLM_SEC_ENT_KIND_BITS) | sub);
-            };
-            for (uint32_t r = threadIdx.x; r < n_rec; r += NT) {
-                const uint32_t nt = keep_hi >> 16;
-                const uint32_t rid = BIG ? rec_index(r, nch) : r;
-                if (r == threadIdx.x && nt != MLM_SEC_KEEP_MORE) { // (its targets' table entries are remembered)
-                    for (uint32_t k = 0; k < nt; ++k) {
-                        const uint32_t t = k < 4u ? (uint32_t)(keep_lo >> (16u * k)) & 0xFFFFu : keep_hi & 0xFFFFu;
-                        emit(t & 0xFFFu, t >> 12, rid);
-                    }
-                    continue;
-                }
-                const uint32_t cell = BIG ? ((const MLM_GLOBAL uint32_t *)(recs + rid))[0] : ((const uint32_t *)(s_rec + r))[0];
-                if (cell & MLM_SEC_OUTER) continue;
-                const int z = (int)(cell >> 16), rho = (int)(cell & 0xFFFFu);
-                mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int) {
-                    const int e = mlm_sec_entry<false>(s_tab, tab_mask, key);
-                    if (e >= 0) emit((uint32_t)e, (uint32_t)sub, rid);
-                });
-            }
-            __syncthreads();
-            for (uint32_t m = threadIdx.x; m < n_ord; m += NT) {
-                const uint32_t place = s_ord[m];
-                const MlmSecCell c = s_tab[s_occ[place]];
-                const uint32_t seg = c.key >> 16, ng = c.kg >> MLM_SEC_KIND_BITS;
-                if (seg < lo) continue; // (done in an earlier round)
-                if (seg + ng > lo + ENT_CAP) {
-                    atomicMin(&s_next_lo, seg); // (the next round starts with the first cell that did not fit)
-                    continue;
-                }
-                int rho, z;
-                key_rz(c.key & MLM_SEC_KEY_MASK, rho, z);
-                ent_t *E = s_ent + (seg - lo);
-                // the cell's entries by value (they arrive almost in order: the records were handled in order)
-                for (uint32_t a = 1; a < ng; ++a) {
-                    const ent_t x = E[a];
-                    uint32_t b = a;
-                    while (b > 0 && E[b - 1] > x) {
-                        E[b] = E[b - 1];
-                        --b;
-                    }
-                    E[b] = x;
-                }
-                float p = 0.0f;
-                bool first = true;
-                auto step = [&](float a) {
-                    p = first ? a : 1 - (1 - p) * (1 - a);
-                    first = false;
-                };
-                auto odd_of = [&](uint32_t kind) -> float { return odds[mlm_contribution_index(P, rho, (int)kind)]; };
-                uint32_t i = 0;
-                while (i < ng && p != 1.0f) { // (1.0f is absorbing)
-                    // the groups of one row band: [i, j)
-                    const uint32_t band = rec_yx((uint32_t)E[i] >> MLM_SEC_ENT_KIND_BITS) >> 11;
-                    uint32_t j = i + 1;
-                    while (j < ng && (rec_yx((uint32_t)E[j] >> MLM_SEC_ENT_KIND_BITS) >> 11) == band) ++j;
-                    for (uint32_t row = 0; row < 8u && p != 1.0f; ++row) {
-                        uint32_t g = i;
-                        while (g < j) {
-                            // the groups of one tile: [g, g2) — their lanes of this row, merged in lane order
-                            const uint32_t eg = E[g], rg = eg >> MLM_SEC_ENT_KIND_BITS, yx = rec_yx(rg);
-                            const uint32_t bg = rec_row(rg, row);
-                            uint32_t u = bg, g2 = g + 1;
-                            while (g2 < j && rec_yx((uint32_t)E[g2] >> MLM_SEC_ENT_KIND_BITS) == yx) {
-                                u |= rec_row((uint32_t)E[g2] >> MLM_SEC_ENT_KIND_BITS, row);
-                                ++g2;
-                            }
-                            if (u) {
-                                if (g2 == g + 1) {
-                                    const float a = odd_of(eg & ((1u << MLM_SEC_ENT_KIND_BITS) - 1u));
-                                    for (uint32_t k = (uint32_t)__popc(bg); k && p != 1.0f; --k) step(a);
-                                } else {
-                                    while (u && p != 1.0f) {
-                                        const uint32_t bit = u & (0u - u);
-                                        u &= u - 1u;
-                                        for (uint32_t h = g; h < g2; ++h) {
-                                            const uint32_t eh = E[h];
-                                            if (rec_row(eh >> MLM_SEC_ENT_KIND_BITS, row) & bit) {
-                                                step(odd_of(eh & ((1u << MLM_SEC_ENT_KIND_BITS) - 1u)));
-                                                break;
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                            g = g2;
-                        }
-                    }
-                    i = j;
-                }
-                const uint32_t pos = s_base[0] + place;
-                if (EX || P.record_awareness) mlm_gp(P.hl_odd)[pos] = p;
-                mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
-            }
-            __syncthreads();
-            lo = s_next_lo;
-            __syncthreads(); // (s_next_lo is reset at the top of the next round)
-        }
-    }
+    // ---- references of the multi-kind cells (their fill cursors were set above)
+    if (n_multi) for_records(1);
     MLM_PHASE(5);
     if (EX) {
         // frontier mode: the unique miss list with insertion times and world voxels (what k_ex_collect_misses leaves);
@@ -1873,15 +1790,6 @@ __host__ __device__ inline MlmTileLds mlm_tile_lds(uint32_t n_vox, uint32_t lv_n
     L.total = (o + 15u) & ~15u;
     return L;
 }
-// Iteration-order key of unique hit `pos` of the frame, valid if the frame fits the emulated container without a rehash (the apply
-// kernels check): (first insertion time of the hit's bucket, its own insertion time) — the bucket-first table of the slot is complete
-// once every column of the frame has been through k_sector (a kernel boundary).  A replayed frame's exact keys are in hl_key instead.
-__device__ __forceinline__ unsigned long long mlm_spec_key(const MlmDev &P, uint32_t pos) {
-    const uint32_t b = mlm_gp(P.hl_bkt)[pos];
-    const uint32_t vt = mlm_gp(P.hl_vt)[pos];
-    const unsigned long long first = b < P.sbkt_cap ? mlm_gp(P.sbkt)[b] & 0xFFFFFFFFull : 0ull;
-    return ((first + 1ull) << 32) | (unsigned long long)vt;
-}
 // colw: the tile's column mask (MlmDev::tile_words words, in LDS): bit phi = column phi left a descriptor in its slot
 __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F, const unsigned int tile, const uint32_t *colw) {
     const MLM_GLOBAL mlm_u32x4 *descs = (const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.tile_desc) + 4 * (size_t)tile * (size_t)P.nPhi);
@@ -2049,7 +1957,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
                         keep_pos[q] = pos;
                         keep_v[q] = v;
                         keep_inc[q] = mlm_gp(P.hl_inc)[pos];
-                        keep_key[q] = mlm_spec_key(P, pos);
+                        keep_key[q] = mlm_gp(P.hl_key)[pos];
                         if (v < NV) atomicAdd(&s_cnt[v], 0x10000u);
                         else s_fail = 1;
                     } else if (keep_v[q] < NV) {
@@ -2068,7 +1976,7 @@ __device__ __forceinline__ void mlm_tile_one(const MlmDev &P, const MlmFrame &F,
                     continue;
                 }
                 if (what == 0) atomicAdd(&s_cnt[v], 0x10000u);
-                else place_hit(pos, v, mlm_gp(P.hl_inc)[pos], mlm_spec_key(P, pos));
+                else place_hit(pos, v, mlm_gp(P.hl_inc)[pos], mlm_gp(P.hl_key)[pos]);
             }
         }
     };

@@ -204,7 +204,7 @@ int upload_slot_tab(mlm_handle *h) {
 int widen_sec_tab(mlm_handle *h) {
     MlmDev &P = h->P;
     const unsigned int tab = P.sec_tab * 2u, n_miss = (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW));
-    const unsigned int lds = mlm_sec_lds(tab, n_miss, (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore, P.sec_rec_cap, P.sec_ent_cap, false).total;
+    const unsigned int lds = mlm_sec_lds(tab, n_miss, (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
     const int nt = h->sec_threads == 256 && tab <= 1024u ? 256 : 512;
     if (!h->use_sectors || tab > 2048u || tab > 4u * (unsigned int)nt || lds > 159u * 1024u || (P.sec_tab_big && tab >= P.sec_tab_big)) return MLM_OK;
     {

@@ -255,7 +255,19 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
                 tlaunch(h, "k_sector_big", k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, n,
                         mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
         }
-        // the frame's hits and misses grouped by voxel, tile by tile (needs every column's increments and bucket-first times)
+        tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->rank_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
+                mode == 0 ? F.width : 0, row_w, dm, ds);
+        // blocks per frame: about 400 ranked cells per block in a batch (a lane that finishes a chain draws the next cell; each
+        // block builds the transposed odds table in LDS), as many as the last confirmed frame had; single frames spread wider
+        unsigned int cg = h->chain_grid;
+        if (!cg) {
+            const long long cells = std::max<long long>(1, h->stats.n_multi_cells);
+            cg = n > 4 ? (unsigned int)std::min<long long>(64, std::max<long long>(8, cells / 400)) : (unsigned int)std::min<long long>(128, std::max<long long>(16, cells / 128));
+        }
+        if (!h->no_spread)
+            tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
+                base, n > 4 ? 128u : 64u);
+        // the frame's hits and misses grouped by voxel, tile by tile (needs the increments and keys of the kernels above)
         if (!P.explore)
             tlaunch(h, "k_tile", k_tile, dim3(n > 1 ? h->tile_grid : (unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, n), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     }

@@ -220,8 +220,6 @@ struct MlmDev {
     unsigned int chunk_cap;
     unsigned int sec_tab, sec_lds_bytes; // LDS sizing of k_sector: cell table entries (power of two)
     unsigned int sec_tab_big, sec_big_lds_bytes; // ... of k_sector_big (0 entries: no second pass)
-    unsigned int sec_rec_cap, sec_ent_cap;       // k_sector: records a column keeps in LDS; (record, kind) entries of the cells it orders per round
-    unsigned int sec_ent_cap_big;                // ... of k_sector_big (it reads the records from memory)
     uint32_t *ov_list;         // [nPhi] columns whose cell table overflowed in k_sector (count: MlmCounters::n_ov)
     unsigned int sec_fail_every;         // test hook (MLM_SEC_FAIL_EVERY=k): every k-th frame is made to fall back
     uint32_t *refs;            // [refs_cap] one 4-byte reference (mlm_ref_pack: row byte, kind, position relative to the cell's first pixel) per

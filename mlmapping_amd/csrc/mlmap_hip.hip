@@ -305,22 +305,15 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (P.sec_tab < (unsigned int)h->sec_threads) P.sec_tab = (unsigned int)h->sec_threads;
         if (knob("sec_backoff", kv)) h->sector_backoff_len = std::max(0, (int)kv);
         if (knob("sec_fail_every", kv)) P.sec_fail_every = (unsigned int)std::max(0, (int)kv);
-        // the column orders the contributions of its multi-kind cells itself: its records in LDS (two per thread; a column with more is
-        // left to the large-table pass) and the (record, kind) entries of the cells of a round (at least 2 048: a cell has at most 2 047)
-        P.sec_rec_cap = std::min(2048u, 2u * (unsigned int)h->sec_threads);
-        if (knob("sec_rec_cap", kv)) P.sec_rec_cap = (unsigned int)std::min(2048, std::max(64, (int)kv));
-        P.sec_ent_cap = P.sec_tab >= 2048u ? 4096u : 2048u;
-        if (knob("sec_ent_cap", kv)) P.sec_ent_cap = (unsigned int)std::max(64, (int)kv);
-        P.sec_ent_cap_big = 8192u;
-        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore, P.sec_rec_cap, P.sec_ent_cap, false).total;
+        P.sec_lds_bytes = mlm_sec_lds(P.sec_tab, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total;
         {
             // second pass for the columns that overflow that table: the largest table (up to 4096 entries = 8 per thread) that
             // fits a CU's LDS — an S1 column has 2 665 cells in all, so no scene overflows it there
             unsigned int big = 4096;
-            while (big > P.sec_tab && mlm_sec_lds(big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore, 0u, P.sec_ent_cap_big, true).total > 159u * 1024u) big >>= 1;
+            while (big > P.sec_tab && mlm_sec_lds(big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total > 159u * 1024u) big >>= 1;
             if (knob("sec_tab_big", kv)) big = (unsigned int)(int)kv; // (0 or <= MLM_SEC_TAB: no second pass)
             P.sec_tab_big = big > P.sec_tab && big <= 8u * MLM_SEC_THREADS ? big : 0u;
-            P.sec_big_lds_bytes = P.sec_tab_big ? mlm_sec_lds(P.sec_tab_big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore, 0u, P.sec_ent_cap_big, true).total : 0u;
+            P.sec_big_lds_bytes = P.sec_tab_big ? mlm_sec_lds(P.sec_tab_big, (unsigned int)(P.nZ * (P.explore ? P.nRho : P.RW)), (unsigned int)P.nRho, (unsigned int)P.nZ, P.explore).total : 0u;
         }
         {
             // frame-local voxel grid: the awareness cylinder (radius nRho*dRho, height nZ*dZ) plus four voxels each side, cut
