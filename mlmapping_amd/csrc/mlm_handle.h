@@ -25,7 +25,7 @@ struct KernelTime {
 // simulated allocation failures.  Process-wide, not part of the drop-in contract; the library reads no environment variable
 // for them (only the three diagnostic switches MLM_DEBUG_CREATE / MLM_DEBUG_ALLOC / MLM_DEBUG_DRAIN, which print).
 const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
-                                  "debug_fail_slot", "ex_spec", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "need_slots", "node_lds", "pool_grow",
+                                  "debug_fail_slot", "ex_spec", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "mirror_mb", "need_slots", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
                                   "sectors", "single_chain_grid", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
@@ -77,6 +77,9 @@ struct MlmMirror {
     int max_clean = 256;           // largest batch answered on the host while the mirror is up to date (knob "mirror_max") ...
     int max_dirty = 32;            // ... and while it needs a refresh first (a large batch is then cheaper as one kernel)
     size_t cap = 0;                // blocks the planes hold
+    size_t max_bytes = (size_t)1 << 30; // most pinned host memory the planes may take (mlm_set_host_mirror_limit; knob "mirror_mb"): a map
+                                   // that needs more is queried by kernels only (over_limit) — nothing is pinned behind the caller's back without bound
+    bool over_limit = false;
     float *lo = nullptr;           // [cap * cells] pinned, device-visible
     uint8_t *occ = nullptr, *infl = nullptr; // [cap * cells]
     uint8_t *col = nullptr;        // [cap] released ("collapsed") blocks: element 0 answers

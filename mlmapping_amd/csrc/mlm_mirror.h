@@ -74,23 +74,55 @@ int mirror_reserve(mlm_handle *h, size_t blocks) {
         std::memset(M.stat, 0, (2 + kMirrorGrid) * sizeof(unsigned int));
     }
     if (blocks <= M.cap) return MLM_OK;
-    mirror_free(h); // (the planes are refilled from the device: everything is dirty)
     const size_t cap = std::max<size_t>(256, blocks), C = (size_t)h->P.cells;
-    hipError_t e = hipHostMalloc((void **)&M.lo, cap * C * sizeof(float), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&M.occ, cap * C, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&M.infl, cap * C, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&M.col, cap, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&M.keys, cap * 3 * sizeof(int), hipHostMallocDefault);
+    if (cap * (C * 6 + 13) > M.max_bytes) { // (the map has outgrown what the caller lets the mirror pin: small queries run as kernels from now on)
+        mirror_free(h);
+        M.over_limit = true;
+        M.enabled = false;
+        return MLM_OK;
+    }
+    // New planes; what the old ones hold of blocks [0, n_known) is still valid wherever no box is pending, so it is copied on the
+    // host and only new or changed blocks cross the link (the pending boxes stay as they are).
+    float *lo = nullptr;
+    uint8_t *occ = nullptr, *infl = nullptr, *col = nullptr;
+    int *keys = nullptr;
+    hipError_t e = hipHostMalloc((void **)&lo, cap * C * sizeof(float), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&occ, cap * C, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&infl, cap * C, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&col, cap, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&keys, cap * 3 * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipGetLastError();
+        if (lo) hipHostFree(lo);
+        if (occ) hipHostFree(occ);
+        if (infl) hipHostFree(infl);
+        if (col) hipHostFree(col);
+        if (keys) hipHostFree(keys);
         mirror_free(h);
         h->err = std::string("host mirror: ") + hipGetErrorString(e);
         M.alloc_failed = true; // (the queries fall back to the kernel path for good: run_query)
         M.enabled = false;
         return MLM_ERR_HIP;
     }
+    const bool carry = M.cap > 0 && M.n_known > 0 && !M.boxes.all && !M.eager_pending;
+    const unsigned int known = carry ? M.n_known : 0u;
+    if (carry) {
+        std::memcpy(lo, M.lo, (size_t)known * C * sizeof(float));
+        std::memcpy(occ, M.occ, (size_t)known * C);
+        std::memcpy(infl, M.infl, (size_t)known * C);
+        std::memcpy(col, M.col, known);
+        std::memcpy(keys, M.keys, (size_t)known * 3 * sizeof(int));
+    }
+    const mlm_host::DirtyBoxes boxes = M.boxes;
+    mirror_free(h); // (marks everything stale: undone below where the old contents were carried over)
+    M.lo = lo, M.occ = occ, M.infl = infl, M.col = col, M.keys = keys;
     M.cap = cap;
     M.view.table_reset(cap);
+    if (carry) {
+        for (unsigned int b = 0; b < known; ++b) M.view.table_insert(keys[3 * (size_t)b], keys[3 * (size_t)b + 1], keys[3 * (size_t)b + 2], (int)b);
+        M.n_known = known;
+        M.boxes = boxes;
+    }
     M.view.d_sub = h->P.d_sub, M.view.d_glb = h->P.d_glb, M.view.d_sub_half = h->P.d_sub_half;
     M.view.n = h->P.n, M.view.cells = h->P.cells;
     M.view.lo = M.lo, M.view.occ = M.occ, M.view.infl = M.infl, M.view.col = M.col;

@@ -582,25 +582,31 @@ int grow_slots(mlm_handle *h, const MlmCounters &demand) {
         c.hl = std::min(w.hl, 2 * c.hl), c.mt = std::min(w.mt, 2 * c.mt), c.refs = std::min(w.refs, 2 * c.refs);
         c.sub = std::min(w.sub, 2 * c.sub), c.rec = std::min(w.rec, 2 * c.rec), c.vh = std::min(w.vh, 2 * c.vh);
     }
-    return resize_slots(h);
+    const int rc = resize_slots(h);
+    if (rc) c = before; // (some slots may hold more than this now — resize_slots only ever grows a list —, none holds less)
+    return rc;
 }
 // the emulated hit container has more buckets than the slots' bucket-first tables hold (they are sized by need too)
 int grow_sbkt(mlm_handle *h, size_t buckets) {
     auto &c = h->caps_now;
     if (buckets <= c.sbkt) return MLM_OK;
+    const size_t before = c.sbkt;
     c.sbkt = std::min(h->caps_worst.sbkt, std::max(2 * c.sbkt, buckets));
-    return resize_slots(h);
+    const int rc = resize_slots(h);
+    if (rc) c.sbkt = before; // (the next submission asks again: the slots' own sbkt_cap is what the kernels go by)
+    return rc;
 }
 // The cell-table path's own full-size lists, once per handle, at the first frame that takes that path (slots sized by need)
 int ensure_ct_full(mlm_handle *h) {
     if (!h->need_sized || h->ct_full.ready) return MLM_OK;
     auto &c = h->ct_full;
     const size_t NC = h->caps_worst.hl, SUB = h->caps_worst.sub;
-    int rc;
-    if ((rc = dev_alloc(h, &c.mt_list, NC)) || (rc = dev_alloc(h, &c.mt_rec, NC)) || (rc = dev_alloc(h, &c.contrib, SUB)) || (rc = dev_alloc(h, &c.subs, SUB)) ||
-        (rc = dev_alloc(h, &c.hl_cell, NC)) || (rc = dev_alloc(h, &c.hl_t, NC)) || (rc = dev_alloc(h, &c.hl_odd, NC)) || (rc = dev_alloc(h, &c.hl_inc, NC)) ||
-        (rc = dev_alloc(h, &c.hl_base, NC)) || (rc = dev_alloc(h, &c.hl_cnt, NC)) || (rc = dev_alloc(h, &c.hl_vt, NC)) || (rc = dev_alloc(h, &c.hl_key, NC)) ||
-        (rc = dev_alloc(h, &c.hl_bkt, NC)))
+    int rc = MLM_OK;
+    // (a list obtained by an earlier, partly failed attempt is kept: only the members that are still missing are asked for again)
+    auto need = [&](auto **p, size_t n) { return *p == nullptr && (rc = dev_alloc(h, p, n)) != MLM_OK; };
+    if (need(&c.mt_list, NC) || need(&c.mt_rec, NC) || need(&c.contrib, SUB) || need(&c.subs, SUB) || need(&c.hl_cell, NC) || need(&c.hl_t, NC) ||
+        need(&c.hl_odd, NC) || need(&c.hl_inc, NC) || need(&c.hl_base, NC) || need(&c.hl_cnt, NC) || need(&c.hl_vt, NC) || need(&c.hl_key, NC) ||
+        need(&c.hl_bkt, NC))
         return rc;
     c.ready = true;
     if (getenv("MLM_DEBUG_CREATE")) fprintf(stderr, "[slots] full-size lists of the cell-table path allocated; device memory %.2f GB\n", h->alloc_bytes / 1e9);

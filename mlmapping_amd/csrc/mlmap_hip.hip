@@ -355,7 +355,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         const double cells_per_voxel = (std::ceil(P.d_sub / P.dRho) + 2) * (std::ceil(P.d_sub / P.dZ) + 2) * P.nPhi;
         h->use_sectors = P.bin_block == 256 && P.sec_lds_bytes <= 160u * 1024u - 1024u && h->lim.max_points < (1 << MLM_SEC_CNT_BITS) && P.n <= 255 &&
                          P.sec_tab <= 4u * (unsigned int)h->sec_threads && (size_t)P.nZ * P.RW * 64 <= (size_t)P.sec_tab * sizeof(MlmSecCell) && P.nZ * P.nRho < 65536 &&
-                         /* (nZ * nRho < 65536 also keeps z below 2^15: a column record holds z << 16 | rho below its top bit, MLM_SEC_OUTER) */
+                         P.nZ < 32768 /* a column record holds z << 16 | rho below its top bit, MLM_SEC_OUTER (nZ * nRho < 65536 only implies it for nRho >= 2) */ &&
                          P.nRho <= 512 /* k_chain_lanes: 128 bytes of LDS per rho; k_sector: one thread per rho */ &&
                          P.nPhi <= 32 * MLM_TILE_WORDS /* k_tile: a tile's column mask */ &&
                          (P.explore ? P.nRho <= 256
@@ -457,6 +457,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (knob("ex_spec", kv)) h->ex_spec = (int)kv;
         if (knob("single_chain_grid", kv)) h->single_chain_grid = (unsigned int)std::max(1, (int)kv);
         if (knob("mirror", kv)) h->mir.enabled = (int)kv != 0;
+        if (knob("mirror_mb", kv)) h->mir.max_bytes = (size_t)std::max(0, (int)kv) << 20;
         if (knob("mirror_max", kv)) h->mir.max_clean = std::max(0, (int)kv), h->mir.max_dirty = std::min(h->mir.max_dirty, h->mir.max_clean);
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_g, sizeof(MlmGlobal), hipHostMallocDefault));
@@ -1286,6 +1287,25 @@ int mlm_set_async(mlm_handle *h, int on) {
     const int rc = drain(h);
     h->async_mode = on != 0;
     return rc;
+}
+
+int mlm_set_host_mirror_limit(mlm_handle *h, size_t max_bytes) {
+    if (!h) return MLM_ERR_INVALID;
+    MLM_LOCK(h);
+    MlmMirror &M = h->mir;
+    M.max_bytes = max_bytes;
+    if (M.alloc_failed) return MLM_OK; // (the planes could not be pinned at all: the kernel path stays)
+    const size_t held = M.cap * ((size_t)h->P.cells * 6 + 13);
+    if (held > max_bytes) {
+        HIPCHK(h, hipSetDevice(h->device));
+        mirror_free(h);
+        M.over_limit = true;
+        M.enabled = false;
+    } else if (M.over_limit && max_bytes > 0) { // (a higher limit: the next small query tries again)
+        M.over_limit = false;
+        M.enabled = true;
+    }
+    return MLM_OK;
 }
 
 int mlm_get_frame_stats(mlm_handle *h, mlm_frame_stats *out) {

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "mlm_query_odds", "mlm_query_odd_grad", "mlm_query_odds_at", "mlm_export_frontier_points", "mlm_import_blocks",
     "mlm_merge_pack", "mlm_merge_finish",
     "mlm_set_free_in_bound", "mlm_inflate_map", "mlm_block_count",
-    "mlm_export_blocks", "mlm_export_block_flags", "mlm_export_frontier", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_get_frame_stats",
+    "mlm_export_blocks", "mlm_export_block_flags", "mlm_export_frontier", "mlm_export_global_map", "mlm_sync", "mlm_set_async", "mlm_set_host_mirror_limit", "mlm_get_frame_stats",
     "mlm_get_awareness_hits",
     "mlm_get_awareness_misses", "mlm_get_T_ls", "mlm_get_odds_table", "mlm_get_kernel_times",
     "mlm_enable_kernel_timing", "mlm_set_timed_kernel", "mlm_host_register", "mlm_host_unregister", "mlm_debug_set", "mlm_debug_reset",
@@ -133,6 +133,7 @@ def load_library(path: Optional[str] = None):
     L.mlm_export_frontier.argtypes = [vp, i32, vp, vp]
     L.mlm_sync.argtypes = [vp]
     L.mlm_set_async.argtypes = [vp, i32]
+    L.mlm_set_host_mirror_limit.argtypes = [vp, ctypes.c_size_t]
     L.mlm_get_frame_stats.argtypes = [vp, vp]
     L.mlm_get_awareness_hits.argtypes = [vp, i32, vp, vp, vp, vp]
     L.mlm_get_awareness_misses.argtypes = [vp, i32, vp, vp]
@@ -241,6 +242,10 @@ class MLMap:
     def set_async(self, on: bool = True):
         """Integrate calls return after submission (two batches in flight); sync()/queries wait for everything."""
         self._chk(self._L.mlm_set_async(self._h, int(on)), "mlm_set_async")
+
+    def set_host_mirror_limit(self, max_bytes: int):
+        """Most pinned host memory the mirror of the map (small query batches) may take; 0 = queries always run as kernels."""
+        self._chk(self._L.mlm_set_host_mirror_limit(self._h, int(max_bytes)), "mlm_set_host_mirror_limit")
 
     # ---- update_map (mlmap.cpp:382-386) ---------------------------------------------------------
     def update_map(self, depth_u16: np.ndarray, q_wb, t_wb, pixel_idx=None):

@@ -161,6 +161,42 @@ def test_mirror_in_async_mode_and_through_pool_growth(mods):
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "async + small queries")
 
 
+def test_mirror_growth_carries_its_contents_and_respects_the_limit(mods):
+    """the planes grow with the map: what they held is copied on the host (only new or changed blocks cross the link), and a map
+    that needs more pinned memory than mlm_set_host_mirror_limit allows is queried by kernels — same answers"""
+    MLMap, OracleMap = mods
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=2048), OracleMap(cfg)
+    rng = np.random.default_rng(9)
+    copied = []
+    for k in range(6):  # the sensor walks away: new blocks every frame, the first ones are never touched again
+        q, t = syn.static_pose()
+        t = np.array([4.0 * k, 0.0, 0.0]) + t
+        img = syn.room_depth(cfg)
+        gpu.update_map(img, q, t)
+        cpu.update_depth(img, q, t)
+        b = cpu.export_blocks()
+        pos = np.concatenate([rng.uniform(b["keys"].min(0) - 1.0, b["keys"].max(0) + 2.0, size=(60, 3)), voxel_centres(b, cfg, 120, seed=k)])
+        s0 = gpu.frame_stats()
+        assert np.array_equal(_one_by_one(gpu.getOccupancy, pos), cpu.getOccupancy(pos)), f"frame {k}"
+        assert np.array_equal(_one_by_one(gpu.getOdd, pos).view(np.uint32), cpu.getOdd(pos).view(np.uint32)), f"frame {k}"
+        s1 = gpu.frame_stats()
+        copied.append(s1["n_mirror_blocks"] - s0["n_mirror_blocks"])
+    n_blocks = gpu.frame_stats()["n_blocks"]
+    assert n_blocks > 256, "the planes (256 blocks at first) must have grown in this test"
+    assert sum(copied) < 2 * n_blocks, (copied, n_blocks)  # (growing the planes did not copy the whole map again each time)
+    # a limit below what the planes hold: the copy is freed, small queries still answer (as kernels), and no host query is counted
+    gpu.set_host_mirror_limit(1 << 20)
+    h0 = gpu.frame_stats()["n_host_queries"]
+    assert np.array_equal(_one_by_one(gpu.getOccupancy, pos[:40]), cpu.getOccupancy(pos[:40]))
+    go, co = _one_by_one(gpu.getOdd, pos[:40]), cpu.getOdd(pos[:40])
+    assert np.max(np.abs(go - co)) <= ODDS_TOL
+    assert gpu.frame_stats()["n_host_queries"] == h0
+    gpu.set_host_mirror_limit(1 << 30)  # raised again: the host path returns
+    assert np.array_equal(_one_by_one(gpu.getOdd, pos[:40]).view(np.uint32), co.view(np.uint32))
+    assert gpu.frame_stats()["n_host_queries"] > h0
+
+
 def test_mirror_in_frontier_mode_released_blocks(mods):
     """use_exploration_frontiers: released blocks answer with element 0 (mlmap.h:183-184,221-222) on the host path too"""
     MLMap, OracleMap = mods
