@@ -260,6 +260,9 @@ def roofline_of(res, cfg, B, BPS, K, fps_one_gpu, pmc, pmc_file, pmc_batch, pmc_
             "traffic": traffic, "traffic_source": traffic_src,
             "traffic_whole_path": whole, "traffic_whole_path_unit": "HBM-side bytes per frame, all kernels of the batched path (PMC)",
             "traffic_over_algorithmic": ratio, "traffic_whole_path_source": pmc_batch_file,
+            "traffic_calibration": "read side = 2 x FETCH_SIZE, write side = WRITE_SIZE: both checked against kernels of known byte counts "
+                                   "(tools/probes/hbm_counter_probe.hip, profiles/r6_hbm_counter_table.json: coalesced loads of every width report half their "
+                                   "bytes, coalesced stores of every width their bytes; a lone 4-byte access or atomic per line counts 32 bytes a side)",
             "avg_launch_us": avg_ms * 1e3, "avg_launch_us_pipelined": avg_ms * 1e3,
             "avg_launch_us_isolated": iso_ms * 1e3 if iso_ms else None,
             "frac_isolated": (mean_bytes * frames_per_launch / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if iso_ms else None,
@@ -274,11 +277,48 @@ def roofline_of(res, cfg, B, BPS, K, fps_one_gpu, pmc, pmc_file, pmc_batch, pmc_
                                      **{k + " (instrumented batches before the region)": v[0] * 1e3 / max(1, n_c * B)
                                         for k, v in ktime_c.items()},
                                      **{k + " (alone on the GPU)": v[0] * 1e3 / max(1, 2 * B) for k, v in iso.items()}}}
+    used = [os.path.join(ROOT, "profiles", f) for f in (pmc_batch_file, roof["issue"] and roof["issue"]["counters_source"],
+                                                          roof["by_rocprof_rule"] and roof["by_rocprof_rule"]["source"]) if f]
+    roof["missing_profiles"] = [n for n, v in (("pmc_traffic_batch", pmc_batch), ("pmc_sq", roof["issue"]), ("kernel_stats", roof["by_rocprof_rule"])) if not v]
+    roof["stale_profiles"] = bool(roof["missing_profiles"]) or any(profile_is_stale(f) for f in used)
+    roof["stale_profiles_note"] = ("true: a summary under profiles/ is missing or was taken on other kernel sources than this tree's "
+                                   "(profiles/<tag>_meta.json, tools/prof_round.sh) — traffic / issue / by_rocprof_rule then describe older code")
     return roof, mean_bytes
 
 
 SIMDS = 256 * 4        # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 ENGINE_CLOCK_HZ = 2.4e9  # peak engine clock; a wave's vector instruction takes an issue slot of one quad-cycle
+# What one SIMD really issues, measured on this part with every wave slot filled (tools/probes/valu_issue_probe.hip, profiles/r6_valu_issue_probe.txt):
+# full-rate operations (v_mul_f32 / v_fma_f32 / v_add_u32: 0.78 - 1.05) and the half-rate class (FP64, v_mul_lo_u32, v_mad_u64_u32,
+# v_bfe_u32, v_lshl_or_b32, packed FP32: 0.57) in G wave-instructions per second per SIMD.  The path's kernels mix both classes, so the
+# pipe's utilisation lies between instructions / full-rate peak and instructions / half-rate peak.
+VALU_FULL_RATE_PER_SIMD = 1.05e9
+VALU_HALF_RATE_PER_SIMD = 0.573e9
+
+
+def csrc_sha16():
+    """sha1 (16 hex digits) over the kernel and host sources the library is built from: what a profile set was taken on
+    (tools/prof_round.sh writes it to profiles/<tag>_meta.json)."""
+    import glob
+    import hashlib
+
+    hh = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mlmapping_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "mlmapping_amd", "csrc", "*.hip"))):
+        hh.update(os.path.basename(f).encode())
+        hh.update(open(f, "rb").read())
+    return hh.hexdigest()[:16]
+
+
+def profile_is_stale(path):
+    """True if the profile file's round tag has no profiles/<tag>_meta.json or that names other sources than the tree's."""
+    if not path:
+        return True
+    mm = re.match(r"(r\d+[a-z]*)_", os.path.basename(path))
+    meta = os.path.join(ROOT, "profiles", (mm.group(1) if mm else "none") + "_meta.json")
+    try:
+        return json.load(open(meta)).get("csrc_sha16") != csrc_sha16()
+    except Exception:
+        return True
 
 
 def issue_bound(fps_one_gpu: float, tag: str = ""):
@@ -300,10 +340,18 @@ def issue_bound(fps_one_gpu: float, tag: str = ""):
     if not valu_q or not fps_one_gpu:
         return None
     avail = SIMDS * ENGINE_CLOCK_HZ / 4.0 / fps_one_gpu
-    return {"bound": "valu_issue", "achieved": valu_q, "peak": avail, "unit": "issue slots (quad-cycles) per frame", "frac": valu_q / avail,
+    full, half = SIMDS * VALU_FULL_RATE_PER_SIMD / fps_one_gpu, SIMDS * VALU_HALF_RATE_PER_SIMD / fps_one_gpu
+    return {"bound": "valu_issue", "achieved": valu_n, "unit": "vector wave-instructions per frame",
+            "peak": {"if_all_full_rate": full, "if_all_half_rate": half},
+            "frac": {"lower": valu_n / full, "upper": valu_n / half},
+            "frac_note": "the kernels mix full-rate (2 cycles per wave64) and half-rate (FP64, 32-bit multiply, bit-field: 4 cycles) operations: "
+                         "the vector pipes' utilisation lies between the two",
             "valu_wave_instructions_per_frame": valu_n, "salu_wave_instructions_per_frame": salu_n,
-            "peak_source": "1 024 SIMDs x 2.4 GHz / 4 x the measured time per frame", "counters_source": os.path.basename(f),
-            "per_kernel_slots": {k: v.get("SQ_ACTIVE_INST_VALU", 0.0) for k, v in ker.items()}}
+            "active_inst_valu_quad_cycles_per_frame": valu_q, "quad_cycle_slots_per_frame_at_2.4GHz": avail,
+            "peak_source": "tools/probes/valu_issue_probe.hip on MI355X (profiles/r6_valu_issue_probe.txt): 1.05 / 0.573 G wave-instructions/s per SIMD "
+                           "with eight waves resident, x 1 024 SIMDs x the measured time per frame",
+            "counters_source": os.path.basename(f), "counters_stale": profile_is_stale(f),
+            "per_kernel_valu": {k: v.get("SQ_INSTS_VALU", 0.0) for k, v in ker.items()}}
 
 
 def rocprof_dominant(mean_bytes: float, frames_per_launch: float, tag: str = ""):
@@ -322,7 +370,7 @@ def rocprof_dominant(mean_bytes: float, frames_per_launch: float, tag: str = "")
         avg_us = float(top["AverageNs"]) / 1e3
         ach = mean_bytes * frames_per_launch / (avg_us * 1e-6) / 1e9
         return {"kernel": name, "avg_launch_us": avg_us, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "share_of_gpu_time_pct": float(top["Percentage"]),
-                "source": os.path.basename(f)}
+                "source": os.path.basename(f), "source_stale": profile_is_stale(f)}
     except Exception:
         return None
 

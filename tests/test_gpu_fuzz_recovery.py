@@ -17,14 +17,27 @@ pytestmark = pytest.mark.gpu
 
 
 def test_random_configurations_on_the_recovery_paths(knobs):
+    _recovery_fuzz(knobs, int(os.environ.get("MLM_RFUZZ_SEED", "31")), int(os.environ.get("MLM_RFUZZ_TRIALS", "40")), "MLM_RFUZZ_SEED" not in os.environ)
+
+
+def test_recovery_paths_fresh_seed(knobs):
+    """the same with a seed derived from the kernel sources (a new one with every change of the code; printed, and in every message:
+    MLM_RFUZZ_SEED=<seed> MLM_RFUZZ_TRIALS=12 replays it in the test above)"""
+    from bench import csrc_sha16
+
+    seed = int(csrc_sha16(), 16) % (1 << 31) + 1
+    print("fresh recovery fuzz seed", seed)
+    _recovery_fuzz(knobs, seed, 12, False)
+
+
+def _recovery_fuzz(knobs, seed, trials, expect_all_paths):
     from mlmapping_amd.mlmap import MLMap
     from oracle.binding import OracleMap
 
-    seed = int(os.environ.get("MLM_RFUZZ_SEED", "31"))
     rng = np.random.default_rng(seed)
     krng = np.random.default_rng(seed + 1)  # (limits, knobs and call pattern: a stream of its own, so the inputs are fuzz_trial's)
     seen = {"n_sector_fallbacks": 0, "n_slot_grows": 0, "n_pool_grows": 0, "n_spec_replays": 0}
-    for trial in range(int(os.environ.get("MLM_RFUZZ_TRIALS", "40"))):
+    for trial in range(trials):
         cfg, depths, pos = fuzz_trial(rng, trial)
         kn = {}
         if krng.random() < 0.5:
@@ -78,5 +91,5 @@ def test_random_configurations_on_the_recovery_paths(knobs):
             seen[name] += int(st[name])
         gpu.close()
     print("recovery paths taken:", seen)
-    if "MLM_RFUZZ_SEED" not in os.environ:
+    if expect_all_paths:
         assert all(v > 0 for v in seen.values()), seen  # (the default run does reach every one of them)

@@ -679,15 +679,10 @@ def test_argument_and_capacity_errors(mods, monkeypatch, knobs):
     assert m2.frame_stats()["n_points"] == 576
 
 
-def test_random_configurations(mods):
-    """Fuzz: random map geometries, noise levels, thresholds and camera models — the HIP path must track the oracle on
-    all of them (sets and classes exact, odds within 1e-4)."""
+def _fuzz_configurations(mods, seed, trials):
     MLMap, OracleMap = mods
-    import os
-
-    # MLM_FUZZ_SEED / MLM_FUZZ_TRIALS: longer or different runs of the same fuzz (default: 30 trials, seed 2024)
-    rng = np.random.default_rng(int(os.environ.get("MLM_FUZZ_SEED", "2024")))
-    for trial in range(int(os.environ.get("MLM_FUZZ_TRIALS", "30"))):
+    rng = np.random.default_rng(seed)
+    for trial in range(trials):
         cfg, depths, pos = fuzz_trial(rng, trial)
         gpu, cpu = MLMap(cfg, max_blocks=4096, max_points=320 * 240, record_awareness=True), OracleMap(cfg)
         for k, depth in enumerate(depths):
@@ -695,55 +690,74 @@ def test_random_configurations(mods):
             cpu.update_depth(depth, q, t)
             gpu.update_map(depth, q, t)  # (tiny blocks over a long range need more than the 4096 initial blocks: the pool grows)
             _awareness_equal(gpu, cpu)
-            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"fuzz trial {trial} frame {k} cfg {cfg}")
+            compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"fuzz seed {seed} trial {trial} frame {k} cfg {cfg}")
             if cfg.use_exploration_frontiers:
-                assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"fuzz trial {trial}: frontier"
-        assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos))
+                assert np.array_equal(gpu.export_frontier(), cpu.export_frontier()), f"fuzz seed {seed} trial {trial}: frontier"
+        assert np.array_equal(gpu.getOccupancy(pos), cpu.getOccupancy(pos)), f"fuzz seed {seed} trial {trial}"
         gpu.close()
 
 
-def test_long_stream_cfg2(mods):
+def test_random_configurations(mods):
+    """Fuzz: random map geometries, noise levels, thresholds and camera models — the HIP path must track the oracle on
+    all of them (sets and classes exact, log-odds bits).  MLM_FUZZ_SEED / MLM_FUZZ_TRIALS: longer or different runs of the same
+    fuzz (default: 30 trials, seed 2024)."""
+    import os
+
+    _fuzz_configurations(mods, int(os.environ.get("MLM_FUZZ_SEED", "2024")), int(os.environ.get("MLM_FUZZ_TRIALS", "30")))
+
+
+def test_random_configurations_fresh_seed(mods):
+    """The same fuzz with a seed no earlier run has seen: derived from the kernel sources (bench.csrc_sha16), so every change of the
+    code is fuzzed with inputs of its own — the fixed seeds above only say that nothing KNOWN broke.  The seed is printed and in
+    every assertion message; MLM_FUZZ_SEED=<seed> MLM_FUZZ_TRIALS=10 replays it in test_random_configurations."""
+    from bench import csrc_sha16
+
+    seed = int(csrc_sha16(), 16) % (1 << 31)
+    print("fresh fuzz seed", seed)
+    _fuzz_configurations(mods, seed, 10)
+
+
+def test_long_stream_cfg2(mods, oracle_jobs):
     """BASELINE config 2 at the length SURVEY §8d asks for: 1000 frames of the jittered room with a random SE(3) pose per frame
     in asynchronous mode (three slot sets in flight, speculative Stage B), against the oracle fed frame by frame — full map
-    comparison (keys, classes, log-odds bits) every 50 frames; the pool starts at 64 blocks and grows on the way.  About
-    three minutes, most of it the oracle.  (MLM_LONG_STREAM_FRAMES overrides the length.)"""
+    comparison (keys, classes, log-odds bits) every 50 frames; the pool starts at 64 blocks and grows on the way.  The oracle's
+    two and a half minutes run in a process of their own that starts with the session (tests/oracle_worker.py); this test feeds
+    the GPU and compares at every checkpoint as the oracle's maps arrive.  (MLM_LONG_STREAM_FRAMES overrides the length.)"""
     import os
 
     import torch
 
+    from tests.oracle_worker import long_stream_inputs
+
     MLMap, OracleMap = mods
     cfg = S1
-    n, B, distinct = int(os.environ.get("MLM_LONG_STREAM_FRAMES", "1000")) // 50 * 50, 25, 32
-    base = syn.room_depth(cfg)
-    frames = np.stack([syn.jitter_depth(base, k, seed=42) for k in range(distinct)])
-    poses = syn.random_poses(n, seed=42)
-    q = np.stack([p[0] for p in poses])
-    t = np.stack([p[1] for p in poses])
+    n, B = int(os.environ.get("MLM_LONG_STREAM_FRAMES", "1000")) // 50 * 50, 25
+    frames, q, t = long_stream_inputs(n)
+    distinct = frames.shape[0]
+    fetch = oracle_jobs["long_stream"]
     d_frames = torch.from_numpy(frames.view(np.int16)).cuda()
     torch.cuda.synchronize()
     fsz = cfg.width * cfg.height
-    gpu, cpu = MLMap(cfg, max_blocks=64, max_batch=B), OracleMap(cfg)  # a pool of 64 blocks: it grows on the way (allocate_ram
-    gpu.set_async(True)                                                 # never refuses, map_local.h:215-231)
-    worst = 0.0
+    gpu = MLMap(cfg, max_blocks=64, max_batch=B)  # a pool of 64 blocks: it grows on the way (allocate_ram never refuses, map_local.h:215-231)
+    gpu.set_async(True)
+    worst, n_cpu_blocks = 0.0, 0
     for k0 in range(0, n, B):
         for k in range(k0, k0 + B):  # frames are cycled, so a batch is not contiguous in HBM: one call per frame ...
             gpu.update_map_dev(d_frames.data_ptr() + (k % distinct) * fsz * 2, cfg.width, cfg.height, q[k], t[k])
-            cpu.update_depth(frames[k % distinct], q[k], t[k])
         if (k0 + B) % 50 == 0:
-            d = compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"cfg2 stream after {k0 + B} frames")
-            worst = max(worst, d["max_dodd"])
+            c = fetch(f"ckpt_{k0 + B}.npz")
+            d = compare_maps(gpu.export_blocks(), c, f"cfg2 stream after {k0 + B} frames")
+            worst, n_cpu_blocks = max(worst, d["max_dodd"]), c["keys"].shape[0]
     # ... and the contiguous batch entry point on the first 25 frames of a second map
-    g2, c2 = MLMap(cfg, max_blocks=32768, max_batch=B), OracleMap(cfg)
+    g2 = MLMap(cfg, max_blocks=32768, max_batch=B)
     g2.set_async(True)
-    for rep in range(4):
+    for rep in range(min(4, n // B)):
         g2.update_map_batch_dev(d_frames.data_ptr(), B, cfg.width, cfg.height, q[rep * B:(rep + 1) * B], t[rep * B:(rep + 1) * B])
-        for j in range(B):
-            c2.update_depth(frames[j], q[rep * B + j], t[rep * B + j])
-    d = compare_maps(g2.export_blocks(), c2.export_blocks(), "cfg2 batch_dev 100 frames")
+    d = compare_maps(g2.export_blocks(), fetch("batch_dev.npz"), "cfg2 batch_dev 100 frames")
     print("long stream worst |d odd|", worst, d)
     st = gpu.frame_stats()
     assert st["n_spec_replays"] + st["n_sector_fallbacks"] >= 1  # the emulated container did rehash on the way
-    assert st["n_pool_grows"] >= 1 and st["block_capacity"] >= cpu.block_count() > 64, st
+    assert st["n_pool_grows"] >= 1 and st["block_capacity"] >= n_cpu_blocks > 64, st
 
 
 def test_float_callback_between_packed_host_batches(mods):
@@ -961,38 +975,36 @@ def test_fast_bin_seeds(mods):
     gpu.close()
 
 
-def test_bench_batch64_parity(mods):
+def test_bench_batch64_parity(mods, oracle_jobs):
     """The configuration bench.py TIMES, compared with the oracle at its real size: 192 frames of the bench stream (64 distinct
     jittered room frames resident in HBM, random SE(3) poses) submitted as three asynchronous 64-frame contiguous
     mlm_integrate_depth_batch_dev calls on a handle with max_batch = 64 (three slot sets: all three batches in flight), from a
     pool of 64 blocks.  The 64-frame k_apply_tiles chain — one lane per frame bookkeeping, LDS sized by the batch's spread of
     z origins, voxels LDS-resident across 64 frames — is what no smaller batch exercises; the update is order dependent
-    (map_local.cpp:147-207), so any slip in the frame order inside a batch shows up in the log-odds bits."""
+    (map_local.cpp:147-207), so any slip in the frame order inside a batch shows up in the log-odds bits.  (The oracle's leg runs
+    in a process of its own, started with the session: tests/oracle_worker.py.)"""
     import torch
 
     from bench import make_inputs
 
     MLMap, OracleMap = mods
     cfg, B, nb = S1, 64, 3
+    fetch = oracle_jobs["batch64"]
     frames, q, t = make_inputs(cfg, B, B * nb, seed=42)
     d_frames = torch.from_numpy(frames.view(np.int16)).cuda()
     torch.cuda.synchronize()
-    gpu, cpu = MLMap(cfg, max_blocks=64, max_points=cfg.width * cfg.height, max_batch=B), OracleMap(cfg)
+    gpu = MLMap(cfg, max_blocks=64, max_points=cfg.width * cfg.height, max_batch=B)
     gpu.set_async(True)
     for j in range(nb):
         gpu.update_map_batch_dev(d_frames.data_ptr(), B, cfg.width, cfg.height, q[j * B:(j + 1) * B], t[j * B:(j + 1) * B])
-    for k in range(B * nb):
-        cpu.update_depth(frames[k % B], q[k], t[k])
-    d = compare_maps(gpu.export_blocks(), cpu.export_blocks(), "bench configuration: 3 x 64-frame async batches")
+    d = compare_maps(gpu.export_blocks(), fetch("after_192.npz"), "bench configuration: 3 x 64-frame async batches")
     st = gpu.frame_stats()
     print("batch64 parity", d, {k: st[k] for k in ("n_spec_replays", "n_sector_fallbacks", "n_pool_grows", "block_capacity")})
     assert d["bit_mismatch"] == 0 and st["n_pool_grows"] >= 1
     # the batches after the container has settled run speculatively (no host round trip inside a batch): one more batch on
     # the grown map, still bit-equal
     gpu.update_map_batch_dev(d_frames.data_ptr(), B, cfg.width, cfg.height, q[:B], t[:B])
-    for k in range(B):
-        cpu.update_depth(frames[k], q[k], t[k])
-    compare_maps(gpu.export_blocks(), cpu.export_blocks(), "bench configuration: fourth batch")
+    compare_maps(gpu.export_blocks(), fetch("after_256.npz"), "bench configuration: fourth batch")
     gpu.close()
 
 

@@ -13,9 +13,9 @@
 
 #define ITER 2048
 
-enum Kind { ADD_U32, FMA_F32, MUL_F32, FMA_F64, ADD_F64, MUL_LO_U32, MAD_U64, LSHL_OR, CNDMASK, PK_FMA_F32, RCP_F32, BFE_U32, POPC_B64, SALU_ADD, N_KINDS };
+enum Kind { ADD_U32, FMA_F32, MUL_F32, FMA_F64, ADD_F64, MUL_LO_U32, MAD_U64, LSHL_OR, CNDMASK, PK_FMA_F32, RCP_F32, BFE_U32, POPC_B64, SALU_ADD, AND_B32, LSHR_B32, ADD3_U32, AND_OR, MOV_B32, CMP_U32, N_KINDS };
 static const char *kNames[N_KINDS] = {"v_add_u32", "v_fma_f32", "v_mul_f32", "v_fma_f64", "v_add_f64", "v_mul_lo_u32", "v_mad_u64_u32", "v_lshl_or_b32",
-                                      "v_cndmask_b32", "v_pk_fma_f32", "v_rcp_f32", "v_bfe_u32", "v_bcnt_u32_b32 x2 (popcll)", "s_add_u32 (scalar)"};
+                                      "v_cndmask_b32", "v_pk_fma_f32", "v_rcp_f32", "v_bfe_u32", "v_bcnt_u32_b32", "s_add_u32 (scalar)", "v_and_b32", "v_lshrrev_b32", "v_add3_u32", "v_and_or_b32", "v_mov_b32", "v_cmp_lt_u32"};
 
 // 64 instructions of kind K over CH chains (registers r0..r7 or d0..d7)
 template <int K, int CH> __device__ __forceinline__ void body(uint32_t (&r)[8], double (&d)[8], uint32_t &s) {
@@ -29,8 +29,14 @@ template <int K, int CH> __device__ __forceinline__ void body(uint32_t (&r)[8], 
         if (K == ADD_F64) asm volatile("v_add_f64 %0, %0, %0" : "+v"(d[c]));
         if (K == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %0" : "+v"(r[c]));
         if (K == MAD_U64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(d[c]) : "v"(r[c]) : "vcc");
+        if (K == AND_B32) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r[c]) : "v"(r[(c + 1) & 7]));
+        if (K == LSHR_B32) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(r[c]));
+        if (K == ADD3_U32) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(r[c]) : "v"(r[(c + 1) & 7]));
+        if (K == AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %0" : "+v"(r[c]) : "v"(r[(c + 1) & 7]));
+        if (K == MOV_B32) asm volatile("v_mov_b32 %0, %1" : "+v"(r[c]) : "v"(r[(c + 1) & 7]));
+        if (K == CMP_U32) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(r[c]), "v"(r[(c + 1) & 7]) : "vcc");
         if (K == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 1, %0" : "+v"(r[c]));
-        if (K == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[c]) : "v"(r[(c + 1) & 7]) : "vcc");
+        if (K == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[c]) : "v"(r[(c + 1) & 7]));
         if (K == PK_FMA_F32) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(d[c]));
         if (K == RCP_F32) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[c]));
         if (K == BFE_U32) asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(r[c]));
@@ -120,5 +126,11 @@ int main() {
     sweep<BFE_U32>(n_cu, d_out);
     sweep<POPC_B64>(n_cu, d_out);
     sweep<SALU_ADD>(n_cu, d_out);
+    sweep<AND_B32>(n_cu, d_out);
+    sweep<LSHR_B32>(n_cu, d_out);
+    sweep<ADD3_U32>(n_cu, d_out);
+    sweep<AND_OR>(n_cu, d_out);
+    sweep<MOV_B32>(n_cu, d_out);
+    sweep<CMP_U32>(n_cu, d_out);
     return 0;
 }

@@ -9,6 +9,8 @@ SEC=${2:-"test bench times rows kt pmc sq"}
 R=$PWD
 mkdir -p gpurun_out/$TAG
 O=$R/gpurun_out/$TAG
+# what the set was taken on: bench.py compares it with the tree it runs in (roofline.stale_profiles); copy to profiles/<tag>_meta.json with the set
+python -c "import bench, json, subprocess; print(json.dumps({'tag': '$TAG', 'csrc_sha16': bench.csrc_sha16()}))" > $O/meta.json
 has() { case " $SEC " in *" $1 "*) return 0;; *) return 1;; esac; }
 if has test; then timeout 2400 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; fi
 if has bench; then timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; fi

@@ -61,16 +61,25 @@ int main(int argc, char **argv) {
         for (int k = 0; k + 1 < n_frames; ++k) integrate(k);
         const double ct[3] = {poses[4], poses[5], poses[6]};
         map.inflate_map(Vec3{{ct[0], ct[1], ct[2]}});
-        // the first query after the map changed pays for bringing the host mirror up to date
-        std::vector<double> first;
+        // the first query after the map changed pays for bringing the host mirror up to date; the very first one also pins the planes
         long long sink = 0;
-        for (int r = 0; r < 20; ++r) {
-            integrate(n_frames - 1);
-            const Vec3 p{{pos[0], pos[1], pos[2]}};
-            const double t0 = now_us();
-            sink += map.getOccupancy(p);
-            first.push_back(now_us() - t0);
-        }
+        auto first_after = [&](std::vector<double> &out, int reps) {
+            for (int r = 0; r < reps; ++r) {
+                integrate(n_frames - 1);
+                const Vec3 p{{pos[0], pos[1], pos[2]}};
+                const double t0 = now_us();
+                sink += map.getOccupancy(p);
+                out.push_back(now_us() - t0);
+            }
+        };
+        std::vector<double> ever, first, first_async;
+        first_after(ever, 1);
+        first_after(first, 200);
+        mlm_set_async(map.handle(), 1); // (asynchronous integrate calls: the query itself waits for what was submitted)
+        first_after(first_async, 3);    // (warm-up of the mode)
+        first_async.clear();
+        first_after(first_async, 100);
+        mlm_set_async(map.handle(), 0);
         // steady state: the map does not change between the calls
         std::vector<double> t_occ, t_odd, t_grad, t_occ_i, t_infl, t_clock;
         double fsink = 0;
@@ -100,17 +109,19 @@ int main(int argc, char **argv) {
             }
         mlm_frame_stats st{};
         mlm_get_frame_stats(map.handle(), &st);
-        const Stat a = stat_of(t_occ), b = stat_of(t_odd), c = stat_of(t_grad), d = stat_of(t_occ_i), e = stat_of(t_infl), k = stat_of(t_clock), fi = stat_of(first);
+        const Stat a = stat_of(t_occ), b = stat_of(t_odd), c = stat_of(t_grad), d = stat_of(t_occ_i), e = stat_of(t_infl), k = stat_of(t_clock), fi = stat_of(first), fa = stat_of(first_async);
         std::printf("{\"calls_per_kind\": %zu, \"clock_overhead_us\": %.4f, "
                     "\"getOccupancy\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
                     "\"getOdd\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
                     "\"getOddGrad\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
                     "\"getOccupancy_inflate\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
                     "\"getInflateOccupancy\": {\"p50\": %.4f, \"p99\": %.4f, \"mean\": %.4f}, "
-                    "\"first_query_after_integrate\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f}, "
+                    "\"first_query_after_integrate\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"samples\": %zu, \"includes\": \"the wait for the integrate call's own refresh of the host mirror\"}, "
+                    "\"first_query_after_async_integrate\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"samples\": %zu, \"includes\": \"the frame itself: the query drains what was submitted\"}, "
+                    "\"first_query_ever_us\": %.2f, "
                     "\"n_host_queries\": %lld, \"n_mirror_refreshes\": %lld, \"n_mirror_blocks\": %lld, \"n_blocks\": %lld, \"sink\": %lld}\n",
                     t_occ.size(), k.p50, a.p50, a.p99, a.mean, b.p50, b.p99, b.mean, c.p50, c.p99, c.mean, d.p50, d.p99, d.mean, e.p50, e.p99, e.mean,
-                    fi.p50, fi.p99, fi.mean, (long long)st.n_host_queries, (long long)st.n_mirror_refreshes, (long long)st.n_mirror_blocks,
+                    fi.p50, fi.p99, fi.mean, first.size(), fa.p50, fa.p99, fa.mean, first_async.size(), ever[0], (long long)st.n_host_queries, (long long)st.n_mirror_refreshes, (long long)st.n_mirror_blocks,
                     (long long)st.n_blocks, sink + (long long)fsink);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "query_latency: %s\n", e.what());
