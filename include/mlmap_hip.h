@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MLM_ABI_VERSION 5
+#define MLM_ABI_VERSION 6 /* 6: mlm_set_host_mirror_limit */
 
 typedef enum mlm_status {
     MLM_OK = 0,

@@ -214,7 +214,7 @@ int drain_explore(mlm_handle *h) {
 // Frontier mode, Stage A of the slots base..base+n: by azimuth sector when the handle can (k_sector<true>), else (and for
 // frames whose sector tables overflowed, explore_redo_overflows) on the cell-table path.
 int explore_stage_a(mlm_handle *h, int base, int n, bool on_main = false) {
-    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040;
+    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= MLM_SEC_MAX_WIDTH;
     if (h->sector_backoff > 0) --h->sector_backoff;
     for (int j = 0; j < n; ++j) {
         MlmSlot &S = h->slots[(size_t)(base + j)];

@@ -1,5 +1,5 @@
 // mlm_kernels_sector.h — Stage A by azimuth sector (the default path; mlm_kernels.h keeps the cell-table path that a
-// frame falls back to when a sector's LDS tables overflow and that takes images wider than 2040 pixels).
+// frame falls back to when a sector's LDS tables overflow).
 //
 // Everything awareness_map_cylindrical::input_pc_pose does to one azimuth column phi stays inside that column: the noise
 // spread of a hit moves along rho (and z) at the point's phi (map_awareness.cpp:149-168) and its ray runs radially inwards
@@ -102,14 +102,22 @@ __device__ __forceinline__ uint32_t mlm_mask_rows(unsigned long long m) {
 // A reference of a multi-kind cell = one non-empty row of the 8x8 lane mask of one contribution group, 4 bytes:
 //   bits 0-7 the row's byte of the mask, 8-12 the kind, 13-31 where the row's first lane lies relative to the cell's FIRST pixel
 //   (its earliest contribution, MlmSecCell::tmin: no contribution lies in a row above it):
-//     dense images   (rows below the first pixel's) << 8 | column >> 3          11 + 8 bits (images up to 2040 wide)
+//     dense images   (rows below the first pixel's) << 8 | 128 + (tile column - the first pixel's tile column)   11 + 8 bits
 //     lists          (64-item rows below the first item's) << 3 | mask row      16 + 3 bits (2^22 items)
 #define MLM_REF_DY_DENSE 2047u
 #define MLM_REF_DY_LIST 65535u
-__device__ __forceinline__ uint32_t mlm_ref_pack(uint32_t bits, uint32_t kind, bool dense, uint32_t dy0, uint32_t row, uint32_t x0) {
-    const uint32_t pos = dense ? ((dy0 + row) << 8) | (x0 >> 3) : (dy0 << 3) | row;
+// (xrel: the row's tile column relative to the tile column of the cell's first pixel, + MLM_REF_XREL0: an image may be any width, a cell's
+// contributions lie within 1 016 pixels of its first one's column — else the frame gives the sector path up)
+#define MLM_REF_XREL0 128u
+__device__ __forceinline__ uint32_t mlm_ref_pack(uint32_t bits, uint32_t kind, bool dense, uint32_t dy0, uint32_t row, uint32_t xrel) {
+    const uint32_t pos = dense ? ((dy0 + row) << 8) | xrel : (dy0 << 3) | row;
     return bits | (kind << 8) | (pos << 13);
 }
+// A hit record's tile origin (MlmSecRec, second word).  Dense images: (row >> 3) << 13 | column >> 3 of the wave's 8x8 pixel tile
+// (both multiples of eight: images up to 65 528 pixels wide); lists: the wave's run of 64 items << 11.
+#define MLM_REC_XT_BITS 13
+#define MLM_REC_XT_MASK ((1u << MLM_REC_XT_BITS) - 1u)
+#define MLM_SEC_MAX_WIDTH ((int)(MLM_REC_XT_MASK << 3)) // widest dense image of the sector path
 // -> row byte, kind, rows below the cell's first pixel, column of the row's first lane
 __device__ __forceinline__ void mlm_ref_unpack(uint32_t ref, bool dense, uint32_t &bits, uint32_t &kind, uint32_t &dy, uint32_t &x) {
     bits = ref & 0xFFu;
@@ -265,11 +273,12 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
         }
         rec_place[j] = MLM_NIL;
         rec_cell[j] = leader ? (uint32_t)zi << 16 | (uint32_t)rho : (MLM_SEC_OUTER | (uint32_t)rho); // (hit records: z and rho of the centre cell, nRho * nZ < 65 536)
-        // hit records carry their tile's origin (row << 11 | column of lane 0; list modes: 64 items = one row) for k_rank
+        // hit records carry their tile's origin (MLM_REC_XT_BITS; list modes: 64 items = one row) for k_rank
         uint32_t yx = i00 >> 6 << 11;
-        if (MODE == 0) {
-            const uint32_t y0 = i00 / (uint32_t)F.width;
-            yx = (y0 << 11) | (i00 - y0 * (uint32_t)F.width);
+        if (MODE == 0) { // (from the strip's place in the image: nothing is divided per wave)
+            const uint32_t tiles_x = ((uint32_t)F.width + 31u) >> 5, strip = strip0 + (uint32_t)j;
+            const uint32_t by = strip / tiles_x, bx = strip - by * tiles_x;
+            yx = (by << MLM_REC_XT_BITS) | (bx * 4u + (uint32_t)wid);
         }
         // a record is 16 bytes (MlmSecRec).  Hit: centre cell z << 16 | rho, tile origin yx, lane mask (the wave's first work item
         // follows from yx: y0 * width + x0, lists (yx >> 11) << 6).  Ray of a point outside the map: MLM_SEC_OUTER | rho, z, and in the
@@ -698,14 +707,16 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         const uint32_t at = s_base[2] + (s_tab[e].key >> 16) * MLM_SEC_REF_ALIGN + (left - n_rows);
         const uint32_t pix0 = s_tab[e].tmin / MLM_TIME_SLOTS;
         const uint32_t y0c = tile_w > 0 ? (uint32_t)(((unsigned long long)pix0 * row_m) >> row_s) : pix0 >> 6;
-        const uint32_t dy0 = (yx >> 11) - y0c; // (>= 0: the cell's first pixel is its contributions' smallest)
-        if (dy0 + 7u > (tile_w > 0 ? MLM_REF_DY_DENSE : MLM_REF_DY_LIST)) {
-            s_fail = 1; // (an image more than 2 047 rows tall below the cell's first pixel: not expressible — the frame falls back)
+        const uint32_t dy0 = (tile_w > 0 ? (yx >> MLM_REC_XT_BITS) << 3 : yx >> 11) - y0c; // (>= 0: the cell's first pixel is its contributions' smallest)
+        // (dense images: the tile's column relative to the first pixel's tile column)
+        const uint32_t xrel = tile_w > 0 ? (yx & MLM_REC_XT_MASK) - ((pix0 - y0c * (uint32_t)tile_w) >> 3) + MLM_REF_XREL0 : 0u;
+        if (dy0 + 7u > (tile_w > 0 ? MLM_REF_DY_DENSE : MLM_REF_DY_LIST) || xrel > 255u) {
+            s_fail = 1; // (a cell whose pixels lie more than 2 047 rows below or 1 016 columns beside its first one: not expressible — the frame falls back)
         } else if (at + n_rows <= P.refs_cap) {
             MLM_GLOBAL uint32_t *dst = mlm_gp(P.refs) + at;
             for (uint32_t k = 0; k < n_rows; ++k) {
                 const uint32_t row = (rows3 >> (3u * k)) & 7u;
-                dst[k] = mlm_ref_pack((uint32_t)(mask >> (8u * row)) & 0xFFu, sub, tile_w > 0, dy0, row, yx & 2047u);
+                dst[k] = mlm_ref_pack((uint32_t)(mask >> (8u * row)) & 0xFFu, sub, tile_w > 0, dy0, row, xrel);
             }
         }
     };
@@ -791,7 +802,7 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                     uint32_t nt = 0;
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
                     // (the wave's first work item from the tile origin: dense y0 * width + x0, lists 64 items per "row")
-                    const uint32_t i00 = tile_w > 0 ? (a.y >> 11) * (uint32_t)tile_w + (a.y & 2047u) : (a.y >> 11) << 6;
+                    const uint32_t i00 = tile_w > 0 ? ((a.y >> MLM_REC_XT_BITS) << 3) * (uint32_t)tile_w + ((a.y & MLM_REC_XT_MASK) << 3) : (a.y >> 11) << 6;
                     const uint32_t i_first = i00 + (tile_w > 0 ? (uint32_t)((l0 >> 3) * tile_w + (l0 & 7)) : (uint32_t)l0);
                     const uint32_t cnt = (uint32_t)__popcll(mask), n_rows = mlm_mask_rows(mask);
                     mlm_sec_targets(P, rho, phi, z, s_sigma[rho], [&](uint32_t key, int sub, int rho_t) {
@@ -1300,7 +1311,9 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
                        n_refs = (uint32_t)__builtin_amdgcn_readfirstlane((int)rf.y);
         const uint32_t pix0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.w) / MLM_TIME_SLOTS; // the cell's first work item: smallest row of the window
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
-        const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64; // multiple of 8: a record's row byte never straddles a word
+        // (left edge of the 128-column window, multiple of 8: a record's row byte never straddles a word; dense images: the references' columns
+        // are relative to the first pixel's tile column, MLM_REF_XREL0)
+        const int xlo = tile_w > 0 ? (int)(MLM_REF_XREL0 << 3) - 64 : (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64;
         MLM_GLOBAL uint8_t *S = mlm_gp(P.subs) + soff;
         volatile MLM_LDS uint8_t *SL = mlm_lp(s_kinds[wid]);
         const bool staged = n <= 1024u; // kinds are collected in LDS and leave as whole dwords
@@ -1408,7 +1421,9 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
             for (uint32_t p0 = 0; p0 < n_refs; p0 += 64) {
                 uint32_t b, px, sb;
                 load_pair(rf, p0 + lane, b, px, sb);
-                const uint32_t item = (px >> 11) * (uint32_t)row_w + (px & 2047u); // work item of the row's first lane, counted from the first row of the cell
+                // position of the row's first lane, counted from the first row of the cell (dense images: columns relative to the first
+                // pixel's tile column, below 2 048 — any row stride above that keeps the order)
+                const uint32_t item = (px >> 11) * (tile_w > 0 ? 4096u : (uint32_t)row_w) + (px & 2047u);
                 const uint32_t cb = (uint32_t)__popc(b);
                 const uint32_t incl = mlm_wave_incl_scan(cb);
                 uint32_t at = base + incl - cb;
@@ -1460,7 +1475,7 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         const uint32_t soff = rec.y, n = rec.z & MLM_SEC_CNT_MASK, n_refs = rf.y;
         const uint32_t pix0 = rec.w / MLM_TIME_SLOTS;
         const uint32_t y0 = (uint32_t)(((unsigned long long)pix0 * div_m) >> div_s);
-        const int xlo = (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64;
+        const int xlo = tile_w > 0 ? (int)(MLM_REF_XREL0 << 3) - 64 : (int)((pix0 - y0 * (uint32_t)row_w) & ~7u) - 64;
         const bool act = valid && n <= 512u;
 #ifdef MLM_PHASE_PROF // (diagnostic build: how many contributions the ranked cells have — tools/rank_hist.py)
         if (valid && hl == 0) {

@@ -84,9 +84,8 @@ int submit_batch(mlm_handle *h, int base, int n) {
         if (rc == MLM_OK) rc = grow_sbkt(h, h->hit_n_bkt);
         if (rc) return rc;
     }
-    // (the sector path packs a tile's image column into 8 bits of a reference: images up to 2040 pixels wide; its bucket-first
-    // tables hold sbkt_cap buckets)
-    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= 2040 &&
+    // (a column record holds its tile's column in 13 bits: images up to 65 528 pixels wide; the slots' bucket-first tables hold sbkt_cap buckets)
+    const bool sectors = h->use_sectors && h->sector_backoff == 0 && h->slots[(size_t)base].F.width <= MLM_SEC_MAX_WIDTH &&
                          h->hit_n_bkt <= h->slots[(size_t)base].P.sbkt_cap;
     if (h->sector_backoff > 0) --h->sector_backoff;
     if (!sectors) { // the cell-table path cannot replay a frame that ran out of blocks: room for everything in flight + this batch
@@ -435,7 +434,7 @@ inline bool fast_handle_ok(const mlm_handle *h) {
 bool single_fast_ok(const mlm_handle *h, int n) {
     if (n != 1 || !fast_handle_ok(h)) return false;
     const MlmSlot &S = h->slots[(size_t)(h->cur_set * h->lim.max_batch)];
-    return S.F.width <= 2040 && h->hit_n_bkt <= S.P.sbkt_cap && S.F.n > 0;
+    return S.F.width <= MLM_SEC_MAX_WIDTH && h->hit_n_bkt <= S.P.sbkt_cap && S.F.n > 0;
 }
 // the stream uploads of a call's inputs go to: the one its Stage A will run on (a frame-level veto of the graph path is
 // repaired by run_slots with an event between the two streams)

@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for s in decl:
         assert hasattr(lib, s), f"{s} declared in include/mlmap_hip.h but not exported"
     assert sorted(ABI_SYMBOLS) == decl, "python binding and header disagree on the ABI surface"
-    assert lib.mlm_abi_version() == 5
+    assert lib.mlm_abi_version() == 6
 
 
 def test_no_cpu_fallback():

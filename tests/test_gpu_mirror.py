@@ -171,7 +171,7 @@ def test_mirror_growth_carries_its_contents_and_respects_the_limit(mods):
     copied = []
     for k in range(6):  # the sensor walks away: new blocks every frame, the first ones are never touched again
         q, t = syn.static_pose()
-        t = np.array([4.0 * k, 0.0, 0.0]) + t
+        t = np.array([20.0 * k, 0.0, 0.0]) + t  # (farther apart than the awareness cylinder is wide: an integrate call marks what it can reach)
         img = syn.room_depth(cfg)
         gpu.update_map(img, q, t)
         cpu.update_depth(img, q, t)

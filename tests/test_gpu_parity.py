@@ -116,11 +116,12 @@ def test_forced_buffer_overflows(mods, monkeypatch, knobs, node_lds, agg_lds):
     gpu.close()
 
 
-@pytest.mark.parametrize("w,h", [(333, 77), (5, 3), (33, 9), (640, 1), (1, 240), (2040, 48), (2041, 40), (4000, 24), (24, 3000)])
+@pytest.mark.parametrize("w,h", [(333, 77), (5, 3), (33, 9), (640, 1), (1, 240), (2040, 48), (2041, 40), (4000, 24), (9000, 12), (24, 3000)])
 def test_odd_image_sizes(mods, w, h):
     """Frame sizes that are not multiples of the 32x8 pixel tiles / the 4x4 tile groups (partial tiles, single rows and
-    columns), the widest image the sector path takes (2 040 pixels), wider ones (the cell-table path) and one taller than the
-    2 047 rows a reference of the ranking kernel can span must give the same map as the oracle."""
+    columns), images wider than the 2 040 pixels a reference of the ranking kernel used to span (its columns are relative to the
+    cell's first pixel since round 6: any width stays on the sector path) and one taller than the 2 047 rows it can span must
+    give the same map as the oracle — without a frame taking the cell-table path."""
     MLMap, OracleMap = mods
     cfg = S1.with_(width=w, height=h, cam_cx=w / 2.0, cam_cy=h / 2.0)
     gpu, cpu = MLMap(cfg, max_blocks=8192, max_points=max(w * h, 4096), record_awareness=True), OracleMap(cfg)
@@ -133,6 +134,7 @@ def test_odd_image_sizes(mods, w, h):
         cpu.update_depth(depth, q, t)
         _awareness_equal(gpu, cpu)
         compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"{w}x{h} frame {k}")
+    assert gpu.frame_stats()["n_sector_fallbacks"] == 0, (w, h)
     gpu.close()
 
 
