@@ -88,6 +88,9 @@ __host__ __device__ __forceinline__ uint32_t mlm_sec_strength(float a) { return 
 // A cell with exactly TWO contributions needs no order either: p = 1 - (1 - a)(1 - b) whichever comes first (the first step sets
 // p to the first value, the float product commutes) — the far cells of a frame, where a pixel's spread meets a neighbour's centre.
 __device__ __forceinline__ bool mlm_sec_needs_order(const MlmSecCell &c) {
+#ifdef MLM_EXP_KEEP_ONE_IN // (throughput experiment, results are wrong: only one ordered cell in N keeps its order — what would the pipeline gain if the rest were free?)
+    if ((((c.key & MLM_SEC_KEY_MASK) * 2654435761u) >> 16) % MLM_EXP_KEEP_ONE_IN != 0u) return false;
+#endif
     return __popc(c.kg & MLM_SEC_KIND_MASK) > 1 && (c.cnt >> MLM_SEC_CNT_BITS) < MLM_SEC_STRONG_ENOUGH && (c.cnt & MLM_SEC_CNT_MASK) > 2u;
 }
 
@@ -684,6 +687,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
     // keeps the record it handled first: a column with at most NT records (the usual case) is not read twice.
     uint32_t keep_cell = MLM_NIL, keep_yx = 0, keep_total = 0xFFFFFFFFu;
     unsigned long long keep_mask = 0;
+    // ... and the record it handled second as it came (its targets are looked up again): a column with at most 2 NT records — nearly
+    // every column of a camera frame — is not read from memory twice (the second read, with its descriptors staged again, was a
+    // fifth of the kernel's wave-cycles: tools/sector_phase.py)
+    uint32_t keep2_cell = MLM_NIL, keep2_yx = 0;
+    unsigned long long keep2_mask = 0;
     // ... and the table entries of its targets, so that the second pass neither recomputes them nor probes the table:
     // (entry | kind << 12) in 16 bits each, four in keep_lo, the fifth in keep_hi's low half, the count in its high half
     // (MLM_SEC_KEEP_MORE: more than five targets or a kind above 15 — the record is recomputed)
@@ -743,8 +751,9 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
         }
     };
     auto for_records = [&](int pass) {
-        if (pass == 1 && nch <= CH && keep_total <= NT) {
+        if (pass == 1 && nch <= CH && keep_total <= 2u * NT) {
             if (keep_cell != MLM_NIL) refs_of_kept();
+            if (keep2_cell != MLM_NIL) refs_of(keep2_cell, keep2_yx, keep2_mask);
             return;
         }
         for (uint32_t c0 = 0; c0 < nch; c0 += CH) {
@@ -798,6 +807,11 @@ __device__ __forceinline__ void mlm_sector_column(const MlmDev &P, const MlmFram
                         keep_cell = cell;
                         keep_yx = a.y;
                         keep_mask = mask;
+                    }
+                    if (c0 == 0 && r == threadIdx.x + (uint32_t)NT) {
+                        keep2_cell = cell;
+                        keep2_yx = a.y;
+                        keep2_mask = mask;
                     }
                     uint32_t nt = 0;
                     const int l0 = __ffsll((long long)mask) - 1; // lowest lane = earliest insertion time of the record
