@@ -1,5 +1,6 @@
 # usage: bash tools/prof_round.sh [tag] [sections]   (everything under gpurun_out/<tag>/; copy the summaries to profiles/<tag>_*)
 # sections (default "test bench times rows kt pmc sq"): test = pytest -m gpu; bench = bench.py; times = isolated kernel times;
+# (kt also traces a config-3 run, sq also runs tools/sq_cfg3.sh)
 # rows = the widened rows; kt = rocprofv3 kernel trace of bench.py; pmc = FETCH/WRITE passes over the batched path (cfg2 from a fresh
 # stream and in the steady state after eight warm-up batches, cfg3) and
 # over single frames; sq = SQ counter passes over the batched path
@@ -26,6 +27,8 @@ cd /tmp && export TMPDIR=/tmp
 if has kt; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-extra --steps 12 > $O/kt.log 2>&1
 cp $(find $O/kt -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv; rm -rf $O/kt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt3 -- python3 $R/bench.py --workload cfg3 --batch 32 --batches-per-step 3 --distinct 32 --no-cpu-baseline --no-extra --steps 12 > $O/kt3.log 2>&1
+cp $(find $O/kt3 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_cfg3.csv; rm -rf $O/kt3
 fi
 if has pmc; then
 NB=6
@@ -52,5 +55,6 @@ python $R/tools/pmc_sq_json.py $S $S2 $O/pmc_sq.json frames=192 > $O/pmc_sq.log 
 rm -rf $O/sq $O/sq2
 fi
 cd $R
+if has sq; then bash tools/sq_cfg3.sh $TAG > $O/sq_cfg3.log 2>&1; fi
 # (raw counter CSVs are large: only the summaries are kept)
 tail -3 $O/pytest.log 2>/dev/null; cat $O/bench.json 2>/dev/null
