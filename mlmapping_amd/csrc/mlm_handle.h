@@ -27,7 +27,7 @@ struct KernelTime {
 const char *const kKnobNames[] = {"agg_lds", "big_arm", "big_grid", "bin_block", "chain_grid", "collect_grid", "cu_reserve", "cu_split",
                                   "debug_fail_slot", "ex_spec", "expand_block", "graph", "lean_slots", "logit_exact", "mirror", "mirror_max", "mirror_mb", "need_slots", "node_lds", "pool_grow",
                                   "rank_grid", "sc_block", "sc_grid", "sec_backoff", "sec_fail_every", "sec_tab", "sec_tab_big", "sec_threads",
-                                  "sectors", "single_chain_grid", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
+                                  "sectors", "single_chain_grid", "single_rank_grid", "slot_sets", "sort_block", "sort_grid", "tile_grid", "tile_sh"};
 struct KnobStore {
     std::mutex mu;
     std::unordered_map<std::string, long long> v;
@@ -101,6 +101,10 @@ struct MlmMirror {
     long long n_eager = 0;
 };
 
+// A frame on its own with at most this many strips of 256 points (sampled callbacks, point lists: 4 096 points) runs its cells' float chains
+// inside k_rank<true> instead of launching k_chain_lanes — two dependent launches are 4.4 us apart whatever they do; a dense frame's
+// thousands of cells keep k_chain_lanes' cell-per-lane replay (measured: 128 -> 201 us for a dense VGA frame with the chains in k_rank)
+constexpr unsigned int kFusedChainStrips = 16;
 static inline double mlm_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct mlm_handle {
     int device = 0;
@@ -209,6 +213,7 @@ struct mlm_handle {
     int sec_threads = 512;           // threads of a column's workgroup (k_sector<.., 256 | 512>; MLM_SEC_THREADS)
     double clk[8] = {}, clk_t = 0;   // host clocks of the single-frame path (mlm_debug_clocks): microseconds per section, summed over the calls
     unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
+    unsigned int single_rank_grid = 256;   // workgroups of a lone frame's k_rank<true> (ranking + chains; knob "single_rank_grid")
     unsigned int single_chain_grid = 64;  // workgroups of a lone frame's k_chain_lanes: 256 waves x 64 cells cover a dense VGA frame's ranked cells in one turn
     unsigned int single_apply_grid = 256; // workgroups of k_apply_single: a VGA frame's ~33 k voxel records, one per thread (more: in turns)
     unsigned int tile_grid = 0;      // workgroups of k_tile per frame of a batch: they walk the frame's touched tiles (MLM_TILE_GRID)

@@ -1270,6 +1270,11 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector_big(const MlmDev *__
 #else
 #define MLM_RANK_ATTR
 #endif
+// CHAIN (the launches of a frame on its own): the wave that has ranked a cell runs its float chain at once, from the kinds it has just
+// put in order, and k_chain_lanes is not launched — a lone frame's cells are a handful per wave, so the chain by one lane per cell
+// (a quarter of a microsecond) is cheaper than a kernel boundary plus a kernel that starts from memory again; in a batch, where a wave
+// ranks dozens of cells, one lane per cell would idle the other sixty-three and k_chain_lanes' cell-per-lane replay stays.
+template <bool CHAIN>
 __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s) {
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) unsigned long long s_rows[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
@@ -1316,6 +1321,26 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
         yx = (dy << 11) | x;
     };
     auto load_pair = [&](const mlm_u32x2 &rf, uint32_t p, uint32_t &bits, uint32_t &yx, uint32_t &sub) { unpack(load_ref(rf, p), bits, yx, sub); };
+    // (CHAIN) the float noisy-OR chain of ONE cell by the calling lane (update_odds_hashmap, map_awareness.h:147-154) over its n kinds in
+    // pixel order, read with kind_at(j); hit-list place and rho from the cell's descriptor — what k_chain_lanes does for a lane's cell
+    // (the cell's 21 possible odds — one per kind, at its rho — are put into LDS by the lanes of the half / wave first: a look-up per step
+    // from memory would make a chain of 77 steps 77 trips)
+    __shared__ float s_odd[CHAIN ? MLM_BLOCK / 64 : 1][2][32];
+    auto chain_odds = [&](const mlm_u32x4 &rec, int h, int l) { // lanes l = 0 .. 31 of the cell's half h (both halves for a whole-wave cell: h = 0)
+        const int rho = (int)(rec.z >> MLM_SEC_CNT_BITS), d = (l + 1) >> 1, rho_s = l == 0 ? rho : ((l & 1) ? rho - d : rho + d);
+        if (l < 32) s_odd[CHAIN ? wid : 0][h][l] = (l <= 2 * MLM_DIFF_RANGE && rho_s >= 0 && rho_s < P.nRho) ? mlm_gp(P.odds_table)[mlm_contribution_index(P, rho, l)] : 0.0f;
+    };
+    auto chain_cell = [&](const mlm_u32x4 &rec, int h, uint32_t n, auto &&kind_at) {
+        volatile MLM_LDS float *odd = mlm_lp(s_odd[CHAIN ? wid : 0][h]);
+        float p = 0.0f;
+        for (uint32_t j = 0; j < n && p != 1.0f; ++j) { // (1.0f is absorbing)
+            const float a = odd[kind_at(j) & 31u];
+            p = j == 0u ? a : 1 - (1 - p) * (1 - a);
+        }
+        const uint32_t pos = rec.x;
+        if (P.record_awareness || P.explore) mlm_gp(P.hl_odd)[pos] = p;
+        mlm_gp(P.hl_inc)[pos] = mlm_logit(P, p);
+    };
     auto process = [&](const mlm_u32x4 &rec, const mlm_u32x2 &rf, const uint32_t (&r_raw)[4]) {
         uint32_t r_bits[4], r_yx[4], r_sub[4];
 #pragma unroll
@@ -1424,8 +1449,20 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
             if (staged) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t j = lane; j < (n + 3u) >> 2; j += 64) // (segments are padded to 16 bytes)
-                    ((MLM_GLOBAL uint32_t *)S)[j] = ((volatile MLM_LDS uint32_t *)SL)[j];
+                if (CHAIN) {
+                    chain_odds(rec, 0, lane);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) chain_cell(rec, 0, n, [&](uint32_t j) -> uint32_t { return SL[j]; });
+                } else {
+                    for (uint32_t j = lane; j < (n + 3u) >> 2; j += 64) // (segments are padded to 16 bytes)
+                        ((MLM_GLOBAL uint32_t *)S)[j] = ((volatile MLM_LDS uint32_t *)SL)[j];
+                }
+            } else if (CHAIN) { // (more than 1 024 contributions: the kinds went straight to memory)
+                chain_odds(rec, 0, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) chain_cell(rec, 0, n, [&](uint32_t j) -> uint32_t { return __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); });
             }
         } else {
             // slow exact path (a contribution outside the bitmap window, or a huge cell): write every contribution's
@@ -1455,6 +1492,12 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
                 uint32_t r = 0;
                 for (uint32_t q = 0; q < n; ++q) r += __hip_atomic_load(&K[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < my;
                 S[r] = (uint8_t)(my & 31u);
+            }
+            if (CHAIN) {
+                chain_odds(rec, 0, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) chain_cell(rec, 0, n, [&](uint32_t j) -> uint32_t { return __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); });
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1593,7 +1636,12 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
             }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (ok) {
+        if (CHAIN) { // (the staged kinds are complete: the barrier above)
+            if (ok) chain_odds(rec, half, hl);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (ok && hl == 0) chain_cell(rec, half, n, [&](uint32_t j) -> uint32_t { return SL_h[j]; });
+        } else if (ok) {
             MLM_GLOBAL uint32_t *S32 = (MLM_GLOBAL uint32_t *)(mlm_gp(P.subs) + soff);
             for (uint32_t j = (uint32_t)hl; j < (n + 3u) >> 2; j += 32) S32[j] = ((volatile MLM_LDS uint32_t *)SL_h)[j]; // (segments are padded to 16 bytes)
         }

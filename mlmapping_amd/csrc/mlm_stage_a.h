@@ -255,8 +255,12 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
                 tlaunch(h, "k_sector_big", k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, n,
                         mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
         }
-        tlaunch(h, "k_rank", k_rank, dim3(n > 4 ? h->rank_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
-                mode == 0 ? F.width : 0, row_w, dm, ds);
+        const bool fused_chain = n == 1 && nb <= kFusedChainStrips; // (a small frame on its own: k_rank<true> runs the chains of the cells it ranks)
+        if (fused_chain)
+            tlaunch(h, "k_rank", k_rank<true>, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, mode == 0 ? F.width : 0, row_w, dm, ds);
+        else
+            tlaunch(h, "k_rank", k_rank<false>, dim3(n > 4 ? h->rank_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
+                    mode == 0 ? F.width : 0, row_w, dm, ds);
         // blocks per frame: about 400 ranked cells per block in a batch (a lane that finishes a chain draws the next cell; each
         // block builds the transposed odds table in LDS), as many as the last confirmed frame had; single frames spread wider
         unsigned int cg = h->chain_grid;
@@ -264,7 +268,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
             const long long cells = std::max<long long>(1, h->stats.n_multi_cells);
             cg = n > 4 ? (unsigned int)std::min<long long>(64, std::max<long long>(8, cells / 400)) : (unsigned int)std::min<long long>(128, std::max<long long>(16, cells / 128));
         }
-        if (!h->no_spread)
+        if (!h->no_spread && !fused_chain)
             tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
                 base, n > 4 ? 128u : 64u);
         // the frame's hits and misses grouped by voxel, tile by tile (needs the increments and keys of the kernels above)

@@ -456,6 +456,7 @@ int mlm_create(const mlm_config *cfg, const mlm_limits *lim_in, int device, mlm_
         if (knob("big_arm", kv)) h->big_arm_len = std::max(0, (int)kv);
         if (knob("ex_spec", kv)) h->ex_spec = (int)kv;
         if (knob("single_chain_grid", kv)) h->single_chain_grid = (unsigned int)std::max(1, (int)kv);
+        if (knob("single_rank_grid", kv)) h->single_rank_grid = (unsigned int)std::max(1, (int)kv);
         if (knob("mirror", kv)) h->mir.enabled = (int)kv != 0;
         if (knob("mirror_mb", kv)) h->mir.max_bytes = (size_t)std::max(0, (int)kv) << 20;
         if (knob("mirror_max", kv)) h->mir.max_clean = std::max(0, (int)kv), h->mir.max_dirty = std::min(h->mir.max_dirty, h->mir.max_clean);
