@@ -759,6 +759,9 @@ def main():
                 from tools.query_latency import measure as query_latency
 
                 out["extra"]["single_query_us"] = query_latency(cfg, with_oracle=not args.no_cpu_baseline)
+                cb = out["extra"]["single_query_us"].pop("callback_sampled500_cpp", None)
+                if cb:  # (the same 500-sample callback as single_frame_us.callback_sampled500, called from a C++ process instead of through ctypes)
+                    out["extra"]["single_frame_us"]["callback_sampled500_cpp_client"] = cb
             except Exception as e:  # noqa: BLE001 (the headline must not depend on this row)
                 out["extra"]["single_query_us"] = {"error": str(e)[:300]}
             out["extra"]["other_scenes"] = other_scenes(MLMap, cfg, frames, q, t, d_frames, local_rank)

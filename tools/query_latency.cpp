@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -107,6 +108,21 @@ int main(int argc, char **argv) {
                 t_infl.push_back(t5 - t4);
                 t_clock.push_back(t6 - t5);
             }
+        // the reference's own call: depth_odom_input_callback with its 500 rand() samples (src/mlmap.cpp:463-507), one frame per call, from
+        // this C++ process (no interpreter between the clock and the library)
+        std::vector<double> t_cb;
+        {
+            const double zero3[3] = {0, 0, 0};
+            for (int r = 0; r < 320; ++r) {
+                const int k = r % n_frames;
+                const double t0 = now_us();
+                if (mlm_integrate_callback(map.handle(), imgs[(size_t)k].data(), 0, W, H, 0.0, &poses[(size_t)k * 7 + 4], &poses[(size_t)k * 7], zero3, 0.0, zero3, 0.0, 0.0, 1,
+                                           nullptr) != MLM_OK)
+                    throw std::runtime_error(mlm_last_error(map.handle()));
+                if (r >= 20) t_cb.push_back(now_us() - t0);
+            }
+        }
+        const Stat cb = stat_of(t_cb);
         mlm_frame_stats st{};
         mlm_get_frame_stats(map.handle(), &st);
         const Stat a = stat_of(t_occ), b = stat_of(t_odd), c = stat_of(t_grad), d = stat_of(t_occ_i), e = stat_of(t_infl), k = stat_of(t_clock), fi = stat_of(first), fa = stat_of(first_async);
@@ -119,9 +135,10 @@ int main(int argc, char **argv) {
                     "\"first_query_after_integrate\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"samples\": %zu, \"includes\": \"the wait for the integrate call's own refresh of the host mirror\"}, "
                     "\"first_query_after_async_integrate\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"samples\": %zu, \"includes\": \"the frame itself: the query drains what was submitted\"}, "
                     "\"first_query_ever_us\": %.2f, "
+                    "\"callback_sampled500_cpp\": {\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"calls\": %zu}, "
                     "\"n_host_queries\": %lld, \"n_mirror_refreshes\": %lld, \"n_mirror_blocks\": %lld, \"n_blocks\": %lld, \"sink\": %lld}\n",
                     t_occ.size(), k.p50, a.p50, a.p99, a.mean, b.p50, b.p99, b.mean, c.p50, c.p99, c.mean, d.p50, d.p99, d.mean, e.p50, e.p99, e.mean,
-                    fi.p50, fi.p99, fi.mean, first.size(), fa.p50, fa.p99, fa.mean, first_async.size(), ever[0], (long long)st.n_host_queries, (long long)st.n_mirror_refreshes, (long long)st.n_mirror_blocks,
+                    fi.p50, fi.p99, fi.mean, first.size(), fa.p50, fa.p99, fa.mean, first_async.size(), ever[0], cb.p50, cb.p99, cb.mean, t_cb.size(), (long long)st.n_host_queries, (long long)st.n_mirror_refreshes, (long long)st.n_mirror_blocks,
                     (long long)st.n_blocks, sink + (long long)fsink);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "query_latency: %s\n", e.what());
