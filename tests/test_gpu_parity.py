@@ -653,6 +653,26 @@ def test_heavy_cell_beyond_lds_window(mods):
     compare_maps(gpu.export_blocks(), cpu.export_blocks(), "heavy cell")
 
 
+@pytest.mark.parametrize("n", [300, 900, 3000, 4096])
+def test_heavy_cells_in_a_small_frame(mods, n):
+    """A frame of at most 4 096 points on its own runs its cells' float chains inside k_rank<true> (no k_chain_lanes launch): cells with
+    a few dozen contributions (half a wave ranks them), several hundred (the whole wave redoes them) and more than 1 024 (the kinds
+    go through memory) — the same two adjacent range cells as above, which spread into each other."""
+    MLMap, OracleMap = mods
+    cfg = S1
+    gpu, cpu = MLMap(cfg, max_blocks=2048, record_awareness=True), OracleMap(cfg)
+    q, t = syn.static_pose()
+    rng = np.random.default_rng(n)
+    z = np.where(rng.random(n) < 0.5, 5.93, 6.03) + rng.uniform(-0.004, 0.004, n)
+    pts = np.stack([rng.uniform(-0.003, 0.003, n), rng.uniform(-0.003, 0.003, n), z], axis=1)
+    for k in range(2):  # (the second call replays the single-frame graph)
+        gpu.update_map_points(pts, q, t)
+        cpu.update_points(pts, q, t)
+        _awareness_equal(gpu, cpu)
+        compare_maps(gpu.export_blocks(), cpu.export_blocks(), f"heavy cells, {n} points, call {k}")
+    assert gpu.frame_stats()["n_multi_cells"] >= 2
+
+
 def test_argument_and_capacity_errors(mods, monkeypatch, knobs):
     """Error behaviour of the boundary: statuses, never exceptions or silent corruption."""
     import ctypes as C
