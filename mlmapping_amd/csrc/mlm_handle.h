@@ -231,6 +231,9 @@ struct mlm_handle {
         int mode, width, height, base, big;
         unsigned int nb, sec_tab; // (sec_tab stands for the column kernel's launch geometry: threads and LDS follow from it)
         size_t n_bkt;
+        bool no_prologue; // the variant for a small frame whose slot counters are clear (k_bin_sectors_hostf first)
+        const int32_t *list; // ... and the staged pixel list its first kernel prefetches (null: none), `list_n` entries in front of the depths
+        unsigned int list_n;
         hipGraphExec_t exec;
     };
     std::vector<SingleGraph> graphs;
@@ -307,6 +310,7 @@ inline unsigned int bin_grid(const MlmDev &P, const MlmFrame &F, int mode) {
     if (mode == 0) return (unsigned int)(((F.width + 31) / 32) * ((F.height + tile_h - 1) / tile_h));
     return (unsigned int)(((size_t)F.n + P.bin_block - 1) / P.bin_block);
 }
+constexpr unsigned int kHostFrameStrips = 16; // a frame of at most this many strips may start its graph without k_frame_prologue (submit_single_graph)
 constexpr unsigned int kListGrid = 256; // blocks of the grid-stride kernels that walk a device-sized list
 
 struct Timed {

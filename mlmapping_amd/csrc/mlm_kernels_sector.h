@@ -164,8 +164,8 @@ template <int MODE> __device__ __forceinline__ MlmTile mlm_strip_item(const MlmF
 // its place in the strip's slice is known (a lane leads at most one record) — what is staged per strip is the column table (phi,
 // count, offset: 768 bytes for a dense strip).
 template <int MODE, int S>
-__global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int n_strips) {
-    MLM_SLOT_SETUP
+__device__ __forceinline__ void mlm_bin_sectors_body(const MlmDev &P, const MlmFrame &F, unsigned int n_strips, bool pre = false, int pre_pix = 0,
+                                                     int pre_raw = 0) { // (pre: this thread's list entry has been fetched already, k_bin_sectors_hostf)
     constexpr uint32_t COLS = MODE == 0 ? 64u : (uint32_t)MLM_SEC_COLS; // entries of a strip's column table
     static_assert(MODE == 0 || S == 1, "list modes: one strip per workgroup (one column entry per thread)");
     __shared__ uint32_t s_col_phi[S][COLS], s_col_cnt[S][COLS], s_col_off[S][COLS];
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
                 ys[j] = mlm_gp(F.pts)[3 * (size_t)T.i + 1];
                 zs[j] = mlm_gp(F.pts)[3 * (size_t)T.i + 2];
             } else {
-                const int pix = (MODE == 1) ? mlm_gp(F.pix)[T.i] : T.i;
+                const int pix = (MODE == 1) ? (pre ? pre_pix : mlm_gp(F.pix)[T.i]) : T.i;
                 const int v = pix / F.width;
                 const int u = pix - v * F.width;
-                raw[j] = (MODE == 1 && F.raw) ? (uint16_t)mlm_gp(F.raw)[T.i] : mlm_gp(F.img)[(size_t)v * F.row_stride + u];
+                raw[j] = (MODE == 1 && pre) ? (uint16_t)pre_raw : (MODE == 1 && F.raw) ? (uint16_t)mlm_gp(F.raw)[T.i] : mlm_gp(F.img)[(size_t)v * F.row_stride + u];
                 // mlmap.cpp:329,344-346: (size_t u - float cx_) is a float subtraction, the rest is double (the depth factor below)
                 xs[j] = (double)((float)u - P.cx);
                 ys[j] = (double)((float)v - P.cy);
@@ -360,6 +360,40 @@ __global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int
         else
             mlm_sector_fail(P, F);
     }
+}
+template <int MODE, int S>
+__global__ __launch_bounds__(256) void k_bin_sectors(MLM_SLOT_ARGS, unsigned int n_strips) {
+    MLM_SLOT_SETUP
+    mlm_bin_sectors_body<MODE, S>(P, F, n_strips);
+}
+// First node of a SMALL frame's graph (at most kHostFrameStrips strips: the reference's 500-sample callback): the frame's parameters
+// come straight from pinned host memory — every workgroup fetches the 248 bytes across the link into LDS, the first one leaves the
+// copy in the device-resident table for the kernels behind it — and the slot's counters are already clear (the last workgroup of the
+// previous frame's k_apply_single cleared them after handing them to the host): no prologue kernel in front of this one.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bin_sectors_hostf(const MlmDev *__restrict__ slot_tab, const MlmFrame *host_frame, MlmFrame *dev_frame,
+                                                           int slot_base, unsigned int n_strips, const int32_t *list_pix, const int32_t *list_raw,
+                                                           unsigned int list_n) {
+    const MlmDev &P = slot_tab[slot_base];
+    __shared__ MlmFrame s_F;
+    static_assert(sizeof(MlmFrame) % 4 == 0 && sizeof(MlmFrame) / 4 <= 256, "one word per thread");
+    // (list_pix / list_raw: where the frame's pixel list and depths will turn out to be — the callback's pinned staging buffer, the same
+    // for every call —, so that a thread's entry crosses the link together with the parameters instead of after them)
+    const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+    bool pre = MODE == 1 && list_pix && list_raw && i < list_n;
+    int pre_pix = 0, pre_raw = 0;
+    if (pre) {
+        pre_pix = mlm_gp(list_pix)[i];
+        pre_raw = mlm_gp(list_raw)[i];
+    }
+    if (threadIdx.x < sizeof(MlmFrame) / 4) {
+        const uint32_t w = __hip_atomic_load((const uint32_t *)host_frame + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ((uint32_t *)&s_F)[threadIdx.x] = w;
+        if (blockIdx.x == 0) ((uint32_t *)dev_frame)[threadIdx.x] = w;
+    }
+    __syncthreads();
+    pre = pre && s_F.pix == list_pix && s_F.raw == list_raw;
+    mlm_bin_sectors_body<MODE, 1>(P, s_F, n_strips, pre, pre_pix, pre_raw);
 }
 
 // find (or with INSERT create) the table entry of a column-local cell key; -1: table full
@@ -2499,16 +2533,32 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS, MlmCo
     __shared__ unsigned int s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        // (no release fence: nothing the host does on the ticket alone reads what the workgroups stored into the map — whatever reads the
+        // map is a later kernel of the stream; the counters were final before this kernel, the flag a frame that is not applied raises is
+        // an atomic of workgroup 0's first thread, fenced here.  An agent-scope fence is 2-4 us of a lone frame's latency.)
+        if (!ok) __threadfence();
         s_last = g_atomic_add(&mlm_gp(P.ctr)->apply_done, 1u) == gridDim.x - 1u ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x)
-        ((uint32_t *)host_ctr)[i] = __hip_atomic_load((const uint32_t *)P.ctr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < 3) ((uint32_t *)host_g)[threadIdx.x] = __hip_atomic_load((const uint32_t *)P.g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
+    // the words of MlmCounters the host reads: the 18 scalars and [k][0], [k][1] of the six spread arrays (the rest is padding that keeps
+    // the partial sums 128 bytes apart and is never written) — 114 words by 114 lanes, read with agent-scope loads
+    if (threadIdx.x < 128u) {
+        const unsigned int t = threadIdx.x;
+        if (t < MLM_CTR_SCALARS + 96u) {
+            const unsigned int w = mlm_ctr_live_word(t);
+            uint32_t val = __hip_atomic_load((const uint32_t *)P.ctr + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a frame that has been applied leaves its slot's counters clear for the slot's next frame and says so in the word the host has
+            // no other use for (submit_single_graph: such a frame's graph starts without k_frame_prologue); a frame that was not applied keeps
+            // them — the host's replay reads them
+            if (run) ((uint32_t *)P.ctr)[w] = 0u;
+            if (w == MLM_CTR_APPLY_DONE) val = run ? MLM_CTR_CLEARED : 0u;
+            ((uint32_t *)host_ctr)[w] = val;
+        } else if (t >= 120u && t < 123u) {
+            ((uint32_t *)host_g)[t - 120u] = __hip_atomic_load((const uint32_t *)P.g + (t - 120u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence_system();
+    }
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&host_g->pad, (unsigned int)F.seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -2550,7 +2600,7 @@ __global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_fra
     const uint32_t *src = (const uint32_t *)host_frame;
     uint32_t *dst = (uint32_t *)dev_frame, *c = (uint32_t *)ctr;
     for (unsigned int i = threadIdx.x; i < sizeof(MlmFrame) / 4; i += blockDim.x) dst[i] = src[i];
-    for (unsigned int i = threadIdx.x; i < sizeof(MlmCounters) / 4; i += blockDim.x) c[i] = 0u;
+    if (threadIdx.x < MLM_CTR_SCALARS + 96u) c[mlm_ctr_live_word(threadIdx.x)] = 0u; // (the words that are ever written: see k_apply_single)
 }
 
 // Test hook (mlm_debug_probe_seeds): the largest relative error of the v_rcp_f64 / v_rsq_f64 seeds and of their once-refined

@@ -122,7 +122,10 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n, bool on_main = false) {
         HIPCHK(h, hipEventRecord(h->inputs_ready, h->stream));
         HIPCHK(h, hipStreamWaitEvent(st, h->inputs_ready, 0));
     }
-    for (int j = 0; j < n; ++j) h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
+    for (int j = 0; j < n; ++j) {
+        h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
+        h->slots[(size_t)(base + j)].h_ctr->apply_done = 0u; // (the slot's counters are in use: not "left clear by a single-frame graph", submit_single_graph)
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
                              hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));
@@ -203,7 +206,10 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
         HIPCHK(h, hipEventRecord(h->inputs_ready, h->stream));
         HIPCHK(h, hipStreamWaitEvent(st, h->inputs_ready, 0));
     }
-    for (int j = 0; j < n; ++j) h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
+    for (int j = 0; j < n; ++j) {
+        h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
+        h->slots[(size_t)(base + j)].h_ctr->apply_done = 0u; // (the slot's counters are in use: not "left clear by a single-frame graph", submit_single_graph)
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
                              hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));

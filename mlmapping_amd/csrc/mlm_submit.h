@@ -444,13 +444,29 @@ inline hipStream_t upload_stream(const mlm_handle *h) {
 // The launch sequence of ONE frame on stream `st` (the sector path, everything on one stream): a prologue kernel takes the frame's
 // parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, whose last workgroup writes the
 // counters, the map-wide flags and — last — the completion ticket back to pinned memory.  Issued directly, or captured into a graph.
-hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int big, hipStream_t st) {
+// the callback's sampled pixels lie in the handle's pinned staging buffer, indices first, depths `n` entries behind: a small frame's first
+// kernel fetches its entries together with the parameters (only that buffer: its extent is known).  n = 0: some other list, or none.
+inline unsigned int staged_list_len(const mlm_handle *h, const MlmSlot &S) {
+    if (S.mode == 1 && h->h_stage && S.F.pix == h->h_stage && S.F.raw > S.F.pix && (size_t)(S.F.raw - h->h_stage) + (size_t)(S.F.raw - S.F.pix) <= h->stage_cap)
+        return (unsigned int)(S.F.raw - S.F.pix);
+    return 0u;
+}
+hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int big, bool no_prologue, hipStream_t st) {
     const MlmSlot &S = h->slots[(size_t)base];
     const MlmDev &P = S.P;
-    hipLaunchKernelGGL(k_frame_prologue, dim3(1), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
-    if (S.mode == 0) hipLaunchKernelGGL((k_bin_sectors<0, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
-    else if (S.mode == 1) hipLaunchKernelGGL((k_bin_sectors<1, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
-    else hipLaunchKernelGGL((k_bin_sectors<2, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+    if (no_prologue) { // (a small frame behind a frame that left the slot's counters clear: k_bin_sectors_hostf)
+        const MlmFrame *hf = h->h_frame_tab + base;
+        const unsigned int ln = staged_list_len(h, S);
+        const int32_t *lp = ln ? S.F.pix : nullptr, *lr = ln ? S.F.raw : nullptr;
+        if (S.mode == 0) hipLaunchKernelGGL(k_bin_sectors_hostf<0>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, hf, h->d_frame_tab + base, base, nb, lp, lr, ln);
+        else if (S.mode == 1) hipLaunchKernelGGL(k_bin_sectors_hostf<1>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, hf, h->d_frame_tab + base, base, nb, lp, lr, ln);
+        else hipLaunchKernelGGL(k_bin_sectors_hostf<2>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, hf, h->d_frame_tab + base, base, nb, lp, lr, ln);
+    } else {
+        hipLaunchKernelGGL(k_frame_prologue, dim3(1), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
+        if (S.mode == 0) hipLaunchKernelGGL((k_bin_sectors<0, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+        else if (S.mode == 1) hipLaunchKernelGGL((k_bin_sectors<1, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+        else hipLaunchKernelGGL((k_bin_sectors<2, 1>), dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, h->d_frame_tab, base, nb);
+    }
     const int row_w = S.mode == 0 ? S.F.width : 64;
     unsigned long long dm, rm;
     int ds, rs;
@@ -500,17 +516,24 @@ int submit_single_graph(mlm_handle *h, int base) {
     h->h_frame_tab[base] = S.F;
     h->h_g->pad = 0u; // (k_apply_single ends with a ticket in the host copy of the map-wide flags: drain polls it)
     h->wait_ticket = (unsigned int)S.F.seq + 1u;
+    // The slot's last frame went through this graph and was applied: its last workgroup left the device counters clear and said so
+    // (MLM_CTR_CLEARED; every other use of the slot copies the real counters over the mark, or withdraws it: launch_stage_a_*).  A small frame
+    // then starts without the prologue kernel — its first kernel takes the parameters from pinned memory itself.
+    const bool no_prologue = nb <= kHostFrameStrips && S.h_ctr->apply_done == MLM_CTR_CLEARED;
+    S.h_ctr->apply_done = 0u; // (consumed: the counters are in use from here on)
     mlm_handle::SingleGraph *G = nullptr;
     for (auto &g : h->graphs)
-        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.sec_tab == P.sec_tab && g.n_bkt == h->hit_n_bkt && g.big == big) G = &g;
+        if (g.mode == S.mode && g.width == S.F.width && g.height == S.F.height && g.base == base && g.nb == nb && g.sec_tab == P.sec_tab && g.n_bkt == h->hit_n_bkt && g.big == big &&
+            g.no_prologue == no_prologue && (!no_prologue || (g.list == (staged_list_len(h, S) ? S.F.pix : nullptr) && g.list_n == staged_list_len(h, S))))
+            G = &g;
     if (!G) {
-        if (h->graphs.size() >= 8) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
+        if (h->graphs.size() >= 16) { // (a handful of frame geometries at most; the bucket count of the emulated container changes a dozen times per stream)
             for (auto &g : h->graphs) hipGraphExecDestroy(g.exec);
             h->graphs.clear();
         }
         hipStream_t st = h->stream;
         HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        const hipError_t e = enqueue_single_frame(h, base, nb, big, st);
+        const hipError_t e = enqueue_single_frame(h, base, nb, big, no_prologue, st);
         hipGraph_t graph = nullptr;
         const hipError_t e2 = hipStreamEndCapture(st, &graph);
         if (e != hipSuccess || e2 != hipSuccess || !graph) {
@@ -525,7 +548,7 @@ int submit_single_graph(mlm_handle *h, int base) {
             h->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3);
             return MLM_ERR_HIP;
         }
-        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, exec});
+        h->graphs.push_back(mlm_handle::SingleGraph{S.mode, S.F.width, S.F.height, base, big, nb, P.sec_tab, h->hit_n_bkt, no_prologue, staged_list_len(h, S) ? S.F.pix : nullptr, staged_list_len(h, S), exec});
         G = &h->graphs.back();
     }
     clk_mark(h, 1);

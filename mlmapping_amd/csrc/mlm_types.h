@@ -47,7 +47,19 @@ struct MlmGlobal {
                               // miss); INT_MAX = none.  Stage B/C kernels of frames >= it do nothing.
     unsigned int pad;
 };
-#define MLM_CTR_FRAME_BYTES (64 + 6 * 8 * 32 * 4)
+#define MLM_CTR_SCALARS 18u // scalar members in front of the six [8][32] arrays (k_apply_single hands those and the arrays' [k][0], [k][1] to the host)
+static_assert(sizeof(MlmCounters) == (MLM_CTR_SCALARS + 6u * 8u * 32u) * 4u, "MlmCounters layout");
+#define MLM_CTR_APPLY_DONE 17u       // word index of MlmCounters::apply_done
+static_assert(offsetof(MlmCounters, apply_done) == MLM_CTR_APPLY_DONE * 4u && offsetof(MlmCounters, ray_cnt) == MLM_CTR_SCALARS * 4u, "MlmCounters layout");
+#define MLM_CTR_CLEARED 0xC1EA4ED0u  // host copy of apply_done after a single-frame graph: the device counters of the slot are clear again
+// the t-th of the 114 words of MlmCounters that are ever written: the scalars, then [k][0] and [k][1] of the six spread arrays
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned int mlm_ctr_live_word(unsigned int t) {
+    const unsigned int u = t - MLM_CTR_SCALARS;
+    return t < MLM_CTR_SCALARS ? t : MLM_CTR_SCALARS + (u >> 4) * 256u + ((u >> 1) & 7u) * 32u + (u & 1u);
+}
 #define MLM_RAY_LISTS 8
 #define MLM_MISS_COPIES 8 // private copies of the miss bit mask (chosen by blockIdx): rays of the whole image converge
                           // on the words next to the sensor, and same-line atomics serialise (~11 ns each)
