@@ -49,7 +49,7 @@ void explore_flush_tail(mlm_handle *h) {
     if (!h->ex_tail) return;
     const dim3 blk(MLM_BLOCK);
     tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, h->stream, h->ex_tail->P);
-    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, h->stream, h->ex_tail->P);
+    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, h->stream, h->ex_tail->P, (MlmCounters *)nullptr, (MlmGlobal *)nullptr, 0u);
     h->ex_tail = nullptr;
 }
 
@@ -103,7 +103,7 @@ int explore_stage_bc(mlm_handle *h, int slot_index) {
 // observation, misses, release scan — behind the frame's Stage A without a synchronisation in between (the host used to wait for the
 // counts, replay both rehash policies and only then enqueue seven launches: the GPU idled through a copy, a wake-up and the first
 // launch's way down).  The kernels read the counts themselves and do nothing unless the frame fits both containers as they are
-// (MlmDev::spec_on, mlm_ex_spec_skip); the host checks the same condition once the frame has drained and, if it did not hold — the
+// (MlmDev::spec_on, mlm_ex_spec_skip); the host checks the same condition once the frame has drained (wait_for_ticket) and, if it did not hold — the
 // first frames of a stream, while the emulated containers still grow, or a Stage A that left the sector path —, runs the general
 // path with the counts it now has.  Returns with everything enqueued; thresholds in thr[2].
 int explore_stage_bc_spec(mlm_handle *h, int slot_index, unsigned int thr[2]) {
@@ -129,8 +129,11 @@ int explore_stage_bc_spec(mlm_handle *h, int slot_index, unsigned int thr[2]) {
     tlaunch(h, "k_apply", k_apply, dim3(64, 1), blk, 0, st, Ps, 0, 1);
     tlaunch(h, "k_ex_observe", k_ex_observe, dim3(4 * kListGrid), blk, 0, st, Ps, S.F);
     tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, st, Ps);
-    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, st, Ps);
-    HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, st));
+    // (the frame's counters, the map-wide flags and the completion ticket go to the host with the last workgroup of the last launch)
+    h->h_g->pad = 0u;
+    h->wait_ticket = (unsigned int)S.F.pad2 + 1u;
+    // (128 workgroups: the hand-back counts their arrivals on one word, ~10 ns each)
+    tlaunch(h, "k_ex_release", k_ex_release, dim3(128), blk, 0, st, Ps, h->h_ctr_all + slot_index, h->h_g, h->wait_ticket);
     return MLM_OK;
 }
 // end of a batch (or of a single frame): the last frame's tail, the map-wide counters.  (Deferring that tail to the next synchronous

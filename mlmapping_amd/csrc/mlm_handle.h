@@ -436,3 +436,21 @@ static inline hipError_t mlm_spin_sync(hipStream_t st) {
     }
     return hipStreamSynchronize(st);
 }
+// ... and when the frame's last launch ends with a ticket in pinned memory (mlm_hand_back): poll that word — it arrives a few microseconds
+// before the stream reads as idle; past a few milliseconds (or with no ticket expected) wait for the stream
+static inline hipError_t wait_for_ticket(mlm_handle *h, hipStream_t st) {
+    const unsigned int want = h->wait_ticket;
+    h->wait_ticket = 0u;
+    if (want && !h->timing) { // (per-kernel timing: the events behind the last launch must have completed too)
+        const volatile unsigned int *ticket = &h->h_g->pad;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned int spins = 0;; ++spins) {
+            if (*ticket == want) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return hipSuccess;
+            }
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+    }
+    return mlm_spin_sync(st);
+}

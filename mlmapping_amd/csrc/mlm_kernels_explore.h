@@ -335,30 +335,46 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) {
 // release scan (map_local.cpp:208-232): one workgroup per allocated block; blocks observed this frame whose frontier is
 // empty and whose occupancy is uniform are collapsed (they stop accepting updates; element 0 answers queries)
 __device__ __forceinline__ void mlm_ex_release_body(const MlmDev &P) {
+    // A workgroup's blocks are blockIdx.x, blockIdx.x + gridDim.x, ...; few of them were observed this frame: the flags of MLM_BLOCK
+    // candidates are read in ONE trip (a thread each) and the observed ones queued in LDS, so that a workgroup's time is one trip
+    // for the flags plus the scans of its observed blocks — not a dependent load per candidate.
     __shared__ int s_bad;
+    __shared__ unsigned int s_nq, s_q[MLM_BLOCK];
     const unsigned int n_blocks = min(P.g->n_blocks, (unsigned int)P.max_blocks); // read on the device: no host sync
-    for (unsigned int b = blockIdx.x; b < n_blocks; b += gridDim.x) {
-        if (!P.blk_observed[b]) continue; // uniform per workgroup
+    for (unsigned int b0 = blockIdx.x; b0 < n_blocks; b0 += gridDim.x * MLM_BLOCK) { // (uniform)
         __syncthreads();
-        if (threadIdx.x == 0) s_bad = 0;
+        if (threadIdx.x == 0) s_nq = 0;
         __syncthreads();
-        if (!P.blk_collapsed[b]) {
-            const uint8_t first = P.occ[(size_t)b * P.cells];
-            int bad = 0;
-            for (int c = threadIdx.x; c < P.cells; c += blockDim.x)
-                bad |= (P.frnt[(size_t)b * P.cells + c] != 0) | (P.occ[(size_t)b * P.cells + c] != first);
-            if (bad) s_bad = 1;
-        }
+        const unsigned long long bb = (unsigned long long)b0 + (unsigned long long)threadIdx.x * gridDim.x;
+        if (bb < n_blocks && P.blk_observed[bb]) s_q[atomicAdd(&s_nq, 1u)] = (unsigned int)bb;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            if (!P.blk_collapsed[b] && !s_bad) P.blk_collapsed[b] = 1;
-            P.blk_observed[b] = 0;
+        const unsigned int nq = s_nq;
+        for (unsigned int k = 0; k < nq; ++k) {
+            const unsigned int b = s_q[k];
+            __syncthreads();
+            if (threadIdx.x == 0) s_bad = 0;
+            __syncthreads();
+            if (!P.blk_collapsed[b]) {
+                const uint8_t first = P.occ[(size_t)b * P.cells];
+                int bad = 0;
+                for (int c = threadIdx.x; c < P.cells; c += blockDim.x)
+                    bad |= (P.frnt[(size_t)b * P.cells + c] != 0) | (P.occ[(size_t)b * P.cells + c] != first);
+                if (bad) s_bad = 1;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (!P.blk_collapsed[b] && !s_bad) P.blk_collapsed[b] = 1;
+                P.blk_observed[b] = 0;
+            }
         }
     }
 }
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) {
-    if (mlm_ex_spec_skip(P)) return;
-    mlm_ex_release_body(P);
+__device__ __forceinline__ void mlm_hand_back(const MlmDev &P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket, bool cleared); // (mlm_kernels_sector.h)
+// host_ctr (a synchronous call's lone frame, explore_stage_bc_spec): the last launch of the frame — its last workgroup hands the slot's
+// counters, the map-wide flags and the ticket to the host (instead of two copies on the stream, 4 us each and a gap in front)
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket) {
+    if (!mlm_ex_spec_skip(P)) mlm_ex_release_body(P);
+    if (host_ctr) mlm_hand_back(P, host_ctr, host_g, ticket, false);
 }
 
 // frontier read-out: (gx,gy,gz,cell) of every frontier cell

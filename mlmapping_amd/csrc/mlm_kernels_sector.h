@@ -2488,6 +2488,45 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
     }
 }
 
+// In front of a Stage A (first node of the single-frame graph; first launch of a batch's Stage A on the sector path): the frames'
+// parameters come from pinned host memory — workgroup j copies frame j's into the device-resident table and clears the slot's
+// counters (the words that are ever written: mlm_ctr_live_word) — one kernel instead of a copy and a fill (which is two fill kernels
+// for the 6 KB of MlmCounters: 15 us in front of a lone frame); the counters and the map-wide flags go back the same way (the tail of
+// k_apply_single, k_ex_release).
+__global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_frame, MlmFrame *dev_frame, MlmCounters *ctr) {
+    const uint32_t *src = (const uint32_t *)(host_frame + blockIdx.x);
+    uint32_t *dst = (uint32_t *)(dev_frame + blockIdx.x), *c = (uint32_t *)(ctr + blockIdx.x);
+    for (unsigned int i = threadIdx.x; i < sizeof(MlmFrame) / 4; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x < MLM_CTR_SCALARS + 96u) c[mlm_ctr_live_word(threadIdx.x)] = 0u;
+}
+
+// The hand-back of a lone frame, by the workgroup of its last kernel that finishes last (counted in MlmCounters::apply_done): the live
+// words of the slot's counters and the map-wide flags into pinned host memory, then — as the last store — the ticket in the host copy's
+// MlmGlobal::pad, which the calling thread polls instead of sleeping in hipStreamSynchronize.  cleared: the device counters are left
+// clear for the slot's next frame and the host is told so (MLM_CTR_CLEARED in the word it has no other use for).  Call with all threads.
+__device__ __forceinline__ void mlm_hand_back(const MlmDev &P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket, bool cleared) {
+    __shared__ unsigned int s_hb_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_hb_last = g_atomic_add(&mlm_gp(P.ctr)->apply_done, 1u) == gridDim.x * gridDim.y - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_hb_last) return;
+    if (threadIdx.x < 128u) {
+        const unsigned int t = threadIdx.x;
+        if (t < MLM_CTR_SCALARS + 96u) {
+            const unsigned int w = mlm_ctr_live_word(t);
+            uint32_t val = __hip_atomic_load((const uint32_t *)P.ctr + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cleared) ((uint32_t *)P.ctr)[w] = 0u;
+            if (w == MLM_CTR_APPLY_DONE) val = cleared ? MLM_CTR_CLEARED : 0u;
+            ((uint32_t *)host_ctr)[w] = val;
+        } else if (t >= 120u && t < 123u) {
+            ((uint32_t *)host_g)[t - 120u] = __hip_atomic_load((const uint32_t *)P.g + (t - 120u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&host_g->pad, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The same for ONE frame (a synchronous single-frame call — the reference's call pattern, src/mlmap.cpp:463-507 — and the replay
 // of one frame): nothing is carried from frame to frame, so nothing is staged in LDS, and the tiles do not matter — the frame's
 // records lie in one list.  What a single frame costs is the number of DEPENDENT trips to memory (a kernel's first touch of what
@@ -2526,41 +2565,13 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_single(MLM_SLOT_ARGS, MlmCo
         }
     }
     if (!host_ctr) return; // (a replayed frame: the host reads the counters back itself)
-    // Last node of the single-frame graph: the workgroup that finishes last hands the frame's counters and the map-wide flags to the
-    // host (pinned memory) and writes, as its last word, a ticket — the frame's sequence number + 1 in MlmGlobal::pad of the HOST
-    // copy.  The calling thread polls the ticket instead of sleeping in hipStreamSynchronize: a synchronous call's wake-up is part
-    // of its latency, and so would be a kernel of its own for these few stores (4 us between two dependent kernels).
-    __shared__ unsigned int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (no release fence: nothing the host does on the ticket alone reads what the workgroups stored into the map — whatever reads the
-        // map is a later kernel of the stream; the counters were final before this kernel, the flag a frame that is not applied raises is
-        // an atomic of workgroup 0's first thread, fenced here.  An agent-scope fence is 2-4 us of a lone frame's latency.)
-        if (!ok) __threadfence();
-        s_last = g_atomic_add(&mlm_gp(P.ctr)->apply_done, 1u) == gridDim.x - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // the words of MlmCounters the host reads: the 18 scalars and [k][0], [k][1] of the six spread arrays (the rest is padding that keeps
-    // the partial sums 128 bytes apart and is never written) — 114 words by 114 lanes, read with agent-scope loads
-    if (threadIdx.x < 128u) {
-        const unsigned int t = threadIdx.x;
-        if (t < MLM_CTR_SCALARS + 96u) {
-            const unsigned int w = mlm_ctr_live_word(t);
-            uint32_t val = __hip_atomic_load((const uint32_t *)P.ctr + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // a frame that has been applied leaves its slot's counters clear for the slot's next frame and says so in the word the host has
-            // no other use for (submit_single_graph: such a frame's graph starts without k_frame_prologue); a frame that was not applied keeps
-            // them — the host's replay reads them
-            if (run) ((uint32_t *)P.ctr)[w] = 0u;
-            if (w == MLM_CTR_APPLY_DONE) val = run ? MLM_CTR_CLEARED : 0u;
-            ((uint32_t *)host_ctr)[w] = val;
-        } else if (t >= 120u && t < 123u) {
-            ((uint32_t *)host_g)[t - 120u] = __hip_atomic_load((const uint32_t *)P.g + (t - 120u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __threadfence_system();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&host_g->pad, (unsigned int)F.seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // Last node of the single-frame graph.  No release fence in front of the arrival: nothing the host does on the ticket alone reads what
+    // the workgroups stored into the map — whatever reads the map is a later kernel of the stream —, the counters were final before this
+    // kernel, and the flag a frame that is not applied raises is an atomic of workgroup 0's first thread, fenced here (an agent-scope
+    // fence costs a lone frame 2-4 us).  A frame that has been applied leaves its slot's counters clear (submit_single_graph: the
+    // slot's next small frame starts without k_frame_prologue); one that was not keeps them — the host's replay reads them.
+    if (!ok && threadIdx.x == 0) __threadfence();
+    mlm_hand_back(P, host_ctr, host_g, (unsigned int)F.seq + 1u, run);
 }
 
 // After the host has grown the block pool: the blocks a frame's voxel records still lack (k_tile found the pool full) are created
@@ -2591,16 +2602,6 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_alloc_retry(const MlmDev P, const
 // (second launch of the pair: turns "not seen short by the pass above" into "complete")
 __global__ void k_alloc_retry_done(const MlmDev P) {
     if (threadIdx.x == 0 && blockIdx.x == 0) mlm_gp(P.ctr)->pool_short = mlm_gp(P.ctr)->pool_short == 2u ? 1u : 0u;
-}
-
-// First node of the single-frame graph: the frame's parameters come from pinned host memory (one 128-thread block
-// copies them into the device-resident table and clears the slot's counters), the counters and the map-wide flags go back
-// the same way (the tail of k_apply_single) — kernel nodes with fixed arguments instead of memcpy / memset nodes.
-__global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_frame, MlmFrame *dev_frame, MlmCounters *ctr) {
-    const uint32_t *src = (const uint32_t *)host_frame;
-    uint32_t *dst = (uint32_t *)dev_frame, *c = (uint32_t *)ctr;
-    for (unsigned int i = threadIdx.x; i < sizeof(MlmFrame) / 4; i += blockDim.x) dst[i] = src[i];
-    if (threadIdx.x < MLM_CTR_SCALARS + 96u) c[mlm_ctr_live_word(threadIdx.x)] = 0u; // (the words that are ever written: see k_apply_single)
 }
 
 // Test hook (mlm_debug_probe_seeds): the largest relative error of the v_rcp_f64 / v_rsq_f64 seeds and of their once-refined

@@ -210,9 +210,8 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
         h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
         h->slots[(size_t)(base + j)].h_ctr->apply_done = 0u; // (the slot's counters are in use: not "left clear by a single-frame graph", submit_single_graph)
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_frame_tab + base, h->h_frame_tab + base, (size_t)n * sizeof(MlmFrame),
-                             hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemsetAsync(h->d_ctr_all + base, 0, (size_t)n * sizeof(MlmCounters), st));
+    // (the frames' parameters into the device table, their counters cleared: one kernel that reads the pinned table itself)
+    tlaunch(h, "k_frame_prologue", k_frame_prologue, dim3((unsigned int)n), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
     unsigned int nb = 0;
     if (F.n > 0) {
         nb = mode == 0 ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : (unsigned int)(((size_t)F.n + 255) / 256);
@@ -281,7 +280,7 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
         if (!P.explore)
             tlaunch(h, "k_tile", k_tile, dim3(n > 1 ? h->tile_grid : (unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, n), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     }
-    HIPCHK(h, hipEventRecord(h->stage_a_done[set], st));
+    if (!on_main) HIPCHK(h, hipEventRecord(h->stage_a_done[set], st)); // (on the main stream the order is the stream's: an event between two launches is a 5 us gap)
     return MLM_OK;
 }
 

@@ -128,7 +128,7 @@ int submit_batch(mlm_handle *h, int base, int n) {
         rc = sectors ? launch_stage_a_sector(h, base, n, on_main) : launch_stage_a_batch(h, base, n, on_main);
     }
     if (rc) return rc;
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0));
+    if (h->async_mode) HIPCHK(h, hipStreamWaitEvent(h->stream, h->stage_a_done[set], 0)); // (a synchronous call's Stage A ran on this stream)
     if (sectors) {
         // ONE launch for the batch: Stage A has grouped every frame's hits and misses by voxel, tile by tile (k_apply_tiles)
         Timed t(h, h->stream, "stage_bc_batch");
@@ -633,15 +633,16 @@ int run_slots_inner(mlm_handle *h, int n) {
         auto sync_path = [&]() -> int {
             int rc = explore_stage_a(h, base, n, true); // (on the main stream: nothing to overlap with in a synchronous call)
             if (rc) return rc;
-            HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
             // one frame, both emulated containers past their first insertion, nothing deferred: the map-dependent part goes out now,
-            // guarded on the device by the condition the host checks afterwards (explore_stage_bc_spec)
-            if (n == 1 && h->ex_spec && !h->ex_tail && h->hit_pol._M_next_resize >= 1 && h->miss_pol._M_next_resize >= 1 &&
-                h->hit_n_bkt <= h->max_buckets && h->miss_n_bkt <= h->max_buckets) {
+            // guarded on the device by the condition the host checks afterwards (explore_stage_bc_spec); its last launch hands the counters back
+            const bool spec = n == 1 && h->ex_spec && !h->ex_tail && h->hit_pol._M_next_resize >= 1 && h->miss_pol._M_next_resize >= 1 &&
+                              h->hit_n_bkt <= h->max_buckets && h->miss_n_bkt <= h->max_buckets;
+            if (!spec) HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
+            if (spec) {
                 unsigned int thr[2];
                 rc = explore_stage_bc_spec(h, base, thr);
                 if (rc) return rc;
-                HIPCHK(h, mlm_spin_sync(h->stream));
+                HIPCHK(h, wait_for_ticket(h, h->stream));
                 HIPCHK(h, hipGetLastError());
                 MlmSlot &S = h->slots[(size_t)base];
                 const MlmCounters &c = *S.h_ctr;
