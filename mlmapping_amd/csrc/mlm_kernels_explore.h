@@ -373,8 +373,9 @@ __device__ __forceinline__ void mlm_hand_back(const MlmDev &P, MlmCounters *host
 // host_ctr (a synchronous call's lone frame, explore_stage_bc_spec): the last launch of the frame — its last workgroup hands the slot's
 // counters, the map-wide flags and the ticket to the host (instead of two copies on the stream, 4 us each and a gap in front)
 __global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket) {
-    if (!mlm_ex_spec_skip(P)) mlm_ex_release_body(P);
-    if (host_ctr) mlm_hand_back(P, host_ctr, host_g, ticket, false);
+    const bool ran = !mlm_ex_spec_skip(P);
+    if (ran) mlm_ex_release_body(P);
+    if (host_ctr) mlm_hand_back(P, host_ctr, host_g, ticket, ran); // (a frame that ran leaves the slot's counters clear: launch_stage_a_sector)
 }
 
 // frontier read-out: (gx,gy,gz,cell) of every frontier cell

@@ -190,6 +190,13 @@ int launch_stage_a_batch(mlm_handle *h, int base, int n, bool on_main = false) {
     return MLM_OK;
 }
 
+// the callback's sampled pixels lie in the handle's pinned staging buffer, indices first, depths `n` entries behind: a small frame's first
+// kernel fetches its entries together with the parameters (only that buffer: its extent is known).  n = 0: some other list, or none.
+inline unsigned int staged_list_len(const mlm_handle *h, const MlmSlot &S) {
+    if (S.mode == 1 && h->h_stage && S.F.pix == h->h_stage && S.F.raw > S.F.pix && (size_t)(S.F.raw - h->h_stage) + (size_t)(S.F.raw - S.F.pix) <= h->stage_cap)
+        return (unsigned int)(S.F.raw - S.F.pix);
+    return 0u;
+}
 // Stage A by azimuth sector (mlm_kernels_sector.h): two launches per batch.
 // on_main: on the main stream, in front of the frames' map-dependent launches (frontier mode's synchronous calls: nothing to overlap
 // with, and a dependency between two streams costs such a call up to 60 us — measured: the first stream a process creates after the
@@ -206,15 +213,28 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
         HIPCHK(h, hipEventRecord(h->inputs_ready, h->stream));
         HIPCHK(h, hipStreamWaitEvent(st, h->inputs_ready, 0));
     }
+    // a lone small frame in a slot whose last frame left the counters clear (mlm_hand_back, MLM_CTR_CLEARED): no prologue launch, the
+    // first kernel takes the parameters from pinned memory itself (k_bin_sectors_hostf; submit_single_graph does the same for its graph)
+    const unsigned int nb_all = F.n <= 0 ? 0u : mode == 0 ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : (unsigned int)(((size_t)F.n + 255) / 256);
+    const bool no_prologue = n == 1 && nb_all > 0 && nb_all <= kHostFrameStrips && nb_all <= P.nb_cap && S0.h_ctr->apply_done == MLM_CTR_CLEARED;
     for (int j = 0; j < n; ++j) {
         h->h_frame_tab[base + j] = h->slots[(size_t)(base + j)].F;
-        h->slots[(size_t)(base + j)].h_ctr->apply_done = 0u; // (the slot's counters are in use: not "left clear by a single-frame graph", submit_single_graph)
+        h->slots[(size_t)(base + j)].h_ctr->apply_done = 0u; // (the slot's counters are in use from here on)
     }
     // (the frames' parameters into the device table, their counters cleared: one kernel that reads the pinned table itself)
-    tlaunch(h, "k_frame_prologue", k_frame_prologue, dim3((unsigned int)n), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
+    if (!no_prologue)
+        tlaunch(h, "k_frame_prologue", k_frame_prologue, dim3((unsigned int)n), dim3(128), 0, st, (const MlmFrame *)(h->h_frame_tab + base), h->d_frame_tab + base, h->d_ctr_all + base);
     unsigned int nb = 0;
-    if (F.n > 0) {
-        nb = mode == 0 ? (unsigned int)(((F.width + 31) / 32) * ((F.height + 7) / 8)) : (unsigned int)(((size_t)F.n + 255) / 256);
+    if (no_prologue) {
+        nb = nb_all;
+        const unsigned int ln = staged_list_len(h, S0);
+        const int32_t *lp = ln ? F.pix : nullptr, *lr = ln ? F.raw : nullptr;
+        const MlmFrame *hf = h->h_frame_tab + base;
+        if (mode == 0) tlaunch(h, "k_bin_sectors", k_bin_sectors_hostf<0>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, hf, h->d_frame_tab + base, base, nb, lp, lr, ln);
+        else if (mode == 1) tlaunch(h, "k_bin_sectors", k_bin_sectors_hostf<1>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, hf, h->d_frame_tab + base, base, nb, lp, lr, ln);
+        else tlaunch(h, "k_bin_sectors", k_bin_sectors_hostf<2>, dim3(nb, 1, 1), dim3(256), 0, st, h->d_slot_tab, hf, h->d_frame_tab + base, base, nb, lp, lr, ln);
+    } else if (F.n > 0) {
+        nb = nb_all;
         if (nb > P.nb_cap) {
             h->err = "frame geometry exceeds the queues sized from mlm_limits.max_points";
             return MLM_ERR_CAPACITY;

@@ -444,13 +444,6 @@ inline hipStream_t upload_stream(const mlm_handle *h) {
 // The launch sequence of ONE frame on stream `st` (the sector path, everything on one stream): a prologue kernel takes the frame's
 // parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, whose last workgroup writes the
 // counters, the map-wide flags and — last — the completion ticket back to pinned memory.  Issued directly, or captured into a graph.
-// the callback's sampled pixels lie in the handle's pinned staging buffer, indices first, depths `n` entries behind: a small frame's first
-// kernel fetches its entries together with the parameters (only that buffer: its extent is known).  n = 0: some other list, or none.
-inline unsigned int staged_list_len(const mlm_handle *h, const MlmSlot &S) {
-    if (S.mode == 1 && h->h_stage && S.F.pix == h->h_stage && S.F.raw > S.F.pix && (size_t)(S.F.raw - h->h_stage) + (size_t)(S.F.raw - S.F.pix) <= h->stage_cap)
-        return (unsigned int)(S.F.raw - S.F.pix);
-    return 0u;
-}
 hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int big, bool no_prologue, hipStream_t st) {
     const MlmSlot &S = h->slots[(size_t)base];
     const MlmDev &P = S.P;
