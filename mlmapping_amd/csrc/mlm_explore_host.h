@@ -106,24 +106,41 @@ int explore_stage_bc(mlm_handle *h, int slot_index) {
 // (MlmDev::spec_on, mlm_ex_spec_skip); the host checks the same condition once the frame has drained (wait_for_ticket) and, if it did not hold — the
 // first frames of a stream, while the emulated containers still grow, or a Stage A that left the sector path —, runs the general
 // path with the counts it now has.  Returns with everything enqueued; thresholds in thr[2].
+// explore_spec_begin (before the frame's Stage A is enqueued): thresholds, tag and bucket counts of the frame — h->ex_om, which the frame's
+// k_rank takes along (launch_stage_a_sector) so that the bucket-first pass needs no launch of its own.
+int explore_spec_begin(mlm_handle *h) {
+    MlmExOrder &om = h->ex_om;
+    om.thr_hit = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
+    om.thr_miss = (unsigned int)std::min<size_t>(h->miss_pol._M_next_resize, 0xFFFFFFFFu);
+    if (h->ex_spec == 2) om.thr_hit = om.thr_miss = 0u; // (test knob: every frame with a hit or a miss cell misses the speculation)
+    om.tag = h->ex_tag++;
+    if (h->ex_tag > 0x3FFFFFFF) { // tags restart: the tables must forget them
+        h->ex_tag = 0;
+        HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long), h->stream));
+    }
+    om.nb_hit = h->hit_n_bkt;
+    om.nb_miss = h->miss_n_bkt;
+    om.on = 1;
+    h->ex_om_launched = false;
+    return MLM_OK;
+}
 int explore_stage_bc_spec(mlm_handle *h, int slot_index, unsigned int thr[2]) {
     MlmSlot &S = h->slots[(size_t)slot_index];
     hipStream_t st = h->stream;
     const dim3 blk(MLM_BLOCK);
-    thr[0] = (unsigned int)std::min<size_t>(h->hit_pol._M_next_resize, 0xFFFFFFFFu);
-    thr[1] = (unsigned int)std::min<size_t>(h->miss_pol._M_next_resize, 0xFFFFFFFFu);
-    if (h->ex_spec == 2) thr[0] = thr[1] = 0u; // (test knob: every frame with a hit or a miss cell misses the speculation)
+    const MlmExOrder om = h->ex_om;
+    h->ex_om.on = 0;
+    thr[0] = om.thr_hit;
+    thr[1] = om.thr_miss;
     MlmDev Ps = S.P;
     Ps.spec_on = 1;
     Ps.spec_hit_thr = thr[0];
     Ps.spec_miss_thr = thr[1];
-    const int tag = h->ex_tag++;
-    if (h->ex_tag > 0x3FFFFFFF) { // tags restart: the tables must forget them
-        h->ex_tag = 0;
-        HIPCHK(h, hipMemsetAsync(h->P.bkt64, 0xFF, 2 * h->max_buckets * sizeof(unsigned long long), st));
-    }
-    const unsigned long long hn = h->hit_n_bkt, mn = h->miss_n_bkt;
-    tlaunch(h, "k_ex_order_min", k_ex_order_min, dim3(kListGrid, 2), blk, 0, st, Ps, 0u, 0u, hn, mn, tag, Ps);
+    const int tag = om.tag;
+    const unsigned long long hn = om.nb_hit, mn = om.nb_miss;
+    if (!h->ex_om_launched) // (the frame's Stage A did not go through launch_stage_a_sector: the cell-table path)
+        tlaunch(h, "k_ex_order_min", k_ex_order_min, dim3(kListGrid, 2), blk, 0, st, Ps, 0u, 0u, hn, mn, tag, Ps);
+    h->ex_om_launched = false;
     tlaunch(h, "k_ex_order_keys", k_ex_order_keys, dim3(kListGrid, 2), blk, 0, st, Ps, 0u, 0u, hn, mn, Ps);
     tlaunch(h, "k_ex_register", k_ex_register, dim3(4 * kListGrid, 2), blk, 0, st, Ps, S.F);
     tlaunch(h, "k_apply", k_apply, dim3(64, 1), blk, 0, st, Ps, 0, 1);

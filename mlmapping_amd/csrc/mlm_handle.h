@@ -212,6 +212,8 @@ struct mlm_handle {
     bool want_widen = false;         // ... the cell table is doubled before the next submission (widen_sec_tab)
     int sec_threads = 512;           // threads of a column's workgroup (k_sector<.., 256 | 512>; MLM_SEC_THREADS)
     double clk[8] = {}, clk_t = 0;   // host clocks of the single-frame path (mlm_debug_clocks): microseconds per section, summed over the calls
+    MlmExOrder ex_om{};              // frontier mode: what the next lone frame's k_rank needs to run the bucket-first pass (explore_spec_begin; on = 0: nothing)
+    bool ex_om_launched = false;     // ... and whether the frame's Stage A took it along (else explore_stage_bc_spec launches k_ex_order_min)
     unsigned int wait_ticket = 0;    // nonzero: the single-frame graph in flight ends by writing this into h_g->pad (pinned)
     unsigned int single_rank_grid = 256;   // workgroups of a lone frame's k_rank<true> (ranking + chains; knob "single_rank_grid")
     unsigned int single_chain_grid = 64;  // workgroups of a lone frame's k_chain_lanes: 256 waves x 64 cells cover a dense VGA frame's ranked cells in one turn

@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector_big(const MlmDev *__
 // (a quarter of a microsecond) is cheaper than a kernel boundary plus a kernel that starts from memory again; in a batch, where a wave
 // ranks dozens of cells, one lane per cell would idle the other sixty-three and k_chain_lanes' cell-per-lane replay stays.
 template <bool CHAIN>
-__global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s) {
+__global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS, int tile_w, int row_w, unsigned long long div_m, int div_s, const MlmExOrder om) {
     MLM_SLOT_SETUP
     __shared__ __attribute__((aligned(16))) unsigned long long s_rows[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
     __shared__ uint16_t s_pref[MLM_BLOCK / 64][MLM_SEC_RANK_WORDS];
@@ -1330,6 +1330,21 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
             const uint32_t b = mlm_gp(P.hl_bkt)[i];
             const unsigned long long first = b < P.sbkt_cap ? mlm_gp(P.sbkt)[b] & 0xFFFFFFFFull : 0ull;
             mlm_gp(P.hl_key)[i] = ((first + 1ull) << 32) | (unsigned long long)mlm_gp(P.hl_vt)[i];
+        }
+    } else if (om.on) {
+        // frontier mode, a lone frame whose map-dependent launches follow without the host having seen its counts: the bucket-first
+        // pass of both containers (what k_ex_order_min does, one launch later otherwise) — fire-and-forget atomics in front of the ranking
+        const MLM_GLOBAL MlmCounters *c = mlm_gp(P.ctr);
+        const unsigned int n_hit = c->u_hit, n_miss = c->n_ex_miss;
+        if (c->sector_overflow == 0u && n_hit <= om.thr_hit && n_miss <= om.thr_miss) { // (else: mlm_ex_spec_skip holds the frame's other launches back)
+            const unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+            for (unsigned int i = i0; i < n_hit; i += stride) {
+                int rho, phi, z;
+                mlm_cell_rpz(P, P.hl_cell[i], rho, phi, z);
+                atomicMin(&P.bkt64[mlm_hash_rpz(rho, phi, z) % om.nb_hit], mlm_bkt_entry(om.tag, P.hl_vt[i]));
+            }
+            for (unsigned int i = i0; i < n_miss; i += stride)
+                atomicMin(&P.bkt64[P.bkt_stride + (unsigned long long)P.ex_cell[i] % om.nb_miss], mlm_bkt_entry(om.tag, P.ex_vt[i]));
         }
     }
     MLM_LDS unsigned long long *rows = mlm_lp(s_rows[wid]);

@@ -281,11 +281,14 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
                         mode == 0 ? F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
         }
         const bool fused_chain = n == 1 && nb <= kFusedChainStrips; // (a small frame on its own: k_rank<true> runs the chains of the cells it ranks)
+        // (frontier mode, a synchronous call's lone frame: the bucket-first pass of its containers rides along, explore_spec_begin)
+        const MlmExOrder om = (on_main && n == 1 && P.explore) ? h->ex_om : MlmExOrder{};
+        h->ex_om_launched = om.on != 0;
         if (fused_chain)
-            tlaunch(h, "k_rank", k_rank<true>, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, mode == 0 ? F.width : 0, row_w, dm, ds);
+            tlaunch(h, "k_rank", k_rank<true>, dim3(1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, mode == 0 ? F.width : 0, row_w, dm, ds, om);
         else
             tlaunch(h, "k_rank", k_rank<false>, dim3(n > 4 ? h->rank_grid : 1024, 1, n), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base,
-                    mode == 0 ? F.width : 0, row_w, dm, ds);
+                    mode == 0 ? F.width : 0, row_w, dm, ds, om);
         // blocks per frame: about 400 ranked cells per block in a batch (a lane that finishes a chain draws the next cell; each
         // block builds the transposed odds table in LDS), as many as the last confirmed frame had; single frames spread wider
         unsigned int cg = h->chain_grid;

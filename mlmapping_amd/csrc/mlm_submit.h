@@ -190,7 +190,7 @@ int redo_overflow_columns(mlm_handle *h, MlmSlot &R) {
     div_magic((unsigned int)P.nRho, rm, rs);
     tlaunch(h, "k_sector_big", k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, si, 1, tile_w, 0, rm,
             rs, (unsigned long long)h->hit_n_bkt, dm, ds);
-    tlaunch(h, "k_rank", k_rank<false>, dim3(1024, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, si, tile_w, row_w, dm, ds);
+    tlaunch(h, "k_rank", k_rank<false>, dim3(1024, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, si, tile_w, row_w, dm, ds, MlmExOrder{});
     tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(64, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, si, 64u);
     tlaunch(h, "k_tile", k_tile, dim3((unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab,
             h->d_frame_tab, si);
@@ -476,9 +476,9 @@ hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int bi
         hipLaunchKernelGGL(k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base, 1,
                            S.mode == 0 ? S.F.width : 0, (int)nb, rm, rs, (unsigned long long)h->hit_n_bkt, dm, ds);
     if (nb <= kFusedChainStrips) { // (a small frame on its own: the wave that ranks a cell runs its chain, no k_chain_lanes — k_rank<true>)
-        hipLaunchKernelGGL(k_rank<true>, dim3(h->single_rank_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
+        hipLaunchKernelGGL(k_rank<true>, dim3(h->single_rank_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds, MlmExOrder{});
     } else {
-        hipLaunchKernelGGL(k_rank<false>, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds);
+        hipLaunchKernelGGL(k_rank<false>, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds, MlmExOrder{});
         if (!h->no_spread)
             hipLaunchKernelGGL(k_chain_lanes, dim3(h->single_chain_grid, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base, 64u);
     }
@@ -624,12 +624,16 @@ int run_slots_inner(mlm_handle *h, int n) {
         // Stage A of all frames in one launch sequence (it does not depend on the map), one synchronisation to learn the
         // frames' hit/miss counts, then the map-dependent part frame by frame without further synchronisation
         auto sync_path = [&]() -> int {
-            int rc = explore_stage_a(h, base, n, true); // (on the main stream: nothing to overlap with in a synchronous call)
-            if (rc) return rc;
-            // one frame, both emulated containers past their first insertion, nothing deferred: the map-dependent part goes out now,
-            // guarded on the device by the condition the host checks afterwards (explore_stage_bc_spec); its last launch hands the counters back
+            // one frame, both emulated containers past their first insertion, nothing deferred: the map-dependent part goes out behind the
+            // frame's Stage A at once, guarded on the device by the condition the host checks afterwards (explore_spec_begin,
+            // explore_stage_bc_spec); its last launch hands the counters back
             const bool spec = n == 1 && h->ex_spec && !h->ex_tail && h->hit_pol._M_next_resize >= 1 && h->miss_pol._M_next_resize >= 1 &&
                               h->hit_n_bkt <= h->max_buckets && h->miss_n_bkt <= h->max_buckets;
+            h->ex_om.on = 0;
+            int rc = spec ? explore_spec_begin(h) : MLM_OK;
+            if (rc) return rc;
+            rc = explore_stage_a(h, base, n, true); // (on the main stream: nothing to overlap with in a synchronous call)
+            if (rc) return rc;
             if (!spec) HIPCHK(h, hipMemcpyAsync(h->h_ctr_all + base, h->d_ctr_all + base, (size_t)n * sizeof(MlmCounters), hipMemcpyDeviceToHost, h->stream));
             if (spec) {
                 unsigned int thr[2];

@@ -75,6 +75,14 @@ struct MlmNode {
     unsigned long long mask;
 };
 #define MLM_NIL 0xFFFFFFFFu
+// Frontier mode, a synchronous call's lone frame: the bucket-first pass of both emulated containers (k_ex_order_min) rides in the
+// frame's k_rank — it needs the hit and miss lists, which are complete by then, not the map.  on = 0: not this launch.
+struct MlmExOrder {
+    unsigned long long nb_hit, nb_miss; // bucket counts of the two containers (neither rehashes in this frame: thr_*)
+    int tag;                            // the frame's tag in the bucket-first tables (mlm_bkt_entry)
+    unsigned int thr_hit, thr_miss;     // the frame is left to the general path when it has more unique hit / miss cells than this
+    int on;
+};
 
 // What one k_bin_points block contributes to one awareness cell (its groups merged in LDS).  k_book_cells books the
 // pair on the cell with three atomics and records the returned count in `base`: the position of the block's
