@@ -479,6 +479,12 @@ def single_frame_latency(MLMap, cfg, frames, q, t, d_frames, n_calls=120, cpu=Tr
     m.close()
     row = {"value": float(np.median(ts) * 1e6), "unit": "us per callback (median; every 3rd also runs inflate_map)",
            "workload": "config2.yaml verbatim: frontier mode + inflation, 424x240 32FC1, 500 samples"}
+    try:  # the same calls from a C++ process (tools/query_latency.cpp --callback)
+        from tools.query_latency import measure_callback
+
+        row["cpp_client"] = measure_callback(C2, depth, [traj[k] for k in range(len(traj))], latency=C2.camera2odom_latency, calls=n_calls - 12, inflate_every=3)
+    except Exception as e:  # (the client is a convenience row: its absence does not fail the bench line)
+        row["cpp_client"] = {"error": str(e)[:200]}
     if cpu:
         from oracle.binding import OracleMap
 

@@ -32,8 +32,58 @@ static Stat stat_of(std::vector<double> &v) {
     return Stat{v[v.size() / 2], v[(size_t)(v.size() * 0.99)], s / v.size()};
 }
 
+// `--callback <blob>`: only the reference's callback (src/mlmap.cpp:463-532), `calls` times after 20 untimed ones, every third followed by
+// inflate_map like the shipped 10 Hz timer (launch files with mlmapping_apply_inflate) when the blob says so.  Blob: mlm_config,
+// {frames, W, H, is_f32, calls, inflate_every, poses}, double camera2odom_latency, the images (float32 metres or uint16 millimetres), the
+// poses (q w,x,y,z then t; call r uses image r % frames and pose r % poses).  Output: one JSON object.
+static int callback_mode(const char *path) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return 2;
+    mlm_config cfg;
+    int32_t hdr[7];
+    double latency = 0;
+    if (!read_exact(f, &cfg, sizeof cfg) || !read_exact(f, hdr, sizeof hdr) || !read_exact(f, &latency, sizeof latency)) return 2;
+    const int n_frames = hdr[0], W = hdr[1], H = hdr[2], is_f32 = hdr[3], calls = hdr[4], inflate_every = hdr[5], n_poses = hdr[6];
+    const size_t px_bytes = is_f32 ? 4 : 2;
+    try {
+        mlmap_hip::mlmap map;
+        mlm_limits lim{};
+        lim.max_blocks = 16384;
+        lim.max_points = W * H;
+        lim.max_batch = 2;
+        map.init_map(cfg, 0, &lim);
+        std::vector<std::vector<unsigned char>> imgs((size_t)n_frames, std::vector<unsigned char>((size_t)W * H * px_bytes));
+        std::vector<double> poses((size_t)n_poses * 7);
+        for (int k = 0; k < n_frames; ++k)
+            if (!read_exact(f, imgs[(size_t)k].data(), imgs[(size_t)k].size())) return 2;
+        if (n_poses < 1 || !read_exact(f, poses.data(), poses.size() * 8)) return 2;
+        std::fclose(f);
+        const double zero3[3] = {0, 0, 0};
+        std::vector<double> t_cb;
+        for (int r = 0; r < calls + 20; ++r) {
+            const int k = r % n_frames;
+            const double *pose = &poses[(size_t)(r % n_poses) * 7];
+            double T[7];
+            const double t0 = now_us();
+            if (mlm_integrate_callback(map.handle(), imgs[(size_t)k].data(), is_f32, W, H, 0.0, pose + 4, pose, zero3, 0.0, zero3, 0.0, latency, 1,
+                                       T) != MLM_OK)
+                throw std::runtime_error(mlm_last_error(map.handle()));
+            if (inflate_every > 0 && r % inflate_every == inflate_every - 1 && mlm_inflate_map(map.handle(), T + 4) != MLM_OK)
+                throw std::runtime_error(mlm_last_error(map.handle()));
+            if (r >= 20) t_cb.push_back(now_us() - t0);
+        }
+        const Stat cb = stat_of(t_cb);
+        std::printf("{\"p50\": %.2f, \"p99\": %.2f, \"mean\": %.2f, \"calls\": %zu}\n", cb.p50, cb.p99, cb.mean, t_cb.size());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "query_latency: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
+    if (argc >= 3 && std::string(argv[1]) == "--callback") return callback_mode(argv[2]);
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) return 2;
     mlm_config cfg;

@@ -58,5 +58,30 @@ def measure(cfg=None, n_frames=6, n_pos=20000, with_oracle=True):
     return res
 
 
+def measure_callback(cfg, depth_frames, poses, latency=0.0, calls=300, inflate_every=0):
+    """The reference's callback (500 rand() samples per call) from the C++ client: depth_frames float32 metres or uint16 mm (cycled),
+    poses (q, t) per call (cycled; 20 untimed calls first).  Returns {p50, p99, mean, calls} in microseconds per call."""
+    from mlmapping_amd.config import to_c
+
+    d0 = np.ascontiguousarray(depth_frames[0])
+    is_f32 = int(d0.dtype == np.float32)
+    blob = bytearray(bytes(to_c(cfg)))
+    blob += struct.pack("7i", len(depth_frames), d0.shape[1], d0.shape[0], is_f32, calls, inflate_every, len(poses))
+    blob += struct.pack("d", float(latency))
+    for d in depth_frames:
+        blob += np.ascontiguousarray(d, dtype=np.float32 if is_f32 else np.uint16).tobytes()
+    for q, t in poses:
+        blob += np.concatenate([q, t]).astype(np.float64).tobytes()
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        f.write(bytes(blob))
+        path = f.name
+    try:
+        res = json.loads(subprocess.run([EXE, "--callback", path], check=True, capture_output=True, text=True).stdout)
+    finally:
+        os.unlink(path)
+    res["unit"] = "us per callback, C++ client of the C ABI (no interpreter between the clock and the library)"
+    return res
+
+
 if __name__ == "__main__":
     print(json.dumps(measure()))
