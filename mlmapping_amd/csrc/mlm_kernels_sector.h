@@ -1767,6 +1767,10 @@ __global__ __launch_bounds__(MLM_BLOCK) MLM_RANK_ATTR void k_rank(MLM_SLOT_ARGS,
 // k_chain_lanes lasts as long as a lane's cells do); loads are issued one round ahead of their use (cell descriptor,
 // then 16 kinds per 16-byte load), so a round's arithmetic covers the next round's memory latency.  The odds table is kept
 // transposed in LDS ([rho][kind], 32 kinds per row): one shift-add per lookup.  p == 1.0f is absorbing and ends a chain.
+// R: 16-byte loads of kinds a lane keeps in flight per round.  1 in a batch (most chains are a handful of steps: the second load would be
+// wasted on nearly every cell, and the pipeline hides the rounds); 4 for a frame on its own, whose k_chain_lanes lasts as long as
+// its LONGEST chain has rounds — several hundred kinds are five rounds of 64 instead of twenty of 16, a microsecond each.
+template <int R>
 __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS, unsigned int reserve) {
     MLM_SLOT_SETUP
     extern __shared__ float s_odds_t[]; // [nRho][32]: odd of a contribution of kind k into a cell at rho
@@ -1785,7 +1789,9 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS, unsign
     uint32_t loc_next = 0, loc_end = 0; // (uniform) the wave's reserved cells not handed to a lane yet
     bool exhausted = false;             // (uniform) the frame's counter is past the last cell
     int state = 0;                      // 0 idle, 1 descriptor in flight, 2 first kinds in flight, 3 running
-    mlm_u32x4 desc_in = mlm_u32x4{0u, 0u, 0u, 0u}, kinds_in = desc_in, kinds = desc_in;
+    mlm_u32x4 desc_in = mlm_u32x4{0u, 0u, 0u, 0u}, kinds_in[R], kinds[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) kinds_in[r] = kinds[r] = desc_in;
     uint32_t pos = 0, base = 0, n = 0, j0 = 0, row = 0;
     float p = 0.0f;
     bool first = true;
@@ -1802,12 +1808,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS, unsign
     };
     for (;;) {
         // ---- what was requested in the previous round has arrived
-        if (state == 2 || state == 3) kinds = kinds_in;
+        if (state == 2 || state == 3) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) kinds[r] = kinds_in[r];
+        }
         if (state == 2) state = 3;
         // (both loads of a round — the next sixteen kinds, the next descriptor — are issued by EVERY lane, from a harmless address where
         // the lane needs nothing: the compiler counts outstanding loads only through straight-line code, behind a per-lane branch it
         // waits for them on the spot instead of at the top of the next round)
-        uint32_t k_at = 0u; // offset in `subs` of the kinds this lane requests this round
+        uint32_t k_at = 0u, k_left = 0u; // offset in `subs` of the kinds this lane requests this round, and how many of them are the cell's
         if (state == 1) {
             pos = desc_in.x;
             base = desc_in.y;
@@ -1817,11 +1826,15 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS, unsign
             first = true;
             p = 0.0f;
             k_at = base;
+            k_left = n;
             state = 2;
-        } else if (state == 3 && j0 + 16u < n) {
-            k_at = base + j0 + 16u; // (one round ahead)
+        } else if (state == 3 && j0 + 16u * R < n) {
+            k_at = base + j0 + 16u * R; // (one round ahead)
+            k_left = n - (j0 + 16u * R);
         }
-        kinds_in = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.subs) + k_at);
+#pragma unroll
+        for (int r = 0; r < R; ++r) // (a cell's segment of `subs` is padded to whole 16-byte words; past it: the harmless address)
+            kinds_in[r] = *(const MLM_GLOBAL mlm_u32x4 *)(mlm_gp(P.subs) + ((r == 0 || 16u * r < k_left) ? k_at + 16u * r : 0u));
         // ---- idle lanes draw cells
         const unsigned long long need = __ballot(state == 0);
         uint32_t d_at = 0u; // the descriptor this lane requests this round
@@ -1853,16 +1866,20 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_chain_lanes(MLM_SLOT_ARGS, unsign
         // ---- sixteen steps of the running chains
         if (state == 3) {
             const uint32_t rem = n - j0; // >= 1
-            const uint32_t w[4] = {kinds.x, kinds.y, kinds.z, kinds.w};
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float a = s_odds_t[row + ((w[q >> 2] >> ((q & 3) * 8)) & 31u)]; // (padding bytes: any value, not used)
-                if ((uint32_t)q < rem) {
-                    p = first ? a : 1 - (1 - p) * (1 - a);
-                    first = false;
+            for (int r = 0; r < R; ++r) {
+                if (r > 0 && 16u * r >= rem) break; // (per lane: the later words of a round are a long chain's)
+                const uint32_t w[4] = {kinds[r].x, kinds[r].y, kinds[r].z, kinds[r].w};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float a = s_odds_t[row + ((w[q >> 2] >> ((q & 3) * 8)) & 31u)]; // (padding bytes: any value, not used)
+                    if ((uint32_t)(16 * r + q) < rem) {
+                        p = first ? a : 1 - (1 - p) * (1 - a);
+                        first = false;
+                    }
                 }
             }
-            j0 += 16u;
+            j0 += 16u * R;
         }
         const bool fin = state == 3 && (j0 >= n || p == 1.0f);
         if (__any(fin && pend)) flush();

@@ -296,9 +296,12 @@ int launch_stage_a_sector(mlm_handle *h, int base, int n, bool on_main = false) 
             const long long cells = std::max<long long>(1, h->stats.n_multi_cells);
             cg = n > 4 ? (unsigned int)std::min<long long>(64, std::max<long long>(8, cells / 400)) : (unsigned int)std::min<long long>(128, std::max<long long>(16, cells / 128));
         }
-        if (!h->no_spread && !fused_chain)
-            tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab,
-                base, n > 4 ? 128u : 64u);
+        if (!h->no_spread && !fused_chain) {
+            if (n > 4)
+                tlaunch(h, "k_chain_lanes", k_chain_lanes<1>, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base, 128u);
+            else // (a frame or a few on their own: the kernel lasts as long as the longest chain has rounds)
+                tlaunch(h, "k_chain_lanes", k_chain_lanes<4>, dim3(cg, 1, n), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base, 64u);
+        }
         // the frame's hits and misses grouped by voxel, tile by tile (needs the increments and keys of the kernels above)
         if (!P.explore)
             tlaunch(h, "k_tile", k_tile, dim3(n > 1 ? h->tile_grid : (unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, n), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);

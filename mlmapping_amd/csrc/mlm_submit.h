@@ -191,7 +191,7 @@ int redo_overflow_columns(mlm_handle *h, MlmSlot &R) {
     tlaunch(h, "k_sector_big", k_sector_big<false>, dim3(h->big_grid), dim3(MLM_SEC_THREADS), P.sec_big_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, si, 1, tile_w, 0, rm,
             rs, (unsigned long long)h->hit_n_bkt, dm, ds);
     tlaunch(h, "k_rank", k_rank<false>, dim3(1024, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, si, tile_w, row_w, dm, ds, MlmExOrder{});
-    tlaunch(h, "k_chain_lanes", k_chain_lanes, dim3(64, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, si, 64u);
+    tlaunch(h, "k_chain_lanes", k_chain_lanes<4>, dim3(64, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, si, 64u);
     tlaunch(h, "k_tile", k_tile, dim3((unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab,
             h->d_frame_tab, si);
     HIPCHK(h, hipGetLastError());
@@ -480,7 +480,7 @@ hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int bi
     } else {
         hipLaunchKernelGGL(k_rank<false>, dim3(256, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, S.mode == 0 ? S.F.width : 0, row_w, dm, ds, MlmExOrder{});
         if (!h->no_spread)
-            hipLaunchKernelGGL(k_chain_lanes, dim3(h->single_chain_grid, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base, 64u);
+            hipLaunchKernelGGL(k_chain_lanes<4>, dim3(h->single_chain_grid, 1, 1), dim3(MLM_BLOCK), (size_t)32 * P.nRho * sizeof(float), st, h->d_slot_tab, h->d_frame_tab, base, 64u);
     }
     hipLaunchKernelGGL(k_tile, dim3((unsigned int)(P.n_tiles <= 4096 ? P.n_tiles : 1024), 1, 1), dim3(MLM_TILE_THREADS), h->tile_lds_bytes, st, h->d_slot_tab, h->d_frame_tab, base);
     hipLaunchKernelGGL(k_apply_single, dim3(h->single_apply_grid, 1, 1), dim3(MLM_BLOCK), 0, st, h->d_slot_tab, h->d_frame_tab, base, h->h_ctr_all + base, h->h_g);
