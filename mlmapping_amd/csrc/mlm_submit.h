@@ -343,6 +343,9 @@ int drain(mlm_handle *h, bool g_copied) {
                 HIPCHK(h, hipMemcpyAsync(h->h_g, h->P.g, sizeof(MlmGlobal), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(h, hipStreamSynchronize(h->stream));
                 HIPCHK(h, hipGetLastError());
+                // (a LATER pending frame's k_tile may have found the pool full when the frames were first submitted — the flag is sticky on the
+                // device until that frame's turn comes, fix_pool_short; with everything confirmed the top of the loop looks at it again)
+                if (h->pool_grow) h->h_g->err &= ~1u;
                 if (h->h_g->err) { // (pool full with growth off, a queue overflow)
                     rc = check_queues(h, R);
                     if (rc) return rc;

@@ -121,3 +121,4 @@ def test_default_callback_stream_sdef(knobs):
     st = gpu.frame_stats()
     assert st["n_graph_launches"] >= 55, st
     gpu.close()
+
