@@ -1284,12 +1284,19 @@ __global__ __launch_bounds__(MLM_SEC_THREADS) void k_sector_big(const MlmDev *__
     }
     __syncthreads();
     const unsigned int n_tasks = s_first[64];
-    for (unsigned int t = blockIdx.x; t < n_tasks; t += gridDim.x) { // (uniform)
+    // (tasks are drawn from a counter, not dealt out by index: a crowded column takes several times as long as a sparse one, and the
+    // heavy columns of consecutive frames are the same columns — dealt out by index they would meet in the same workgroups)
+    __shared__ unsigned int s_task;
+    for (;;) { // (uniform)
+        __syncthreads(); // (the previous column's shared state, and s_task, are no longer read)
+        if (threadIdx.x == 0) s_task = g_atomic_add(&mlm_gp(slot_tab[slot_base].ctr)->big_next, 1u);
+        __syncthreads();
+        const unsigned int t = s_task;
+        if (t >= n_tasks) break;
         int j = 0;
         while (j + 1 < n_frames && s_first[j + 1] <= t) ++j;
         const MlmDev &P = slot_tab[slot_base + j];
         const MlmFrame &F = frame_tab[slot_base + j];
-        __syncthreads(); // (the previous column's shared state is no longer read)
         mlm_sector_column<EX, true, MLM_SEC_THREADS>(P, F, (int)mlm_gp(P.ov_list)[t - s_first[j]], tile_w, n_bin_blocks, rho_m, rho_s, n_bkt, 0, row_m, row_s);
     }
 }

@@ -183,6 +183,7 @@ int redo_overflow_columns(mlm_handle *h, MlmSlot &R) {
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipMemsetAsync(&P.ctr->sector_overflow, 0, sizeof(unsigned int), st));
     HIPCHK(h, hipMemsetAsync(&P.ctr->chain_next, 0, sizeof(unsigned int), st));
+    HIPCHK(h, hipMemsetAsync(&P.ctr->big_next, 0, sizeof(unsigned int), st)); // (k_sector_big's task counter: this frame is the launch's first)
     const int tile_w = R.mode == 0 ? R.F.width : 0, row_w = R.mode == 0 ? R.F.width : 64;
     unsigned long long dm, rm;
     int ds, rs;

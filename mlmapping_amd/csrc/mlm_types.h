@@ -30,6 +30,7 @@ struct MlmCounters {
     unsigned int n_unassigned;// contribution groups that overflowed a block's LDS buffer (booked by k_assign_nodes)
     unsigned int bin_exact;   // sector path: waves of k_bin_sectors that evaluated the reference's own sequence (a lane too near a cell boundary)
     unsigned int apply_done;  // single-frame graph: workgroups of k_apply_single that have finished (the last one reports to the host)
+    unsigned int big_next;    // sector path, in the counters of a batch's FIRST frame: next (frame, column) task of k_sector_big to hand to a workgroup
     unsigned int ray_cnt[8][32]; // [k][0] = rays walked (statistic), partial sums spread by blockIdx & 7, 128 B apart;
                                  // [k][1] = device-scope atomics the frame's kernels issued (sector path, counted by k_sector)
     unsigned int touch_cnt[8][32]; // [k][0] = first-touched hit cells queued in sub-list k
@@ -47,7 +48,7 @@ struct MlmGlobal {
                               // miss); INT_MAX = none.  Stage B/C kernels of frames >= it do nothing.
     unsigned int pad;
 };
-#define MLM_CTR_SCALARS 18u // scalar members in front of the six [8][32] arrays (k_apply_single hands those and the arrays' [k][0], [k][1] to the host)
+#define MLM_CTR_SCALARS 19u // scalar members in front of the six [8][32] arrays (k_apply_single hands those and the arrays' [k][0], [k][1] to the host)
 static_assert(sizeof(MlmCounters) == (MLM_CTR_SCALARS + 6u * 8u * 32u) * 4u, "MlmCounters layout");
 #define MLM_CTR_APPLY_DONE 17u       // word index of MlmCounters::apply_done
 static_assert(offsetof(MlmCounters, apply_done) == MLM_CTR_APPLY_DONE * 4u && offsetof(MlmCounters, ray_cnt) == MLM_CTR_SCALARS * 4u, "MlmCounters layout");
