@@ -122,3 +122,28 @@ def test_default_callback_stream_sdef(knobs):
     assert st["n_graph_launches"] >= 55, st
     gpu.close()
 
+
+
+def test_launches_of_a_lone_frontier_callback(knobs):
+    """What a synchronous frontier-mode callback enqueues once the stream is under way (per-call kernel timing lists the launches):
+    Stage A without a prologue kernel (the previous frame left the slot's counters clear), the bucket-first pass inside k_rank (no
+    k_ex_order_min), the map-dependent launches, k_ex_release last (it hands the counters back) — nine kernels, no copies between them.
+    Reference call: src/mlmap.cpp:463-507."""
+    from mlmapping_amd.mlmap import MLMap
+
+    cfg = CONFIG2_YAML
+    gpu = MLMap(cfg, max_blocks=1024, max_points=cfg.width * cfg.height, max_batch=2)
+    base = syn.room_depth(cfg)
+    traj = syn.smooth_trajectory(24, 5)
+    z = np.zeros(3)
+    gpu.enable_kernel_timing(1)
+    names = None
+    for k in range(24):
+        depth = syn.jitter_depth(base, k, seed=3).astype(np.float32) / 1000.0
+        q, t = traj[k]
+        gpu.depth_odom_callback(depth, 0.0, t, q, z, 0.0, z, 0.0, cfg.camera2odom_latency, sampled=True)
+        names = [n for n, _ in gpu.kernel_times()]
+    assert names == ["k_bin_sectors", "k_sector", "k_rank", "k_ex_order_keys", "k_ex_register", "k_apply", "k_ex_observe", "k_ex_apply_misses",
+                     "k_ex_release"], names
+    assert gpu.frame_stats()["n_spec_replays"] <= 6  # (the stream's first frames, while the emulated containers grow)
+    gpu.close()
