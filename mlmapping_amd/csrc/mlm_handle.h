@@ -102,8 +102,9 @@ struct MlmMirror {
 };
 
 // A frame on its own with at most this many strips of 256 points (sampled callbacks, point lists: 4 096 points) runs its cells' float chains
-// inside k_rank<true> instead of launching k_chain_lanes — two dependent launches are 4.4 us apart whatever they do; a dense frame's
-// thousands of cells keep k_chain_lanes' cell-per-lane replay (measured: 128 -> 201 us for a dense VGA frame with the chains in k_rank)
+// inside k_rank<true> instead of launching k_chain_lanes — a launch of its own costs a lone frame the kernel boundary (1.5 us) and the few
+// dependent trips to memory every kernel starts with (parameters, counts, its list); a dense frame's thousands of cells keep
+// k_chain_lanes' cell-per-lane replay (measured: 128 -> 201 us for a dense VGA frame with the chains in k_rank)
 constexpr unsigned int kFusedChainStrips = 16;
 static inline double mlm_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 struct mlm_handle {

@@ -106,6 +106,14 @@ int submit_batch(mlm_handle *h, int base, int n) {
         // the cell-table path's per-frame state exists once: every frame runs alone, Stage A and the two map-dependent kernels
         // back to back on the main stream (behind whatever the frames before it left there)
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->set_free[set], 0));
+        if (h->async_mode) {
+            // (an asynchronous call's inputs — image, pixel list, points — went up on the set's Stage A stream, where its Stage A was
+            // expected to run: run_slots_inner; this one runs on the main stream, which must wait for them.  Found by the recovery fuzzer's
+            // scenario in tests/test_gpu_small_frames.py: a list read before it had arrived, one run in twenty-five.)
+            if (!h->upload_ev) HIPCHK(h, hipEventCreateWithFlags(&h->upload_ev, hipEventDisableTiming));
+            HIPCHK(h, hipEventRecord(h->upload_ev, h->stream_as[set]));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->upload_ev, 0));
+        }
         for (int j = 0; j < n; ++j) {
             MlmSlot &S = h->slots[(size_t)(base + j)];
             rc = launch_stage_a_batch(h, base + j, 1, true);
@@ -446,8 +454,10 @@ inline hipStream_t upload_stream(const mlm_handle *h) {
     return (fast_handle_ok(h) || !h->async_mode) ? h->stream : h->stream_as[h->cur_set]; // (synchronous calls: everything on the main stream)
 }
 // The launch sequence of ONE frame on stream `st` (the sector path, everything on one stream): a prologue kernel takes the frame's
-// parameters from pinned host memory and clears the slot's counters, Stage A, k_apply_single, whose last workgroup writes the
-// counters, the map-wide flags and — last — the completion ticket back to pinned memory.  Issued directly, or captured into a graph.
+// parameters from pinned host memory and clears the slot's counters (no_prologue — a small frame in a slot whose counters the frame
+// before left clear —: the first Stage A kernel fetches the parameters itself), Stage A, k_apply_single, whose last workgroup writes
+// the counters, the map-wide flags and — last — the completion ticket back to pinned memory and clears the slot's counters
+// (mlm_hand_back).  Kernels only: a copy or fill node is 4-5 us of a lone frame's time.  Issued directly, or captured into a graph.
 hipError_t enqueue_single_frame(mlm_handle *h, int base, unsigned int nb, int big, bool no_prologue, hipStream_t st) {
     const MlmSlot &S = h->slots[(size_t)base];
     const MlmDev &P = S.P;

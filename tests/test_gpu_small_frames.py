@@ -147,3 +147,64 @@ def test_launches_of_a_lone_frontier_callback(knobs):
                      "k_ex_release"], names
     assert gpu.frame_stats()["n_spec_replays"] <= 6  # (the stream's first frames, while the emulated containers grow)
     gpu.close()
+
+
+def test_async_frame_on_the_shared_cell_table_path_waits_for_its_inputs(knobs):
+    """An asynchronous call while the handle backs off from the sector path (a frame's Stage A gave up shortly before) runs its Stage A
+    on the MAIN stream (the cell-table path's per-frame state exists once), while its pixel list went up on the slot set's Stage A
+    stream: the main stream has to wait for it.  Without that wait the list was read before it had arrived in one run in twenty-five of
+    the scenario of test_small_frames_between_everything_else[stage_a_gives_up] (a third of the runs with the round-5 library, late in
+    a process) — the scenario again, on thirty fresh handles, the map compared after its asynchronous frames.
+    Reference: the callback hands over a complete frame, src/mlmap.cpp:463-507."""
+    from mlmapping_amd import mlmap
+    from mlmapping_amd.mlmap import MLMap
+    from oracle.binding import OracleMap
+
+    cfg = S1
+    frames = list(syn.stream(cfg, "room_jitter", "random", 30, seed=4))
+    rng = np.random.default_rng(31)
+    ops, k, n_small = [], 0, 0
+    while k < len(frames):
+        if k % 9 == 4:
+            ops.append(("dense", k, None))
+        elif k % 9 == 7 and k + 1 < len(frames):
+            ops.append(("batch", k, None))
+            k += 1
+        elif k % 9 == 2:
+            ops.append(("async", k, _pix(rng, cfg, 700)))
+        else:
+            ops.append(("small", k, _pix(rng, cfg, (500, 3000, 4096, 1)[n_small % 4])))
+            n_small += 1
+        k += 1
+    cpu, want = OracleMap(cfg), []
+    for kind, k, pix in ops:
+        img, (q, t) = frames[k]
+        if kind == "dense":
+            cpu.update_depth(img, q, t)
+        elif kind == "batch":
+            cpu.update_depth(img, q, t)
+            cpu.update_depth(frames[k + 1][0], *frames[k + 1][1])
+        else:
+            cpu.update_depth_indexed(img, pix, q, t)
+        want.append(cpu.export_blocks() if kind == "async" else None)
+    for rep in range(30):
+        knobs.set("sec_fail_every", "3")
+        gpu = MLMap(cfg, max_blocks=4096, max_points=cfg.width * cfg.height, max_batch=2)
+        mlmap.debug_reset()
+        for j, (kind, k, pix) in enumerate(ops):
+            img, (q, t) = frames[k]
+            if kind == "dense":
+                gpu.update_map(img, q, t)
+            elif kind == "batch":
+                img2, (q2, t2) = frames[k + 1]
+                gpu.update_map_batch(np.stack([img, img2]), np.stack([q, q2]), np.stack([t, t2]))
+            elif kind == "async":
+                gpu.set_async(True)
+                gpu.update_map(img, q, t, pixel_idx=pix)
+                gpu.sync()
+                gpu.set_async(False)
+                compare_maps(gpu.export_blocks(), want[j], f"fresh handle {rep}, asynchronous frame {k}")
+            else:
+                gpu.update_map(img, q, t, pixel_idx=pix)
+        assert gpu.frame_stats()["n_sector_fallbacks"] > 0
+        gpu.close()
