@@ -12,7 +12,8 @@ from tests.util import compare_maps
 
 variants = sys.argv[1].split(",")
 reps = int(sys.argv[2])
-cfg = S1
+FRONTIER = bool(os.environ.get("FRONTIER"))  # use_exploration_frontiers: true (the frontier sets are compared as well)
+cfg = S1.with_(use_exploration_frontiers=True) if FRONTIER else S1
 frames = list(syn.stream(cfg, "room_jitter", "random", 30, seed=4))
 def _pix(rng, n):
     return (rng.integers(0, cfg.height, n) * cfg.width + rng.integers(0, cfg.width, n)).astype(np.int32)
@@ -34,7 +35,7 @@ for kind, k, pix in ops:
     elif kind == "batch":
         cpu.update_depth(img, q, t); img2, (q2, t2) = frames[k + 1]; cpu.update_depth(img2, q2, t2)
     else: cpu.update_depth_indexed(img, pix, q, t)
-    ref.append(cpu.export_blocks())
+    ref.append((cpu.export_blocks(), cpu.export_frontier() if FRONTIER else None))
 fails = 0
 for rep in range(reps):
     for variant in variants:
@@ -56,12 +57,13 @@ for rep in range(reps):
                         gpu.set_async(True); gpu.update_map(img, q, t, pixel_idx=pix); gpu.sync(); gpu.set_async(False)
                 else: gpu.update_map(img, q, t, pixel_idx=pix)
                 st_before = gpu.frame_stats()
-                compare_maps(gpu.export_blocks(), ref[j], f"rep {rep} {variant} op {j} {kind} frame {k}")
+                compare_maps(gpu.export_blocks(), ref[j][0], f"rep {rep} {variant} op {j} {kind} frame {k}")
+                if FRONTIER: assert np.array_equal(gpu.export_frontier(), ref[j][1]), f"rep {rep} {variant} op {j} {kind} frame {k}: frontier sets differ"
                 if rep == 0 and j >= 24: print("ok op", j, kind, {x: st_before[x] for x in ("n_sector_fallbacks", "n_spec_replays", "n_graph_launches", "n_pool_grows", "n_blocks", "block_capacity")}, flush=True)
         except AssertionError as e:
             fails += 1
             try:
-                compare_maps(gpu.export_blocks(), ref[j - 1], "vs the map BEFORE this frame")
+                compare_maps(gpu.export_blocks(), ref[j - 1][0], "vs the map BEFORE this frame")
                 print("  -> equal to the map before this frame: the frame was not applied", flush=True)
             except AssertionError as e2:
                 print("  -> also differs from the map before:", str(e2)[:160], flush=True)
