@@ -48,8 +48,8 @@ int order_misses_exact(mlm_handle *h, MlmSlot &S, unsigned int U) {
 void explore_flush_tail(mlm_handle *h) {
     if (!h->ex_tail) return;
     const dim3 blk(MLM_BLOCK);
-    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, h->stream, h->ex_tail->P);
-    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, h->stream, h->ex_tail->P, (MlmCounters *)nullptr, (MlmGlobal *)nullptr, 0u);
+    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, h->stream, h->ex_tail->P, (MlmCounters *)nullptr, (MlmGlobal *)nullptr, 0u);
+    tlaunch(h, "k_ex_release", k_ex_release, dim3(1024), blk, 0, h->stream, h->ex_tail->P);
     h->ex_tail = nullptr;
 }
 
@@ -145,12 +145,12 @@ int explore_stage_bc_spec(mlm_handle *h, int slot_index, unsigned int thr[2]) {
     tlaunch(h, "k_ex_register", k_ex_register, dim3(4 * kListGrid, 2), blk, 0, st, Ps, S.F);
     tlaunch(h, "k_apply", k_apply, dim3(64, 1), blk, 0, st, Ps, 0, 1);
     tlaunch(h, "k_ex_observe", k_ex_observe, dim3(4 * kListGrid), blk, 0, st, Ps, S.F);
-    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(kListGrid), blk, 0, st, Ps);
-    // (the frame's counters, the map-wide flags and the completion ticket go to the host with the last workgroup of the last launch)
+    // (the frame's counters, the map-wide flags and the completion ticket go to the host with the last workgroup of the miss phase — 128
+    // workgroups: the hand-back counts their arrivals on one word, ~10 ns each —; the release scan runs behind it)
     h->h_g->pad = 0u;
     h->wait_ticket = (unsigned int)S.F.pad2 + 1u;
-    // (128 workgroups: the hand-back counts their arrivals on one word, ~10 ns each)
-    tlaunch(h, "k_ex_release", k_ex_release, dim3(128), blk, 0, st, Ps, h->h_ctr_all + slot_index, h->h_g, h->wait_ticket);
+    tlaunch(h, "k_ex_apply_misses", k_ex_apply_misses, dim3(128), blk, 0, st, Ps, h->h_ctr_all + slot_index, h->h_g, h->wait_ticket);
+    tlaunch(h, "k_ex_release", k_ex_release, dim3(128), blk, 0, st, Ps);
     return MLM_OK;
 }
 // end of a batch (or of a single frame): the last frame's tail, the map-wide counters.  (Deferring that tail to the next synchronous

@@ -327,9 +327,16 @@ __device__ __forceinline__ void mlm_ex_apply_misses_body(const MlmDev &P) {
         if (o == 'f' && o0 != 'f') P.frnt[v] = 0;
     }
 }
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P) {
-    if (mlm_ex_spec_skip(P)) return;
-    mlm_ex_apply_misses_body(P);
+__device__ __forceinline__ void mlm_hand_back(const MlmDev &P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket, bool cleared); // (mlm_kernels_sector.h)
+// host_ctr (a synchronous call's lone frame, explore_stage_bc_spec): the last workgroup hands the slot's counters, the map-wide flags and
+// the ticket to the host (instead of two copies on the stream, 4 us each and a gap in front) — from HERE, one launch before the frame's
+// last: the release scan that follows changes nothing the caller is handed (it marks uniform, frontier-free blocks as collapsed for the
+// launches behind it in the stream), so it runs while the calling thread is already sampling its next frame.  A frame that ran leaves
+// the slot's counters clear (launch_stage_a_sector); k_ex_release then finds them clear and runs, as it must.
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_apply_misses(const MlmDev P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket) {
+    const bool ran = !mlm_ex_spec_skip(P);
+    if (ran) mlm_ex_apply_misses_body(P);
+    if (host_ctr) mlm_hand_back(P, host_ctr, host_g, ticket, ran);
 }
 
 // release scan (map_local.cpp:208-232): one workgroup per allocated block; blocks observed this frame whose frontier is
@@ -369,13 +376,11 @@ __device__ __forceinline__ void mlm_ex_release_body(const MlmDev &P) {
         }
     }
 }
-__device__ __forceinline__ void mlm_hand_back(const MlmDev &P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket, bool cleared); // (mlm_kernels_sector.h)
-// host_ctr (a synchronous call's lone frame, explore_stage_bc_spec): the last launch of the frame — its last workgroup hands the slot's
-// counters, the map-wide flags and the ticket to the host (instead of two copies on the stream, 4 us each and a gap in front)
-__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P, MlmCounters *host_ctr, MlmGlobal *host_g, unsigned int ticket) {
-    const bool ran = !mlm_ex_spec_skip(P);
-    if (ran) mlm_ex_release_body(P);
-    if (host_ctr) mlm_hand_back(P, host_ctr, host_g, ticket, ran); // (a frame that ran leaves the slot's counters clear: launch_stage_a_sector)
+// (a lone frame's release scan runs behind the frame's hand-back: see k_ex_apply_misses.  A frame whose launches were held back —
+// mlm_ex_spec_skip — kept its counters, and is skipped here as well.)
+__global__ __launch_bounds__(MLM_BLOCK) void k_ex_release(const MlmDev P) {
+    if (mlm_ex_spec_skip(P)) return;
+    mlm_ex_release_body(P);
 }
 
 // frontier read-out: (gx,gy,gz,cell) of every frontier cell

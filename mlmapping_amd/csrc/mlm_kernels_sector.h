@@ -2531,7 +2531,7 @@ __global__ __launch_bounds__(MLM_BLOCK) void k_apply_tiles(const MlmDev *__restr
 // parameters come from pinned host memory — workgroup j copies frame j's into the device-resident table and clears the slot's
 // counters (the words that are ever written: mlm_ctr_live_word) — one kernel instead of a copy and a fill (which is two fill kernels
 // for the 6 KB of MlmCounters: 15 us in front of a lone frame); the counters and the map-wide flags go back the same way (the tail of
-// k_apply_single, k_ex_release).
+// k_apply_single, k_ex_apply_misses).
 __global__ __launch_bounds__(128) void k_frame_prologue(const MlmFrame *host_frame, MlmFrame *dev_frame, MlmCounters *ctr) {
     const uint32_t *src = (const uint32_t *)(host_frame + blockIdx.x);
     uint32_t *dst = (uint32_t *)(dev_frame + blockIdx.x), *c = (uint32_t *)(ctr + blockIdx.x);

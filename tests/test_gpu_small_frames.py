@@ -127,7 +127,8 @@ def test_default_callback_stream_sdef(knobs):
 def test_launches_of_a_lone_frontier_callback(knobs):
     """What a synchronous frontier-mode callback enqueues once the stream is under way (per-call kernel timing lists the launches):
     Stage A without a prologue kernel (the previous frame left the slot's counters clear), the bucket-first pass inside k_rank (no
-    k_ex_order_min), the map-dependent launches, k_ex_release last (it hands the counters back) — nine kernels, no copies between them.
+    k_ex_order_min), the map-dependent launches — k_ex_apply_misses hands the counters back, the release scan runs behind the ticket —:
+    nine kernels, no copies between them.
     Reference call: src/mlmap.cpp:463-507."""
     from mlmapping_amd.mlmap import MLMap
 
