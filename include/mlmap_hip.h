@@ -236,7 +236,9 @@ int mlm_host_unregister(mlm_handle *h, const void *ptr);
 int mlm_sync(mlm_handle *h);
 /* async = 1: integrate calls return once the work is SUBMITTED (up to three batches may be in flight, one per slot set); errors of
  * a batch and mlm_get_frame_stats lag by one call; mlm_sync, queries and exports wait for everything.  Default 0: integrate
- * calls return when the map is updated.  Host buffers stay BORROWED FOR THE CALL in both modes: an asynchronous call returns
+ * calls return when the map is updated (a lone frame's call returns on a completion ticket its last map-updating kernel writes to pinned
+ * memory; in frontier mode the release scan of map_local.cpp:208-232 — which marks blocks, not voxels — may still be running then:
+ * everything that reads the map afterwards is ordered behind it).  Host buffers stay BORROWED FOR THE CALL in both modes: an asynchronous call returns
  * only after its copies out of the caller's buffer have completed (also from a buffer pinned with mlm_host_register, whose
  * copies are truly asynchronous) — the buffer may be refilled as soon as the call returns.  Device inputs of the *_dev entry
  * points are read by the frames' kernels and must stay unmodified until mlm_sync (or until three further batches were submitted). */
